@@ -1,0 +1,224 @@
+/*
+ * oracle/oracle.h -- CPU restatement of the PaddlePaddle/XWorld hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product.
+ * Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may
+ * load liboracle.so; the product (xworld_amd/, libxwb.so) never links, imports
+ * or calls it and fails loudly when its HIP library is missing.
+ *
+ * What this is: a plain-C, one-environment-at-a-time restatement of the
+ * reference's GameSimulator::take_action / get_screen / reset_game path for
+ * SimpleGame, SimpleRace and XWorld2D, written to follow the reference
+ * function by function (every function cites the reference file:line it
+ * restates; paths are relative to the reference root).  It deliberately keeps
+ * the reference's own data shapes (per-env one-hot vector + reward vector,
+ * entity lists, item stacks per cell, a 64 px canvas that is then resized) so
+ * that it is an independent check of the SoA / bit-packed / tile-table HIP
+ * product rather than a copy of it.
+ *
+ * Pinning status (see DESIGN.md "Oracle pinning"):
+ *   - SimpleGame           pinned by tests/test_simple_game_simulator.cpp:21-47
+ *   - minstd RNG           pinned by tests/test_simulator_seed.cpp:22-50
+ *   - StatePacket wire     pinned by tests/test_statepacket.cpp:77-104 (round trip)
+ *   - maze / BFS / maps / NavTarget teacher: pinned by golden vectors produced
+ *     by importing the reference's Python modules in the build container
+ *     (tests/golden/make_golden.py)
+ *   - SimpleRace           no reference test exists and the reference C++
+ *     cannot be built here without stand-in headers: pinned only by the
+ *     known-answer values recorded in SURVEY.md 8(a) -> "parity partially pinned"
+ *   - XWorld2D pixels      OpenCV 3.2.0 is absent: the resize / BGR2GRAY
+ *     arithmetic is restated from the library's published algorithm ->
+ *     "parity unpinned" for pixel values (bit-exact vs this restatement only)
+ */
+#ifndef XW_ORACLE_H
+#define XW_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* GameOverCode, simulator.h:42-48 */
+enum { ORC_ALIVE = 0, ORC_MAX_STEP = 1, ORC_DEAD = 2, ORC_SUCCESS = 4, ORC_LOST_LIFE = 8 };
+
+/* ---------------------------------------------------------------- RNG ---- */
+/* libstdc++ minstd_rand0 + distributions as used by simulator_util.cpp:38-73 */
+typedef struct { uint32_t x; } orc_minstd;
+void     orc_minstd_seed(orc_minstd *g, uint64_t s);            /* engine.seed(s) */
+uint32_t orc_minstd_next(orc_minstd *g);                        /* engine()      */
+int      orc_minstd_rand_ind(orc_minstd *g, int size);          /* get_rand_ind  */
+float    orc_minstd_rand_range(orc_minstd *g, float upper);     /* get_rand_range_val */
+uint64_t orc_std_hash_string(const char *s, size_t len);        /* std::hash<std::string> (libstdc++ murmur2-64, seed 0xc70f6907) */
+/* seed of the n-th ThreadCounter (n = value of ++__num_threads) for FLAGS_simulator_seed */
+void     orc_minstd_seed_thread(orc_minstd *g, int simulator_seed, int nth_thread);
+
+/* Philox4x32-10 (Salmon et al. 2011) -- the *build's* counter-based stream
+ * ("xwb-rng-v1"): no reference counterpart, restated here so the
+ * GPU reset / random-policy streams can be replayed on the CPU. */
+void     orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+typedef struct { uint32_t key[2]; uint32_t ctr[4]; uint32_t buf[4]; int have; } orc_stream;
+void     orc_stream_init(orc_stream *s, uint32_t seed, uint32_t env_gid, uint32_t episode, uint32_t stream_id);
+uint32_t orc_stream_u32(orc_stream *s);
+uint32_t orc_stream_below(orc_stream *s, uint32_t n);  /* (u32 * n) >> 32 ; consumes a draw iff n > 1 */
+float    orc_stream_unit(orc_stream *s);               /* (u32 >> 8) * 2^-24 in [0,1) */
+int32_t  orc_policy_action(uint32_t policy_seed, uint32_t env_gid, uint32_t step, int num_actions);
+
+/* ---------------------------------------------------------- SimpleGame ---- */
+typedef struct orc_simple_game orc_simple_game;
+orc_simple_game *orc_sg_create(int array_size, int max_steps, int context);
+void    orc_sg_destroy(orc_simple_game *g);
+void    orc_sg_reset_game(orc_simple_game *g);                 /* SimulatorInterface::reset_game ordering */
+float   orc_sg_take_actions(orc_simple_game *g, int action, int act_rep);
+int     orc_sg_game_over(const orc_simple_game *g);
+int     orc_sg_get_lives(const orc_simple_game *g);
+int64_t orc_sg_num_steps(const orc_simple_game *g);
+int     orc_sg_pos(const orc_simple_game *g);
+void    orc_sg_get_screen(const orc_simple_game *g, uint8_t *out /* array_size */);
+void    orc_sg_get_state_screen(const orc_simple_game *g, uint8_t *out /* context*array_size */);
+
+/* ---------------------------------------------------------- SimpleRace ---- */
+typedef struct {
+    int   track_type;         /* 0 straight, 1 circle */
+    double track_width, track_length, track_radius;   /* gflags are doubles */
+    int   race_full_manouver;
+    int   random;
+    int   difficulty_hard;    /* 0 easy, 1 hard */
+    double reward_scale;
+    int   max_steps;
+    int   context;
+    int   simulator_seed;     /* only used when random: minstd thread seed */
+    int   nth_thread;
+} orc_race_cfg;
+typedef struct orc_simple_race orc_simple_race;
+void    orc_race_default_cfg(orc_race_cfg *c);
+orc_simple_race *orc_race_create(const orc_race_cfg *c);
+void    orc_race_destroy(orc_simple_race *g);
+void    orc_race_reset_game(orc_simple_race *g);
+/* reset with externally supplied uniforms in [0,1) (the batched product draws them from Philox) */
+void    orc_race_reset_game_with(orc_simple_race *g, float u_track, float u_dy, float u_dx, float u_angle);
+float   orc_race_take_actions(orc_simple_race *g, int action, int act_rep);
+int     orc_race_game_over(const orc_simple_race *g);
+int     orc_race_get_lives(const orc_simple_race *g);
+int     orc_race_num_actions(const orc_simple_race *g);
+int64_t orc_race_num_steps(const orc_simple_race *g);
+void    orc_race_get_car(const orc_simple_race *g, float *x, float *y, float *angle);
+void    orc_race_set_car(orc_simple_race *g, float x, float y, float angle);
+void    orc_race_get_screen(const orc_simple_race *g, float *out4);
+void    orc_race_get_state_screen(const orc_simple_race *g, float *out /* context*4 */);
+
+/* ------------------------------------------------------------ XWorld2D ---- */
+/* icon table: one record per 64x64 icon of games/xworld/images */
+typedef struct {
+    int type;      /* 0 goal, 1 block, 2 agent  (xworld_env.py grid_types) */
+    int name_id;   /* index into the sorted list of names of that type     */
+} orc_icon_info;
+
+enum { ORC_MAP_NAV = 0, ORC_MAP_WALLS = 1 };
+enum { ORC_EV_NONE = 0, ORC_EV_CORRECT = 1, ORC_EV_WRONG = 2, ORC_EV_TIMEUP = 3 };
+enum { ORC_STAGE_IDLE = 0, ORC_STAGE_NAV = 1, ORC_STAGE_TERMINAL = 2 };
+enum { ORC_TASKMODE_LANG_ACQ = 0, ORC_TASKMODE_ONE_CHANNEL = 1 };
+
+typedef struct {
+    int map_kind;            /* ORC_MAP_NAV | ORC_MAP_WALLS */
+    int max_dim;             /* max_height == max_width (XWorldNav 8, XWorldWalls 7) */
+    int dim;                 /* actual dim this episode (== max_dim when curriculum == 0) */
+    int num_goals, num_blocks;
+    int max_steps;           /* FLAGS_max_steps */
+    int max_steps_factor;    /* FLAGS_max_steps_factor (10) */
+    int task_mode;           /* ORC_TASKMODE_* */
+    int color;               /* FLAGS_color */
+    int context;
+    uint32_t seed;           /* xwb-rng-v1 seed */
+} orc_xw_cfg;
+
+typedef struct {
+    int type;            /* 0 goal 1 block 2 agent */
+    int x, y;
+    int icon;            /* global icon index */
+    int name_id;
+    int serial;          /* running id -> "<name>_<serial>" */
+} orc_entity;
+
+typedef struct orc_xworld orc_xworld;
+/* icons64: n_icons*64*64*3 BGR bytes (may be NULL when no rendering is asked for) */
+orc_xworld *orc_xw_create(const orc_xw_cfg *cfg, int n_icons, const orc_icon_info *info,
+                          const uint8_t *icons64);
+void    orc_xw_destroy(orc_xworld *w);
+/* SimulatorInterface::reset_game: map generation from stream (seed, env_gid, episode), teacher idle */
+void    orc_xw_reset_game(orc_xworld *w, uint32_t env_gid, uint32_t episode);
+/* replay an externally produced map (e.g. a reference-generated golden map), then teacher idle
+ * with an explicit target pick (index into the reachable-goal list, or -1 to draw from the stream) */
+void    orc_xw_load_map(orc_xworld *w, int n_entities, const orc_entity *ents, int dim,
+                        int target_pick, uint32_t env_gid, uint32_t episode);
+float   orc_xw_take_actions(orc_xworld *w, int action, int act_rep);
+int     orc_xw_game_over(const orc_xworld *w);
+int     orc_xw_get_lives(const orc_xworld *w);
+int     orc_xw_num_actions(const orc_xworld *w);
+int64_t orc_xw_num_steps(const orc_xworld *w);
+int     orc_xw_last_action_success(const orc_xworld *w);
+int     orc_xw_event(const orc_xworld *w);
+int     orc_xw_stage(const orc_xworld *w);
+int     orc_xw_target_name(const orc_xworld *w);
+int     orc_xw_steps_in_task(const orc_xworld *w);
+int     orc_xw_n_entities(const orc_xworld *w);
+void    orc_xw_get_entities(const orc_xworld *w, orc_entity *out);
+void    orc_xw_agent_xy(const orc_xworld *w, int *x, int *y);
+/* grid of (icon+1) per cell, 0 = empty, top item of the stack; max_dim*max_dim ints, row-major [y][x] */
+void    orc_xw_get_grid(const orc_xworld *w, int32_t *out);
+void    orc_xw_screen_dims(const orc_xworld *w, int *h, int *wd, int *c);
+/* XWorldSimulator::get_screen: canvas -> get_screen_rgb -> down_sample_image */
+void    orc_xw_get_screen(const orc_xworld *w, uint8_t *out);
+void    orc_xw_get_state_screen(const orc_xworld *w, uint8_t *out /* context * c*h*w */);
+
+/* reference helper restatements exposed for golden-vector tests */
+/* maze2d.spanning_tree_maze_generator with the shuffle decisions drawn from `s`;
+ * maze: X*X chars, ' ' or '#', row-major [y][x] */
+void    orc_maze_generate(orc_stream *s, int X, char *maze);
+/* maze2d.bfs reachability (obstacles given as a mask X*Y, row-major [y][x]) */
+int     orc_bfs_reachable(int sx, int sy, int ex, int ey, int X, int Y, const uint8_t *obstacle);
+
+/* OpenCV 3.2 restatements (third-party, version pinned by cmake/opencv.cmake:5-6) */
+void    orc_cv_resize_linear_8u(const uint8_t *src, int sh, int sw, int cn, uint8_t *dst, int dh, int dw);
+void    orc_cv_bgr2gray_8u(const uint8_t *src, int n_pixels, uint8_t *dst);
+
+/* -------------------------------------------------- StatePacket wire ---- */
+/* data_packet.h:313-319, data_packet.cpp:143-174, memory_util.h:307-333 */
+typedef struct {
+    const char *key;
+    int has_reals;  const float   *reals;  size_t n_reals;
+    int has_pixels; const uint8_t *pixels; size_t n_pixels;
+    int has_id;     const int32_t *id;     size_t n_id;
+    int has_str;    const char    *str;
+} orc_packet_field;
+/* returns bytes needed; writes when out != NULL and cap is large enough */
+size_t  orc_packet_encode(const orc_packet_field *fields, int n_fields, uint8_t *out, size_t cap);
+/* decodes into caller arrays of at most max_fields; pointers alias `buf`; returns n_fields or -1 */
+int     orc_packet_decode(const uint8_t *buf, size_t len, orc_packet_field *fields, int max_fields);
+
+/* GameSimulator::decode_game_over_code, simulator.cpp:125-144 ; returns length written */
+int     orc_decode_game_over_code(int code, char *out, int cap);
+
+/* --------------------------------------------------- batch drivers ---- */
+/* bench.py cpu_baseline + large parity tests: run n envs for `steps` steps of the
+ * reference example loop (game_over? -> reset; get_state; random action; take_actions)
+ * with the xwb-rng-v1 policy stream; returns number of env-steps executed.  */
+typedef struct {
+    double   reward_sum;
+    uint64_t resets;
+    uint64_t state_hash;     /* FNV-1a over (reward bits, game_over code) of every env-step */
+    uint64_t obs_hash;       /* FNV-1a over every observation produced                    */
+} orc_rollout_stats;
+uint64_t orc_sg_rollout(int n_envs, int array_size, int steps, uint32_t policy_seed,
+                        uint32_t env_gid0, orc_rollout_stats *st);
+uint64_t orc_race_rollout(int n_envs, const orc_race_cfg *cfg, int steps, uint32_t policy_seed,
+                          uint32_t env_gid0, orc_rollout_stats *st);
+uint64_t orc_xw_rollout(int n_envs, const orc_xw_cfg *cfg, int n_icons, const orc_icon_info *info,
+                        const uint8_t *icons64, int steps, uint32_t policy_seed,
+                        uint32_t env_gid0, int render, orc_rollout_stats *st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XW_ORACLE_H */
