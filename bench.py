@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched XWorld simulator on N MI355X (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload xworld7|xworld8|xworld11|simple_game|simple_race]
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path over the whole batch with inputs resident in HBM:
+SimulatorInterface::take_actions(act_rep=1) for every env under the built-in uniform random policy
+(actions drawn on device), observation of every env materialised in HBM, then the reference example
+loop's `if game_over: reset_game()` for the envs that finished (wavefront-ballot compaction, map
+generation, re-render).  Default workload = BASELINE.json config C4 (the configuration the north-star
+target is quoted on): XWorld2D 7x7, 84x84x3 uint8 planar BGR, 32 768 envs per GPU.
+
+Multi-GPU: the env batch is sharded by global env id (weak scaling: 32 768 envs per GPU); every step
+rank 0 receives each shard's (reward, game_over) through one RCCL gather.  `--gather-screens` also
+gathers every shard's screens into one contiguous tensor on rank 0 (xGMI-link bound).
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (game, opts, envs per GPU, algorithmic bytes per env-step, bytes per env per render launch)
+    "xworld7": ("xworld", {"max_dim": 7, "num_blocks": 16, "color": True}, 32768),
+    "xworld8": ("xworld", {"color": True}, 32768),
+    "xworld11": ("xworld", {"max_dim": 11, "num_blocks": 30, "color": True}, 32768),
+    "simple_game": ("simple_game", {"array_size": 64}, 65536),
+    "simple_race": ("simple_race", {"track_width": 20.0, "track_length": 100.0, "track_radius": 30.0}, 65536),
+}
+
+
+def make_sim(workload, n_envs, device, gid0):
+    from xworld_amd.batched import BatchedSimulator
+    game, opts, _ = WORKLOADS[workload]
+    opts = dict(opts)
+    if game == "xworld":
+        opts["xwd_conf_path"] = os.path.join(ROOT, "xworld_amd", "confs", "navigation2d.json")
+        opts["task_mode"] = "lang_acquisition"
+    return BatchedSimulator(game, opts, num_envs=n_envs, device=device, env_gid0=gid0,
+                            seed=0xC0FFEE, policy_seed=0x5EED)
+
+
+def algorithmic_bytes(workload, sim):
+    """logical bytes per env-step, and per env per launch of the dominant kernel."""
+    game = WORKLOADS[workload][0]
+    if game == "simple_game":
+        a = sim.cfg.array_size
+        return 27 + a, 27 + a, "sg_kernel"
+    if game == "simple_race":
+        return 57, 57, "race_kernel"
+    d = sim.cfg.max_dim
+    c = sim.screen_dims[2]
+    obs = c * 144 * d * d
+    return 33 + 2 * d * d + obs, 2 * d * d + obs, "xw_render_all_kernel"
+
+
+def cpu_baseline(workload, seconds_target=12.0):
+    """The oracle (CPU restatement of the reference path, kind = "port") timed on this box's host cores,
+    1 thread, on a bounded sample of the same workload (same loop: game_over? -> reset; get_state;
+    random action; take_actions incl. screen)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    game = WORKLOADS[workload][0]
+    n, steps = 8, 50
+    t_used, done = 0.0, 0
+    while True:
+        t0 = time.perf_counter()
+        if game == "simple_game":
+            O.sg_rollout(n, 64, steps, 0x5EED)
+        elif game == "simple_race":
+            O.race_rollout(n, O.race_cfg(), 0xC0FFEE, steps, 0x5EED)
+        else:
+            sim_opts = WORKLOADS[workload][1]
+            d = sim_opts.get("max_dim", 8)
+            pal = O.Palette(O.NAV_SUBTREES)
+            cfg = O.xw_cfg(map_kind=0, max_dim=d, dim=d, num_goals=4, num_blocks=sim_opts.get("num_blocks", 16),
+                           color=1, seed=0xC0FFEE)
+            O.xw_rollout(n, cfg, pal, steps, 0x5EED, render=True)
+        dt = time.perf_counter() - t0
+        t_used += dt
+        done += n * steps
+        if t_used >= seconds_target or dt <= 0:
+            break
+        # grow the sample until one call takes a couple of seconds
+        if dt < 2.0:
+            n *= 4
+    return {"value": done / t_used, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d env-steps of %s through oracle/liboracle.so (reset, step, teacher, 64px-canvas render), "
+                      "%.1f s, 1 thread" % (done, workload, t_used)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="xworld7", choices=list(WORKLOADS))
+    ap.add_argument("--envs-per-gpu", type=int, default=0)
+    ap.add_argument("--gather-screens", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--autoreset", action="store_true", help="use the fused step+reset+single-render call")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    n_gpus = world
+    dev = torch.device("cuda", local_rank)
+    n_local = args.envs_per_gpu or WORKLOADS[args.workload][2]
+    sim = make_sim(args.workload, n_local, local_rank, rank * n_local)
+    per_step, per_launch, kernel_name = algorithmic_bytes(args.workload, sim)
+
+    # per-step exchange: (reward, game_over) of every shard to rank 0
+    small = torch.empty((n_local, 2), dtype=torch.float32, device=dev)
+    small_all = [torch.empty_like(small) for _ in range(world)] if (world > 1 and rank == 0) else None
+    screens_all = None
+    if world > 1 and args.gather_screens:
+        if rank == 0:
+            screens_all = torch.empty((world * n_local,) + tuple(sim.obs.shape[1:]), dtype=sim.obs.dtype, device=dev)
+            sim.bind_obs(screens_all[:n_local])          # rank 0 renders straight into its slice
+
+    def exchange():
+        if world == 1:
+            return
+        small[:, 0] = sim.reward
+        small[:, 1] = sim.game_over_codes.to(torch.float32)
+        dist.gather(small, small_all, dst=0)
+        if args.gather_screens:
+            if rank == 0:
+                ops = [dist.P2POp(dist.irecv, screens_all[r * n_local:(r + 1) * n_local], r) for r in range(1, world)]
+            else:
+                ops = [dist.P2POp(dist.isend, sim.obs, 0)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def one_step():
+        if args.autoreset:
+            sim.step_autoreset()
+        else:
+            sim.step()
+            sim.reset_done()
+        exchange()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    # ---- the timed region: exactly K steps between two barrier + synchronize fences ----
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    dt_clean = time.perf_counter() - t0
+    dt_max = dt_clean
+    if world > 1:
+        tt = torch.tensor([dt_clean], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_max = float(tt.item())
+
+    # ---- same K steps again with hipEvents around every launch of the dominant kernel (on its
+    # launch stream, recorded inside libxwb) to get that kernel's average duration for the roofline ----
+    sim.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    kern = "render" if WORKLOADS[args.workload][0] == "xworld" else "step"
+    kern_us, kern_n = sim.profile_end(kern)
+    sim.profile_stop()
+    errs = sim.check_errors()
+    assert errs == 0
+
+    if rank == 0:
+        total_envs = n_local * world
+        value = total_envs * args.steps / dt_max
+        achieved = n_local * per_launch / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
+        line = {
+            "metric": "env-steps/sec (batched random policy)",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8" if WORKLOADS[args.workload][0] != "simple_race" else "f32 (f64 trig)",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "envs_per_gpu": n_local, "total_envs": total_envs,
+                       "obs": list(sim.obs.shape[1:]), "policy": "uniform random, drawn on device",
+                       "loop": "step_autoreset" if args.autoreset else "step + reset_done",
+                       "exchange": ("gather(reward,done)" + ("+gather(screens)" if args.gather_screens else ""))
+                       if world > 1 else "none", "parallelism": "env-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel_name,
+                         "kernel_avg_us": kern_us, "kernel_launches": kern_n,
+                         "algorithmic_bytes_per_launch": n_local * per_launch,
+                         "algorithmic_bytes_per_env_step": per_step,
+                         "step_loop_GBps": total_envs * per_step * args.steps / dt_max / 1e9},
+            "timed_with_events_ms_per_step": dt / args.steps * 1e3,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(line))
+    sim.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

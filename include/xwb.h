@@ -1,0 +1,207 @@
+/*
+ * include/xwb.h -- C ABI of libxwb.so, the MI355X-native batched XWorld simulator.
+ *
+ * The reference (PaddlePaddle/XWorld) has no C ABI / FFI: its plugin boundary is
+ * the C++ class simulator::GameSimulator (simulator.h:52-231) behind the facade
+ * simulator::SimulatorInterface (simulator_interface.h:40-89), exported to Python
+ * by the Boost.Python module py_simulator (python/py_simulator.cpp:310-329).
+ * Each entry point below states which reference interface it replaces; the
+ * reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - one xwb_sim = one *batch* of num_envs independent environments resident on
+ *     one GPU (the reference: one object = one environment);
+ *   - all per-env state lives in HBM as structure-of-arrays, env index fastest;
+ *   - pointers named *_dev are device pointers; `stream` is a hipStream_t passed
+ *     as void* (NULL = the default stream).  Calls are asynchronous on `stream`
+ *     unless stated otherwise;
+ *   - every function returns XWB_OK (0) or a negative error code; the message of
+ *     the last error on the calling thread is xwb_last_error().  The reference
+ *     aborts the process (CHECK / LOG(FATAL)) where this ABI returns an error;
+ *   - there is no CPU fallback: xwb_create fails with XWB_ERR_HIP when no gfx950
+ *     device is usable.
+ */
+#ifndef XWB_H
+#define XWB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XWB_ABI_VERSION 1
+
+enum {
+    XWB_OK = 0,
+    XWB_ERR_ARG = -1,       /* bad argument / unsupported configuration */
+    XWB_ERR_HIP = -2,       /* HIP runtime failure (message has hipGetErrorString) */
+    XWB_ERR_STATE = -3,     /* call not valid in the current state */
+    XWB_ERR_ACTION = -4     /* action id out of range (reference: CHECK_LT -> abort) */
+};
+
+/* games selected by name in SimulatorInterface::SimulatorInterface, simulator_interface.cpp:41-56 */
+enum { XWB_SIMPLE_GAME = 0, XWB_SIMPLE_RACE = 1, XWB_XWORLD2D = 2 };
+
+/* GameOverCode, simulator.h:42-48 */
+enum { XWB_ALIVE = 0, XWB_MAX_STEP = 1, XWB_DEAD = 2, XWB_SUCCESS = 4, XWB_LOST_LIFE = 8 };
+
+enum { XWB_MAP_NAV = 0, XWB_MAP_WALLS = 1 };             /* games/xworld/maps/XWorldNav.py, XWorldWalls.py */
+enum { XWB_TASKMODE_LANG_ACQ = 0, XWB_TASKMODE_ONE_CHANNEL = 1 };   /* FLAGS_task_mode, xworld_simulator.cpp:33-37 */
+enum { XWB_EV_NONE = 0, XWB_EV_CORRECT_GOAL = 1, XWB_EV_WRONG_GOAL = 2, XWB_EV_TIME_UP = 3 };
+enum { XWB_ICON_GOAL = 0, XWB_ICON_BLOCK = 1, XWB_ICON_AGENT = 2 };  /* xworld_env.py:66 grid_types */
+
+/*
+ * Batch configuration.  Field names follow the reference's gflags / py_simulator
+ * option names (python/py_simulator.cpp:97-136, simulator.cpp:21-27).  The
+ * reference keeps these as process-global gflags; here they are per batch.
+ */
+typedef struct xwb_config {
+    int32_t  abi_version;        /* XWB_ABI_VERSION */
+    int32_t  game;               /* XWB_SIMPLE_GAME | XWB_SIMPLE_RACE | XWB_XWORLD2D */
+    int32_t  num_envs;           /* environments in this batch (this GPU's shard) */
+    int32_t  device;             /* HIP device ordinal */
+    uint32_t env_gid0;           /* global id of local env 0: RNG streams are keyed by global id,
+                                    so results do not depend on how a batch is sharded over GPUs */
+    uint32_t seed;               /* xwb-rng-v1 seed for reset streams */
+    uint32_t policy_seed;        /* xwb-rng-v1 seed for the built-in uniform random policy */
+    int32_t  context;            /* FLAGS_context (simulator.cpp:21) */
+    int32_t  max_steps;          /* FLAGS_max_steps (simulator.cpp:22), 0 = off */
+
+    /* simple_game (simple_game_simulator.cpp:19) */
+    int32_t  array_size;
+
+    /* simple_race (simple_race_simulator.cpp:17-26) */
+    int32_t  track_type;         /* 0 "straight", 1 "circle" */
+    int32_t  race_full_manouver;
+    int32_t  random;
+    int32_t  difficulty_hard;    /* 0 "easy", 1 "hard" */
+    double   track_width, track_length, track_radius, reward_scale;
+
+    /* xworld (xworld_simulator.cpp:22-37, teacher.cpp:22-25, simulator.cpp:23-25) */
+    int32_t  map_kind;           /* XWB_MAP_* : the "map" key of the conf JSON (xworld.cpp:73-76) */
+    int32_t  max_dim;            /* max_height == max_width of the map class */
+    int32_t  dim;                /* actual dim (== max_dim when FLAGS_curriculum == 0) */
+    int32_t  num_goals, num_blocks;
+    int32_t  max_steps_factor;   /* FLAGS_max_steps_factor (10) */
+    int32_t  task_mode;          /* XWB_TASKMODE_* */
+    int32_t  color;              /* FLAGS_color: 3-channel planar BGR when set, else 1-channel gray */
+    int32_t  n_icons;            /* icons this map class can place (its "palette") */
+    const uint8_t *icons64;      /* host, n_icons x 64 x 64 x 3, BGR as cv::imread(path, 1) (xitem.cpp:38) */
+    const int32_t *icon_type;    /* host, n_icons, XWB_ICON_* */
+    const int32_t *icon_name;    /* host, n_icons, index into the sorted names of that type */
+} xwb_config;
+
+typedef struct xwb_sim xwb_sim;
+
+/* fills *cfg with the reference's defaults for `game` (gflags DEFINE_* defaults) */
+int xwb_default_config(int32_t game, xwb_config *cfg);
+
+/* SimulatorInterface::SimulatorInterface(name, false) for num_envs envs, simulator_interface.cpp:37-85.
+ * Allocates the SoA state in HBM, uploads the icon atlas.  Synchronous. */
+int xwb_create(const xwb_config *cfg, xwb_sim **out);
+int xwb_destroy(xwb_sim *sim);
+
+/* SimulatorInterface::reset_game for every env, simulator_interface.cpp:95-105
+ * (game reset -> teacher reset + idle stage -> init_screen). */
+int xwb_reset(xwb_sim *sim, void *stream);
+
+/* The reference example loop's `if game_over() != alive: reset_game()` (examples/test_xworld.cpp:41-45,
+ * python/examples/test_simple_game.py:19-21) applied to every env whose game_over code is non-zero:
+ * wavefront-ballot compaction of the done mask, reset of the compacted list, re-render of those envs. */
+int xwb_reset_done(xwb_sim *sim, void *stream);
+
+/* same, for an explicit device mask (mask_dev[e] != 0 -> reset env e) */
+int xwb_reset_masked(xwb_sim *sim, const uint8_t *mask_dev, void *stream);
+
+/* SimulatorInterface::take_actions(actions, act_rep, false) for every env, simulator_interface.cpp:126-137:
+ * GameSimulator::take_actions (num_steps_++ once, act_rep x take_action) -> teacher -> make_context_screens.
+ * actions_dev: int32[num_envs] ("action" id of each env's StatePacket), or NULL to draw each env's action
+ * from the built-in uniform random policy (xwb-rng-v1 stream 1; the actions used are kept in xwb_actions_dev).
+ * Out-of-range action ids set the env's error flag (see xwb_check_errors) and leave that env untouched. */
+int xwb_step(xwb_sim *sim, const int32_t *actions_dev, int32_t act_rep, void *stream);
+
+/* xwb_step followed by xwb_reset_done in one call, with a single render of the final state
+ * (the observation of a finished env is the first frame of its next episode; reward / game_over
+ * keep the values of the terminal transition). */
+int xwb_step_autoreset(xwb_sim *sim, const int32_t *actions_dev, int32_t act_rep, void *stream);
+
+/* returns the number of envs that flagged an out-of-range action since the last call (synchronises stream) */
+int xwb_check_errors(xwb_sim *sim, void *stream, int32_t *n_bad);
+
+/* ---- observation / result buffers (device pointers, valid until xwb_destroy) ---- */
+/* "screen" of get_state(): [num_envs][context][c][h][w]; uint8 for simple_game / xworld (planar B,G,R),
+ * float32 for simple_race (simple_race_simulator.cpp:412-430).  Newest frame last (simulator.cpp:51-60). */
+int xwb_obs_dev(xwb_sim *sim, void **ptr, size_t *bytes_per_env);
+/* redirect the observation output to caller-owned device memory (e.g. a shard of a gathered tensor) */
+int xwb_bind_obs(xwb_sim *sim, void *obs_dev);
+int xwb_reward_dev(xwb_sim *sim, float **ptr);          /* float[num_envs]: return value of take_actions */
+int xwb_game_over_dev(xwb_sim *sim, uint8_t **ptr);     /* uint8[num_envs]: SimulatorInterface::game_over() code */
+int xwb_actions_dev(xwb_sim *sim, int32_t **ptr);       /* int32[num_envs]: actions applied by the last step */
+int xwb_num_steps_dev(xwb_sim *sim, int32_t **ptr);     /* int32[num_envs]: get_num_steps() */
+int xwb_success_dev(xwb_sim *sim, uint8_t **ptr);       /* uint8[num_envs]: last_action_success() */
+int xwb_episode_dev(xwb_sim *sim, uint32_t **ptr);      /* uint32[num_envs]: resets so far (RNG episode index) */
+int xwb_xw_grid_dev(xwb_sim *sim, uint16_t **ptr);      /* xworld: uint16[num_envs][max_dim*max_dim] cell codes */
+int xwb_done_count(xwb_sim *sim, void *stream, int32_t *n_done);   /* envs reset by the last reset_done (sync) */
+
+/* ---- static queries (SimulatorInterface getters) ---- */
+int xwb_get_num_actions(const xwb_sim *sim, int32_t *n);                         /* get_num_actions() */
+int xwb_get_screen_out_dimensions(const xwb_sim *sim, size_t *h, size_t *w, size_t *c);
+int xwb_get_world_dimensions(const xwb_sim *sim, double *X, double *Y, double *Z);
+int xwb_num_envs(const xwb_sim *sim, int32_t *n);
+
+/* ---- per-env host access: the scalar SimulatorInterface surface (all synchronise `stream`) ---- */
+typedef struct xwb_env_state {
+    float    reward;             /* last take_actions return value */
+    int32_t  game_over;          /* SimulatorInterface::game_over() */
+    int32_t  lives;              /* get_lives() */
+    int64_t  num_steps;          /* get_num_steps() */
+    int32_t  last_action;        /* last_action() as an id, -1 before the first step */
+    int32_t  last_action_success;
+    /* game specific */
+    int32_t  sg_pos;             /* simple_game: _cur_pos */
+    float    race_x, race_y, race_angle;
+    int32_t  xw_agent_x, xw_agent_y, xw_event, xw_stage, xw_target_name, xw_steps_in_task;
+    uint32_t episode;
+} xwb_env_state;
+int xwb_get_env_state(xwb_sim *sim, int32_t env, void *stream, xwb_env_state *out);
+/* copies env's "screen" (context frames) to host memory; bytes must equal bytes_per_env */
+int xwb_get_env_obs(xwb_sim *sim, int32_t env, void *stream, void *out_host, size_t bytes);
+/* xworld: cell codes (palette icon + 1, 0 = empty), max_dim*max_dim uint16, row-major [y][x] */
+int xwb_get_env_grid(xwb_sim *sim, int32_t env, void *stream, uint16_t *out_host);
+
+/* replay an externally generated map into env (golden-map parity): grid cell codes, agent cell,
+ * teacher target name id and actual dim; runs init_screen.  Synchronous. */
+int xwb_xw_load_map(xwb_sim *sim, int32_t env, const uint16_t *grid_host, int32_t agent_x, int32_t agent_y,
+                    int32_t target_name, int32_t dim);
+/* simple_race: overwrite the car state of env (test hook).  Synchronous. */
+int xwb_race_set_car(xwb_sim *sim, int32_t env, float x, float y, float angle);
+
+/* SimulatorInterface::get_state(reward) of one env, serialised in the reference's StatePacket wire
+ * layout (data_packet.h:313-319, data_packet.cpp:143-174, memory_util.h:307-333): keys "reward",
+ * "screen" [, "sentence" for xworld].  Returns bytes needed in *need; writes when cap suffices. */
+int xwb_get_state_packet(xwb_sim *sim, int32_t env, float reward, void *stream,
+                         uint8_t *out_host, size_t cap, size_t *need);
+
+/* GameSimulator::decode_game_over_code, simulator.cpp:125-144 ("alive" | "max_step|dead|...") */
+int xwb_decode_game_over_code(int32_t code, char *out, size_t cap);
+
+/* the xworld 12x12 tile table built from icons64 by the OpenCV-3.2 fixed-point bilinear rule
+ * (what XWorldSimulator::down_sample_image produces for one cell): host copy,
+ * n_icons x c x 12 x 12 bytes. */
+int xwb_xw_get_tile_table(const xwb_sim *sim, uint8_t *out_host, size_t cap, size_t *need);
+
+/* timing hook: average duration in microseconds of the named kernel ("render", "step", "reset")
+ * over the launches recorded since xwb_profile_begin (hipEvents on the launch stream). */
+int xwb_profile_begin(xwb_sim *sim);
+int xwb_profile_end(xwb_sim *sim, void *stream, const char *kernel, double *avg_us, int64_t *launches);
+int xwb_profile_stop(xwb_sim *sim);
+
+const char *xwb_last_error(void);
+const char *xwb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XWB_H */

@@ -207,16 +207,21 @@ int     orc_decode_game_over_code(int code, char *out, int cap);
 typedef struct {
     double   reward_sum;
     uint64_t resets;
-    uint64_t state_hash;     /* FNV-1a over (reward bits, game_over code) of every env-step */
-    uint64_t obs_hash;       /* FNV-1a over every observation produced                    */
 } orc_rollout_stats;
-uint64_t orc_sg_rollout(int n_envs, int array_size, int steps, uint32_t policy_seed,
-                        uint32_t env_gid0, orc_rollout_stats *st);
-uint64_t orc_race_rollout(int n_envs, const orc_race_cfg *cfg, int steps, uint32_t policy_seed,
-                          uint32_t env_gid0, orc_rollout_stats *st);
+/* optional per-step outputs, layout [steps][n_envs] (pass NULL to skip):
+ *   rewards  float   return value of take_actions
+ *   codes    uint8   game_over() after the step
+ *   obs_ck   uint64  position-weighted checksum of the observation get_state() returned *before*
+ *                    the step:  sum_i obs_byte[i] * ((i+1) * 0x9E3779B97F4A7C15)  mod 2^64        */
+typedef struct { float *rewards; uint8_t *codes; uint64_t *obs_ck; } orc_rollout_out;
+uint64_t orc_obs_checksum(const void *obs, size_t n_bytes);
+uint64_t orc_sg_rollout(int n_envs, int array_size, int context, int steps, uint32_t policy_seed,
+                        uint32_t env_gid0, orc_rollout_stats *st, const orc_rollout_out *out);
+uint64_t orc_race_rollout(int n_envs, const orc_race_cfg *cfg, uint32_t seed, int steps, uint32_t policy_seed,
+                          uint32_t env_gid0, orc_rollout_stats *st, const orc_rollout_out *out);
 uint64_t orc_xw_rollout(int n_envs, const orc_xw_cfg *cfg, int n_icons, const orc_icon_info *info,
                         const uint8_t *icons64, int steps, uint32_t policy_seed,
-                        uint32_t env_gid0, int render, orc_rollout_stats *st);
+                        uint32_t env_gid0, int render, orc_rollout_stats *st, const orc_rollout_out *out);
 
 #ifdef __cplusplus
 }

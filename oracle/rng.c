@@ -170,3 +170,11 @@ int orc_decode_game_over_code(int code, char *out, int cap) {
     if (out && cap > n) memcpy(out, buf, (size_t)n + 1);
     return n;
 }
+
+/* position-weighted observation checksum used by the large-batch parity tests */
+uint64_t orc_obs_checksum(const void *obs, size_t n_bytes) {
+    const uint8_t *b = (const uint8_t *)obs;
+    uint64_t acc = 0;
+    for (size_t i = 0; i < n_bytes; ++i) acc += (uint64_t)b[i] * ((uint64_t)(i + 1) * 0x9E3779B97F4A7C15ULL);
+    return acc;
+}

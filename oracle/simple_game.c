@@ -154,30 +154,28 @@ void orc_sg_get_state_screen(const orc_simple_game *g, uint8_t *out) {
 }
 
 /* ---- batch driver (reference example loop, python/examples/test_simple_game.py:15-30) ---- */
-static uint64_t fnv1a(uint64_t h, const void *p, size_t n) {
-    const uint8_t *b = (const uint8_t *)p;
-    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ULL; }
-    return h;
-}
-
-uint64_t orc_sg_rollout(int n_envs, int array_size, int steps, uint32_t policy_seed,
-                        uint32_t env_gid0, orc_rollout_stats *st) {
+uint64_t orc_sg_rollout(int n_envs, int array_size, int context, int steps, uint32_t policy_seed,
+                        uint32_t env_gid0, orc_rollout_stats *st, const orc_rollout_out *out) {
     uint64_t n_steps = 0;
-    orc_rollout_stats s = {0.0, 0, 0xcbf29ce484222325ULL, 0xcbf29ce484222325ULL};
-    uint8_t *obs = (uint8_t *)malloc((size_t)array_size);
+    orc_rollout_stats s = {0.0, 0};
+    size_t osz = (size_t)array_size * (size_t)(context < 1 ? 1 : context);
+    uint8_t *obs = (uint8_t *)malloc(osz);
     for (int e = 0; e < n_envs; ++e) {
-        orc_simple_game *g = orc_sg_create(array_size, 0, 1);
+        orc_simple_game *g = orc_sg_create(array_size, 0, context);
         orc_sg_reset_game(g);
         for (int t = 0; t < steps; ++t) {
             if (orc_sg_game_over(g) != ORC_ALIVE) { orc_sg_reset_game(g); s.resets++; }
             orc_sg_get_state_screen(g, obs);
-            s.obs_hash = fnv1a(s.obs_hash, obs, (size_t)array_size);
             int a = orc_policy_action(policy_seed, env_gid0 + (uint32_t)e, (uint32_t)t, 2);
             float r = orc_sg_take_actions(g, a, 1);
             int code = orc_sg_game_over(g);
             s.reward_sum += r;
-            s.state_hash = fnv1a(s.state_hash, &r, 4);
-            s.state_hash = fnv1a(s.state_hash, &code, 4);
+            if (out) {
+                size_t k = (size_t)t * (size_t)n_envs + (size_t)e;
+                if (out->rewards) out->rewards[k] = r;
+                if (out->codes) out->codes[k] = (uint8_t)code;
+                if (out->obs_ck) out->obs_ck[k] = orc_obs_checksum(obs, osz);
+            }
             n_steps++;
         }
         orc_sg_destroy(g);

@@ -365,36 +365,49 @@ void orc_race_get_state_screen(const orc_simple_race *g, float *out) {
     memcpy(out, g->screens, sizeof(float) * 4 * (size_t)g->cfg.context);
 }
 
-/* ---- batch driver (examples/test_simple_race.cpp:26-53 loop shape) ---- */
-static uint64_t fnv1a(uint64_t h, const void *p, size_t n) {
-    const uint8_t *b = (const uint8_t *)p;
-    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ULL; }
-    return h;
+/* ---- batch driver (examples/test_simple_race.cpp:26-53 loop shape).  In random mode the reset
+ * uniforms come from the xwb-rng-v1 stream (seed, env, episode, 0): track, start #1, start #2, angle. ---- */
+static void race_reset_stream(orc_simple_race *g, uint32_t seed, uint32_t gid, uint32_t episode) {
+    if (!g->cfg.random) { orc_race_reset_game(g); return; }
+    orc_stream rs;
+    orc_stream_init(&rs, seed, gid, episode, 0);
+    float u0 = orc_stream_unit(&rs), u1 = orc_stream_unit(&rs), u2 = orc_stream_unit(&rs), u3 = orc_stream_unit(&rs);
+    orc_race_reset_game_with(g, u0, u1, u2, u3);
 }
 
-uint64_t orc_race_rollout(int n_envs, const orc_race_cfg *cfg, int steps, uint32_t policy_seed,
-                          uint32_t env_gid0, orc_rollout_stats *st) {
+uint64_t orc_race_rollout(int n_envs, const orc_race_cfg *cfg, uint32_t seed, int steps, uint32_t policy_seed,
+                          uint32_t env_gid0, orc_rollout_stats *st, const orc_rollout_out *out) {
     uint64_t n_steps = 0;
-    orc_rollout_stats s = {0.0, 0, 0xcbf29ce484222325ULL, 0xcbf29ce484222325ULL};
-    float obs[4];
+    orc_rollout_stats s = {0.0, 0};
+    size_t osz = sizeof(float) * 4 * (size_t)(cfg->context < 1 ? 1 : cfg->context);
+    float *obs = (float *)malloc(osz);
     for (int e = 0; e < n_envs; ++e) {
         orc_simple_race *g = orc_race_create(cfg);
-        orc_race_reset_game(g);
+        uint32_t episode = 0;
+        race_reset_stream(g, seed, env_gid0 + (uint32_t)e, episode);
         int na = orc_race_num_actions(g);
         for (int t = 0; t < steps; ++t) {
-            if (orc_race_game_over(g) != ORC_ALIVE) { orc_race_reset_game(g); s.resets++; }
-            orc_race_get_screen(g, obs);
-            s.obs_hash = fnv1a(s.obs_hash, obs, sizeof obs);
+            if (orc_race_game_over(g) != ORC_ALIVE) {
+                episode++;
+                race_reset_stream(g, seed, env_gid0 + (uint32_t)e, episode);
+                s.resets++;
+            }
+            orc_race_get_state_screen(g, obs);
             int a = orc_policy_action(policy_seed, env_gid0 + (uint32_t)e, (uint32_t)t, na);
             float r = orc_race_take_actions(g, a, 1);
             int code = orc_race_game_over(g);
             s.reward_sum += r;
-            s.state_hash = fnv1a(s.state_hash, &r, 4);
-            s.state_hash = fnv1a(s.state_hash, &code, 4);
+            if (out) {
+                size_t k = (size_t)t * (size_t)n_envs + (size_t)e;
+                if (out->rewards) out->rewards[k] = r;
+                if (out->codes) out->codes[k] = (uint8_t)code;
+                if (out->obs_ck) out->obs_ck[k] = orc_obs_checksum(obs, osz);
+            }
             n_steps++;
         }
         orc_race_destroy(g);
     }
+    free(obs);
     if (st) *st = s;
     return n_steps;
 }

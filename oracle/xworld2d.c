@@ -408,9 +408,15 @@ static void task_idle(orc_xworld *w, int pick) {
     int cand[MAXENT], nc = 0;
     for (int i = 0; i < w->n_ents; ++i)
         if (w->ents[i].type == 0 && task_reachable(w, i)) cand[nc++] = i;
-    if (nc == 0) abort();                         /* assert targets, "map too crowded?" */
-    int k = pick >= 0 ? pick : (int)orc_stream_below(&w->rs, (uint32_t)nc);
-    w->target_name = w->ents[cand[k]].name_id;
+    if (nc == 0) {
+        /* reference: `assert targets, "map too crowded?"` aborts the process.  The batched product
+         * cannot abort one env of a batch; both sides instead keep an untargeted episode (every goal
+         * reached counts as wrong).  Cannot happen on XWorldNav maps (the maze is connected). */
+        w->target_name = -1;
+    } else {
+        int k = pick >= 0 ? pick : (int)orc_stream_below(&w->rs, (uint32_t)nc);
+        w->target_name = w->ents[cand[k]].name_id;
+    }
     w->teacher_reward += 0.0;
     w->stage = ORC_STAGE_NAV;
 }
@@ -745,17 +751,11 @@ void orc_xw_get_state_screen(const orc_xworld *w, uint8_t *out) {
 }
 
 /* ---- batch driver (examples/test_xworld.cpp:34-61 loop shape) ---- */
-static uint64_t fnv1a(uint64_t h, const void *p, size_t n) {
-    const uint8_t *b = (const uint8_t *)p;
-    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ULL; }
-    return h;
-}
-
 uint64_t orc_xw_rollout(int n_envs, const orc_xw_cfg *cfg, int n_icons, const orc_icon_info *info,
                         const uint8_t *icons64, int steps, uint32_t policy_seed,
-                        uint32_t env_gid0, int render, orc_rollout_stats *st) {
+                        uint32_t env_gid0, int render, orc_rollout_stats *st, const orc_rollout_out *out) {
     uint64_t n_steps = 0;
-    orc_rollout_stats s = {0.0, 0, 0xcbf29ce484222325ULL, 0xcbf29ce484222325ULL};
+    orc_rollout_stats s = {0.0, 0};
     orc_xworld *w = orc_xw_create(cfg, n_icons, info, render ? icons64 : NULL);
     size_t sz = screen_size(w) * (size_t)w->cfg.context;
     uint8_t *obs = (uint8_t *)malloc(sz ? sz : 1);
@@ -768,16 +768,17 @@ uint64_t orc_xw_rollout(int n_envs, const orc_xw_cfg *cfg, int n_icons, const or
                 orc_xw_reset_game(w, env_gid0 + (uint32_t)e, episode);
                 s.resets++;
             }
-            if (render) {
-                orc_xw_get_state_screen(w, obs);
-                s.obs_hash = fnv1a(s.obs_hash, obs, sz);
-            }
+            if (render) orc_xw_get_state_screen(w, obs);
             int a = orc_policy_action(policy_seed, env_gid0 + (uint32_t)e, (uint32_t)t, 4);
             float r = orc_xw_take_actions(w, a, 1);
             int code = orc_xw_game_over(w);
             s.reward_sum += r;
-            s.state_hash = fnv1a(s.state_hash, &r, 4);
-            s.state_hash = fnv1a(s.state_hash, &code, 4);
+            if (out) {
+                size_t k = (size_t)t * (size_t)n_envs + (size_t)e;
+                if (out->rewards) out->rewards[k] = r;
+                if (out->codes) out->codes[k] = (uint8_t)code;
+                if (out->obs_ck && render) out->obs_ck[k] = orc_obs_checksum(obs, sz);
+            }
             n_steps++;
         }
     }

@@ -58,8 +58,11 @@ class PacketField(C.Structure):
 
 
 class RolloutStats(C.Structure):
-    _fields_ = [("reward_sum", C.c_double), ("resets", C.c_uint64), ("state_hash", C.c_uint64),
-                ("obs_hash", C.c_uint64)]
+    _fields_ = [("reward_sum", C.c_double), ("resets", C.c_uint64)]
+
+
+class RolloutOut(C.Structure):
+    _fields_ = [("rewards", f32p), ("codes", u8p), ("obs_ck", C.POINTER(C.c_uint64))]
 
 
 _lib = None
@@ -144,11 +147,13 @@ def lib():
     sig("orc_packet_encode", C.c_size_t, C.POINTER(PacketField), C.c_int, u8p, C.c_size_t)
     sig("orc_packet_decode", C.c_int, u8p, C.c_size_t, C.POINTER(PacketField), C.c_int)
     sig("orc_decode_game_over_code", C.c_int, C.c_int, C.c_char_p, C.c_int)
-    sig("orc_sg_rollout", C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(RolloutStats))
-    sig("orc_race_rollout", C.c_uint64, C.c_int, C.POINTER(RaceCfg), C.c_int, C.c_uint32, C.c_uint32,
-        C.POINTER(RolloutStats))
+    sig("orc_obs_checksum", C.c_uint64, C.c_void_p, C.c_size_t)
+    sig("orc_sg_rollout", C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+        C.POINTER(RolloutStats), C.POINTER(RolloutOut))
+    sig("orc_race_rollout", C.c_uint64, C.c_int, C.POINTER(RaceCfg), C.c_uint32, C.c_int, C.c_uint32, C.c_uint32,
+        C.POINTER(RolloutStats), C.POINTER(RolloutOut))
     sig("orc_xw_rollout", C.c_uint64, C.c_int, C.POINTER(XwCfg), C.c_int, C.POINTER(IconInfo), u8p,
-        C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(RolloutStats))
+        C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(RolloutStats), C.POINTER(RolloutOut))
     _lib = L
     return L
 
@@ -409,3 +414,41 @@ def decode_game_over_code(code):
     buf = C.create_string_buffer(64)
     lib().orc_decode_game_over_code(code, buf, 64)
     return buf.value.decode()
+
+
+class Rollout:
+    """Outputs of an oracle batch rollout: arrays shaped [steps, n_envs]."""
+
+    def __init__(self, n_envs, steps, want_obs=True):
+        self.rewards = np.zeros((steps, n_envs), np.float32)
+        self.codes = np.zeros((steps, n_envs), np.uint8)
+        self.obs_ck = np.zeros((steps, n_envs), np.uint64) if want_obs else None
+        self.stats = RolloutStats()
+        self.out = RolloutOut(ptr(self.rewards, f32p), ptr(self.codes, u8p),
+                              ptr(self.obs_ck, C.POINTER(C.c_uint64)) if want_obs else None)
+
+
+def sg_rollout(n_envs, array_size, steps, policy_seed, env_gid0=0, context=1):
+    r = Rollout(n_envs, steps)
+    lib().orc_sg_rollout(n_envs, array_size, context, steps, policy_seed, env_gid0, C.byref(r.stats), C.byref(r.out))
+    return r
+
+
+def race_rollout(n_envs, cfg, seed, steps, policy_seed, env_gid0=0):
+    r = Rollout(n_envs, steps)
+    lib().orc_race_rollout(n_envs, C.byref(cfg), seed, steps, policy_seed, env_gid0, C.byref(r.stats), C.byref(r.out))
+    return r
+
+
+def xw_rollout(n_envs, cfg, palette, steps, policy_seed, env_gid0=0, render=False):
+    r = Rollout(n_envs, steps, want_obs=render)
+    lib().orc_xw_rollout(n_envs, C.byref(cfg), len(palette), palette.info, ptr(palette.icons64, u8p), steps,
+                         policy_seed, env_gid0, 1 if render else 0, C.byref(r.stats), C.byref(r.out))
+    return r
+
+
+def obs_checksum_np(obs2d):
+    """numpy version of orc_obs_checksum for rows of a [n, bytes] uint8 view."""
+    n = obs2d.shape[1]
+    w = (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+    return (obs2d.astype(np.uint64) * w[None, :]).sum(axis=1, dtype=np.uint64)

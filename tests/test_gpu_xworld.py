@@ -1,0 +1,254 @@
+"""GPU parity: XWorld2D HIP kernels (step + teacher rule, reset / map generation, render)
+through the C ABI vs the CPU oracle.  Everything here is integer / byte work: bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CONF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xworld_amd", "confs")
+NAV = os.path.join(CONF, "navigation2d.json")
+WALLS = os.path.join(CONF, "walls7.json")
+
+# (conf, options for the product, oracle cfg overrides)
+MAPS = {
+    "nav8": (NAV, {}, dict(map_kind=0, max_dim=8, dim=8, num_goals=4, num_blocks=16)),
+    "nav7": (NAV, {"max_dim": 7, "num_blocks": 16}, dict(map_kind=0, max_dim=7, dim=7, num_goals=4, num_blocks=16)),
+    "nav11": (NAV, {"max_dim": 11, "num_blocks": 30}, dict(map_kind=0, max_dim=11, dim=11, num_goals=4, num_blocks=30)),
+    "nav8_dim5": (NAV, {"dim": 5, "num_goals": 2, "num_blocks": 6},
+                  dict(map_kind=0, max_dim=8, dim=5, num_goals=2, num_blocks=6)),
+    "walls7": (WALLS, {}, dict(map_kind=1, max_dim=7, dim=7, num_goals=12, num_blocks=12)),
+}
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _make(oracle, key, n, seed=0xC0FFEE, policy_seed=0x5EED, gid0=0, render=False, **opts):
+    from xworld_amd.batched import BatchedSimulator
+    conf, popts, ocfg = MAPS[key]
+    o = {"xwd_conf_path": conf, "task_mode": "lang_acquisition"}
+    o.update(popts)
+    o.update(opts)
+    sim = BatchedSimulator("xworld", o, num_envs=n, seed=seed, policy_seed=policy_seed, env_gid0=gid0)
+    pal = oracle.Palette(oracle.NAV_SUBTREES if ocfg["map_kind"] == 0 else oracle.WALLS_SUBTREES)
+    assert len(pal) == len(sim.palette)
+    assert [m["path"] for m in pal.meta] == [m["path"] for m in sim.palette.meta]
+    cfg = dict(ocfg)
+    cfg.update(seed=seed, color=int(bool(opts.get("color", False))), context=int(opts.get("context", 1)),
+               max_steps=int(opts.get("max_steps", 0)), max_steps_factor=int(opts.get("max_steps_factor", 10)),
+               task_mode=0 if o["task_mode"] == "lang_acquisition" else 1)
+    return sim, pal, cfg
+
+
+@pytest.mark.parametrize("key", list(MAPS))
+def test_reset_map_generation(oracle, key):
+    """xwb-mapgen-v1: the GPU reset kernel and the oracle produce the same map, agent cell and target."""
+    _torch()
+    n = 384
+    sim, pal, cfg = _make(oracle, key, n, seed=99, gid0=1000)
+    ow = oracle.XWorld(pal, render=False, **cfg)
+    for episode in range(3):
+        if episode:
+            sim.reset()
+        for e in range(n):
+            ow.reset_game(1000 + e, episode)
+            assert np.array_equal(sim.env_grid(e).astype(np.int32), ow.grid()), (episode, e)
+            st = sim.env_state(e)
+            assert (st.xw_agent_x, st.xw_agent_y) == ow.agent_xy()
+            assert st.xw_target_name == ow.target_name() and st.xw_stage == ow.stage() == 1
+            assert st.episode == episode and st.num_steps == 0 and st.game_over == 0
+    sim.close()
+
+
+@pytest.mark.parametrize("key,mode", [("nav8", "lang_acquisition"), ("nav7", "lang_acquisition"),
+                                      ("walls7", "lang_acquisition"), ("nav8", "one_channel"),
+                                      ("nav8_dim5", "lang_acquisition")])
+def test_step_teacher_rollout(oracle, key, mode):
+    """Random-policy rollouts with resets: reward bits and game_over codes of every env-step."""
+    _torch()
+    n, steps = 1536, 220
+    extra = {"task_mode": mode}
+    if mode == "one_channel":
+        extra["max_steps"] = 37          # the only way an episode ends in one_channel mode
+    sim, pal, cfg = _make(oracle, key, n, seed=7, policy_seed=11, gid0=50, **extra)
+    ref = oracle.xw_rollout(n, oracle.xw_cfg(**cfg), pal, steps, policy_seed=11, env_gid0=50)
+    resets = 0
+    for t in range(steps):
+        sim.reset_done()
+        resets += sim.done_count()
+        sim.step()
+        assert np.array_equal(sim.reward.cpu().numpy().view(np.uint32), ref.rewards[t].view(np.uint32)), t
+        assert np.array_equal(sim.game_over_codes.cpu().numpy(), ref.codes[t]), t
+    assert resets == ref.stats.resets and resets > 0
+    print(key, mode, "resets", resets, "mean reward", ref.stats.reward_sum / (n * steps))
+    sim.close()
+
+
+def test_step_details_and_act_rep(oracle):
+    """Per-env lock-step replay with explicit actions and act_rep > 1: agent cell, success flag, event, stage."""
+    torch = _torch()
+    n = 96
+    sim, pal, cfg = _make(oracle, "nav8", n, seed=3)
+    envs = [oracle.XWorld(pal, render=False, **cfg) for _ in range(n)]
+    eps = [0] * n
+    for e, w in enumerate(envs):
+        w.reset_game(e, 0)
+    rng = np.random.default_rng(5)
+    for t in range(150):
+        sim.reset_done()
+        for e, w in enumerate(envs):
+            if w.game_over() != 0:
+                eps[e] += 1
+                w.reset_game(e, eps[e])
+        acts = rng.integers(0, 4, n).astype(np.int32)
+        rep = int(rng.integers(1, 4))
+        sim.step(torch.from_numpy(acts).cuda(), act_rep=rep)
+        rew = sim.reward.cpu().numpy()
+        for e, w in enumerate(envs):
+            r = np.float32(w.take_actions(int(acts[e]), rep))
+            st = sim.env_state(e)
+            assert r.view(np.uint32) == rew[e:e + 1].view(np.uint32)[0], (t, e)
+            assert (st.xw_agent_x, st.xw_agent_y) == w.agent_xy(), (t, e)
+            assert st.last_action_success == w.last_action_success()
+            assert st.xw_event == w.event() and st.xw_stage == w.stage()
+            assert st.xw_steps_in_task == w.steps_in_task() and st.game_over == w.game_over()
+            assert st.lives == w.get_lives() and st.num_steps == w.num_steps()
+    for e, w in enumerate(envs):
+        assert np.array_equal(sim.env_grid(e).astype(np.int32), w.grid())
+    sim.close()
+
+
+@pytest.mark.parametrize("key,color,context", [("nav8", True, 1), ("nav8", False, 1), ("nav7", True, 2),
+                                               ("nav11", True, 1), ("walls7", False, 3), ("nav8_dim5", True, 1)])
+def test_render_vs_canvas_oracle(oracle, key, color, context):
+    """Screens: the tile-table expansion kernel vs the oracle's 64 px canvas + OpenCV-spec resize."""
+    _torch()
+    n, steps = 20, 14
+    sim, pal, cfg = _make(oracle, key, n, seed=21, policy_seed=2, color=color, context=context)
+    envs = [oracle.XWorld(pal, render=True, **cfg) for _ in range(n)]
+    eps = [0] * n
+    for e, w in enumerate(envs):
+        w.reset_game(e, 0)
+    h, wd, c = sim.screen_dims
+    assert (h, wd, c) == envs[0].dims
+    for t in range(steps):
+        sim.reset_done()
+        for e, w in enumerate(envs):
+            if w.game_over() != 0:
+                eps[e] += 1
+                w.reset_game(e, eps[e])
+        obs = sim.obs.cpu().numpy()
+        for e, w in enumerate(envs):
+            assert np.array_equal(obs[e], w.state_screen()), (t, e)
+        sim.step()
+        acts = sim.actions.cpu().numpy()
+        for e, w in enumerate(envs):
+            w.take_actions(int(acts[e]))
+    obs = sim.obs.cpu().numpy()
+    for e, w in enumerate(envs):
+        assert np.array_equal(obs[e], w.state_screen())
+    sim.close()
+
+
+@pytest.mark.parametrize("color", [True, False])
+def test_tile_table_every_icon(oracle, color):
+    """Each icon's 12x12 tile == the oracle's full render of a map holding only that icon (next to the agent)."""
+    _torch()
+    sim, pal, cfg = _make(oracle, "nav8", 1, color=color)
+    table = sim.tile_table()
+    ow = oracle.XWorld(pal, render=True, **cfg)
+    agent_icon = int(np.nonzero(pal.type_arr == 2)[0][0])
+    for i in range(len(pal)):
+        ents = [(2, 0, 0, agent_icon, 0, 0), (int(pal.type_arr[i]) if pal.type_arr[i] != 2 else 1, 3, 5, i, int(pal.name_arr[i]), 1)]
+        # the goal list must not be empty for the teacher's idle stage; put one reachable goal at (1, 0)
+        goal_icon = int(np.nonzero(pal.type_arr == 0)[0][0])
+        ents.append((0, 1, 0, goal_icon, int(pal.name_arr[goal_icon]), 2))
+        ow.load_map(ents, 8, target_pick=0)
+        scr = ow.screen()
+        cell = scr[:, 5 * 12:6 * 12, 3 * 12:4 * 12]
+        assert np.array_equal(cell, table[i]), i
+        assert (scr[:, 7 * 12:, 7 * 12:] == 255).all()         # empty cell = canvas fill
+    sim.close()
+
+
+def test_full_size_c4(oracle):
+    """BASELINE config C4: 32 768 envs, 7x7, 84x84x3.  Rewards / codes vs the oracle batch driver;
+    screens through the size-independent property obs == tile_table[grid] (table checked above)."""
+    torch = _torch()
+    n, steps = 32768, 24
+    sim, pal, cfg = _make(oracle, "nav7", n, seed=5, policy_seed=6, color=True)
+    ref = oracle.xw_rollout(n, oracle.xw_cfg(**cfg), pal, steps, policy_seed=6)
+    table = torch.from_numpy(sim.tile_table()).cuda()
+    full = torch.cat([torch.full_like(table[:1], 255), table])          # index 0 = empty cell
+    D = 7
+    for t in range(steps):
+        sim.reset_done()
+        sim.step()
+        assert np.array_equal(sim.reward.cpu().numpy().view(np.uint32), ref.rewards[t].view(np.uint32)), t
+        assert np.array_equal(sim.game_over_codes.cpu().numpy(), ref.codes[t]), t
+        if t % 8 == 0 or t == steps - 1:
+            for lo in range(0, n, 8192):                                # every env, in slabs
+                G = sim.grid[lo:lo + 8192].to(torch.int64)
+                exp = full[G]                                           # [m, D, D, C, 12, 12]
+                exp = exp.permute(0, 3, 1, 4, 2, 5).reshape(G.shape[0], 3, 12 * D, 12 * D)
+                assert torch.equal(sim.obs[lo:lo + 8192], exp), (t, lo)
+    sim.close()
+
+
+def test_autoreset_equals_step_then_reset(oracle):
+    torch = _torch()
+    n = 4096
+    a, _, _ = _make(oracle, "nav8", n, seed=8, policy_seed=9, color=True)
+    b, _, _ = _make(oracle, "nav8", n, seed=8, policy_seed=9, color=True)
+    for t in range(100):
+        a.step_autoreset()
+        b.step()
+        rb, cb = b.reward.clone(), b.game_over_codes.clone()
+        b.reset_done()
+        assert torch.equal(a.reward, rb) and torch.equal(a.game_over_codes, cb), t
+        assert torch.equal(a.num_steps, b.num_steps), t
+        assert torch.equal(a.obs, b.obs), t
+    a.close()
+    b.close()
+
+
+def test_sharding_invariance(oracle):
+    """Results are keyed by global env id: a batch split in two shards equals the unsplit batch."""
+    torch = _torch()
+    n = 2048
+    whole, _, _ = _make(oracle, "nav8", n, seed=4, policy_seed=4, color=True)
+    lo, _, _ = _make(oracle, "nav8", n // 2, seed=4, policy_seed=4, gid0=0, color=True)
+    hi, _, _ = _make(oracle, "nav8", n // 2, seed=4, policy_seed=4, gid0=n // 2, color=True)
+    for t in range(40):
+        for s in (whole, lo, hi):
+            s.step_autoreset()
+        assert torch.equal(whole.reward, torch.cat([lo.reward, hi.reward]))
+        assert torch.equal(whole.game_over_codes, torch.cat([lo.game_over_codes, hi.game_over_codes]))
+    assert torch.equal(whole.obs, torch.cat([lo.obs, hi.obs]))
+    for s in (whole, lo, hi):
+        s.close()
+
+
+def test_bind_obs_and_masked_reset(oracle):
+    torch = _torch()
+    n = 512
+    sim, pal, cfg = _make(oracle, "nav8", n, seed=12, color=False)
+    buf = torch.zeros((2 * n,) + tuple(sim.obs.shape[1:]), dtype=torch.uint8, device="cuda")
+    before = sim.obs.clone()
+    sim.bind_obs(buf[n:])
+    sim.step()
+    assert (buf[:n] == 0).all() and not torch.equal(buf[n:], torch.zeros_like(buf[n:]))
+    mask = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    mask[::3] = 1
+    ep0 = np.array([sim.env_state(e).episode for e in range(0, n, 50)])
+    sim.reset_masked(mask)
+    ep1 = np.array([sim.env_state(e).episode for e in range(0, n, 50)])
+    exp = np.array([1 if e % 3 == 0 else 0 for e in range(0, n, 50)])
+    assert np.array_equal(ep1 - ep0, exp)
+    sim.close()

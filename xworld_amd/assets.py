@@ -1,0 +1,55 @@
+"""Icon palette loading for XWorld2D (the product's render input).
+
+The reference walks `item_path` for *.jpg icons and groups them by type / name
+(games/xworld/maps/xworld_env.py:76-91,236-255); a map class restricts the goal
+icons to some sub-directories (XWorldNav.py:17, XWorldWalls.py:16).  Here the
+decoded icons ship as xworld_amd/assets/icons64.npz + icons.json
+(tools/make_assets.py).
+"""
+import json
+import os
+
+import numpy as np
+
+ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+TYPE_ID = {"goal": 0, "block": 1, "agent": 2}
+
+# map class -> (max_dim, goal subtrees, num_goals, num_blocks, map_kind)
+MAP_CLASSES = {
+    # XWorldNav.py:8-13,17,27-39 (curriculum == 0: 8x8, 4 goals, 16 blocks, maze on)
+    "XWorldNav": dict(map_kind=0, max_dim=8, num_goals=4, num_blocks=16,
+                      subtrees=("animal", "fruit", "furniture", "vegetable")),
+    # XWorldWalls.py:7-36 (7x7, agent, 12 goals, 7 + 5 bricks)
+    "XWorldWalls": dict(map_kind=1, max_dim=7, num_goals=12, num_blocks=12,
+                        subtrees=("animal", "fruit", "shape")),
+}
+
+
+class Palette:
+    """Icons a map class can place, with the per-type name ids the C ABI wants."""
+
+    def __init__(self, subtrees, assets_dir=ASSETS):
+        with open(os.path.join(assets_dir, "icons.json")) as f:
+            meta = json.load(f)
+        icons = np.load(os.path.join(assets_dir, "icons64.npz"))["icons"]
+        keep = [i for i, m in enumerate(meta) if m["type"] != "goal" or m["subtree"] in subtrees]
+        self.meta = [meta[i] for i in keep]
+        self.icons64 = np.ascontiguousarray(icons[keep], dtype=np.uint8)
+        self.names = {t: sorted({m["name"] for m in self.meta if m["type"] == t}) for t in TYPE_ID}
+        self.icon_type = np.array([TYPE_ID[m["type"]] for m in self.meta], np.int32)
+        self.icon_name = np.array([self.names[m["type"]].index(m["name"]) for m in self.meta], np.int32)
+
+    def __len__(self):
+        return len(self.meta)
+
+    def goal_name(self, name_id):
+        return self.names["goal"][name_id]
+
+
+def read_conf(path):
+    """The two keys of the world conf JSON the batched path uses (xworld.cpp:65-76, teacher.cpp:110-141)."""
+    with open(path) as f:
+        conf = json.load(f)
+    if "map" not in conf or "item_path" not in conf:
+        raise ValueError("world config needs 'item_path' and 'map' (xworld.cpp:71-72)")
+    return conf

@@ -1,0 +1,269 @@
+"""BatchedSimulator: num_envs reference `SimulatorInterface`s as one object on one MI355X.
+
+Host-side mirror of simulator::SimulatorInterface (simulator_interface.h:40-89) over the C ABI
+of libxwb.so.  Option names and defaults are those of python/py_simulator.cpp:97-136.
+torch is used for device memory views and streams only.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import assets, lib
+from .lib import XWB_SIMPLE_GAME, XWB_SIMPLE_RACE, XWB_XWORLD2D
+
+GAMES = {"simple_game": XWB_SIMPLE_GAME, "simple_race": XWB_SIMPLE_RACE, "xworld": XWB_XWORLD2D}
+
+
+class _DevArray:
+    """Zero-copy view of library-owned device memory through __cuda_array_interface__."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.owner = owner
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def _require(opts, key):
+    # extract_py_dict_val(required=True), py_simulator.cpp:40-57 -> RuntimeError
+    if key not in opts:
+        raise RuntimeError("Key '%s' is required but not provided." % key)
+    return opts[key]
+
+
+class BatchedSimulator:
+    def __init__(self, name, opts=None, num_envs=1, device=0, env_gid0=0, seed=0xC0FFEE, policy_seed=0x5EED):
+        opts = dict(opts or {})
+        if name not in GAMES:
+            raise RuntimeError("Unrecognized game type: " + name)        # py_simulator.cpp:184-186
+        self.L = lib.load()
+        self.name = name
+        cfg = lib.XwbConfig()
+        lib.check(self.L.xwb_default_config(GAMES[name], C.byref(cfg)))
+        cfg.num_envs = int(num_envs)
+        cfg.device = int(device)
+        cfg.env_gid0 = int(env_gid0)
+        cfg.seed = int(seed) & 0xFFFFFFFF
+        cfg.policy_seed = int(policy_seed) & 0xFFFFFFFF
+        cfg.max_steps = int(opts.get("max_steps", 0))
+        cfg.context = int(opts.get("context", 1))
+        self.palette = None
+        self._keep = []
+        if name == "simple_game":
+            cfg.array_size = int(_require(opts, "array_size"))            # py_simulator.cpp:99-102
+        elif name == "simple_race":                                       # py_simulator.cpp:106-122
+            tt = opts.get("track_type", "straight")
+            if tt not in ("straight", "circle"):
+                raise RuntimeError("track_type must be 'straight' or 'circle'")
+            cfg.track_type = 1 if tt == "circle" else 0
+            cfg.track_width = float(np.float32(_require(opts, "track_width")))
+            cfg.track_length = float(np.float32(_require(opts, "track_length")))
+            cfg.track_radius = float(np.float32(_require(opts, "track_radius")))
+            cfg.race_full_manouver = int(bool(opts.get("race_full_manouver", False)))
+            cfg.random = int(bool(opts.get("random", False)))
+            diff = opts.get("difficulty", "easy")
+            cfg.difficulty_hard = 0 if diff == "easy" else 1
+            cfg.reward_scale = float(opts.get("reward_scale", 1.0))
+        else:                                                             # py_simulator.cpp:126-136
+            conf_path = _require(opts, "xwd_conf_path")
+            conf = assets.read_conf(conf_path)
+            map_name = opts.get("map", conf["map"])
+            if map_name not in assets.MAP_CLASSES:
+                raise RuntimeError("Error loading map: " + str(map_name))  # xworld.cpp:104-105
+            mc = assets.MAP_CLASSES[map_name]
+            cfg.map_kind = mc["map_kind"]
+            cfg.max_dim = int(opts.get("max_dim", mc["max_dim"]))
+            cfg.dim = int(opts.get("dim", cfg.max_dim))
+            cfg.num_goals = int(opts.get("num_goals", mc["num_goals"]))
+            cfg.num_blocks = int(opts.get("num_blocks", mc["num_blocks"]))
+            cfg.max_steps_factor = int(opts.get("max_steps_factor", 10))
+            mode = opts.get("task_mode", "one_channel")                   # py_simulator.cpp:130-131
+            if mode not in ("lang_acquisition", "one_channel"):
+                raise RuntimeError("unsupported task mode: " + str(mode))  # xworld_simulator.cpp:194-196
+            cfg.task_mode = 0 if mode == "lang_acquisition" else 1
+            cfg.color = int(bool(opts.get("color", False)))
+            if int(opts.get("visible_radius", 0)) != 0:
+                raise RuntimeError("visible_radius > 0 (egocentric view) is not built yet (SURVEY 8(f) rank 2)")
+            self.palette = assets.Palette(mc["subtrees"], opts.get("assets_dir", assets.ASSETS))
+            cfg.n_icons = len(self.palette)
+            cfg.icons64 = self.palette.icons64.ctypes.data
+            cfg.icon_type = self.palette.icon_type.ctypes.data
+            cfg.icon_name = self.palette.icon_name.ctypes.data
+        self.cfg = cfg
+        h = C.c_void_p()
+        lib.check(self.L.xwb_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.num_envs = int(num_envs)
+        self.device = int(device)
+        n = C.c_int32()
+        lib.check(self.L.xwb_get_num_actions(self.h, C.byref(n)))
+        self.num_actions = n.value
+        hh, ww, cc = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        lib.check(self.L.xwb_get_screen_out_dimensions(self.h, C.byref(hh), C.byref(ww), C.byref(cc)))
+        self.screen_dims = (hh.value, ww.value, cc.value)
+        p, b = C.c_void_p(), C.c_size_t()
+        lib.check(self.L.xwb_obs_dev(self.h, C.byref(p), C.byref(b)))
+        self.obs_bytes_per_env = b.value
+        self._obs_ptr = p.value
+        self._views = {}
+
+    # ------------------------------------------------------------------ life cycle
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.xwb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _stream(stream):
+        if stream is None:
+            return None
+        return C.c_void_p(int(getattr(stream, "cuda_stream", stream)))
+
+    # ------------------------------------------------------------------ batched verbs
+    def reset(self, stream=None):
+        lib.check(self.L.xwb_reset(self.h, self._stream(stream)))
+
+    def reset_done(self, stream=None):
+        lib.check(self.L.xwb_reset_done(self.h, self._stream(stream)))
+
+    def reset_masked(self, mask, stream=None):
+        lib.check(self.L.xwb_reset_masked(self.h, C.c_void_p(mask.data_ptr()), self._stream(stream)))
+
+    def step(self, actions=None, act_rep=1, stream=None):
+        ptr = None if actions is None else C.c_void_p(actions.data_ptr())
+        lib.check(self.L.xwb_step(self.h, ptr, int(act_rep), self._stream(stream)))
+
+    def step_autoreset(self, actions=None, act_rep=1, stream=None):
+        ptr = None if actions is None else C.c_void_p(actions.data_ptr())
+        lib.check(self.L.xwb_step_autoreset(self.h, ptr, int(act_rep), self._stream(stream)))
+
+    def check_errors(self, stream=None):
+        n = C.c_int32()
+        lib.check(self.L.xwb_check_errors(self.h, self._stream(stream), C.byref(n)))
+        return n.value
+
+    def done_count(self, stream=None):
+        n = C.c_int32()
+        lib.check(self.L.xwb_done_count(self.h, self._stream(stream), C.byref(n)))
+        return n.value
+
+    # ------------------------------------------------------------------ device views (torch)
+    def _view(self, key, getter, shape, typestr):
+        import torch
+        if key not in self._views:
+            p = C.c_void_p()
+            lib.check(getter(self.h, C.byref(p)))
+            self._views[key] = torch.as_tensor(_DevArray(p.value, shape, typestr, self),
+                                               device="cuda:%d" % self.device)
+        return self._views[key]
+
+    @property
+    def reward(self):
+        return self._view("reward", self.L.xwb_reward_dev, (self.num_envs,), "<f4")
+
+    @property
+    def game_over_codes(self):
+        return self._view("done", self.L.xwb_game_over_dev, (self.num_envs,), "|u1")
+
+    @property
+    def actions(self):
+        return self._view("actions", self.L.xwb_actions_dev, (self.num_envs,), "<i4")
+
+    @property
+    def num_steps(self):
+        return self._view("num_steps", self.L.xwb_num_steps_dev, (self.num_envs,), "<i4")
+
+    @property
+    def success(self):
+        return self._view("success", self.L.xwb_success_dev, (self.num_envs,), "|u1")
+
+    @property
+    def grid(self):
+        """xworld: [num_envs, max_dim, max_dim] cell codes (palette icon + 1, 0 = empty), int16 view."""
+        d = self.cfg.max_dim
+        return self._view("grid", self.L.xwb_xw_grid_dev, (self.num_envs, d, d), "<i2")
+
+    @property
+    def obs(self):
+        """[num_envs, context*c, h, w]; uint8 (simple_game, xworld: planar B,G,R) or float32 (simple_race)."""
+        import torch
+        if "obs" not in self._views:
+            h, w, c = self.screen_dims
+            ctx = self.cfg.context
+            if self.name == "simple_race":
+                shape, ts = (self.num_envs, ctx * c, h, w), "<f4"
+            else:
+                shape, ts = (self.num_envs, ctx * c, h, w), "|u1"
+            self._views["obs"] = torch.as_tensor(_DevArray(self._obs_ptr, shape, ts, self),
+                                                 device="cuda:%d" % self.device)
+        return self._views["obs"]
+
+    def bind_obs(self, tensor):
+        """Redirect the observation output into caller-owned device memory (e.g. a shard of a gathered tensor)."""
+        assert tensor.is_contiguous() and tensor.numel() * tensor.element_size() == self.num_envs * self.obs_bytes_per_env
+        lib.check(self.L.xwb_bind_obs(self.h, C.c_void_p(tensor.data_ptr())))
+        h, w, c = self.screen_dims
+        self._obs_ptr = tensor.data_ptr()
+        self._views["obs"] = tensor.view(self.num_envs, self.cfg.context * c, h, w)
+        self._bound = tensor
+
+    # ------------------------------------------------------------------ per-env host access
+    def env_state(self, env=0, stream=None):
+        st = lib.XwbEnvState()
+        lib.check(self.L.xwb_get_env_state(self.h, int(env), self._stream(stream), C.byref(st)))
+        return st
+
+    def env_obs(self, env=0, stream=None):
+        dt = np.float32 if self.name == "simple_race" else np.uint8
+        out = np.empty(self.obs_bytes_per_env // np.dtype(dt).itemsize, dt)
+        lib.check(self.L.xwb_get_env_obs(self.h, int(env), self._stream(stream), out.ctypes.data, self.obs_bytes_per_env))
+        return out
+
+    def env_grid(self, env=0, stream=None):
+        d = self.cfg.max_dim
+        out = np.empty(d * d, np.uint16)
+        lib.check(self.L.xwb_get_env_grid(self.h, int(env), self._stream(stream), out.ctypes.data))
+        return out.reshape(d, d)
+
+    def load_map(self, env, grid, agent_x, agent_y, target_name, dim=None):
+        g = np.ascontiguousarray(grid, np.uint16)
+        lib.check(self.L.xwb_xw_load_map(self.h, int(env), g.ctypes.data, int(agent_x), int(agent_y),
+                                         int(target_name), int(self.cfg.dim if dim is None else dim)))
+
+    def race_set_car(self, env, x, y, angle):
+        lib.check(self.L.xwb_race_set_car(self.h, int(env), float(x), float(y), float(angle)))
+
+    def state_packet(self, env=0, reward=0.0, stream=None):
+        """SimulatorInterface::get_state(reward) of one env in the reference's StatePacket wire layout."""
+        need = C.c_size_t()
+        lib.check(self.L.xwb_get_state_packet(self.h, int(env), float(reward), self._stream(stream), None, 0, C.byref(need)))
+        buf = (C.c_uint8 * need.value)()
+        lib.check(self.L.xwb_get_state_packet(self.h, int(env), float(reward), self._stream(stream), buf, need.value,
+                                              C.byref(need)))
+        return bytes(buf)
+
+    def tile_table(self):
+        need = C.c_size_t()
+        lib.check(self.L.xwb_xw_get_tile_table(self.h, None, 0, C.byref(need)))
+        out = np.empty(need.value, np.uint8)
+        lib.check(self.L.xwb_xw_get_tile_table(self.h, out.ctypes.data, need.value, C.byref(need)))
+        c = self.screen_dims[2]
+        return out.reshape(len(self.palette), c, 12, 12)
+
+    # ------------------------------------------------------------------ profiling hooks
+    def profile_begin(self):
+        lib.check(self.L.xwb_profile_begin(self.h))
+
+    def profile_end(self, kernel, stream=None):
+        us, n = C.c_double(), C.c_int64()
+        lib.check(self.L.xwb_profile_end(self.h, self._stream(stream), kernel.encode(), C.byref(us), C.byref(n)))
+        return us.value, n.value
+
+    def profile_stop(self):
+        lib.check(self.L.xwb_profile_stop(self.h))

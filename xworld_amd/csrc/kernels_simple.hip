@@ -1,0 +1,327 @@
+// kernels_simple.hip -- SimpleGame and SimpleRace as lock-step data-parallel HIP (gfx950).
+//
+// Replaces, for a whole batch of environments per launch:
+//   SimpleGameEngine::reset_game/act/get_reward/get_screen   games/simple_game/simple_game_simulator.cpp:31-76
+//   SimpleGame::take_action/game_over                        :92-103
+//   RaceEngine::reset_game/act/get_reward/get_screen         games/simple_race/simple_race_simulator.cpp:267-341,386-430
+//   BaseCar::move, StraightTrack::*, CircleTrack::*          :52-101,182-243
+//   GameSimulator::take_actions/make_context_screens         simulator.cpp:51-108
+//
+// Layout: structure-of-arrays in HBM, env index fastest; one lane owns one env for the
+// state transition, then the workgroup's 256 envs write their observation rows
+// cooperatively so that consecutive lanes store consecutive 16-byte chunks.
+//
+// Build with -ffp-contract=off: SimpleRace's float state must see the same
+// float/double rounding points as the reference (no FMA contraction).
+#include "xwb_common.h"
+
+namespace xwb {
+
+// ============================================================ SimpleGame ====
+static constexpr float SG_MOVE_REWARD = -0.1f;   // simple_game_simulator.h:52
+static constexpr float SG_DEST_REWARD = 4.0f;    // simple_game_simulator.h:53
+
+// SimpleGameEngine::get_reward (cpp:69-76) with the two non-zero entries of `_rewards`
+// (cpp:36-37: rewards[N-1] = 2 is written first, rewards[0] = 4 second) kept as two
+// "already consumed" bits.
+__device__ __forceinline__ float sg_get_reward(int pos, int A, uint32_t &flags) {
+    float r = SG_MOVE_REWARD;
+    if (pos == 0) {
+        if (!(flags & 1u)) { r = SG_DEST_REWARD; flags |= 1u; }
+    } else if (pos == A - 1) {
+        if (!(flags & 2u)) { r = SG_DEST_REWARD / 2; flags |= 2u; }
+    }
+    return r;
+}
+
+__device__ __forceinline__ bool sg_over(int pos, int A) { return pos <= 0 || pos >= A - 1; }
+
+template <int G> struct ChunkT;
+template <> struct ChunkT<16> { using type = uint4; };
+template <> struct ChunkT<4>  { using type = uint32_t; };
+template <> struct ChunkT<1>  { using type = uint8_t; };
+
+template <int G>
+__device__ __forceinline__ typename ChunkT<G>::type sg_onehot_chunk(int off);
+template <> __device__ __forceinline__ uint4 sg_onehot_chunk<16>(int off) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (off >= 0 && off < 16) {
+        uint32_t w = 1u << ((off & 3) * 8);
+        int q = off >> 2;
+        v.x = q == 0 ? w : 0; v.y = q == 1 ? w : 0; v.z = q == 2 ? w : 0; v.w = q == 3 ? w : 0;
+    }
+    return v;
+}
+template <> __device__ __forceinline__ uint32_t sg_onehot_chunk<4>(int off) {
+    return (off >= 0 && off < 4) ? (1u << (off * 8)) : 0u;
+}
+template <> __device__ __forceinline__ uint8_t sg_onehot_chunk<1>(int off) { return off == 0 ? 1 : 0; }
+
+template <int G> __device__ __forceinline__ typename ChunkT<G>::type zero_chunk();
+template <> __device__ __forceinline__ uint4 zero_chunk<16>() { return make_uint4(0, 0, 0, 0); }
+template <> __device__ __forceinline__ uint32_t zero_chunk<4>() { return 0u; }
+template <> __device__ __forceinline__ uint8_t zero_chunk<1>() { return 0; }
+
+// One launch = one SimulatorInterface::take_actions (or reset_game) for every env.
+template <int G>
+__global__ __launch_bounds__(256) void sg_kernel(SgParams p) {
+    using chunk_t = typename ChunkT<G>::type;
+    __shared__ int s_pos[256];      // -1: leave this env's observation untouched
+    __shared__ uint8_t s_fresh[256];
+    const int tid = threadIdx.x;
+    const int e = blockIdx.x * 256 + tid;
+    const int A = p.array_size;
+    int obs_pos = -1;
+    bool fresh = false;
+    if (e < p.n) {
+        int pos = p.pos[e];
+        uint32_t flags = p.flags[e];
+        int steps = p.num_steps[e];
+        bool do_reset = false;
+        if (p.mode == MODE_STEP) {
+            int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step, 2);
+            p.actions_out[e] = a;
+            if ((unsigned)a >= 2u) {                        // CHECK_LT(action_id, _legal_actions.size())
+                atomicAdd(p.err_count, 1);
+            } else {
+                steps += 1;                                 // GameSimulator::take_actions: num_steps_++ once
+                float r = 0.0f;
+                for (int i = 0; i < p.act_rep; ++i) {
+                    // SimpleGameEngine::act, cpp:44-63
+                    if (!sg_over(pos, A)) pos += (a == 0) ? -1 : 1;
+                    r += sg_get_reward(pos, A, flags);
+                }
+                float rr = 0.0f; rr += r;                   // SimulatorInterface::take_actions: r = 0; r += ...
+                int code = ((p.max_steps > 0 && steps >= p.max_steps) ? MAX_STEP : ALIVE) |
+                           (sg_over(pos, A) ? SUCCESS : ALIVE);
+                p.reward[e] = rr;
+                p.done[e] = (uint8_t)code;
+                obs_pos = pos;
+                if (p.auto_reset && code != ALIVE) do_reset = true;
+            }
+        } else {
+            do_reset = p.mode == MODE_RESET_ALL || (p.mode == MODE_RESET_DONE && p.done[e] != 0) ||
+                       (p.mode == MODE_RESET_MASK && p.mask[e] != 0);
+        }
+        if (do_reset) {
+            // SimpleGameEngine::reset_game cpp:31-38 ; GameSimulator::reset_game
+            pos = A / 2; flags = 0; steps = 0;
+            p.episode[e] += 1;
+            if (p.mode != MODE_STEP) {
+                // game_over() right after reset (over at once for array_size <= 2)
+                p.done[e] = (uint8_t)(sg_over(pos, A) ? SUCCESS : ALIVE);   // num_steps_ == 0 < max_steps
+            }
+            atomicAdd(p.reset_count, 1);
+            obs_pos = pos; fresh = true;
+        }
+        if (obs_pos >= 0) { p.pos[e] = pos; p.flags[e] = (uint8_t)flags; p.num_steps[e] = steps; }
+    }
+    s_pos[tid] = obs_pos;
+    s_fresh[tid] = fresh ? 1 : 0;
+    __syncthreads();
+
+    // observation: [env][context][A] bytes; work item = (env, chunk of one frame); the same lane
+    // walks all context frames of its chunk so the ring shift needs no cross-lane ordering.
+    // make_context_screens / shift_context (simulator.cpp:51-85): oldest frame first, newest last;
+    // init_screen (:110-113): zeros, then one shift.
+    const int cpf = A / G;                                   // chunks per frame
+    const int base_env = blockIdx.x * 256;
+    const int n_here = min(256, p.n - base_env);
+    const int ctx = p.context;
+    for (int i = tid; i < n_here * cpf; i += 256) {
+        int le = i / cpf, j = i - le * cpf;
+        int pos = s_pos[le];
+        if (pos < 0) continue;
+        chunk_t *frame0 = reinterpret_cast<chunk_t *>(p.obs + ((size_t)(base_env + le) * ctx) * A) + j;
+        if (s_fresh[le]) {
+            for (int f = 0; f + 1 < ctx; ++f) frame0[(size_t)f * cpf] = zero_chunk<G>();
+        } else {
+            for (int f = 0; f + 1 < ctx; ++f) frame0[(size_t)f * cpf] = frame0[(size_t)(f + 1) * cpf];
+        }
+        frame0[(size_t)(ctx - 1) * cpf] = sg_onehot_chunk<G>(pos - j * G);
+    }
+}
+
+hipError_t launch_simple_game(const SgParams &p, hipStream_t s) {
+    dim3 grid((p.n + 255) / 256), block(256);
+    if (p.array_size % 16 == 0) hipLaunchKernelGGL(sg_kernel<16>, grid, block, 0, s, p);
+    else if (p.array_size % 4 == 0) hipLaunchKernelGGL(sg_kernel<4>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(sg_kernel<1>, grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
+// ============================================================ SimpleRace ====
+#define RACE_PI 3.1415926       // simple_race_simulator.h:39 (double literal)
+
+struct RaceCar { float x, y, angle; };
+
+// cv::norm(Point2f) -> double
+__device__ __forceinline__ double race_norm(float x, float y) {
+    return sqrt((double)x * x + (double)y * y);
+}
+
+// StraightTrack::out_of_bound cpp:182-186 ; CircleTrack::out_of_bound cpp:75-79
+__device__ __forceinline__ bool race_oob(const RaceParams &p, float x, float y) {
+    if (p.track_type == 1) {
+        float r = (float)race_norm(x - p.center_x, y - p.center_y);
+        return r < p.inner_radius || r > p.outer_radius;
+    }
+    return (x < p.mid_x - p.width / 2) || (x > p.mid_x + p.width / 2) || (y < p.start_y) || (y > p.end_y);
+}
+
+// race_finish: StraightTrack cpp:188-190 ; Track default false
+__device__ __forceinline__ bool race_finish(const RaceParams &p, float y) {
+    return p.track_type == 1 ? false : (y > p.end_y);
+}
+
+// horizontal_displacement: straight cpp:202-204, circle cpp:92-95
+__device__ __forceinline__ float race_h_disp(const RaceParams &p, float x, float y) {
+    if (p.track_type == 1)
+        return (float)((2 * race_norm(x - p.center_x, y - p.center_y) - (double)p.inner_radius -
+                        (double)p.outer_radius) / (double)p.width);
+    return 2 * (x - p.mid_x) / p.width;
+}
+
+// vertical_displacement: straight cpp:210-212 ; Track default 0
+__device__ __forceinline__ float race_v_disp(const RaceParams &p, float y) {
+    return p.track_type == 1 ? 0.0f : 2 * (y - p.mid_y) / p.length;
+}
+
+// get_tangent_vec: straight cpp:218-220, circle cpp:101-104
+__device__ __forceinline__ void race_tangent(const RaceParams &p, float x, float y, float &tx, float &ty) {
+    if (p.track_type == 1) {
+        float ux = p.center_y - y, uy = x - p.center_x;
+        double s = 1 / race_norm(ux, uy);
+        tx = (float)((double)ux * s);
+        ty = (float)((double)uy * s);
+    } else {
+        tx = 0.0f; ty = 1.0f;
+    }
+}
+
+// RaceEngine::get_screen, cpp:412-430
+__device__ __forceinline__ float4 race_screen(const RaceParams &p, const RaceCar &c) {
+    float tx, ty;
+    race_tangent(p, c.x, c.y, tx, ty);
+    double ca = cos((double)c.angle), sa = sin((double)c.angle);
+    double d = (double)tx * ca + (double)ty * sa;
+    float cos_theta = (float)fmax(-1.0, fmin(1.0, d));
+    float sin_theta = (float)sqrt((double)(1 - cos_theta * cos_theta));
+    if (ca * (double)ty + sa * (double)tx < 0) sin_theta = -sin_theta;
+    return make_float4(cos_theta, sin_theta, race_h_disp(p, c.x, c.y), race_v_disp(p, c.y));
+}
+
+// RaceEngine::reset_game cpp:267-284 ; draws (random mode): track, start-pos #1, start-pos #2, angle
+__device__ __forceinline__ void race_reset(const RaceParams &p, RaceCar &c, uint32_t gid, uint32_t episode) {
+    if (!p.random) {
+        if (p.track_type == 1) {           // CircleTrack::get_start_pos cpp:81-85
+            c.x = (p.inner_radius + p.width / 2) + p.center_x;
+            c.y = 0.0f + p.center_y;
+        } else {                           // StraightTrack::get_start_pos cpp:192-195
+            c.x = p.start_x; c.y = p.start_y;
+        }
+        c.angle = (float)(RACE_PI / 2);    // BaseCar::set_angle(false)
+        return;
+    }
+    Stream s;
+    s.init(p.seed, gid, episode, 0);
+    float u_track = s.unit(); (void)u_track;       // one track in the pool -> index 0
+    float u_a = s.unit(), u_b = s.unit(), u_ang = s.unit();
+    if (p.track_type == 1) {               // cpp:86-89
+        float theta = (float)((double)(u_a * 2) * RACE_PI);
+        float r = p.inner_radius + u_b * p.width;
+        float qx = (float)((double)r * cos((double)theta));
+        float qy = (float)((double)r * sin((double)theta));
+        c.x = qx + p.center_x; c.y = qy + p.center_y;
+    } else {                               // cpp:196-199
+        float dy = u_a * p.length / 2;
+        float dx = (float)(((double)u_b - 0.5) * (double)p.width);
+        c.x = dx + p.start_x; c.y = dy + p.start_y;
+    }
+    c.angle = (float)((double)(u_ang * 2) * RACE_PI);   // BaseCar::set_angle(true) cpp:237-243
+}
+
+__global__ __launch_bounds__(256) void race_kernel(RaceParams p) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.n) return;
+    RaceCar c = {p.x[e], p.y[e], p.angle[e]};
+    int steps = p.num_steps[e];
+    bool do_reset = false, touched = false;
+    if (p.mode == MODE_STEP) {
+        int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step, p.n_legal);
+        p.actions_out[e] = a;
+        if ((unsigned)a >= (unsigned)p.n_legal) {
+            atomicAdd(p.err_count, 1);
+        } else {
+            int action = p.legal[a];               // _legal_actions[action_id], cpp:474
+            steps += 1;
+            float reward = 0.0f;
+            for (int i = 0; i < p.act_rep; ++i) {
+                // RaceEngine::act cpp:290-341
+                int id = action;
+                float d_forward = 0.0f, d_turn = 0.0f;
+                int m = id % 3;
+                if (m == 1) d_forward = p.delta_fwd; else if (m == 2) d_forward = -p.delta_fwd;
+                id /= 3;
+                m = id % 3;
+                if (m == 1) d_turn = p.delta_ang; else if (m == 2) d_turn = -p.delta_ang;
+                // BaseCar::move cpp:227-235
+                c.angle += d_turn;
+                if ((double)c.angle > 2 * RACE_PI) c.angle = (float)((double)c.angle - 2 * RACE_PI);
+                else if (c.angle < 0) c.angle = (float)((double)c.angle + 2 * RACE_PI);
+                float dirx = (float)cos((double)c.angle), diry = (float)sin((double)c.angle);
+                float sx = d_forward * dirx, sy = d_forward * diry;
+                c.x += sx; c.y += sy;
+                // RaceEngine::get_reward cpp:386-410
+                float tx, ty;
+                race_tangent(p, c.x, c.y, tx, ty);
+                float vx = dirx, vy = diry;        // cos(angle), sin(angle) narrowed to float again
+                float reward_speed = (vx * tx + vy * ty) * d_forward;
+                float reward_finish = race_finish(p, c.y) ? 2.0f : 0.0f;
+                float reward_boundary;
+                if (!p.difficulty_hard) reward_boundary = (float)(-fabs((double)race_h_disp(p, c.x, c.y)));
+                else reward_boundary = (race_oob(p, c.x, c.y) && !race_finish(p, c.y)) ? -2.0f : 0.0f;
+                float rwd = reward_finish + reward_boundary + reward_speed;
+                reward += (float)((double)rwd * p.reward_scale);
+            }
+            float rr = 0.0f; rr += reward;
+            int code = ((p.max_steps > 0 && steps >= p.max_steps) ? MAX_STEP : ALIVE) |
+                       (race_oob(p, c.x, c.y) ? DEAD : ALIVE);
+            p.reward[e] = rr;
+            p.done[e] = (uint8_t)code;
+            touched = true;
+            if (p.auto_reset && code != ALIVE) do_reset = true;
+        }
+    } else {
+        do_reset = p.mode == MODE_RESET_ALL || (p.mode == MODE_RESET_DONE && p.done[e] != 0) ||
+                   (p.mode == MODE_RESET_MASK && p.mask[e] != 0);
+    }
+    if (do_reset) {
+        uint32_t ep = p.episode[e] + 1;
+        p.episode[e] = ep;
+        race_reset(p, c, p.env_gid0 + (uint32_t)e, ep);
+        steps = 0;
+        if (p.mode != MODE_STEP)
+            p.done[e] = (uint8_t)(race_oob(p, c.x, c.y) ? DEAD : ALIVE);
+        atomicAdd(p.reset_count, 1);
+        touched = true;
+    }
+    if (!touched) return;
+    p.x[e] = c.x; p.y[e] = c.y; p.angle[e] = c.angle; p.num_steps[e] = steps;
+    // make_context_screens: [env][context][4] floats, 16 bytes per frame -> one float4 per lane
+    float4 *frames = reinterpret_cast<float4 *>(p.obs) + (size_t)e * p.context;
+    if (do_reset) {
+        for (int f = 0; f + 1 < p.context; ++f) frames[f] = make_float4(0, 0, 0, 0);
+    } else {
+        for (int f = 0; f + 1 < p.context; ++f) frames[f] = frames[f + 1];
+    }
+    frames[p.context - 1] = race_screen(p, c);
+}
+
+hipError_t launch_simple_race(const RaceParams &p, hipStream_t s) {
+    dim3 grid((p.n + 255) / 256), block(256);
+    hipLaunchKernelGGL(race_kernel, grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace xwb

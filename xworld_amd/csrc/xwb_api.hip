@@ -1,0 +1,835 @@
+// xwb_api.hip -- host side of libxwb.so: the C ABI of include/xwb.h.
+//
+// A xwb_sim is the batched counterpart of simulator::SimulatorInterface
+// (simulator_interface.h:40-89): it owns the SoA state of num_envs environments in
+// HBM and sequences the kernels in the reference's call order
+// (simulator_interface.cpp:95-143).  No CPU fallback exists: without a usable
+// gfx950 device xwb_create fails.
+#include "../../include/xwb.h"
+#include "xwb_common.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace xwb;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(XWB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+struct EventPair { hipEvent_t a, b; };
+
+struct KernelTimer {
+    std::vector<EventPair> pool;
+    size_t used = 0;
+};
+
+}  // namespace
+
+struct xwb_sim {
+    xwb_config cfg;
+    int n = 0;
+    size_t obs_bytes_per_env = 0;
+    int out_h = 0, out_w = 0, out_c = 0;
+    int num_actions = 0;
+    uint32_t policy_step = 0;
+    bool list_valid = false;
+    int count_sel = 0;
+    bool profiling = false;
+    KernelTimer t_render, t_step, t_reset;
+    // common device buffers
+    int32_t *d_actions = nullptr, *d_num_steps = nullptr, *d_err = nullptr, *d_reset_count = nullptr;
+    uint32_t *d_episode = nullptr;
+    float *d_reward = nullptr;
+    uint8_t *d_done = nullptr, *d_success = nullptr;
+    void *d_obs = nullptr, *d_obs_owned = nullptr;
+    // simple_game
+    int32_t *d_pos = nullptr;
+    uint8_t *d_flags = nullptr;
+    // simple_race
+    float *d_x = nullptr, *d_y = nullptr, *d_angle = nullptr;
+    RaceParams race{};
+    // xworld
+    uint16_t *d_grid = nullptr;
+    int32_t *d_agent = nullptr, *d_task_steps = nullptr, *d_task_state = nullptr, *d_done_list = nullptr,
+            *d_done_count = nullptr;
+    uint8_t *d_fresh = nullptr, *d_icon_type = nullptr;
+    int16_t *d_icon_name = nullptr, *d_name_first = nullptr, *d_name_variants = nullptr;
+    uint32_t *d_atlas = nullptr;
+    std::vector<uint8_t> tile_table;   // host copy, n_icons x c x 12 x 12
+    XwParams xw{};
+    std::vector<void *> allocs;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(xwb_sim *s, T **p, size_t count, int fill = 0) {
+    void *q = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    HIP_TRY(hipMalloc(&q, bytes));
+    HIP_TRY(hipMemset(q, fill, bytes));
+    s->allocs.push_back(q);
+    *p = static_cast<T *>(q);
+    return XWB_OK;
+}
+
+hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- host restatement of the SimpleRace constructors (float/double conversion points matter) ----
+void race_setup(const xwb_config &c, RaceParams &r) {
+    const double PI = 3.1415926;                       // simple_race_simulator.h:39
+    r.track_type = c.track_type;
+    r.random = c.random;
+    r.difficulty_hard = c.difficulty_hard;
+    r.reward_scale = c.reward_scale;
+    r.delta_ang = (float)(PI / 10);                    // RaceEngine ctor, cpp:257-261
+    r.delta_fwd = 1;
+    if (c.race_full_manouver) { r.n_legal = 9; for (int i = 0; i < 9; ++i) r.legal[i] = i; }
+    else { r.n_legal = 2; r.legal[0] = 4; r.legal[1] = 7; }         // get_action_set, cpp:432-440
+    const float cx = (float)(480 / 2), cy = (float)(720 / 2);       // WINDOW_WIDTH/HEIGHT, cpp:34-35,446
+    if (c.track_type == 1) {                           // CircleTrack ctor, cpp:55-59
+        float r_in = (float)c.track_radius, width = (float)c.track_width;
+        r.center_x = cx; r.center_y = cy;
+        r.inner_radius = r_in;
+        r.width = width;
+        r.outer_radius = r_in + r.width;
+        r.length = 0; r.mid_x = r.mid_y = r.start_x = r.start_y = r.end_x = r.end_y = 0;
+    } else {                                           // StraightTrack ctor, cpp:105-110
+        float length = (float)c.track_length, width = (float)c.track_width;
+        r.mid_x = cx; r.mid_y = cy;
+        r.length = length;
+        r.width = width;
+        float d0 = (float)(0.4 * (double)r.length), d1 = (float)(0.6 * (double)r.length);
+        r.start_x = r.mid_x - 0.0f; r.start_y = r.mid_y - d0;
+        r.end_x = r.mid_x + 0.0f;   r.end_y = r.mid_y + d1;
+        r.center_x = r.center_y = r.inner_radius = r.outer_radius = 0;
+    }
+}
+
+int round_half_even(float v) { return (int)lrintf(v); }          // cvRound
+
+}  // namespace
+
+namespace xwb {
+
+// The 12x12 tile of one icon = what cv::resize(INTER_LINEAR) makes of that icon's cell when the
+// 64 px/cell canvas is shrunk to 12 px/cell (xworld_simulator.cpp:521-522).  The ratio is 16/3 in
+// both axes for every map size, so output pixel k of a cell takes source pixels s_k, s_k+1 of the
+// *same* cell with 11-bit weights; OpenCV 3.2 fixed-point arithmetic (imgwarp.cpp): horizontal pass
+// in int32, vertical pass (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.  Gray: BGR2GRAY
+// (B*1868 + G*9617 + R*4899 + 8192) >> 14 applied to the resized BGR tile (cvtColor after resize).
+void build_tile_table(const uint8_t *icons64, int n_icons, int channels, uint8_t *out) {
+    int tap[12];
+    short w0[12], w1[12];
+    const double scale = 1.0 / (12.0 / 64.0);
+    for (int k = 0; k < 12; ++k) {
+        float f = (float)((k + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        tap[k] = s;
+        w0[k] = (short)round_half_even((1.f - f) * 2048);
+        w1[k] = (short)round_half_even(f * 2048);
+    }
+    for (int ic = 0; ic < n_icons; ++ic) {
+        const uint8_t *src = icons64 + (size_t)ic * 64 * 64 * 3;
+        uint8_t bgr[12][12][3];
+        for (int py = 0; py < 12; ++py)
+            for (int px = 0; px < 12; ++px)
+                for (int c = 0; c < 3; ++c) {
+                    const uint8_t *r0 = src + (size_t)tap[py] * 64 * 3, *r1 = r0 + 64 * 3;
+                    int h0 = r0[tap[px] * 3 + c] * w0[px] + r0[(tap[px] + 1) * 3 + c] * w1[px];
+                    int h1 = r1[tap[px] * 3 + c] * w0[px] + r1[(tap[px] + 1) * 3 + c] * w1[px];
+                    bgr[py][px][c] = (uint8_t)((((w0[py] * (h0 >> 4)) >> 16) + ((w1[py] * (h1 >> 4)) >> 16) + 2) >> 2);
+                }
+        uint8_t *dst = out + (size_t)ic * channels * 144;
+        for (int py = 0; py < 12; ++py)
+            for (int px = 0; px < 12; ++px) {
+                if (channels == 3) {
+                    for (int c = 0; c < 3; ++c) dst[c * 144 + py * 12 + px] = bgr[py][px][c];
+                } else {
+                    dst[py * 12 + px] = (uint8_t)((bgr[py][px][0] * 1868 + bgr[py][px][1] * 9617 +
+                                                   bgr[py][px][2] * 4899 + (1 << 13)) >> 14);
+                }
+            }
+    }
+}
+
+}  // namespace xwb
+
+namespace {
+
+int xw_setup(xwb_sim *s) {
+    const xwb_config &c = s->cfg;
+    if (c.max_dim < 1 || c.max_dim > XW_MAX_DIM || c.dim < 1 || c.dim > c.max_dim)
+        return fail(XWB_ERR_ARG, "xworld: need 1 <= dim <= max_dim <= 16");
+    if (c.num_goals < 1 || c.num_goals > XW_MAX_GOALS) return fail(XWB_ERR_ARG, "xworld: need 1 <= num_goals <= 16");
+    if (c.n_icons < 1 || !c.icons64 || !c.icon_type || !c.icon_name)
+        return fail(XWB_ERR_ARG, "xworld: icons64 / icon_type / icon_name are required (the reference loads item_path images)");
+    if (c.n_icons > 4000) return fail(XWB_ERR_ARG, "xworld: too many icons");
+    const int n = s->n, cells = c.max_dim * c.max_dim, ch = c.color ? 3 : 1;
+    // name tables (xworld_env.py:247-255): per type, names -> icon variants (icon order = path order)
+    int n_names[3] = {0, 0, 0};
+    for (int i = 0; i < c.n_icons; ++i) {
+        int t = c.icon_type[i];
+        if (t < 0 || t > 2 || c.icon_name[i] < 0) return fail(XWB_ERR_ARG, "xworld: bad icon_type / icon_name");
+        if (c.icon_name[i] + 1 > n_names[t]) n_names[t] = c.icon_name[i] + 1;
+    }
+    if (n_names[1] < 1 || n_names[2] < 1 || n_names[0] < 1)
+        return fail(XWB_ERR_ARG, "xworld: palette needs at least one goal, one block and one agent icon");
+    if (c.map_kind == XWB_MAP_NAV && c.num_goals > n_names[0])
+        return fail(XWB_ERR_ARG, "xworld: XWorldNav needs num_goals distinct goal names");
+    std::vector<int16_t> first, variants;
+    int off[3];
+    for (int t = 0; t < 3; ++t) {
+        off[t] = (int)first.size();
+        for (int nm = 0; nm < n_names[t]; ++nm) {
+            first.push_back((int16_t)variants.size());
+            int cnt = 0;
+            for (int i = 0; i < c.n_icons; ++i)
+                if (c.icon_type[i] == t && c.icon_name[i] == nm) { variants.push_back((int16_t)i); cnt++; }
+            if (cnt == 0) return fail(XWB_ERR_ARG, "xworld: name ids of a type must be dense");
+        }
+        first.push_back((int16_t)variants.size());
+    }
+    // free cells / block capacity checks the reference leaves to Python asserts
+    if (c.map_kind == XWB_MAP_NAV) {
+        int X = c.dim % 2 == 0 ? c.dim - 1 : c.dim;
+        int nodes = ((X + 1) / 2) * ((X + 1) / 2);
+        int hashes = X * X - nodes - (nodes - 1) + (c.dim % 2 == 0 ? (X / 2) + (c.dim / 2) : 0);
+        if (c.num_blocks > hashes) return fail(XWB_ERR_ARG, "xworld: too many blocks for a valid maze");
+        int free_cells = c.dim * c.dim - hashes;
+        if (c.num_goals + 1 > free_cells) return fail(XWB_ERR_ARG, "xworld: not enough free cells");
+        if (nodes > 64) return fail(XWB_ERR_ARG, "xworld: maze node lattice larger than 8x8");
+    } else {
+        int walls = std::min(c.num_blocks, c.dim) + std::min(std::max(c.num_blocks - c.dim, 0), c.dim - 1);
+        if (c.num_goals + 1 + walls > c.dim * c.dim) return fail(XWB_ERR_ARG, "xworld: not enough free cells");
+    }
+    // tile table: entry 0 = empty cell (canvas fill 255, xmap.cpp:129-132), entry i+1 = icon i
+    s->tile_table.assign((size_t)c.n_icons * ch * 144, 0);
+    build_tile_table(c.icons64, c.n_icons, ch, s->tile_table.data());
+    std::vector<uint8_t> atlas((size_t)(c.n_icons + 1) * ch * 144, 255);
+    memcpy(atlas.data() + (size_t)ch * 144, s->tile_table.data(), s->tile_table.size());
+    std::vector<uint8_t> types(c.n_icons);
+    std::vector<int16_t> names(c.n_icons);
+    for (int i = 0; i < c.n_icons; ++i) { types[i] = (uint8_t)c.icon_type[i]; names[i] = (int16_t)c.icon_name[i]; }
+
+    int rc;
+    if ((rc = dev_alloc(s, &s->d_grid, (size_t)n * cells))) return rc;
+    if ((rc = dev_alloc(s, &s->d_agent, n))) return rc;
+    if ((rc = dev_alloc(s, &s->d_task_steps, n))) return rc;
+    if ((rc = dev_alloc(s, &s->d_task_state, n))) return rc;
+    if ((rc = dev_alloc(s, &s->d_done_list, n))) return rc;
+    if ((rc = dev_alloc(s, &s->d_done_count, 2))) return rc;
+    if ((rc = dev_alloc(s, &s->d_fresh, n))) return rc;
+    if ((rc = dev_alloc(s, &s->d_icon_type, c.n_icons))) return rc;
+    if ((rc = dev_alloc(s, &s->d_icon_name, c.n_icons))) return rc;
+    if ((rc = dev_alloc(s, &s->d_name_first, first.size()))) return rc;
+    if ((rc = dev_alloc(s, &s->d_name_variants, variants.size()))) return rc;
+    if ((rc = dev_alloc(s, &s->d_atlas, atlas.size() / 4))) return rc;
+    HIP_TRY(hipMemcpy(s->d_icon_type, types.data(), types.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_icon_name, names.data(), names.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_name_first, first.data(), first.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_name_variants, variants.data(), variants.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_atlas, atlas.data(), atlas.size(), hipMemcpyHostToDevice));
+    HIP_TRY(xw_render_prepare(c.device));
+
+    XwParams &p = s->xw;
+    p.n = n; p.context = c.context; p.max_steps = c.max_steps; p.act_rep = 1; p.auto_reset = 0;
+    p.map_kind = c.map_kind; p.max_dim = c.max_dim; p.dim = c.dim; p.num_goals = c.num_goals;
+    p.num_blocks = c.num_blocks; p.max_steps_factor = c.max_steps_factor; p.task_mode = c.task_mode;
+    p.channels = ch; p.n_icons = c.n_icons;
+    p.policy_seed = c.policy_seed; p.env_gid0 = c.env_gid0; p.policy_step = 0; p.seed = c.seed;
+    p.icon_type = s->d_icon_type; p.icon_name = s->d_icon_name;
+    p.name_first = s->d_name_first; p.name_variants = s->d_name_variants;
+    for (int t = 0; t < 3; ++t) { p.n_names[t] = n_names[t]; p.name_first_off[t] = off[t]; }
+    p.atlas = s->d_atlas;
+    p.actions = nullptr; p.mask = nullptr; p.actions_out = s->d_actions;
+    p.grid = s->d_grid; p.agent_xy = s->d_agent; p.task_steps = s->d_task_steps; p.task_state = s->d_task_state;
+    p.num_steps = s->d_num_steps; p.episode = s->d_episode; p.success = s->d_success; p.fresh = s->d_fresh;
+    p.reward = s->d_reward; p.done = s->d_done; p.obs = static_cast<uint8_t *>(s->d_obs);
+    p.done_list = s->d_done_list; p.done_count = s->d_done_count; p.done_count_next = s->d_done_count + 1;
+    p.err_count = s->d_err;
+    return XWB_OK;
+}
+
+void timer_begin(xwb_sim *s, KernelTimer &t, hipStream_t st) {
+    if (!s->profiling) return;
+    if (t.used == t.pool.size()) {
+        EventPair ep;
+        if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) return;
+        t.pool.push_back(ep);
+    }
+    hipEventRecord(t.pool[t.used].a, st);
+}
+
+void timer_end(xwb_sim *s, KernelTimer &t, hipStream_t st) {
+    if (!s->profiling || t.used >= t.pool.size()) return;
+    hipEventRecord(t.pool[t.used].b, st);
+    t.used++;
+}
+
+SgParams sg_params(xwb_sim *s) {
+    SgParams p{};
+    const xwb_config &c = s->cfg;
+    p.n = s->n; p.array_size = c.array_size; p.context = c.context; p.max_steps = c.max_steps;
+    p.act_rep = 1; p.mode = MODE_STEP; p.auto_reset = 0;
+    p.policy_seed = c.policy_seed; p.env_gid0 = c.env_gid0; p.policy_step = s->policy_step;
+    p.actions = nullptr; p.mask = nullptr; p.actions_out = s->d_actions;
+    p.pos = s->d_pos; p.flags = s->d_flags; p.num_steps = s->d_num_steps; p.episode = s->d_episode;
+    p.reward = s->d_reward; p.done = s->d_done; p.obs = static_cast<uint8_t *>(s->d_obs);
+    p.err_count = s->d_err; p.reset_count = s->d_reset_count;
+    return p;
+}
+
+RaceParams race_params(xwb_sim *s) {
+    RaceParams p = s->race;
+    const xwb_config &c = s->cfg;
+    p.n = s->n; p.context = c.context; p.max_steps = c.max_steps; p.act_rep = 1; p.mode = MODE_STEP;
+    p.auto_reset = 0;
+    p.policy_seed = c.policy_seed; p.env_gid0 = c.env_gid0; p.policy_step = s->policy_step; p.seed = c.seed;
+    p.actions = nullptr; p.mask = nullptr; p.actions_out = s->d_actions;
+    p.x = s->d_x; p.y = s->d_y; p.angle = s->d_angle; p.num_steps = s->d_num_steps; p.episode = s->d_episode;
+    p.reward = s->d_reward; p.done = s->d_done; p.obs = static_cast<float *>(s->d_obs);
+    p.err_count = s->d_err; p.reset_count = s->d_reset_count;
+    return p;
+}
+
+// reset for the simple games: one launch, mode selects the envs
+int simple_reset(xwb_sim *s, int mode, const uint8_t *mask, hipStream_t st) {
+    HIP_TRY(hipMemsetAsync(s->d_reset_count, 0, sizeof(int32_t), st));
+    timer_begin(s, s->t_reset, st);
+    if (s->cfg.game == XWB_SIMPLE_GAME) {
+        SgParams p = sg_params(s);
+        p.mode = mode; p.mask = mask;
+        HIP_TRY(launch_simple_game(p, st));
+    } else {
+        RaceParams p = race_params(s);
+        p.mode = mode; p.mask = mask;
+        HIP_TRY(launch_simple_race(p, st));
+    }
+    timer_end(s, s->t_reset, st);
+    return XWB_OK;
+}
+
+XwParams xw_params(xwb_sim *s) {
+    XwParams p = s->xw;
+    p.obs = static_cast<uint8_t *>(s->d_obs);
+    p.policy_step = s->policy_step;
+    p.done_count = s->d_done_count + s->count_sel;
+    p.done_count_next = s->d_done_count + (1 - s->count_sel);
+    return p;
+}
+
+// xworld: reset the compacted list (or all), then re-render those envs
+int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t st) {
+    XwParams p = xw_params(s);
+    p.auto_reset = keep_done ? 1 : 0;
+    timer_begin(s, s->t_reset, st);
+    HIP_TRY(launch_xw_reset(p, mode, st));
+    timer_end(s, s->t_reset, st);
+    if (render) {
+        if (mode == MODE_RESET_ALL) {
+            timer_begin(s, s->t_render, st);
+            HIP_TRY(launch_xw_render(p, 0, st));
+            timer_end(s, s->t_render, st);
+        } else {
+            HIP_TRY(launch_xw_render(p, 1, st));
+        }
+    }
+    return XWB_OK;
+}
+
+int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autoreset, hipStream_t st) {
+    if (act_rep < 1) return fail(XWB_ERR_ARG, "act_rep must be >= 1");
+    if (s->cfg.game == XWB_SIMPLE_GAME) {
+        SgParams p = sg_params(s);
+        p.actions = actions_dev; p.act_rep = act_rep; p.auto_reset = autoreset ? 1 : 0;
+        if (autoreset) HIP_TRY(hipMemsetAsync(s->d_reset_count, 0, sizeof(int32_t), st));
+        timer_begin(s, s->t_step, st);
+        HIP_TRY(launch_simple_game(p, st));
+        timer_end(s, s->t_step, st);
+    } else if (s->cfg.game == XWB_SIMPLE_RACE) {
+        RaceParams p = race_params(s);
+        p.actions = actions_dev; p.act_rep = act_rep; p.auto_reset = autoreset ? 1 : 0;
+        if (autoreset) HIP_TRY(hipMemsetAsync(s->d_reset_count, 0, sizeof(int32_t), st));
+        timer_begin(s, s->t_step, st);
+        HIP_TRY(launch_simple_race(p, st));
+        timer_end(s, s->t_step, st);
+    } else {
+        s->count_sel ^= 1;                     // this step appends to the counter the previous one zeroed
+        XwParams p = xw_params(s);
+        p.actions = actions_dev; p.act_rep = act_rep;
+        timer_begin(s, s->t_step, st);
+        HIP_TRY(launch_xw_step(p, st));
+        timer_end(s, s->t_step, st);
+        s->list_valid = true;
+        if (autoreset) {
+            int rc = xw_reset_list(s, MODE_RESET_DONE, true, false, st);
+            if (rc) return rc;
+            s->list_valid = false;
+        }
+        timer_begin(s, s->t_render, st);
+        HIP_TRY(launch_xw_render(p, 0, st));
+        timer_end(s, s->t_render, st);
+    }
+    s->policy_step += 1;
+    return XWB_OK;
+}
+
+// ---- StatePacket wire writer (data_packet.h:313-319, data_packet.cpp:143-162, memory_util.h:307-333) ----
+struct Writer {
+    uint8_t *p; size_t cap, n;
+    void put(const void *d, size_t len) { if (p && n + len <= cap) memcpy(p + n, d, len); n += len; }
+    void u64(uint64_t v) { put(&v, 8); }
+    void str(const char *s) { size_t len = strlen(s); u64(len); put(s, len + 1); }
+};
+
+}  // namespace
+
+// =============================================================== C ABI =====
+extern "C" {
+
+const char *xwb_last_error(void) { return g_err.c_str(); }
+const char *xwb_version(void) { return "xwb 0.1 (gfx950)"; }
+
+int xwb_default_config(int32_t game, xwb_config *c) {
+    if (!c) return fail(XWB_ERR_ARG, "cfg is NULL");
+    memset(c, 0, sizeof *c);
+    c->abi_version = XWB_ABI_VERSION;
+    c->game = game;
+    c->num_envs = 1;
+    c->seed = 0xC0FFEEu;
+    c->policy_seed = 0x5EEDu;
+    c->context = 1;                 // simulator.cpp:21
+    c->max_steps = 0;               // simulator.cpp:22
+    c->array_size = 6;              // simple_game_simulator.cpp:19
+    c->track_type = 0;              // simple_race_simulator.cpp:17
+    c->track_width = 20.0f; c->track_length = 100.0f; c->track_radius = 30.0f;   // :18-20
+    c->reward_scale = 1.0;          // :26
+    c->map_kind = XWB_MAP_NAV; c->max_dim = 8; c->dim = 8; c->num_goals = 4; c->num_blocks = 16;  // XWorldNav.py:8-13,27-39
+    c->max_steps_factor = 10;       // simulator.cpp:23
+    c->task_mode = XWB_TASKMODE_LANG_ACQ;   // xworld_simulator.cpp:33-37
+    c->color = 0;                   // simulator.cpp:25
+    if (game < 0 || game > 2) return fail(XWB_ERR_ARG, "unknown game");
+    return XWB_OK;
+}
+
+int xwb_create(const xwb_config *cfg, xwb_sim **out) {
+    if (!cfg || !out) return fail(XWB_ERR_ARG, "NULL argument");
+    if (cfg->abi_version != XWB_ABI_VERSION) return fail(XWB_ERR_ARG, "abi_version mismatch");
+    if (cfg->num_envs < 1) return fail(XWB_ERR_ARG, "num_envs must be >= 1");
+    if (cfg->context < 1) return fail(XWB_ERR_ARG, "context must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(XWB_ERR_HIP, "no HIP device: libxwb.so has no CPU path");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(XWB_ERR_ARG, "bad device ordinal");
+    HIP_TRY(hipSetDevice(cfg->device));
+    xwb_sim *s = new xwb_sim();
+    s->cfg = *cfg;
+    s->n = cfg->num_envs;
+    const int n = s->n;
+    int rc = XWB_OK;
+    auto bail = [&](int code) { xwb_destroy(s); return code; };
+    switch (cfg->game) {
+        case XWB_SIMPLE_GAME:
+            if (cfg->array_size < 1) return bail(fail(XWB_ERR_ARG, "array_size must be >= 1"));
+            s->out_h = 1; s->out_w = cfg->array_size; s->out_c = 1;       // simple_game_simulator.cpp:118-124
+            s->obs_bytes_per_env = (size_t)cfg->context * cfg->array_size;
+            s->num_actions = 2;
+            break;
+        case XWB_SIMPLE_RACE:
+            if (cfg->track_type != 0 && cfg->track_type != 1) return bail(fail(XWB_ERR_ARG, "track_type must be 0 or 1"));
+            s->out_h = 1; s->out_w = 4; s->out_c = 1;                     // simple_race_simulator.cpp:492-501
+            s->obs_bytes_per_env = (size_t)cfg->context * 4 * sizeof(float);
+            race_setup(*cfg, s->race);
+            s->num_actions = s->race.n_legal;
+            break;
+        case XWB_XWORLD2D:
+            s->out_h = cfg->max_dim * 12; s->out_w = cfg->max_dim * 12; s->out_c = cfg->color ? 3 : 1;   // xworld_simulator.cpp:53-61,106-112
+            s->obs_bytes_per_env = (size_t)cfg->context * s->out_c * s->out_h * s->out_w;
+            s->num_actions = 4;                                           // xitem.cpp:82-83
+            break;
+        default:
+            return bail(fail(XWB_ERR_ARG, "Unrecognized game type"));     // simulator_interface.cpp:82
+    }
+    if ((rc = dev_alloc(s, &s->d_actions, n, 0xff))) return bail(rc);
+    if ((rc = dev_alloc(s, &s->d_num_steps, n))) return bail(rc);
+    if ((rc = dev_alloc(s, &s->d_err, 1))) return bail(rc);
+    if ((rc = dev_alloc(s, &s->d_reset_count, 1))) return bail(rc);
+    if ((rc = dev_alloc(s, &s->d_episode, n, 0xff))) return bail(rc);      // first reset -> episode 0
+    if ((rc = dev_alloc(s, &s->d_reward, n))) return bail(rc);
+    if ((rc = dev_alloc(s, &s->d_done, n))) return bail(rc);
+    if ((rc = dev_alloc(s, &s->d_success, n, 1))) return bail(rc);         // last_action_success_(true), simulator.cpp:33-34
+    {
+        uint8_t *obs = nullptr;
+        if ((rc = dev_alloc(s, &obs, (size_t)n * s->obs_bytes_per_env))) return bail(rc);
+        s->d_obs = s->d_obs_owned = obs;
+    }
+    if (cfg->game == XWB_SIMPLE_GAME) {
+        if ((rc = dev_alloc(s, &s->d_pos, n))) return bail(rc);
+        if ((rc = dev_alloc(s, &s->d_flags, n))) return bail(rc);
+    } else if (cfg->game == XWB_SIMPLE_RACE) {
+        if ((rc = dev_alloc(s, &s->d_x, n))) return bail(rc);
+        if ((rc = dev_alloc(s, &s->d_y, n))) return bail(rc);
+        if ((rc = dev_alloc(s, &s->d_angle, n))) return bail(rc);
+    } else {
+        if ((rc = xw_setup(s))) return bail(rc);
+    }
+    // the reference constructors leave a reset game behind (SimpleGame ctor cpp:82-85, SimpleRaceGame
+    // ctor cpp:457, XWorld ctor xworld.cpp:106); screens_ stays empty until reset_game -> init_screen.
+    s->cfg.icons64 = nullptr; s->cfg.icon_type = nullptr; s->cfg.icon_name = nullptr;   // not owned
+    rc = xwb_reset(s, nullptr);
+    if (rc) return bail(rc);
+    HIP_TRY(hipDeviceSynchronize());
+    *out = s;
+    return XWB_OK;
+}
+
+int xwb_destroy(xwb_sim *s) {
+    if (!s) return XWB_OK;
+    for (void *p : s->allocs) (void)hipFree(p);
+    for (KernelTimer *t : {&s->t_render, &s->t_step, &s->t_reset})
+        for (auto &ep : t->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    delete s;
+    return XWB_OK;
+}
+
+int xwb_reset(xwb_sim *s, void *stream) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    hipStream_t st = as_stream(stream);
+    if (s->cfg.game != XWB_XWORLD2D) return simple_reset(s, MODE_RESET_ALL, nullptr, st);
+    s->list_valid = false;
+    return xw_reset_list(s, MODE_RESET_ALL, false, true, st);
+}
+
+int xwb_reset_done(xwb_sim *s, void *stream) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    hipStream_t st = as_stream(stream);
+    if (s->cfg.game != XWB_XWORLD2D) return simple_reset(s, MODE_RESET_DONE, nullptr, st);
+    if (!s->list_valid) {                      // no step since the last reset: rebuild the list from done[]
+        XwParams p = xw_params(s);
+        HIP_TRY(hipMemsetAsync(p.done_count, 0, sizeof(int32_t), st));
+        HIP_TRY(launch_xw_compact(p, MODE_RESET_DONE, st));
+    }
+    s->list_valid = false;
+    return xw_reset_list(s, MODE_RESET_DONE, false, true, st);
+}
+
+int xwb_reset_masked(xwb_sim *s, const uint8_t *mask_dev, void *stream) {
+    if (!s || !mask_dev) return fail(XWB_ERR_ARG, "NULL argument");
+    hipStream_t st = as_stream(stream);
+    if (s->cfg.game != XWB_XWORLD2D) return simple_reset(s, MODE_RESET_MASK, mask_dev, st);
+    XwParams p = xw_params(s);
+    p.mask = mask_dev;
+    HIP_TRY(hipMemsetAsync(p.done_count, 0, sizeof(int32_t), st));
+    HIP_TRY(launch_xw_compact(p, MODE_RESET_MASK, st));
+    s->list_valid = false;
+    return xw_reset_list(s, MODE_RESET_MASK, false, true, st);
+}
+
+int xwb_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, void *stream) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    return do_step(s, actions_dev, act_rep, false, as_stream(stream));
+}
+
+int xwb_step_autoreset(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, void *stream) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    return do_step(s, actions_dev, act_rep, true, as_stream(stream));
+}
+
+int xwb_check_errors(xwb_sim *s, void *stream, int32_t *n_bad) {
+    if (!s || !n_bad) return fail(XWB_ERR_ARG, "NULL argument");
+    hipStream_t st = as_stream(stream);
+    HIP_TRY(hipMemcpyAsync(n_bad, s->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemsetAsync(s->d_err, 0, sizeof(int32_t), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return XWB_OK;
+}
+
+int xwb_obs_dev(xwb_sim *s, void **ptr, size_t *bytes_per_env) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    if (ptr) *ptr = s->d_obs;
+    if (bytes_per_env) *bytes_per_env = s->obs_bytes_per_env;
+    return XWB_OK;
+}
+
+int xwb_bind_obs(xwb_sim *s, void *obs_dev) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    if (obs_dev && (reinterpret_cast<uintptr_t>(obs_dev) & 15u)) return fail(XWB_ERR_ARG, "obs buffer must be 16-byte aligned");
+    s->d_obs = obs_dev ? obs_dev : s->d_obs_owned;
+    return XWB_OK;
+}
+
+#define XWB_GETTER(NAME, TYPE, FIELD)                                   \
+    int NAME(xwb_sim *s, TYPE **ptr) {                                  \
+        if (!s || !ptr) return fail(XWB_ERR_ARG, "NULL argument");      \
+        *ptr = s->FIELD;                                                \
+        return XWB_OK;                                                  \
+    }
+XWB_GETTER(xwb_reward_dev, float, d_reward)
+XWB_GETTER(xwb_game_over_dev, uint8_t, d_done)
+XWB_GETTER(xwb_actions_dev, int32_t, d_actions)
+XWB_GETTER(xwb_num_steps_dev, int32_t, d_num_steps)
+XWB_GETTER(xwb_success_dev, uint8_t, d_success)
+XWB_GETTER(xwb_episode_dev, uint32_t, d_episode)
+
+int xwb_xw_grid_dev(xwb_sim *s, uint16_t **ptr) {
+    if (!s || !ptr) return fail(XWB_ERR_ARG, "NULL argument");
+    if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
+    *ptr = s->d_grid;
+    return XWB_OK;
+}
+
+int xwb_done_count(xwb_sim *s, void *stream, int32_t *n_done) {
+    if (!s || !n_done) return fail(XWB_ERR_ARG, "NULL argument");
+    hipStream_t st = as_stream(stream);
+    const int32_t *src = s->cfg.game == XWB_XWORLD2D ? s->d_done_count + s->count_sel : s->d_reset_count;
+    HIP_TRY(hipMemcpyAsync(n_done, src, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return XWB_OK;
+}
+
+int xwb_get_num_actions(const xwb_sim *s, int32_t *n) {
+    if (!s || !n) return fail(XWB_ERR_ARG, "NULL argument");
+    *n = s->num_actions;
+    return XWB_OK;
+}
+
+int xwb_get_screen_out_dimensions(const xwb_sim *s, size_t *h, size_t *w, size_t *c) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    if (h) *h = (size_t)s->out_h;
+    if (w) *w = (size_t)s->out_w;
+    if (c) *c = (size_t)s->out_c;
+    return XWB_OK;
+}
+
+int xwb_get_world_dimensions(const xwb_sim *s, double *X, double *Y, double *Z) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    // SimulatorInterface::get_world_dimensions: only teaching environments answer (xworld_simulator.cpp:100-104)
+    if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "get_world_dimensions: not a teaching environment");
+    if (X) *X = s->cfg.max_dim;
+    if (Y) *Y = s->cfg.max_dim;
+    if (Z) *Z = 0;
+    return XWB_OK;
+}
+
+int xwb_num_envs(const xwb_sim *s, int32_t *n) {
+    if (!s || !n) return fail(XWB_ERR_ARG, "NULL argument");
+    *n = s->n;
+    return XWB_OK;
+}
+
+int xwb_get_env_state(xwb_sim *s, int32_t env, void *stream, xwb_env_state *o) {
+    if (!s || !o) return fail(XWB_ERR_ARG, "NULL argument");
+    if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
+    hipStream_t st = as_stream(stream);
+    memset(o, 0, sizeof *o);
+    uint8_t done = 0, succ = 0;
+    int32_t steps = 0, act = -1;
+    HIP_TRY(hipMemcpyAsync(&o->reward, s->d_reward + env, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&done, s->d_done + env, 1, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&succ, s->d_success + env, 1, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&steps, s->d_num_steps + env, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&act, s->d_actions + env, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&o->episode, s->d_episode + env, 4, hipMemcpyDeviceToHost, st));
+    int32_t axy = 0, ts = 0, tsteps = 0;
+    if (s->cfg.game == XWB_SIMPLE_GAME) {
+        HIP_TRY(hipMemcpyAsync(&o->sg_pos, s->d_pos + env, 4, hipMemcpyDeviceToHost, st));
+    } else if (s->cfg.game == XWB_SIMPLE_RACE) {
+        HIP_TRY(hipMemcpyAsync(&o->race_x, s->d_x + env, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&o->race_y, s->d_y + env, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&o->race_angle, s->d_angle + env, 4, hipMemcpyDeviceToHost, st));
+    } else {
+        HIP_TRY(hipMemcpyAsync(&axy, s->d_agent + env, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&ts, s->d_task_state + env, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&tsteps, s->d_task_steps + env, 4, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    o->game_over = done;
+    o->num_steps = steps;
+    o->last_action = act;
+    o->last_action_success = succ;
+    // get_lives: SimpleGame cpp:137 / XWorldSimulator :506 -> game_over ? 0 : 1 ; SimpleRace cpp:503 -> 1
+    o->lives = s->cfg.game == XWB_SIMPLE_RACE ? 1 : (done ? 0 : 1);
+    if (s->cfg.game == XWB_XWORLD2D) {
+        o->xw_agent_x = axy & 0xffff; o->xw_agent_y = axy >> 16;
+        o->xw_target_name = (int16_t)(ts & 0xffff);
+        o->xw_stage = (ts >> 16) & 0xff;
+        o->xw_event = (ts >> 24) & 0xff;
+        o->xw_steps_in_task = tsteps;
+    }
+    return XWB_OK;
+}
+
+int xwb_get_env_obs(xwb_sim *s, int32_t env, void *stream, void *out_host, size_t bytes) {
+    if (!s || !out_host) return fail(XWB_ERR_ARG, "NULL argument");
+    if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
+    if (bytes != s->obs_bytes_per_env) return fail(XWB_ERR_ARG, "bytes must equal bytes_per_env");
+    hipStream_t st = as_stream(stream);
+    HIP_TRY(hipMemcpyAsync(out_host, static_cast<uint8_t *>(s->d_obs) + (size_t)env * bytes, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return XWB_OK;
+}
+
+int xwb_get_env_grid(xwb_sim *s, int32_t env, void *stream, uint16_t *out_host) {
+    if (!s || !out_host) return fail(XWB_ERR_ARG, "NULL argument");
+    if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
+    if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
+    hipStream_t st = as_stream(stream);
+    const size_t cells = (size_t)s->cfg.max_dim * s->cfg.max_dim;
+    HIP_TRY(hipMemcpyAsync(out_host, s->d_grid + (size_t)env * cells, cells * 2, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return XWB_OK;
+}
+
+int xwb_xw_load_map(xwb_sim *s, int32_t env, const uint16_t *grid_host, int32_t agent_x, int32_t agent_y,
+                    int32_t target_name, int32_t dim) {
+    if (!s || !grid_host) return fail(XWB_ERR_ARG, "NULL argument");
+    if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
+    if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
+    if (dim != s->cfg.dim) return fail(XWB_ERR_ARG, "dim differs from the batch's dim");
+    const int D = s->cfg.max_dim;
+    if (agent_x < 0 || agent_y < 0 || agent_x >= D || agent_y >= D) return fail(XWB_ERR_ARG, "agent outside the map");
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t cells = (size_t)D * D;
+    int32_t axy = agent_x | (agent_y << 16);
+    int32_t ts = (target_name & 0xffff) | (1 << 16);
+    int32_t zero = 0;
+    uint8_t z8 = 0, one = 1;
+    HIP_TRY(hipMemcpy(s->d_grid + (size_t)env * cells, grid_host, cells * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_agent + env, &axy, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_task_state + env, &ts, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_task_steps + env, &zero, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_num_steps + env, &zero, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_done + env, &z8, 1, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_fresh + env, &one, 1, hipMemcpyHostToDevice));
+    // init_screen of that env: render the one-entry list
+    XwParams p = xw_params(s);
+    int32_t cnt = 1;
+    HIP_TRY(hipMemcpy(p.done_list, &env, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p.done_count, &cnt, 4, hipMemcpyHostToDevice));
+    HIP_TRY(launch_xw_render(p, 1, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(p.done_count, 0, 4));
+    s->list_valid = false;
+    return XWB_OK;
+}
+
+int xwb_race_set_car(xwb_sim *s, int32_t env, float x, float y, float angle) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    if (s->cfg.game != XWB_SIMPLE_RACE) return fail(XWB_ERR_STATE, "not a simple_race batch");
+    if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(s->d_x + env, &x, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_y + env, &y, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_angle + env, &angle, 4, hipMemcpyHostToDevice));
+    return XWB_OK;
+}
+
+int xwb_get_state_packet(xwb_sim *s, int32_t env, float reward, void *stream, uint8_t *out_host, size_t cap,
+                         size_t *need) {
+    if (!s || !need) return fail(XWB_ERR_ARG, "NULL argument");
+    if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
+    const bool xw = s->cfg.game == XWB_XWORLD2D;
+    const bool is_float = s->cfg.game == XWB_SIMPLE_RACE;
+    const size_t n_screen = is_float ? s->obs_bytes_per_env / 4 : s->obs_bytes_per_env;
+    // sizes first
+    size_t total = 8;
+    total += 8 + 7 + 1 + 8 + 4;                                  // "reward": flags reals, 1 float
+    total += 8 + 7 + 1 + 8 + s->obs_bytes_per_env;               // "screen"
+    if (xw) total += 8 + 9 + 1 + 8 + 2;                          // "sentence": str "-"
+    *need = total;
+    if (!out_host || cap < total) return XWB_OK;
+    std::vector<uint8_t> screen(s->obs_bytes_per_env);
+    int rc = xwb_get_env_obs(s, env, stream, screen.data(), screen.size());
+    if (rc) return rc;
+    Writer w{out_host, cap, 0};
+    w.u64(xw ? 3 : 2);
+    w.str("reward");
+    uint8_t f = 1; w.put(&f, 1); w.u64(1); w.put(&reward, 4);
+    w.str("screen");
+    f = is_float ? 1 : 2; w.put(&f, 1); w.u64(n_screen); w.put(screen.data(), screen.size());
+    if (xw) {
+        // XWorldSimulator::define_state_specs (:486-493): teacher sentence or "-" (language side channel is out of scope)
+        w.str("sentence");
+        f = 8; w.put(&f, 1); w.str("-");
+    }
+    return XWB_OK;
+}
+
+int xwb_decode_game_over_code(int32_t code, char *out, size_t cap) {
+    if (!out || cap == 0) return fail(XWB_ERR_ARG, "NULL argument");
+    std::string sres;
+    if (code == 0) sres = "alive";
+    else {
+        if (code & XWB_MAX_STEP) sres += "max_step|";
+        if (code & XWB_DEAD) sres += "dead|";
+        if (code & XWB_SUCCESS) sres += "success|";
+        if (code & XWB_LOST_LIFE) sres += "lost_life|";
+        if (sres.empty()) return fail(XWB_ERR_ARG, "unknown game over code");     // CHECK(!code_str.empty())
+        sres.pop_back();
+    }
+    if (sres.size() + 1 > cap) return fail(XWB_ERR_ARG, "buffer too small");
+    memcpy(out, sres.c_str(), sres.size() + 1);
+    return XWB_OK;
+}
+
+int xwb_xw_get_tile_table(const xwb_sim *s, uint8_t *out_host, size_t cap, size_t *need) {
+    if (!s || !need) return fail(XWB_ERR_ARG, "NULL argument");
+    if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
+    *need = s->tile_table.size();
+    if (out_host && cap >= s->tile_table.size()) memcpy(out_host, s->tile_table.data(), s->tile_table.size());
+    return XWB_OK;
+}
+
+int xwb_profile_begin(xwb_sim *s) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    s->profiling = true;
+    s->t_render.used = s->t_step.used = s->t_reset.used = 0;
+    return XWB_OK;
+}
+
+int xwb_profile_end(xwb_sim *s, void *stream, const char *kernel, double *avg_us, int64_t *launches) {
+    if (!s || !kernel || !avg_us || !launches) return fail(XWB_ERR_ARG, "NULL argument");
+    KernelTimer *t = nullptr;
+    if (!strcmp(kernel, "render")) t = &s->t_render;
+    else if (!strcmp(kernel, "step")) t = &s->t_step;
+    else if (!strcmp(kernel, "reset")) t = &s->t_reset;
+    else return fail(XWB_ERR_ARG, "kernel must be render | step | reset");
+    HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    double total_ms = 0;
+    for (size_t i = 0; i < t->used; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, t->pool[i].a, t->pool[i].b));
+        total_ms += ms;
+    }
+    *launches = (int64_t)t->used;
+    *avg_us = t->used ? total_ms * 1000.0 / (double)t->used : 0.0;
+    return XWB_OK;
+}
+
+int xwb_profile_stop(xwb_sim *s) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    s->profiling = false;
+    return XWB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+// xwb_common.h -- shared declarations of libxwb.so (MI355X / gfx950 only).
+//
+// Kernel parameter blocks, the xwb-rng-v1 Philox stream (device side) and the
+// launch entry points implemented by the per-game .hip files.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xwb {
+
+// ---------------------------------------------------------------- RNG ------
+// xwb-rng-v1: Philox4x32-10; key = (seed, global env id);
+// counter = (block index, episode, stream id, 0); draws are successive words.
+// stream 0 = reset decisions of that episode, stream 1 = built-in random policy
+// (block index = rollout step).  DESIGN.md "xwb-rng-v1".
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct Stream {
+    uint32_t k0, k1, blk, episode, sid;
+    uint32_t buf[4];
+    int have;
+    __device__ __forceinline__ void init(uint32_t seed, uint32_t gid, uint32_t ep, uint32_t stream_id) {
+        k0 = seed; k1 = gid; blk = 0; episode = ep; sid = stream_id; have = 0;
+    }
+    __device__ __forceinline__ uint32_t u32() {
+        if (have == 0) {
+            philox4x32_10(blk, episode, sid, 0u, k0, k1, buf);
+            blk += 1; have = 4;
+        }
+        // select without dynamic indexing of a register array
+        int i = 4 - have;
+        uint32_t v = i == 0 ? buf[0] : (i == 1 ? buf[1] : (i == 2 ? buf[2] : buf[3]));
+        have -= 1;
+        return v;
+    }
+    // uniform in [0, n): multiply-shift; consumes a draw only when n > 1
+    __device__ __forceinline__ uint32_t below(uint32_t n) {
+        if (n <= 1) return 0;
+        return __umulhi(u32(), n);
+    }
+    // uniform float in [0, 1): 24 bits
+    __device__ __forceinline__ float unit() { return (float)(u32() >> 8) * (1.0f / 16777216.0f); }
+};
+
+__device__ __forceinline__ int policy_action(uint32_t policy_seed, uint32_t gid, uint32_t step, int num_actions) {
+    uint32_t o[4];
+    philox4x32_10(step, 0u, 1u, 0u, policy_seed, gid, o);
+    return (int)__umulhi(o[0], (uint32_t)num_actions);
+}
+
+// GameOverCode bits (simulator.h:42-48)
+enum : int { ALIVE = 0, MAX_STEP = 1, DEAD = 2, SUCCESS = 4, LOST_LIFE = 8 };
+
+// which envs a state-changing kernel applies to
+enum : int { MODE_STEP = 0, MODE_RESET_ALL = 1, MODE_RESET_DONE = 2, MODE_RESET_MASK = 3 };
+
+// ------------------------------------------------------------ SimpleGame ---
+struct SgParams {
+    int n, array_size, context, max_steps, act_rep, mode, auto_reset;
+    uint32_t policy_seed, env_gid0, policy_step;
+    const int32_t *actions;     // nullable
+    const uint8_t *mask;        // MODE_RESET_MASK
+    int32_t *actions_out;
+    int32_t *pos;               // _cur_pos
+    uint8_t *flags;             // bit0: rewards[0] consumed, bit1: rewards[N-1] consumed
+    int32_t *num_steps;
+    uint32_t *episode;
+    float   *reward;
+    uint8_t *done;
+    uint8_t *obs;               // [n][context][array_size]
+    int32_t *err_count;
+    int32_t *reset_count;
+};
+hipError_t launch_simple_game(const SgParams &p, hipStream_t s);
+
+// ------------------------------------------------------------ SimpleRace ---
+struct RaceParams {
+    int n, context, max_steps, act_rep, mode, auto_reset;
+    uint32_t policy_seed, env_gid0, policy_step, seed;
+    int track_type, random, difficulty_hard, n_legal;
+    int legal[9];
+    // track constants, computed on the host with the reference's float/double conversions
+    float width, length;
+    float mid_x, mid_y, start_x, start_y, end_x, end_y;          // StraightTrack
+    float center_x, center_y, inner_radius, outer_radius;         // CircleTrack
+    float delta_fwd, delta_ang;
+    double reward_scale;
+    const int32_t *actions;
+    const uint8_t *mask;
+    int32_t *actions_out;
+    float *x, *y, *angle;
+    int32_t *num_steps;
+    uint32_t *episode;
+    float *reward;
+    uint8_t *done;
+    float *obs;                 // [n][context][4]
+    int32_t *err_count;
+    int32_t *reset_count;
+};
+hipError_t launch_simple_race(const RaceParams &p, hipStream_t s);
+
+// -------------------------------------------------------------- XWorld2D ---
+constexpr int XW_MAX_DIM = 16;
+constexpr int XW_MAX_GOALS = 16;
+constexpr int XW_TILE = 12;           // block_size, xworld_simulator.cpp:57
+constexpr int XW_TILE_DW = 3;         // dwords per tile row (12 bytes)
+
+struct XwParams {
+    int n, context, max_steps, act_rep, auto_reset;
+    int map_kind, max_dim, dim, num_goals, num_blocks, max_steps_factor, task_mode, channels;
+    int n_icons;
+    uint32_t policy_seed, env_gid0, policy_step, seed;
+    // icon tables (device)
+    const uint8_t *icon_type;    // [n_icons]
+    const int16_t *icon_name;    // [n_icons]
+    const int16_t *name_first;   // [3][max_names+1] flattened: offsets into name_variants, per type
+    const int16_t *name_variants;
+    int n_names[3];
+    int name_first_off[3];       // start of each type's offset table inside name_first
+    const uint32_t *atlas;       // [n_icons][channels][12][3] dwords (tile table)
+    const int32_t *actions;
+    const uint8_t *mask;
+    int32_t *actions_out;
+    // state
+    uint16_t *grid;              // [n][max_dim*max_dim] cell code = icon + 1, 0 empty
+    int32_t *agent_xy;           // x | y << 16
+    int32_t *task_steps;         // steps_in_cur_task
+    int32_t *task_state;         // target name (low 16) | stage << 16 | event << 24
+    int32_t *num_steps;
+    uint32_t *episode;
+    uint8_t *success;            // last_action_success
+    uint8_t *fresh;              // set by reset, consumed by render (context ring init)
+    float *reward;
+    uint8_t *done;
+    uint8_t *obs;                // [n][context][channels][12*max_dim][12*max_dim]
+    int32_t *done_list;          // compacted env ids
+    int32_t *done_count;         // counter the current step / compaction appends to
+    int32_t *done_count_next;    // the other one of the pair; zeroed by the step kernel
+    int32_t *err_count;
+};
+hipError_t launch_xw_step(const XwParams &p, hipStream_t s);
+// reset envs: mode RESET_ALL -> every env; otherwise the compacted done_list / done_count
+hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s);
+// compaction of done[] (mode RESET_DONE) or mask (RESET_MASK) into done_list / done_count
+hipError_t launch_xw_compact(const XwParams &p, int mode, hipStream_t s);
+// render: indexed == 0 -> all envs (LDS-resident atlas, persistent workgroups);
+//         indexed == 1 -> envs in done_list (atlas through L2)
+hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s);
+hipError_t xw_render_prepare(int device);   // opt-in to > 64 KiB dynamic LDS once per process
+
+// host: builds the 12x12 tile table (OpenCV 3.2 fixed-point bilinear + BGR2GRAY) from 64x64 icons
+void build_tile_table(const uint8_t *icons64, int n_icons, int channels, uint8_t *out /* n*c*12*12 */);
+
+}  // namespace xwb

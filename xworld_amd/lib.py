@@ -1,0 +1,125 @@
+"""ctypes binding of libxwb.so (include/xwb.h).
+
+There is no fallback: if the HIP library is missing it is built with hipcc, and
+if that fails, or no gfx950 device is usable at create time, an exception is
+raised.  Nothing here (or anywhere in xworld_amd/) imports the test oracle.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libxwb.so")
+
+XWB_ABI_VERSION = 1
+XWB_SIMPLE_GAME, XWB_SIMPLE_RACE, XWB_XWORLD2D = 0, 1, 2
+XWB_MAP_NAV, XWB_MAP_WALLS = 0, 1
+XWB_TASKMODE_LANG_ACQ, XWB_TASKMODE_ONE_CHANNEL = 0, 1
+ALIVE, MAX_STEP, DEAD, SUCCESS, LOST_LIFE = 0, 1, 2, 4, 8
+
+
+class XwbConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("game", C.c_int32), ("num_envs", C.c_int32), ("device", C.c_int32),
+        ("env_gid0", C.c_uint32), ("seed", C.c_uint32), ("policy_seed", C.c_uint32),
+        ("context", C.c_int32), ("max_steps", C.c_int32),
+        ("array_size", C.c_int32),
+        ("track_type", C.c_int32), ("race_full_manouver", C.c_int32), ("random", C.c_int32),
+        ("difficulty_hard", C.c_int32),
+        ("track_width", C.c_double), ("track_length", C.c_double), ("track_radius", C.c_double),
+        ("reward_scale", C.c_double),
+        ("map_kind", C.c_int32), ("max_dim", C.c_int32), ("dim", C.c_int32), ("num_goals", C.c_int32),
+        ("num_blocks", C.c_int32), ("max_steps_factor", C.c_int32), ("task_mode", C.c_int32),
+        ("color", C.c_int32), ("n_icons", C.c_int32),
+        ("icons64", C.c_void_p), ("icon_type", C.c_void_p), ("icon_name", C.c_void_p),
+    ]
+
+
+class XwbEnvState(C.Structure):
+    _fields_ = [
+        ("reward", C.c_float), ("game_over", C.c_int32), ("lives", C.c_int32), ("num_steps", C.c_int64),
+        ("last_action", C.c_int32), ("last_action_success", C.c_int32),
+        ("sg_pos", C.c_int32),
+        ("race_x", C.c_float), ("race_y", C.c_float), ("race_angle", C.c_float),
+        ("xw_agent_x", C.c_int32), ("xw_agent_y", C.c_int32), ("xw_event", C.c_int32), ("xw_stage", C.c_int32),
+        ("xw_target_name", C.c_int32), ("xw_steps_in_task", C.c_int32),
+        ("episode", C.c_uint32),
+    ]
+
+
+# every symbol include/xwb.h declares: (name, restype, argtypes)
+_vp = C.c_void_p
+_SIGS = [
+    ("xwb_default_config", C.c_int, [C.c_int32, C.POINTER(XwbConfig)]),
+    ("xwb_create", C.c_int, [C.POINTER(XwbConfig), C.POINTER(_vp)]),
+    ("xwb_destroy", C.c_int, [_vp]),
+    ("xwb_reset", C.c_int, [_vp, _vp]),
+    ("xwb_reset_done", C.c_int, [_vp, _vp]),
+    ("xwb_reset_masked", C.c_int, [_vp, _vp, _vp]),
+    ("xwb_step", C.c_int, [_vp, _vp, C.c_int32, _vp]),
+    ("xwb_step_autoreset", C.c_int, [_vp, _vp, C.c_int32, _vp]),
+    ("xwb_check_errors", C.c_int, [_vp, _vp, C.POINTER(C.c_int32)]),
+    ("xwb_obs_dev", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    ("xwb_bind_obs", C.c_int, [_vp, _vp]),
+    ("xwb_reward_dev", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("xwb_game_over_dev", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("xwb_actions_dev", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("xwb_num_steps_dev", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("xwb_success_dev", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("xwb_episode_dev", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("xwb_xw_grid_dev", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("xwb_done_count", C.c_int, [_vp, _vp, C.POINTER(C.c_int32)]),
+    ("xwb_get_num_actions", C.c_int, [_vp, C.POINTER(C.c_int32)]),
+    ("xwb_get_screen_out_dimensions", C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("xwb_get_world_dimensions", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("xwb_num_envs", C.c_int, [_vp, C.POINTER(C.c_int32)]),
+    ("xwb_get_env_state", C.c_int, [_vp, C.c_int32, _vp, C.POINTER(XwbEnvState)]),
+    ("xwb_get_env_obs", C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_size_t]),
+    ("xwb_get_env_grid", C.c_int, [_vp, C.c_int32, _vp, _vp]),
+    ("xwb_xw_load_map", C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    ("xwb_race_set_car", C.c_int, [_vp, C.c_int32, C.c_float, C.c_float, C.c_float]),
+    ("xwb_get_state_packet", C.c_int, [_vp, C.c_int32, C.c_float, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("xwb_decode_game_over_code", C.c_int, [C.c_int32, C.c_char_p, C.c_size_t]),
+    ("xwb_xw_get_tile_table", C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("xwb_profile_begin", C.c_int, [_vp]),
+    ("xwb_profile_end", C.c_int, [_vp, _vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    ("xwb_profile_stop", C.c_int, [_vp]),
+    ("xwb_last_error", C.c_char_p, []),
+    ("xwb_version", C.c_char_p, []),
+]
+EXPORTED_SYMBOLS = [s[0] for s in _SIGS]
+
+_lib = None
+
+
+class XwbError(RuntimeError):
+    pass
+
+
+def load(build_if_missing=True):
+    """dlopen libxwb.so (building it in-tree with hipcc first if absent). Raises on failure."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise XwbError("libxwb.so is missing (run `python -m xworld_amd.build`); there is no CPU fallback")
+        from . import build as _build
+        _build.build()
+    L = C.CDLL(LIB_PATH)
+    for name, res, args in _SIGS:
+        f = getattr(L, name)          # AttributeError if the library lacks a declared symbol
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise XwbError("xwb error %d: %s" % (rc, load().xwb_last_error().decode()))
+
+
+def decode_game_over_code(code):
+    buf = C.create_string_buffer(64)
+    check(load().xwb_decode_game_over_code(int(code), buf, 64))
+    return buf.value.decode()
