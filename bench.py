@@ -130,28 +130,22 @@ def main():
     sim = make_sim(args.workload, n_local, local_rank, rank * n_local)
     per_step, per_launch, kernel_name = algorithmic_bytes(args.workload, sim)
 
-    # per-step exchange: (reward, game_over) of every shard to rank 0
-    small = torch.empty((n_local, 2), dtype=torch.float32, device=dev)
-    small_all = [torch.empty_like(small) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # per-step exchange (xworld_amd/sharding.py): (reward, game_over) of every shard to rank 0 through one
+    # RCCL gather; with --gather-screens also every shard's screens into one contiguous tensor on rank 0
+    from xworld_amd import sharding
+    counts = [n_local] * world
+    results = sharding.ResultGather(counts, rank, dev) if world > 1 else None
     screens_all = None
-    if world > 1 and args.gather_screens:
-        if rank == 0:
-            screens_all = torch.empty((world * n_local,) + tuple(sim.obs.shape[1:]), dtype=sim.obs.dtype, device=dev)
-            sim.bind_obs(screens_all[:n_local])          # rank 0 renders straight into its slice
+    if world > 1 and args.gather_screens and rank == 0:
+        screens_all = torch.empty((world * n_local,) + tuple(sim.obs.shape[1:]), dtype=sim.obs.dtype, device=dev)
+        sim.bind_obs(screens_all[:n_local])              # rank 0 renders straight into its slice
 
     def exchange():
         if world == 1:
             return
-        small[:, 0] = sim.reward
-        small[:, 1] = sim.game_over_codes.to(torch.float32)
-        dist.gather(small, small_all, dst=0)
+        results(sim.reward, sim.game_over_codes)
         if args.gather_screens:
-            if rank == 0:
-                ops = [dist.P2POp(dist.irecv, screens_all[r * n_local:(r + 1) * n_local], r) for r in range(1, world)]
-            else:
-                ops = [dist.P2POp(dist.isend, sim.obs, 0)]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            sharding.gather_slabs(sim.obs, screens_all, counts, rank)
 
     def one_step():
         if args.autoreset:

@@ -76,8 +76,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        build()
+    try:
+        build()                      # `make` is a no-op when liboracle.so is up to date
+    except Exception:
+        if not os.path.exists(LIB_PATH):
+            raise
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
 

@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.json by IMPORTING the reference's Python modules (build container only).
+
+    python tests/golden/make_golden.py            # needs /root/reference, numpy, oracle/liboracle.so
+
+Nothing of the reference's source is copied: the fixtures are inputs and the outputs the reference
+modules produced for them.  What is imported from /root/reference:
+    python/maze2d.py                      spanning_tree_maze_generator, bfs
+    python/py_util.py
+    games/xworld/maps/xworld_env.py, XWorldNav.py, XWorldWalls.py
+    games/xworld3d/tasks/xworld3d_task.py, XWorld3DNavTarget.py
+
+Harness shims (this file, clearly not reference code):
+  * `py_gflags`: in the reference this module is provided by the embedding C++ program
+    (python/py_init.cpp:37-58) and simply returns gflags values; here get_flag() reads a dict holding the
+    flag values of the configuration under test (visible_radius 0, max_steps_factor 10, curriculum 0,
+    task_mode lang_acquisition).
+  * `context_free_grammar`: the teacher's sentence generator (language side, out of scope; the real module is
+    Python-2 only): a no-op CFG so that XWorld3DTask can be constructed.
+  * Python 2 -> 3: XWorldEnv.set_dims uses `/` on ints (xworld_env.py:129-130) and
+    get_all_possible_names returns dict.keys() that is later shuffled (:292); both are patched to their
+    Python-2 meaning (integer division, list).
+  * the ~30 lines of C++ glue between the simulator and the Python task (teaching_task.cpp:64-116: push the
+    entities / events into the env, call the stage, read event + reward; xmap.cpp:76-101: 4-way move into an
+    empty in-bounds cell, contact list; xworld_simulator.cpp:124-137: "collision:<ids>\n") are restated
+    in `Harness` below.
+
+Fixtures written:
+  maze.json      reference maze generator driven by the xwb-rng-v1 shuffle decisions -> maze rows
+  bfs.json       reference bfs() reachability on random obstacle maps
+  maps_nav.json  XWorldNav.reset() maps (python random seeded), entity lists as palette indices,
+                 + reference _reachable() per goal
+  maps_walls.json  same for XWorldWalls
+  teacher.json   XWorld3DNavTarget idle/navigation_reward run over random action strings on those maps:
+                 per step action, reward, event, stage, agent cell, action success
+"""
+import ctypes as C
+import json
+import os
+import random
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("XWORLD_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.dont_write_bytecode = True
+
+FLAGS = {"visible_radius": 0, "max_steps_factor": 10, "task_mode": "lang_acquisition", "curriculum": 0.0}
+
+py_gflags = types.ModuleType("py_gflags")
+py_gflags.get_flag = lambda name: FLAGS[name]
+py_gflags.log_info = lambda *a: None
+py_gflags.log_fatal = lambda *a: None
+sys.modules["py_gflags"] = py_gflags
+
+
+class _CFG(object):
+    def __init__(self, *a, **k):
+        pass
+
+    def bind(self, *a):
+        pass
+
+    def generate(self, *a):
+        return ""
+
+    def generate_all(self, *a):
+        return []
+
+    def set_production_rule(self, *a):
+        pass
+
+    def total_possible_sentences(self):
+        return 0
+
+    def show(self):
+        pass
+
+
+cfg_mod = types.ModuleType("context_free_grammar")
+cfg_mod.CFG = _CFG
+sys.modules["context_free_grammar"] = cfg_mod
+
+for sub in ("python", "games/xworld/maps", "games/xworld3d/tasks"):
+    sys.path.insert(0, os.path.join(REF, sub))
+
+import maze2d                                   # noqa: E402  (reference)
+import xworld_env                               # noqa: E402  (reference)
+from XWorldNav import XWorldNav                 # noqa: E402  (reference)
+from XWorldWalls import XWorldWalls             # noqa: E402  (reference)
+from XWorld3DNavTarget import XWorld3DNavTarget  # noqa: E402  (reference)
+
+import _oracle as O                             # noqa: E402  (only for the xwb-rng-v1 stream + palettes)
+
+
+def _set_dims(self, h, w):
+    # xworld_env.py:118-134 with Python-2 integer division
+    assert h >= 1 and w >= 1
+    assert h <= self.max_height and w <= self.max_width
+    self.height = h
+    self.width = w
+    self.offset_h = (self.max_height - h) // 2
+    self.offset_w = (self.max_width - w) // 2
+    self.pad_blocks = self._XWorldEnv__padding_walls()
+    existing_entities = [e.loc for e in self.entities]
+    self.available_grids = list(set(self._XWorldEnv__generate_all_grids(h, w)) - set(existing_entities))
+    self.changed = True
+
+
+xworld_env.XWorldEnv.set_dims = _set_dims
+_orig_names = xworld_env.XWorldEnv.get_all_possible_names
+xworld_env.XWorldEnv.get_all_possible_names = lambda self, t: sorted(_orig_names(self, t))
+
+ITEM_PATH = os.path.join(REF, "games", "xworld", "images")
+
+
+# ------------------------------------------------------------------ maze ----
+class StreamRandom(object):
+    """random.shuffle replacement drawing from the xwb-rng-v1 stream: Fisher-Yates i = n-1..1, j = below(i+1)."""
+
+    def __init__(self, seed, gid, episode):
+        self.s = O.Stream()
+        O.lib().orc_stream_init(C.byref(self.s), seed, gid, episode, 0)
+
+    def shuffle(self, lst):
+        for i in range(len(lst) - 1, 0, -1):
+            j = O.lib().orc_stream_below(C.byref(self.s), i + 1)
+            lst[i], lst[j] = lst[j], lst[i]
+
+
+def gen_maze():
+    cases = []
+    real_random = maze2d.random
+    try:
+        for X in (3, 4, 5, 6, 7, 8, 9, 11, 12, 15, 16):
+            for k in range(6):
+                seed, gid, ep = 1000 + X, 7 * k + 1, k
+                maze2d.random = StreamRandom(seed, gid, ep)
+                maze = maze2d.spanning_tree_maze_generator(X, X)
+                cases.append({"X": X, "seed": seed, "gid": gid, "episode": ep,
+                              "maze": ["".join(r) for r in maze]})
+    finally:
+        maze2d.random = real_random
+    return cases
+
+
+def gen_bfs():
+    rnd = random.Random(12345)
+    cases = []
+    for k in range(300):
+        X = rnd.randint(2, 11)
+        Y = rnd.randint(2, 11)
+        cells = [(x, y, 0) for x in range(X) for y in range(Y)]
+        rnd.shuffle(cells)
+        start, end = cells[0], cells[1]
+        n_obst = rnd.randint(0, max(0, (X * Y) // 2))
+        obst = cells[2:2 + n_obst]
+        random.seed(k)
+        path = maze2d.bfs(start, end, X, Y, obst)
+        cases.append({"X": X, "Y": Y, "start": start[:2], "end": end[:2],
+                      "obstacles": [o[:2] for o in obst], "reachable": path is not None,
+                      "path_len": None if path is None else len(path)})
+    return cases
+
+
+# ------------------------------------------------------------------ maps ----
+def entity_records(env, pal):
+    """cpp_get_entities() -> (type, x, y, palette icon, name id, serial) in the order C++ receives them."""
+    path_to_icon = {m["path"]: i for i, m in enumerate(pal.meta)}
+    out = []
+    for e in env.cpp_get_entities():
+        rel = os.path.relpath(e["asset_path"], ITEM_PATH)
+        t = O.TYPE_ID[e["type"]]
+        icon = path_to_icon[rel]
+        assert pal.meta[icon]["name"] == e["name"], (rel, e["name"])
+        serial = int(e["id"].split("_")[-1])
+        out.append([t, int(e["loc"][0]), int(e["loc"][1]), icon, int(pal.name_arr[icon]), serial])
+    return out
+
+
+def gen_maps(cls, pal, n_maps, seed0):
+    maps = []
+    env = cls(ITEM_PATH)
+    for k in range(n_maps):
+        random.seed(seed0 + k)
+        env.reset()
+        h, w = env.get_dims()
+        ents = entity_records(env, pal)
+        task = XWorld3DNavTarget(env)
+        agent = [e for e in env.get_entities() if e.type == "agent"][0]
+        reach = [bool(task._reachable(agent.loc, g.loc)) for g in env.get_goals()]
+        maps.append({"py_seed": seed0 + k, "dim": h, "max_dim": env.get_max_dims()[0], "entities": ents,
+                     "goal_reachable": reach})
+    return maps
+
+
+# --------------------------------------------------------------- teacher ----
+class Harness(object):
+    """The C++ side of one XWorld2D env as far as a Python task can see it."""
+
+    def __init__(self, env):
+        self.env = env
+        self.ents = [dict(e) for e in env.cpp_get_entities()]
+        for e in self.ents:
+            e["loc"] = tuple(e["loc"])
+        self.H, self.W = env.get_max_dims()
+        self.agent = [e for e in self.ents if e["type"] == "agent"][0]
+        self.game_events = ""
+        self.success = False
+
+    def cell(self, x, y):
+        return [e for e in self.ents if e["loc"][0] == x and e["loc"][1] == y]
+
+    def act(self, a):
+        # XAgent::act (xitem.cpp:89-101) + XMap::move_item (xmap.cpp:76-101) + record_collision_events
+        x, y = self.agent["loc"][0], self.agent["loc"][1]
+        tx, ty = [(x, y - 1), (x, y + 1), (x - 1, y), (x + 1, y)][a]
+        contact = []
+        ok = False
+        if 0 <= tx < self.W and 0 <= ty < self.H:
+            items = self.cell(tx, ty)
+            contact = [i["id"] for i in items if i["id"] != self.agent["id"]]
+            ok = len(items) == 0
+        if ok:
+            self.agent["loc"] = (tx, ty, 0)
+        if contact:
+            self.game_events += "collision:" + "|".join(contact) + "\n"
+        self.success = ok
+
+    def py_stage(self, task, stage):
+        # Task::py_stage, teaching_task.cpp:64-116
+        self.env.update_entities_from_cpp([dict(e) for e in self.ents])
+        self.env.update_agent_sentence_from_cpp("")
+        self.env.update_agent_action_success_from_cpp(self.success)
+        ev, self.game_events = self.game_events, ""
+        self.env.update_game_event_from_cpp(ev)
+        ret = getattr(task, stage)()
+        assert not self.env.env_changed() or stage == "idle" or True
+        event = task.get_event()
+        return ret[0], float(ret[1]), event
+
+
+def gen_teacher(cls, pal, n_maps, seed0, steps):
+    runs = []
+    env = cls(ITEM_PATH)
+    rnd = random.Random(999)
+    import XWorld3DNavTarget as nav_mod
+    for k in range(n_maps):
+        random.seed(seed0 + k)
+        env.reset()
+        env.env_changed()
+        ents = entity_records(env, pal)
+        h = Harness(env)
+        task = XWorld3DNavTarget(env)
+        task.reset()
+        picked = {}
+        real_choice = nav_mod.random.choice
+
+        def choice(seq, _p=picked, _r=real_choice):
+            v = _r(seq)
+            _p["index"] = list(seq).index(v)
+            _p["n"] = len(seq)
+            return v
+        nav_mod.random.choice = choice
+        try:
+            stage, reward, event = h.py_stage(task, "idle")
+        finally:
+            nav_mod.random.choice = real_choice
+        assert stage == "navigation_reward" and reward == 0.0 and event == ""
+        # per step: [action, reward, event, stage, agent x, agent y, success]; a few steps past the end
+        trace = []
+        after_end = 0
+        for t in range(steps):
+            a = rnd.randrange(4)
+            h.act(a)
+            stage, reward, event = h.py_stage(task, stage)
+            trace.append([a, reward, event, stage, h.agent["loc"][0], h.agent["loc"][1], int(bool(h.success))])
+            if stage == "terminal":
+                after_end += 1
+                if after_end > 3:
+                    break
+        runs.append({"py_seed": seed0 + k, "dim": env.get_dims()[0], "max_dim": env.get_max_dims()[0],
+                     "entities": ents, "target_pick": picked["index"], "n_candidates": picked["n"],
+                     "target_name": int(pal.names["goal"].index(task.target[0].name)), "trace": trace})
+    return runs
+
+
+def main():
+    nav_pal = O.Palette(O.NAV_SUBTREES)
+    walls_pal = O.Palette(O.WALLS_SUBTREES)
+    out = {
+        "maze.json": gen_maze(),
+        "bfs.json": gen_bfs(),
+        "maps_nav.json": gen_maps(XWorldNav, nav_pal, 60, 100),
+        "maps_walls.json": gen_maps(XWorldWalls, walls_pal, 30, 500),
+        "teacher.json": {"nav": gen_teacher(XWorldNav, nav_pal, 40, 2000, 700),
+                         "walls": gen_teacher(XWorldWalls, walls_pal, 24, 3000, 500)},
+    }
+    for name, data in out.items():
+        with open(os.path.join(HERE, name), "w") as f:
+            json.dump(data, f, separators=(",", ":"))
+        print(name, os.path.getsize(os.path.join(HERE, name)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

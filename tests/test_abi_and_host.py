@@ -1,0 +1,108 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/xwb.h declares, fails loudly
+without a GPU (no CPU fallback, no oracle in the product), and the py_simulator-compatible host layer
+keeps the reference's option handling and errors.  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_library_exports_every_declared_symbol():
+    from xworld_amd import lib
+    L = lib.load()
+    header = open(os.path.join(ROOT, "include", "xwb.h")).read()
+    declared = set(re.findall(r"\b(xwb_[a-z0-9_]+)\s*\(", header))
+    declared -= {"xwb_sim", "xwb_config", "xwb_env_state"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), "libxwb.so does not export " + name
+    assert declared == set(lib.EXPORTED_SYMBOLS), declared ^ set(lib.EXPORTED_SYMBOLS)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (xwb_[a-z0-9_]+)", out))
+    assert declared <= exported
+
+
+def test_ctypes_struct_matches_header_layout():
+    """xwb_default_config writes through the C struct: field values land where the ctypes mirror reads them."""
+    from xworld_amd import lib
+    L = lib.load()
+    for game in (0, 1, 2):
+        c = lib.XwbConfig()
+        assert L.xwb_default_config(game, C.byref(c)) == 0
+        assert c.abi_version == lib.XWB_ABI_VERSION and c.game == game and c.num_envs == 1
+        assert c.context == 1 and c.max_steps == 0 and c.array_size == 6
+        assert c.track_width == 20.0 and c.track_length == 100.0 and c.track_radius == 30.0 and c.reward_scale == 1.0
+        assert (c.map_kind, c.max_dim, c.dim, c.num_goals, c.num_blocks, c.max_steps_factor) == (0, 8, 8, 4, 16, 10)
+    assert L.xwb_default_config(7, C.byref(c)) != 0
+    assert b"unknown game" in L.xwb_last_error()
+
+
+def test_decode_game_over_code_matches_reference_strings():
+    from xworld_amd import lib
+    assert lib.decode_game_over_code(0) == "alive"
+    assert lib.decode_game_over_code(1) == "max_step"
+    assert lib.decode_game_over_code(2) == "dead"
+    assert lib.decode_game_over_code(4 | 1) == "max_step|success"
+    assert lib.decode_game_over_code(15) == "max_step|dead|success|lost_life"
+    with pytest.raises(lib.XwbError):
+        lib.decode_game_over_code(16)
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
+def test_create_fails_loudly_without_gpu():
+    from xworld_amd import lib
+    from xworld_amd.batched import BatchedSimulator
+    with pytest.raises(lib.XwbError, match="no CPU path|HIP"):
+        BatchedSimulator("simple_game", {"array_size": 6})
+
+
+def test_option_errors_match_py_simulator():
+    """Missing required options / unknown games raise RuntimeError before anything touches the device
+    (python/py_simulator.cpp:40-57,184-186)."""
+    from xworld_amd.py_simulator import Simulator
+    with pytest.raises(RuntimeError, match="Unrecognized game type"):
+        Simulator.create("pong", {})
+    with pytest.raises(RuntimeError, match="Key 'array_size' is required"):
+        Simulator.create("simple_game", {})
+    with pytest.raises(RuntimeError, match="Key 'track_width' is required"):
+        Simulator.create("simple_race", {"track_type": "straight"})
+    with pytest.raises(RuntimeError, match="Key 'xwd_conf_path' is required"):
+        Simulator.create("xworld", {})
+    with pytest.raises(RuntimeError):
+        Simulator()
+
+
+def test_palettes_and_conf():
+    from xworld_amd import assets
+    nav = assets.Palette(assets.MAP_CLASSES["XWorldNav"]["subtrees"])
+    walls = assets.Palette(assets.MAP_CLASSES["XWorldWalls"]["subtrees"])
+    assert len(nav) == 347 and len(walls) == 246          # 180+48+66+51+2 ; 180+48+16+2
+    assert nav.icons64.shape == (347, 64, 64, 3)
+    assert nav.names["block"] == ["brick"] and nav.names["agent"] == ["robot"]
+    assert "shape" not in {m["subtree"] for m in nav.meta}
+    conf = assets.read_conf(os.path.join(ROOT, "xworld_amd", "confs", "navigation2d.json"))
+    assert conf["map"] == "XWorldNav"
+
+
+def test_product_never_touches_the_oracle():
+    """The product package must not import, link or execute anything under oracle/ or tests/."""
+    pkg = os.path.join(ROOT, "xworld_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "liboracle" not in src and "_oracle" not in src and "oracle/" not in src.replace("the test oracle", ""), f
+    out = subprocess.check_output(["ldd", os.path.join(pkg, "libxwb.so")]).decode()
+    assert "oracle" not in out

@@ -252,3 +252,71 @@ def test_bind_obs_and_masked_reset(oracle):
     exp = np.array([1 if e % 3 == 0 else 0 for e in range(0, n, 50)])
     assert np.array_equal(ep1 - ep0, exp)
     sim.close()
+
+
+# ---------------------------------------------------------------- reference golden vectors ----
+import json                                                                  # noqa: E402
+
+GOLD_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+EVENTS = {"": 0, "correct_goal": 1, "wrong_goal": 2, "time_up": 3}
+STAGES = {"idle": 0, "navigation_reward": 1, "terminal": 2}
+
+
+def _grid_from_entities(ents, d):
+    g = np.zeros((d, d), np.uint16)
+    for t, x, y, icon, name, serial in ents:
+        g[y, x] = icon + 1
+    return g
+
+
+@pytest.mark.parametrize("kind", ["nav", "walls"])
+def test_reference_teacher_traces_through_product(kind):
+    """The reference's own XWorld3DNavTarget task (Python, run in the build container on reference-generated
+    maps, tests/golden/teacher.json) vs the HIP step kernel: same maps, same actions ->
+    reward (float32 of the Python double), event, stage, agent cell, action success, game_over code."""
+    torch = _torch()
+    from xworld_amd.batched import BatchedSimulator
+    with open(os.path.join(GOLD_DIR, "teacher.json")) as f:
+        runs = json.load(f)[kind]
+    n = len(runs)
+    conf = NAV if kind == "nav" else WALLS
+    sim = BatchedSimulator("xworld", {"xwd_conf_path": conf, "task_mode": "lang_acquisition"}, num_envs=n)
+    d = sim.cfg.max_dim
+    for e, run in enumerate(runs):
+        assert run["max_dim"] == d and run["dim"] == d
+        agent = [x for x in run["entities"] if x[0] == 2][0]
+        sim.load_map(e, _grid_from_entities(run["entities"], d), agent[1], agent[2], run["target_name"])
+    T = max(len(r["trace"]) for r in runs)
+    for t in range(T):
+        acts = np.array([r["trace"][t][0] if t < len(r["trace"]) else 0 for r in runs], np.int32)
+        sim.step(torch.from_numpy(acts).cuda())
+        rew = sim.reward.cpu().numpy()
+        codes = sim.game_over_codes.cpu().numpy()
+        for e, r in enumerate(runs):
+            if t >= len(r["trace"]):
+                continue
+            a, reward, event, stage, ax, ay, success = r["trace"][t]
+            st = sim.env_state(e)
+            assert rew[e] == np.float32(reward), (e, t)
+            assert st.xw_event == EVENTS[event] and st.xw_stage == STAGES[stage], (e, t)
+            assert (st.xw_agent_x, st.xw_agent_y) == (ax, ay) and st.last_action_success == success, (e, t)
+            assert codes[e] == {0: 0, 1: 4, 2: 2, 3: 1}[EVENTS[event]]
+    sim.close()
+
+
+def test_reference_maps_render_through_product(oracle):
+    """Reference-generated XWorldNav maps: product screen == oracle canvas render of the same entity list."""
+    _torch()
+    from xworld_amd.batched import BatchedSimulator
+    with open(os.path.join(GOLD_DIR, "maps_nav.json")) as f:
+        maps = json.load(f)[:16]
+    pal = oracle.Palette(oracle.NAV_SUBTREES)
+    sim = BatchedSimulator("xworld", {"xwd_conf_path": NAV, "task_mode": "lang_acquisition", "color": True},
+                           num_envs=len(maps))
+    ow = oracle.XWorld(pal, render=True, map_kind=0, max_dim=8, dim=8, num_goals=4, color=1)
+    for e, m in enumerate(maps):
+        agent = [x for x in m["entities"] if x[0] == 2][0]
+        sim.load_map(e, _grid_from_entities(m["entities"], 8), agent[1], agent[2], 0)
+        ow.load_map([tuple(x) for x in m["entities"]], 8, target_pick=0)
+        assert np.array_equal(sim.env_obs(e).reshape(3, 96, 96), ow.screen()), e
+    sim.close()

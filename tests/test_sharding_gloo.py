@@ -1,0 +1,78 @@
+"""The N > 1 path on CPU: world_size 2 (and 3, ragged) over gloo -- shard ranges, per-step result gather,
+screen-slab gather into one contiguous tensor on rank 0."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from xworld_amd import sharding
+
+
+def test_shard_ranges_cover_the_batch():
+    for total in (1, 7, 32768, 262144, 100003):
+        for world in (1, 2, 3, 4, 8):
+            spans = [sharding.shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+            for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+                assert s0 + c0 == s1
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_range(8, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        counts = sharding.shard_counts(total, world)
+        start, n = sharding.shard_range(total, world, rank)
+        # what a rank's simulator would hold: values are functions of the GLOBAL env id
+        gid = torch.arange(start, start + n)
+        reward = gid.to(torch.float32) * 0.5 - 3.0
+        done = (gid % 5 == 0).to(torch.uint8) * 4
+        obs = (gid[:, None] * 7 + torch.arange(12)[None, :]).to(torch.uint8).reshape(n, 1, 3, 4)
+        rg = sharding.ResultGather(counts, rank, torch.device("cpu"))
+        for step in range(3):
+            r_all, d_all = rg(reward + step, done)
+            out = torch.zeros((total, 1, 3, 4), dtype=torch.uint8) if rank == 0 else None
+            got = sharding.gather_slabs(obs, out, counts, rank)
+            if rank == 0:
+                g = torch.arange(total)
+                assert torch.equal(r_all, g.to(torch.float32) * 0.5 - 3.0 + step)
+                assert torch.equal(d_all, (g % 5 == 0).to(torch.uint8) * 4)
+                exp = (g[:, None] * 7 + torch.arange(12)[None, :]).to(torch.uint8).reshape(total, 1, 3, 4)
+                assert torch.equal(got, exp) and got.is_contiguous()
+            else:
+                assert r_all is None and got is None
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:                               # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total", [(2, 64), (2, 33), (3, 100)])
+def test_gather_over_gloo(world, total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res

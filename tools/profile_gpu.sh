@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + HBM PMC passes for the bench workload.
+# Usage: tools/profile_gpu.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
+set -u
+TAG=${1:-r1}; shift || true
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+REPO=$PWD
+cd /tmp
+# 1. per-kernel time (same command as the bench line)
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -- python $REPO/bench.py --steps 100 --warmup 10 --no-cpu-baseline "$@" > $OUT/bench_under_rocprof.log 2>&1
+# 2. HBM traffic counters, separate passes (FETCH_SIZE and WRITE_SIZE cannot share a pass)
+rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/pmc_fetch -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline "$@" > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/pmc_write -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline "$@" > $OUT/pmc_write.log 2>&1
+cd $REPO
+python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt

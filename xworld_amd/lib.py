@@ -100,6 +100,12 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64; load it first so that libxwb.so binds to the HIP runtime
+    # already in the process (two HIP runtimes in one process cannot both own the device).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         if not build_if_missing:
             raise XwbError("libxwb.so is missing (run `python -m xworld_amd.build`); there is no CPU fallback")
