@@ -61,7 +61,7 @@ void     orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
 typedef struct { uint32_t key[2]; uint32_t ctr[4]; uint32_t buf[4]; int have; } orc_stream;
 void     orc_stream_init(orc_stream *s, uint32_t seed, uint32_t env_gid, uint32_t episode, uint32_t stream_id);
 uint32_t orc_stream_u32(orc_stream *s);
-uint32_t orc_stream_below(orc_stream *s, uint32_t n);  /* (u32 * n) >> 32 ; consumes a draw iff n > 1 */
+uint32_t orc_stream_below(orc_stream *s, uint32_t n);  /* (u32 * n) >> 32 ; always consumes one draw */
 float    orc_stream_unit(orc_stream *s);               /* (u32 >> 8) * 2^-24 in [0,1) */
 int32_t  orc_policy_action(uint32_t policy_seed, uint32_t env_gid, uint32_t step, int num_actions);
 

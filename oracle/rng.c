@@ -135,8 +135,11 @@ uint32_t orc_stream_u32(orc_stream *s) {
 }
 
 uint32_t orc_stream_below(orc_stream *s, uint32_t n) {
+    /* always consumes exactly one draw (also for n <= 1): the number of draws a reset consumes is then a
+     * function of the configuration only, never of the data */
+    uint32_t v = orc_stream_u32(s);
     if (n <= 1) return 0;
-    return (uint32_t)(((uint64_t)orc_stream_u32(s) * (uint64_t)n) >> 32);
+    return (uint32_t)(((uint64_t)v * (uint64_t)n) >> 32);
 }
 
 float orc_stream_unit(orc_stream *s) {

@@ -280,7 +280,7 @@ static void set_dims(orc_xworld *w, int h, int wd) {
  *        goal : loc = avail[below(n_avail)] (order-preserving remove); icon variant below(nv)
  *        block: loc = blocks.pop(); name below(#block names); variant below(nv)
  *        agent: loc = avail[below(n_avail)]; name below(#agent names); variant below(nv)
- *      (below(n) consumes a draw only when n > 1)                                     */
+ *      (below(n) always consumes one draw, also for n <= 1)                           */
 static void gen_map_nav(orc_xworld *w) {
     int D = w->cfg.dim;
     set_dims(w, D, D);

@@ -21,26 +21,10 @@
 // expansion  obs[n][c][12*cy+py][12*cx+px] = tile[grid[n][cy][cx]][c][py][px]  of a
 // (n_icons+1) x C x 12 x 12 table that lives in LDS; HBM traffic is the output stream plus 2 B/cell.
 #include "xwb_common.h"
+#include <cstdlib>
+#include "xw_device.h"
 
 namespace xwb {
-
-enum : int { STAGE_IDLE = 0, STAGE_NAV = 1, STAGE_TERMINAL = 2 };
-enum : int { EV_NONE = 0, EV_CORRECT = 1, EV_WRONG = 2, EV_TIMEUP = 3 };
-
-__device__ __forceinline__ int pack_task(int target, int stage, int event) {
-    return (target & 0xffff) | (stage << 16) | (event << 24);
-}
-
-__device__ __forceinline__ int done_code(const XwParams &p, int num_steps, int event) {
-    // AgentSpecificSimulator::game_over = GameSimulator::game_over | XWorldSimulator::game_over
-    int code = (p.max_steps > 0 && num_steps >= p.max_steps) ? MAX_STEP : ALIVE;
-    if (p.task_mode == 0) {       // lang_acquisition, xworld_simulator.cpp:166-177
-        if (event == EV_CORRECT) code |= SUCCESS;
-        else if (event == EV_WRONG) code |= DEAD;
-        else if (event == EV_TIMEUP) code |= MAX_STEP;
-    }
-    return code;
-}
 
 // wave-aggregated append of the lanes with `flag` set: one atomic per wavefront
 __device__ __forceinline__ void wave_append(bool flag, int value, int32_t *list, int32_t *count) {
@@ -61,6 +45,7 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
     if (e == 0) *p.done_count_next = 0;        // double-buffered done counter: zero the next step's
     bool is_done = false;
     if (e < p.n) {
+        p.fresh[e] = 0;                        // reset -> render hand-off flag of the previous step is spent
         int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step, 4);
         p.actions_out[e] = a;
         if ((unsigned)a >= 4u) {               // CHECK_LT(action_idx, get_num_actions())
@@ -143,230 +128,6 @@ __global__ __launch_bounds__(256) void xw_compact_kernel(XwParams p, int mode, i
     wave_append(flag, e, p.done_list, count_now);
 }
 
-// ------------------------------------------------------------------ reset --
-struct IconTables {
-    const int16_t *first[3];
-    const int16_t *variants;
-    __device__ __forceinline__ int nv(int type, int name) const { return first[type][name + 1] - first[type][name]; }
-    __device__ __forceinline__ int icon(int type, int name, int k) const { return variants[first[type][name] + k]; }
-};
-
-// maze2d.spanning_tree_maze_generator: mz[y*D+x] = 1 for '#'.  Randomised DFS over the node lattice
-// with an explicit stack; shuffle = Fisher-Yates i = 3..1, j = below(i+1) on [(-1,0),(1,0),(0,1),(0,-1)].
-__device__ void xw_maze(Stream &s, int D, uint8_t *mz) {
-    int X = D;
-    const bool pad = (X % 2) == 0;
-    if (pad) X -= 1;
-    const int n = (X + 1) / 2;
-    for (int y = 0; y < X; ++y)
-        for (int x = 0; x < X; ++x) mz[y * D + x] = (x % 2 == 0 && y % 2 == 0) ? 0 : 1;
-    uint64_t visited = 0;                     // n*n <= 64 nodes
-    uint8_t st_node[64], st_perm[64], st_next[64];
-    int sp = 0;
-    st_node[0] = 0; st_next[0] = 0xff; sp = 1;
-    while (sp > 0) {
-        const int top = sp - 1;
-        const int node = st_node[top];
-        const int cx = node % n, cy = node / n;
-        if (st_next[top] == 0xff) {
-            visited |= 1ull << node;
-            int mv[4] = {0, 1, 2, 3};
-            for (int i = 3; i >= 1; --i) {
-                const int j = (int)s.below((uint32_t)(i + 1));
-                // swap mv[i], mv[j] without dynamic register indexing
-                int vi = i == 3 ? mv[3] : (i == 2 ? mv[2] : mv[1]);
-                int vj = j == 0 ? mv[0] : (j == 1 ? mv[1] : (j == 2 ? mv[2] : mv[3]));
-                if (j == 0) mv[0] = vi; else if (j == 1) mv[1] = vi; else if (j == 2) mv[2] = vi; else mv[3] = vi;
-                if (i == 3) mv[3] = vj; else if (i == 2) mv[2] = vj; else mv[1] = vj;
-            }
-            st_perm[top] = (uint8_t)(mv[0] | (mv[1] << 2) | (mv[2] << 4) | (mv[3] << 6));
-            st_next[top] = 0;
-        }
-        if (st_next[top] >= 4) { sp--; continue; }
-        const int m = (st_perm[top] >> (2 * st_next[top])) & 3;
-        st_next[top] += 1;
-        const int dx = m == 0 ? -1 : (m == 1 ? 1 : 0);
-        const int dy = m == 2 ? 1 : (m == 3 ? -1 : 0);
-        const int nx = cx + dx, ny = cy + dy;
-        if (nx >= 0 && nx < n && ny >= 0 && ny < n && !((visited >> (ny * n + nx)) & 1ull)) {
-            mz[(cy + ny) * D + (cx + nx)] = 0;              // open the wall between the two nodes
-            st_node[sp] = (uint8_t)(ny * n + nx);
-            st_next[sp] = 0xff;
-            sp++;
-        }
-    }
-    if (pad) {
-        for (int i = 0; i < X; ++i) mz[X * D + i] = (i % 2 == 0) ? 0 : 1;
-        for (int i = 0; i < D; ++i) mz[i * D + X] = (i % 2 == 0) ? 0 : 1;
-    }
-}
-
-__device__ __forceinline__ int list_take(uint8_t *list, int &n, int k) {    // order-preserving remove
-    const int v = list[k];
-    for (int i = k; i + 1 < n; ++i) list[i] = list[i + 1];
-    n -= 1;
-    return v;
-}
-
-__device__ void xw_reset_env(const XwParams &p, const IconTables &T, int e, bool keep_done) {
-    const int MD = p.max_dim, D = p.dim, off = (MD - D) / 2;
-    const uint32_t ep = p.episode[e] + 1;
-    p.episode[e] = ep;
-    Stream s;
-    s.init(p.seed, p.env_gid0 + (uint32_t)e, ep, 0);
-
-    uint16_t cells[XW_MAX_DIM * XW_MAX_DIM];
-    uint8_t avail[XW_MAX_DIM * XW_MAX_DIM];
-    uint8_t blk[XW_MAX_DIM * XW_MAX_DIM];
-    int na = 0, nb = 0;
-    int goal_cell[XW_MAX_GOALS], goal_name[XW_MAX_GOALS];
-    const int ng = p.num_goals;
-    int agent_cell = 0;
-    for (int i = 0; i < D * D; ++i) cells[i] = 0;
-
-    if (p.map_kind == 0) {
-        // ---- XWorldNav: distinct goal names (shuffle + pop), maze, shuffled '#' list, placement ----
-        const int M = p.n_names[0];
-        int ov_idx[XW_MAX_GOALS], ov_val[XW_MAX_GOALS], n_ov = 0;
-        for (int i = 0; i < ng; ++i) {
-            const int j = (int)s.below((uint32_t)(M - i));
-            int vj = j, vl = M - 1 - i;
-            for (int k = 0; k < n_ov; ++k) { if (ov_idx[k] == j) vj = ov_val[k]; if (ov_idx[k] == M - 1 - i) vl = ov_val[k]; }
-            goal_name[i] = vj;
-            bool found = false;                     // names[j] = names[M-1-i]
-            for (int k = 0; k < n_ov; ++k) if (ov_idx[k] == j) { ov_val[k] = vl; found = true; }
-            if (!found) { ov_idx[n_ov] = j; ov_val[n_ov] = vl; n_ov++; }
-        }
-        uint8_t mz[XW_MAX_DIM * XW_MAX_DIM];
-        xw_maze(s, D, mz);
-        for (int c = 0; c < D * D; ++c) { if (mz[c]) blk[nb++] = (uint8_t)c; else avail[na++] = (uint8_t)c; }
-        for (int i = nb - 1; i >= 1; --i) {
-            const int j = (int)s.below((uint32_t)(i + 1));
-            const uint8_t t = blk[i]; blk[i] = blk[j]; blk[j] = t;
-        }
-        for (int i = 0; i < ng; ++i) {
-            const int c = list_take(avail, na, (int)s.below((uint32_t)na));
-            const int v = (int)s.below((uint32_t)T.nv(0, goal_name[i]));
-            cells[c] = (uint16_t)(T.icon(0, goal_name[i], v) + 1);
-            goal_cell[i] = c;
-        }
-        for (int i = 0; i < p.num_blocks; ++i) {
-            const int c = blk[--nb];
-            const int nm = (int)s.below((uint32_t)p.n_names[1]);
-            const int v = (int)s.below((uint32_t)T.nv(1, nm));
-            cells[c] = (uint16_t)(T.icon(1, nm, v) + 1);
-        }
-        {
-            const int c = list_take(avail, na, (int)s.below((uint32_t)na));
-            const int nm = (int)s.below((uint32_t)p.n_names[2]);
-            const int v = (int)s.below((uint32_t)T.nv(2, nm));
-            cells[c] = (uint16_t)(T.icon(2, nm, v) + 1);
-            agent_cell = c;
-        }
-    } else {
-        // ---- XWorldWalls: one full brick row, a partial brick column, then agent, goals, blocks ----
-        for (int c = 0; c < D * D; ++c) avail[na++] = (uint8_t)c;
-        int n_blocks = p.num_blocks;
-        const int row = (int)s.below((uint32_t)D);
-        const int first = n_blocks < D ? n_blocks : D;
-        for (int i = 0; i < first; ++i) blk[nb++] = (uint8_t)(row * D + i);
-        n_blocks -= first;
-        const int column = (int)s.below((uint32_t)D);
-        const int lim = n_blocks < D - 1 ? n_blocks : D - 1;
-        for (int i = 0, j = 0; j < lim; ++i) if (i != row) { blk[nb++] = (uint8_t)(i * D + column); j++; }
-        for (int i = 0; i < nb; ++i) {                      // remove wall cells from the free list
-            int k = 0;
-            while (avail[k] != blk[i]) ++k;
-            (void)list_take(avail, na, k);
-        }
-        {   // agent
-            const int c = list_take(avail, na, (int)s.below((uint32_t)na));
-            const int nm = (int)s.below((uint32_t)p.n_names[2]);
-            const int v = (int)s.below((uint32_t)T.nv(2, nm));
-            cells[c] = (uint16_t)(T.icon(2, nm, v) + 1);
-            agent_cell = c;
-        }
-        for (int i = 0; i < ng; ++i) {
-            const int c = list_take(avail, na, (int)s.below((uint32_t)na));
-            const int nm = (int)s.below((uint32_t)p.n_names[0]);
-            const int v = (int)s.below((uint32_t)T.nv(0, nm));
-            cells[c] = (uint16_t)(T.icon(0, nm, v) + 1);
-            goal_cell[i] = c; goal_name[i] = nm;
-        }
-        for (int i = 0; i < nb; ++i) {
-            const int nm = (int)s.below((uint32_t)p.n_names[1]);
-            const int v = (int)s.below((uint32_t)T.nv(1, nm));
-            cells[blk[i]] = (uint16_t)(T.icon(1, nm, v) + 1);
-        }
-    }
-
-    // ---- XWorld3DNavTarget.idle: goals reachable from the agent (blocks and the other goals are
-    // obstacles).  One flood fill of the empty cells from the agent; a goal is reachable iff one of its
-    // 4-neighbours is the agent cell or a flooded cell (a path's interior can hold neither blocks nor goals).
-    uint8_t *queue = avail;                       // free list no longer needed
-    uint64_t seen[4] = {0, 0, 0, 0};
-    auto mark = [&](int c) { seen[c >> 6] |= 1ull << (c & 63); };
-    auto is_marked = [&](int c) { return (seen[c >> 6] >> (c & 63)) & 1ull; };
-    int qh = 0, qt = 0;
-    queue[qt++] = (uint8_t)agent_cell; mark(agent_cell);
-    while (qh < qt) {
-        const int c = queue[qh++];
-        const int cx = c % D, cy = c / D;
-        if (cx > 0 && !is_marked(c - 1) && cells[c - 1] == 0) { mark(c - 1); queue[qt++] = (uint8_t)(c - 1); }
-        if (cx + 1 < D && !is_marked(c + 1) && cells[c + 1] == 0) { mark(c + 1); queue[qt++] = (uint8_t)(c + 1); }
-        if (cy > 0 && !is_marked(c - D) && cells[c - D] == 0) { mark(c - D); queue[qt++] = (uint8_t)(c - D); }
-        if (cy + 1 < D && !is_marked(c + D) && cells[c + D] == 0) { mark(c + D); queue[qt++] = (uint8_t)(c + D); }
-    }
-    int cand[XW_MAX_GOALS], nc = 0;
-    for (int i = 0; i < ng; ++i) {
-        const int c = goal_cell[i], cx = c % D, cy = c / D;
-        const bool r = (cx > 0 && is_marked(c - 1)) || (cx + 1 < D && is_marked(c + 1)) ||
-                       (cy > 0 && is_marked(c - D)) || (cy + 1 < D && is_marked(c + D));
-        if (r) cand[nc++] = i;
-    }
-    int target = -1;                              // reference asserts nc > 0 ("map too crowded?")
-    if (nc > 0) {
-        const int k = (int)s.below((uint32_t)nc);
-        int pick = cand[0];
-        for (int i = 1; i < nc; ++i) if (i == k) pick = cand[i];
-        target = goal_name[0];
-        for (int i = 1; i < ng; ++i) if (i == pick) target = goal_name[i];
-    }
-
-    // ---- write the env's state: cells shifted by the padding offset, brick padding walls outside ----
-    const uint16_t brick = (uint16_t)(T.icon(1, 0, 0) + 1);     // self.items["block"]["brick"][0]
-    uint16_t *g = p.grid + (size_t)e * MD * MD;
-    for (int y = 0; y < MD; ++y)
-        for (int x = 0; x < MD; ++x) {
-            const int lx = x - off, ly = y - off;
-            g[y * MD + x] = (lx >= 0 && ly >= 0 && lx < D && ly < D) ? cells[ly * D + lx] : brick;
-        }
-    p.agent_xy[e] = (agent_cell % D + off) | ((agent_cell / D + off) << 16);
-    p.task_state[e] = pack_task(target, STAGE_NAV, EV_NONE);
-    p.task_steps[e] = 0;
-    p.num_steps[e] = 0;
-    p.fresh[e] = 1;
-    if (!keep_done) p.done[e] = (uint8_t)done_code(p, 0, EV_NONE);
-}
-
-__global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int keep_done, const int32_t *count_now) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    int e;
-    if (mode == MODE_RESET_ALL) {
-        if (i >= p.n) return;
-        e = i;
-    } else {
-        if (i >= *count_now) return;
-        e = p.done_list[i];
-    }
-    IconTables T;
-    T.first[0] = p.name_first + p.name_first_off[0];
-    T.first[1] = p.name_first + p.name_first_off[1];
-    T.first[2] = p.name_first + p.name_first_off[2];
-    T.variants = p.name_variants;
-    xw_reset_env(p, T, e, keep_done != 0);
-}
-
 // ----------------------------------------------------------------- render --
 // One output chunk = 16 consecutive bytes of an env's planar frame = 4 dwords, each of which lies
 // inside one tile row (12 px = 3 dwords, frame rows are 3*D dwords).
@@ -407,37 +168,98 @@ __device__ __forceinline__ void xw_store_chunk(uint4 *frame0, int cc, int chunks
     __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(&q[(size_t)(ctx - 1) * chunks_per_frame]));
 }
 
-// all envs: persistent workgroups (one per CU), tile table resident in LDS, env tiles staged in LDS
+// all envs: persistent 1024-thread workgroups (one per CU: the table fills the LDS), tile table resident in
+// LDS, env tiles staged in LDS.  Four consecutive dwords of a frame touch at most two cells -- the cell of
+// dword 0 and the cell of dword 3 (cells change every 3 dwords; a row or channel wrap coincides with a cell
+// change) -- so a chunk needs two cell-code reads, not four; two chunks are in flight per lane so that the
+// second chunk's LDS reads overlap the first one's.  tools/render_lab.hip holds the A/B history: this shape
+// is ~13 % faster than one code read per dword and beats the position-major / segment-major variants.
 template <int DIM_T, int CH>
+__device__ __forceinline__ uint4 xw_expand_chunk2(const uint32_t *atlas, const uint16_t *g, int cc, int dim_rt) {
+    const int D = DIM_T ? DIM_T : dim_rt;
+    const int RD = XW_TILE_DW * D, RH = XW_TILE * D;
+    const int d0 = cc * 4;
+    int ch = d0 / (RH * RD);
+    const int rem = d0 - ch * (RH * RD);
+    int y = rem / RD;
+    int dx = rem - y * RD;
+    int cidx[4], aoff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cy = y / XW_TILE, py = y - cy * XW_TILE;
+        const int cx = dx / XW_TILE_DW, kk = dx - cx * XW_TILE_DW;
+        cidx[k] = cy * D + cx;
+        aoff[k] = ch * 36 + py * 3 + kk;
+        dx += 1;
+        if (dx == RD) { dx = 0; y += 1; if (y == RH) { y = 0; ch += 1; } }
+    }
+    const uint32_t ca = g[cidx[0]], cb = g[cidx[3]];
+    uint32_t out[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t code = cidx[k] == cidx[0] ? ca : cb;
+        out[k] = atlas[code * (CH * 36) + aoff[k]];                 // tile 0 = empty cell (white)
+    }
+    return make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+template <int DIM_T, int CH, bool CTX1>
 __global__ __launch_bounds__(1024) void xw_render_all_kernel(XwParams p, int tile_envs, int n_tiles, int atlas_dw) {
     extern __shared__ uint4 smem4[];
     uint32_t *s_atlas = reinterpret_cast<uint32_t *>(smem4);
     uint16_t *s_grid = reinterpret_cast<uint16_t *>(s_atlas + atlas_dw);
     const int D = DIM_T ? DIM_T : p.max_dim;
     const int cells = D * D;
-    uint8_t *s_fresh = reinterpret_cast<uint8_t *>(s_grid + tile_envs * cells);
+    uint8_t *s_fresh = reinterpret_cast<uint8_t *>(s_grid + (tile_envs + 1) * cells);
     const int tid = threadIdx.x;
-    const int ctx = p.context;
+    const int ctx = CTX1 ? 1 : p.context;
     const int cpf = CH * 9 * cells;                       // 16-byte chunks per frame: C*144*D*D/16
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.atlas);
         for (int i = tid; i < atlas_dw / 4; i += 1024) smem4[i] = src[i];
     }
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int e0 = tile * tile_envs;
-        const int ne = min(tile_envs, p.n - e0);
+    // Each workgroup owns one contiguous range of the batch's 16-byte chunks [g_lo, g_hi), cut at 1 KiB
+    // boundaries (64 chunks = one wavefront store) and balanced to +-1 KiB for ANY workgroup count.  Ranges
+    // ignore env boundaries on purpose: an env frame is 16-byte but not 128-byte aligned (7x7x3: 21 168 B),
+    // and wave stores that straddle cache lines cost ~20 % of the write bandwidth (measured: 181 vs 148 us).
+    const long long total_chunks = (long long)p.n * cpf;
+    const long long units = (total_chunks + 63) / 64;
+    const long long g_lo = units * blockIdx.x / gridDim.x * 64;
+    long long g_hi = units * (blockIdx.x + 1) / gridDim.x * 64;
+    if (g_hi > total_chunks) g_hi = total_chunks;
+    const long long win = (long long)tile_envs * cpf;
+    for (long long w0 = g_lo; w0 < g_hi; w0 += win) {
+        const long long w1 = w0 + win < g_hi ? w0 + win : g_hi;
+        const int e_first = (int)(w0 / cpf), e_last = (int)((w1 - 1) / cpf);
+        const int ne = e_last - e_first + 1;                           // <= tile_envs + 1
         __syncthreads();
-        const uint16_t *gsrc = p.grid + (size_t)e0 * cells;
+        const uint16_t *gsrc = p.grid + (size_t)e_first * cells;
         for (int i = tid; i < ne * cells; i += 1024) s_grid[i] = gsrc[i];
-        if (ctx > 1 && tid < ne) { s_fresh[tid] = p.fresh[e0 + tid]; }
+        if (!CTX1 && tid < ne) s_fresh[tid] = p.fresh[e_first + tid];  // cleared by the next step kernel
         __syncthreads();
-        if (ctx > 1 && tid < ne) p.fresh[e0 + tid] = 0;
-        const int total = ne * cpf;
-        for (int c = tid; c < total; c += 1024) {
-            const int le = c / cpf, cc = c - le * cpf;
-            const uint4 v = xw_expand_chunk<DIM_T, CH>(s_atlas, s_grid + le * cells, cc, D);
-            uint4 *frame0 = reinterpret_cast<uint4 *>(p.obs) + (size_t)(e0 + le) * ctx * cpf;
-            xw_store_chunk(frame0, cc, cpf, ctx, ctx > 1 ? s_fresh[le] != 0 : false, v);
+        const unsigned base = (unsigned)(w0 - (long long)e_first * cpf);   // chunk offset of w0 inside env e_first
+        const int span = (int)(w1 - w0);
+        uint4 *win_obs = reinterpret_cast<uint4 *>(p.obs) + w0;             // CTX1: frames are back to back
+        for (int c0 = tid; c0 < span; c0 += 2048) {
+            const int c1 = c0 + 1024;
+            const bool has1 = c1 < span;
+            const unsigned a0 = base + (unsigned)c0, a1 = base + (unsigned)(has1 ? c1 : c0);
+            const int le0 = (int)(a0 / (unsigned)cpf), cc0 = (int)(a0 - (unsigned)le0 * (unsigned)cpf);
+            const int le1 = (int)(a1 / (unsigned)cpf), cc1 = (int)(a1 - (unsigned)le1 * (unsigned)cpf);
+            const uint4 v0 = xw_expand_chunk2<DIM_T, CH>(s_atlas, s_grid + le0 * cells, cc0, D);
+            const uint4 v1 = xw_expand_chunk2<DIM_T, CH>(s_atlas, s_grid + le1 * cells, cc1, D);
+            if (CTX1) {
+                u32x4 n0 = {v0.x, v0.y, v0.z, v0.w};
+                __builtin_nontemporal_store(n0, reinterpret_cast<u32x4 *>(win_obs + c0));
+                if (has1) {
+                    u32x4 n1 = {v1.x, v1.y, v1.z, v1.w};
+                    __builtin_nontemporal_store(n1, reinterpret_cast<u32x4 *>(win_obs + c1));
+                }
+            } else {
+                uint4 *obs4 = reinterpret_cast<uint4 *>(p.obs);
+                xw_store_chunk(obs4 + (size_t)(e_first + le0) * ctx * cpf, cc0, cpf, ctx, s_fresh[le0] != 0, v0);
+                if (has1) xw_store_chunk(obs4 + (size_t)(e_first + le1) * ctx * cpf, cc1, cpf, ctx, s_fresh[le1] != 0, v1);
+            }
         }
     }
 }
@@ -477,30 +299,65 @@ hipError_t xw_render_prepare(int device) {
     return hipSuccess;
 }
 
-template <int DIM_T, int CH>
-static hipError_t render_all(const XwParams &p, hipStream_t s) {
+// launch configuration shared by both render_all variants: how many grids fit next to the table in LDS,
+// and how many persistent workgroups the chip holds (LDS-limited: 1 per CU for the colour NAV palette)
+struct RenderPlan { int tile_envs, n_tiles, atlas_dw, n_blocks; size_t lds; };
+
+template <int CH>
+static hipError_t plan_render(const XwParams &p, int tile_cap, RenderPlan &r) {
     const int cells = p.max_dim * p.max_dim;
-    const int atlas_dw = (p.n_icons + 1) * CH * 36;
-    const size_t atlas_bytes = (size_t)atlas_dw * 4;
+    r.atlas_dw = (p.n_icons + 1) * CH * 36;
+    const size_t atlas_bytes = (size_t)r.atlas_dw * 4;
     const size_t lds_cap = g_max_lds ? g_max_lds : 65536;
-    const size_t per_env = (size_t)cells * 2 + 1;
+    const size_t per_env = (size_t)cells * 2 + 1;          // cell codes + fresh flag
     if (atlas_bytes + per_env + 64 > lds_cap) return hipErrorInvalidValue;
-    int tile_envs = (int)((lds_cap - atlas_bytes - 64) / per_env);
-    if (tile_envs > 16) tile_envs = 16;
-    // even number of cells*tile so the fresh bytes start aligned; nothing else depends on it
-    const int n_tiles = (p.n + tile_envs - 1) / tile_envs;
-    const size_t lds = atlas_bytes + (size_t)tile_envs * per_env + 16;
-    auto kern = xw_render_all_kernel<DIM_T, CH>;
-    static size_t configured = 0;
+    r.tile_envs = (int)((lds_cap - atlas_bytes - 64) / per_env) - 1;
+    if (r.tile_envs > tile_cap) r.tile_envs = tile_cap;
+    r.n_tiles = (p.n + r.tile_envs - 1) / r.tile_envs;
+    r.lds = atlas_bytes + (size_t)(r.tile_envs + 1) * per_env + 16;      // a chunk window can overlap tile_envs + 1 envs
+    const int cus = g_num_cus ? g_num_cus : 256;
+    int per_cu = (int)(lds_cap / r.lds);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 1) per_cu = 1;                            // 1024-thread groups: one per CU keeps the tile split even
+    // Leave one CU per XCD without a render workgroup: the reset kernel's few latency-bound wavefronts run
+    // beside this kernel (side stream) and are 3.5x slower when they must share a CU with 16 render waves
+    // (workgroup b is placed on XCD b % 8, so cus - 8 groups leave exactly one free CU in every XCD).
+    int want = cus * per_cu;
+    if (want >= 64) want -= 8;
+    if (const char *ev = getenv("XWB_RENDER_BLOCKS")) { const int v = atoi(ev); if (v > 0) want = v; }
+    const int n_env_groups = (p.n + 3) / 4;                // at least ~4 envs per workgroup
+    r.n_blocks = n_env_groups < want ? n_env_groups : want;
+    return hipSuccess;
+}
+
+template <typename K>
+static hipError_t allow_big_lds(K kern, size_t lds, size_t &configured) {
     if (lds > 65536 && configured < lds) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(g_max_lds ? g_max_lds : lds));
         if (err != hipSuccess) return err;
-        configured = lds_cap;
+        configured = g_max_lds ? g_max_lds : lds;
     }
-    const int cus = g_num_cus ? g_num_cus : 256;
-    dim3 grid(n_tiles < cus ? n_tiles : cus), block(1024);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, p, tile_envs, n_tiles, atlas_dw);
+    return hipSuccess;
+}
+
+template <int DIM_T, int CH>
+static hipError_t render_all(const XwParams &p, hipStream_t s) {
+    RenderPlan r;
+    hipError_t err = plan_render<CH>(p, 16, r);
+    if (err != hipSuccess) return err;
+    if (p.context == 1) {
+        auto kern = xw_render_all_kernel<DIM_T, CH, true>;
+        static size_t configured = 0;
+        if ((err = allow_big_lds(kern, r.lds, configured)) != hipSuccess) return err;
+        hipLaunchKernelGGL(kern, dim3(r.n_blocks), dim3(1024), r.lds, s, p, r.tile_envs, r.n_tiles, r.atlas_dw);
+    } else {
+        auto kern = xw_render_all_kernel<DIM_T, CH, false>;
+        static size_t configured = 0;
+        if ((err = allow_big_lds(kern, r.lds, configured)) != hipSuccess) return err;
+        hipLaunchKernelGGL(kern, dim3(r.n_blocks), dim3(1024), r.lds, s, p, r.tile_envs, r.n_tiles, r.atlas_dw);
+    }
     return hipGetLastError();
 }
 
@@ -523,12 +380,6 @@ static hipError_t render_dispatch(const XwParams &p, int indexed, hipStream_t s)
 
 hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s) {
     return p.channels == 3 ? render_dispatch<3>(p, indexed, s) : render_dispatch<1>(p, indexed, s);
-}
-
-hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s) {
-    dim3 grid((p.n + 63) / 64), block(64);
-    hipLaunchKernelGGL(xw_reset_kernel, grid, block, 0, s, p, mode, p.auto_reset, (const int32_t *)p.done_count);
-    return hipGetLastError();
 }
 
 hipError_t launch_xw_compact(const XwParams &p, int mode, hipStream_t s) {

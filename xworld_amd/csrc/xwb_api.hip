@@ -53,6 +53,8 @@ struct xwb_sim {
     int count_sel = 0;
     bool profiling = false;
     KernelTimer t_render, t_step, t_reset;
+    hipStream_t side = nullptr;            // reset of finished envs runs here, beside render_all
+    hipEvent_t ev_step = nullptr, ev_reset = nullptr;
     // common device buffers
     int32_t *d_actions = nullptr, *d_num_steps = nullptr, *d_err = nullptr, *d_reset_count = nullptr;
     uint32_t *d_episode = nullptr;
@@ -250,6 +252,9 @@ int xw_setup(xwb_sim *s) {
     HIP_TRY(hipMemcpy(s->d_name_variants, variants.data(), variants.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_atlas, atlas.data(), atlas.size(), hipMemcpyHostToDevice));
     HIP_TRY(xw_render_prepare(c.device));
+    HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_step, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_reset, hipEventDisableTiming));
 
     XwParams &p = s->xw;
     p.n = n; p.context = c.context; p.max_steps = c.max_steps; p.act_rep = 1; p.auto_reset = 0;
@@ -260,6 +265,7 @@ int xw_setup(xwb_sim *s) {
     p.icon_type = s->d_icon_type; p.icon_name = s->d_icon_name;
     p.name_first = s->d_name_first; p.name_variants = s->d_name_variants;
     for (int t = 0; t < 3; ++t) { p.n_names[t] = n_names[t]; p.name_first_off[t] = off[t]; }
+    p.name_first_len = (int)first.size(); p.name_variants_len = (int)variants.size();
     p.atlas = s->d_atlas;
     p.actions = nullptr; p.mask = nullptr; p.actions_out = s->d_actions;
     p.grid = s->d_grid; p.agent_xy = s->d_agent; p.task_steps = s->d_task_steps; p.task_state = s->d_task_state;
@@ -338,13 +344,23 @@ XwParams xw_params(xwb_sim *s) {
     return p;
 }
 
-// xworld: reset the compacted list (or all), then re-render those envs
-int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t st) {
+// xworld: reset the compacted list (or all), then re-render those envs.
+// `beside_render`: the list comes from the step kernel that was just launched on `st` followed by render_all;
+// the (latency-bound, two-wavefront) reset kernel then runs on the side stream as soon as the step kernel is
+// done, i.e. *beside* render_all.  render_all may read grid rows of finished envs while they are being
+// regenerated; those envs' frames are rewritten in full by render(list) below, which waits for both.
+int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t st, bool beside_render = false) {
     XwParams p = xw_params(s);
     p.auto_reset = keep_done ? 1 : 0;
-    timer_begin(s, s->t_reset, st);
-    HIP_TRY(launch_xw_reset(p, mode, st));
-    timer_end(s, s->t_reset, st);
+    hipStream_t rs = beside_render ? s->side : st;
+    if (beside_render) HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
+    timer_begin(s, s->t_reset, rs);
+    HIP_TRY(launch_xw_reset(p, mode, rs));
+    timer_end(s, s->t_reset, rs);
+    if (beside_render) {
+        HIP_TRY(hipEventRecord(s->ev_reset, s->side));
+        HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
+    }
     if (render) {
         if (mode == MODE_RESET_ALL) {
             timer_begin(s, s->t_render, st);
@@ -381,6 +397,7 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         HIP_TRY(launch_xw_step(p, st));
         timer_end(s, s->t_step, st);
         s->list_valid = true;
+        if (!autoreset) HIP_TRY(hipEventRecord(s->ev_step, st));
         if (autoreset) {
             int rc = xw_reset_list(s, MODE_RESET_DONE, true, false, st);
             if (rc) return rc;
@@ -506,6 +523,9 @@ int xwb_create(const xwb_config *cfg, xwb_sim **out) {
 int xwb_destroy(xwb_sim *s) {
     if (!s) return XWB_OK;
     for (void *p : s->allocs) (void)hipFree(p);
+    if (s->side) (void)hipStreamDestroy(s->side);
+    if (s->ev_step) (void)hipEventDestroy(s->ev_step);
+    if (s->ev_reset) (void)hipEventDestroy(s->ev_reset);
     for (KernelTimer *t : {&s->t_render, &s->t_step, &s->t_reset})
         for (auto &ep : t->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     delete s;
@@ -529,8 +549,9 @@ int xwb_reset_done(xwb_sim *s, void *stream) {
         HIP_TRY(hipMemsetAsync(p.done_count, 0, sizeof(int32_t), st));
         HIP_TRY(launch_xw_compact(p, MODE_RESET_DONE, st));
     }
+    const bool beside = s->list_valid;
     s->list_valid = false;
-    return xw_reset_list(s, MODE_RESET_DONE, false, true, st);
+    return xw_reset_list(s, MODE_RESET_DONE, false, true, st, beside);
 }
 
 int xwb_reset_masked(xwb_sim *s, const uint8_t *mask_dev, void *stream) {

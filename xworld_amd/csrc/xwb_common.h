@@ -14,8 +14,11 @@ namespace xwb {
 // counter = (block index, episode, stream id, 0); draws are successive words.
 // stream 0 = reset decisions of that episode, stream 1 = built-in random policy
 // (block index = rollout step).  DESIGN.md "xwb-rng-v1".
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#ifndef XWB_PHILOX_ATTR
+#define XWB_PHILOX_ATTR __forceinline__
+#endif
+__device__ XWB_PHILOX_ATTR uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -26,40 +29,40 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += W0; k1 += W1;
     }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    return make_uint4(c0, c1, c2, c3);
 }
 
 struct Stream {
     uint32_t k0, k1, blk, episode, sid;
-    uint32_t buf[4];
+    uint4 buf;
     int have;
     __device__ __forceinline__ void init(uint32_t seed, uint32_t gid, uint32_t ep, uint32_t stream_id) {
         k0 = seed; k1 = gid; blk = 0; episode = ep; sid = stream_id; have = 0;
     }
     __device__ __forceinline__ uint32_t u32() {
         if (have == 0) {
-            philox4x32_10(blk, episode, sid, 0u, k0, k1, buf);
+            buf = philox4x32_10(blk, episode, sid, 0u, k0, k1);
             blk += 1; have = 4;
         }
-        // select without dynamic indexing of a register array
-        int i = 4 - have;
-        uint32_t v = i == 0 ? buf[0] : (i == 1 ? buf[1] : (i == 2 ? buf[2] : buf[3]));
+        const int i = 4 - have;
+        const uint32_t v = i == 0 ? buf.x : (i == 1 ? buf.y : (i == 2 ? buf.z : buf.w));
         have -= 1;
         return v;
     }
-    // uniform in [0, n): multiply-shift; consumes a draw only when n > 1
+    // uniform in [0, n): multiply-shift.  Always consumes exactly one draw (also for n <= 1), so the
+    // number of draws consumed up to any program point is the same for every lane of a wavefront and
+    // the Philox refill branch stays wave-uniform.
     __device__ __forceinline__ uint32_t below(uint32_t n) {
-        if (n <= 1) return 0;
-        return __umulhi(u32(), n);
+        const uint32_t v = u32();
+        return n <= 1 ? 0u : __umulhi(v, n);
     }
     // uniform float in [0, 1): 24 bits
     __device__ __forceinline__ float unit() { return (float)(u32() >> 8) * (1.0f / 16777216.0f); }
 };
 
 __device__ __forceinline__ int policy_action(uint32_t policy_seed, uint32_t gid, uint32_t step, int num_actions) {
-    uint32_t o[4];
-    philox4x32_10(step, 0u, 1u, 0u, policy_seed, gid, o);
-    return (int)__umulhi(o[0], (uint32_t)num_actions);
+    const uint4 o = philox4x32_10(step, 0u, 1u, 0u, policy_seed, gid);
+    return (int)__umulhi(o.x, (uint32_t)num_actions);
 }
 
 // GameOverCode bits (simulator.h:42-48)
@@ -131,6 +134,7 @@ struct XwParams {
     const int16_t *name_variants;
     int n_names[3];
     int name_first_off[3];       // start of each type's offset table inside name_first
+    int name_first_len, name_variants_len;
     const uint32_t *atlas;       // [n_icons][channels][12][3] dwords (tile table)
     const int32_t *actions;
     const uint8_t *mask;
