@@ -143,7 +143,9 @@ def main():
     def exchange():
         if world == 1:
             return
-        results(sim.reward, sim.game_over_codes)
+        # finish the gather of the previous step (it ran beside this step's kernels), start this step's
+        results.finish()
+        results.start(sim.reward, sim.game_over_codes)
         if args.gather_screens:
             sharding.gather_slabs(sim.obs, screens_all, counts, rank)
 
@@ -156,6 +158,8 @@ def main():
         exchange()
 
     def fence():
+        if results is not None:
+            results.finish()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

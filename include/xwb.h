@@ -44,6 +44,10 @@ enum {
 /* games selected by name in SimulatorInterface::SimulatorInterface, simulator_interface.cpp:41-56 */
 enum { XWB_SIMPLE_GAME = 0, XWB_SIMPLE_RACE = 1, XWB_XWORLD2D = 2 };
 
+/* action id that leaves an env out of a xwb_step call (its state, reward, game_over and observation
+ * are not touched): lets a per-env SimulatorInterface view step one slot of a batch */
+#define XWB_ACTION_SKIP (-1)
+
 /* GameOverCode, simulator.h:42-48 */
 enum { XWB_ALIVE = 0, XWB_MAX_STEP = 1, XWB_DEAD = 2, XWB_SUCCESS = 4, XWB_LOST_LIFE = 8 };
 
@@ -115,12 +119,19 @@ int xwb_reset_done(xwb_sim *sim, void *stream);
 /* same, for an explicit device mask (mask_dev[e] != 0 -> reset env e) */
 int xwb_reset_masked(xwb_sim *sim, const uint8_t *mask_dev, void *stream);
 
+/* reset_game of ONE env (per-slot SimulatorInterface views) */
+int xwb_reset_env(xwb_sim *sim, int32_t env, void *stream);
+
 /* SimulatorInterface::take_actions(actions, act_rep, false) for every env, simulator_interface.cpp:126-137:
  * GameSimulator::take_actions (num_steps_++ once, act_rep x take_action) -> teacher -> make_context_screens.
  * actions_dev: int32[num_envs] ("action" id of each env's StatePacket), or NULL to draw each env's action
  * from the built-in uniform random policy (xwb-rng-v1 stream 1; the actions used are kept in xwb_actions_dev).
  * Out-of-range action ids set the env's error flag (see xwb_check_errors) and leave that env untouched. */
 int xwb_step(xwb_sim *sim, const int32_t *actions_dev, int32_t act_rep, void *stream);
+
+/* xwb_step with the action ids in HOST memory (int32[num_envs]): copied to the device on `stream` first
+ * (4 bytes per env over PCIe; the only host->device traffic of a step). */
+int xwb_step_host(xwb_sim *sim, const int32_t *actions_host, int32_t act_rep, void *stream);
 
 /* xwb_step followed by xwb_reset_done in one call, with a single render of the final state
  * (the observation of a finished env is the first frame of its next episode; reward / game_over

@@ -224,3 +224,26 @@ def test_simple_race_full_size_c3(oracle):
     print("C3 reward bit mismatches:", bad, "of", n * steps)
     assert bad <= max(1, int(1e-6 * n * steps))
     sim.close()
+
+
+def test_action_skip_leaves_env_untouched(oracle):
+    """XWB_ACTION_SKIP (-1): a per-slot view steps one env; the others keep state, reward, code and screen."""
+    torch = _torch()
+    from xworld_amd.batched import BatchedSimulator
+    n = 256
+    sim = BatchedSimulator("simple_game", {"array_size": 16, "context": 2}, num_envs=n)
+    g = oracle.SimpleGame(16, context=2)
+    g.reset_game()
+    before = sim.obs.clone()
+    acts = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    for a in (1, 1, 0, 1):
+        acts[7] = a
+        sim.step(acts)
+        r = np.float32(g.take_actions(a))
+        assert np.float32(float(sim.reward[7])) == r and sim.check_errors() == 0
+    obs = sim.obs.cpu().numpy().reshape(n, -1)
+    assert np.array_equal(obs[7], g.state_screen())
+    keep = torch.ones(n, dtype=torch.bool, device="cuda")
+    keep[7] = False
+    assert torch.equal(sim.obs[keep], before[keep]) and int(sim.num_steps[keep].sum()) == 0
+    sim.close()

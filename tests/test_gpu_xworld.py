@@ -320,3 +320,30 @@ def test_reference_maps_render_through_product(oracle):
         ow.load_map([tuple(x) for x in m["entities"]], 8, target_pick=0)
         assert np.array_equal(sim.env_obs(e).reshape(3, 96, 96), ow.screen()), e
     sim.close()
+
+
+def test_action_skip_and_reset_env(oracle):
+    """One slot of a batch stepped / reset alone (context ring of the other envs must not move)."""
+    torch = _torch()
+    import ctypes as C
+    from xworld_amd import lib
+    n = 64
+    sim, pal, cfg = _make(oracle, "nav8", n, seed=77, context=2)
+    w = oracle.XWorld(pal, render=True, **cfg)
+    w.reset_game(5, 0)
+    before = sim.obs.clone()
+    acts = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    for a in (0, 3, 3, 1, 2):
+        acts[5] = a
+        sim.step(acts)
+        assert np.float32(float(sim.reward[5])) == np.float32(w.take_actions(a))
+    assert np.array_equal(sim.obs[5].cpu().numpy(), w.state_screen())
+    keep = torch.ones(n, dtype=torch.bool, device="cuda")
+    keep[5] = False
+    assert torch.equal(sim.obs[keep], before[keep])
+    lib.check(sim.L.xwb_reset_env(sim.h, 5, None))
+    w.reset_game(5, 1)
+    assert np.array_equal(sim.obs[5].cpu().numpy(), w.state_screen())
+    assert np.array_equal(sim.env_grid(5).astype(np.int32), w.grid())
+    assert torch.equal(sim.obs[keep], before[keep])
+    sim.close()

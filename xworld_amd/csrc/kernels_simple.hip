@@ -81,7 +81,9 @@ __global__ __launch_bounds__(256) void sg_kernel(SgParams p) {
         if (p.mode == MODE_STEP) {
             int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step, 2);
             p.actions_out[e] = a;
-            if ((unsigned)a >= 2u) {                        // CHECK_LT(action_id, _legal_actions.size())
+            if (a == ACTION_SKIP) {
+                // this env does not take part in the call
+            } else if ((unsigned)a >= 2u) {                 // CHECK_LT(action_id, _legal_actions.size())
                 atomicAdd(p.err_count, 1);
             } else {
                 steps += 1;                                 // GameSimulator::take_actions: num_steps_++ once
@@ -250,7 +252,9 @@ __global__ __launch_bounds__(256) void race_kernel(RaceParams p) {
     if (p.mode == MODE_STEP) {
         int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step, p.n_legal);
         p.actions_out[e] = a;
-        if ((unsigned)a >= (unsigned)p.n_legal) {
+        if (a == ACTION_SKIP) {
+            // this env does not take part in the call
+        } else if ((unsigned)a >= (unsigned)p.n_legal) {
             atomicAdd(p.err_count, 1);
         } else {
             int action = p.legal[a];               // _legal_actions[action_id], cpp:474

@@ -45,10 +45,13 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
     if (e == 0) *p.done_count_next = 0;        // double-buffered done counter: zero the next step's
     bool is_done = false;
     if (e < p.n) {
-        p.fresh[e] = 0;                        // reset -> render hand-off flag of the previous step is spent
         int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step, 4);
         p.actions_out[e] = a;
-        if ((unsigned)a >= 4u) {               // CHECK_LT(action_idx, get_num_actions())
+        // render hand-off flag: 0 = env untouched (leave its context ring alone), 1 = stepped, 2 = fresh (reset)
+        p.fresh[e] = (unsigned)a < 4u ? 1 : 0;
+        if (a == ACTION_SKIP) {
+            // XWB_ACTION_SKIP: this env does not take part in the call (per-slot SimulatorInterface views)
+        } else if ((unsigned)a >= 4u) {        // CHECK_LT(action_idx, get_num_actions())
             atomicAdd(p.err_count, 1);
         } else {
             const int D = p.max_dim;
@@ -156,9 +159,12 @@ __device__ __forceinline__ uint4 xw_expand_chunk(const uint32_t *atlas, const ui
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void xw_store_chunk(uint4 *frame0, int cc, int chunks_per_frame, int ctx, bool fresh, uint4 v) {
+// flag: 0 = env untouched by this call (nothing to do), 1 = stepped (ring shift), 2 = fresh (init_screen)
+__device__ __forceinline__ void xw_store_chunk(uint4 *frame0, int cc, int chunks_per_frame, int ctx, int flag, uint4 v) {
     uint4 *q = frame0 + cc;
     if (ctx > 1) {
+        if (flag == 0) return;
+        const bool fresh = flag == 2;
         // shift_context: oldest first; init_screen: zeros.  The same lane owns offset cc in every frame.
         if (fresh) for (int f = 0; f + 1 < ctx; ++f) q[(size_t)f * chunks_per_frame] = make_uint4(0, 0, 0, 0);
         else for (int f = 0; f + 1 < ctx; ++f) q[(size_t)f * chunks_per_frame] = q[(size_t)(f + 1) * chunks_per_frame];
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(1024) void xw_render_all_kernel(XwParams p, int til
         __syncthreads();
         const uint16_t *gsrc = p.grid + (size_t)e_first * cells;
         for (int i = tid; i < ne * cells; i += 1024) s_grid[i] = gsrc[i];
-        if (!CTX1 && tid < ne) s_fresh[tid] = p.fresh[e_first + tid];  // cleared by the next step kernel
+        if (!CTX1 && tid < ne) s_fresh[tid] = p.fresh[e_first + tid];  // rewritten by the next step kernel
         __syncthreads();
         const unsigned base = (unsigned)(w0 - (long long)e_first * cpf);   // chunk offset of w0 inside env e_first
         const int span = (int)(w1 - w0);
@@ -257,8 +263,8 @@ __global__ __launch_bounds__(1024) void xw_render_all_kernel(XwParams p, int til
                 }
             } else {
                 uint4 *obs4 = reinterpret_cast<uint4 *>(p.obs);
-                xw_store_chunk(obs4 + (size_t)(e_first + le0) * ctx * cpf, cc0, cpf, ctx, s_fresh[le0] != 0, v0);
-                if (has1) xw_store_chunk(obs4 + (size_t)(e_first + le1) * ctx * cpf, cc1, cpf, ctx, s_fresh[le1] != 0, v1);
+                xw_store_chunk(obs4 + (size_t)(e_first + le0) * ctx * cpf, cc0, cpf, ctx, s_fresh[le0], v0);
+                if (has1) xw_store_chunk(obs4 + (size_t)(e_first + le1) * ctx * cpf, cc1, cpf, ctx, s_fresh[le1], v1);
             }
         }
     }
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
         uint4 *frame0 = reinterpret_cast<uint4 *>(p.obs) + (size_t)e * ctx * cpf;
         for (int cc = threadIdx.x; cc < cpf; cc += 256) {
             const uint4 v = xw_expand_chunk<DIM_T, CH>(p.atlas, s_grid, cc, D);
-            xw_store_chunk(frame0, cc, cpf, ctx, true, v);
+            xw_store_chunk(frame0, cc, cpf, ctx, 2, v);
         }
         if (threadIdx.x == 0) p.fresh[e] = 0;
     }

@@ -56,6 +56,8 @@ struct xwb_sim {
     hipStream_t side = nullptr;            // reset of finished envs runs here, beside render_all
     hipEvent_t ev_step = nullptr, ev_reset = nullptr;
     // common device buffers
+    int32_t *d_actions_in = nullptr;       // staging for xwb_step_host
+    uint8_t *d_mask = nullptr;             // staging for xwb_reset_env
     int32_t *d_actions = nullptr, *d_num_steps = nullptr, *d_err = nullptr, *d_reset_count = nullptr;
     uint32_t *d_episode = nullptr;
     float *d_reward = nullptr;
@@ -488,6 +490,8 @@ int xwb_create(const xwb_config *cfg, xwb_sim **out) {
             return bail(fail(XWB_ERR_ARG, "Unrecognized game type"));     // simulator_interface.cpp:82
     }
     if ((rc = dev_alloc(s, &s->d_actions, n, 0xff))) return bail(rc);
+    if ((rc = dev_alloc(s, &s->d_actions_in, n, 0xff))) return bail(rc);
+    if ((rc = dev_alloc(s, &s->d_mask, n))) return bail(rc);
     if ((rc = dev_alloc(s, &s->d_num_steps, n))) return bail(rc);
     if ((rc = dev_alloc(s, &s->d_err, 1))) return bail(rc);
     if ((rc = dev_alloc(s, &s->d_reset_count, 1))) return bail(rc);
@@ -566,9 +570,25 @@ int xwb_reset_masked(xwb_sim *s, const uint8_t *mask_dev, void *stream) {
     return xw_reset_list(s, MODE_RESET_MASK, false, true, st);
 }
 
+int xwb_reset_env(xwb_sim *s, int32_t env, void *stream) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
+    hipStream_t st = as_stream(stream);
+    HIP_TRY(hipMemsetAsync(s->d_mask, 0, (size_t)s->n, st));
+    HIP_TRY(hipMemsetAsync(s->d_mask + env, 1, 1, st));
+    return xwb_reset_masked(s, s->d_mask, stream);
+}
+
 int xwb_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, void *stream) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
     return do_step(s, actions_dev, act_rep, false, as_stream(stream));
+}
+
+int xwb_step_host(xwb_sim *s, const int32_t *actions_host, int32_t act_rep, void *stream) {
+    if (!s || !actions_host) return fail(XWB_ERR_ARG, "NULL argument");
+    hipStream_t st = as_stream(stream);
+    HIP_TRY(hipMemcpyAsync(s->d_actions_in, actions_host, sizeof(int32_t) * (size_t)s->n, hipMemcpyHostToDevice, st));
+    return do_step(s, s->d_actions_in, act_rep, false, st);
 }
 
 int xwb_step_autoreset(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, void *stream) {
@@ -734,7 +754,7 @@ int xwb_xw_load_map(xwb_sim *s, int32_t env, const uint16_t *grid_host, int32_t 
     int32_t axy = agent_x | (agent_y << 16);
     int32_t ts = (target_name & 0xffff) | (1 << 16);
     int32_t zero = 0;
-    uint8_t z8 = 0, one = 1;
+    uint8_t z8 = 0, one = 2;
     HIP_TRY(hipMemcpy(s->d_grid + (size_t)env * cells, grid_host, cells * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_agent + env, &axy, 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_task_state + env, &ts, 4, hipMemcpyHostToDevice));

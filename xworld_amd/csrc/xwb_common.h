@@ -68,6 +68,9 @@ __device__ __forceinline__ int policy_action(uint32_t policy_seed, uint32_t gid,
 // GameOverCode bits (simulator.h:42-48)
 enum : int { ALIVE = 0, MAX_STEP = 1, DEAD = 2, SUCCESS = 4, LOST_LIFE = 8 };
 
+// XWB_ACTION_SKIP (include/xwb.h): the env does not take part in this step call
+enum : int { ACTION_SKIP = -1 };
+
 // which envs a state-changing kernel applies to
 enum : int { MODE_STEP = 0, MODE_RESET_ALL = 1, MODE_RESET_DONE = 2, MODE_RESET_MASK = 3 };
 

@@ -29,32 +29,59 @@ def shard_counts(total_envs, world_size):
 
 class ResultGather:
     """Per-step gather of (reward, game_over) to `dst`.  Equal shard sizes -> one dist.gather of a packed
-    [n, 2] float tensor; ragged shards -> point-to-point into slices."""
+    [n, 2] float tensor; ragged shards -> point-to-point into slices.
+
+    `start()` enqueues the exchange of the step that just finished and returns at once; `finish()` waits for
+    it (stream-side) and hands out the gathered tensors.  Calling finish() for step t only after step t+1 has
+    been enqueued lets the (latency-bound, few-hundred-KB) collective run beside the next step's kernels --
+    two packed/out buffers alternate so the in-flight exchange is never overwritten.  `__call__` = start + finish."""
 
     def __init__(self, counts, rank, device, dst=0, group=None):
         self.counts, self.rank, self.dst, self.group = list(counts), rank, dst, group
         self.world = len(counts)
         self.equal = len(set(counts)) == 1
         n = counts[rank]
-        self.packed = torch.empty((n, 2), dtype=torch.float32, device=device)
         self.total = sum(counts)
-        self.offsets = [sum(counts[:r]) for r in range(self.world)]
-        self.out = torch.empty((self.total, 2), dtype=torch.float32, device=device) if rank == dst else None
+        self.packed = [torch.empty((n, 2), dtype=torch.float32, device=device) for _ in range(2)]
+        self.out = [torch.empty((self.total, 2), dtype=torch.float32, device=device) if rank == dst else None
+                    for _ in range(2)]
+        self.slot = 0
+        self.pending = None          # (work handle or None, slot)
 
-    def __call__(self, reward, game_over):
-        self.packed[:, 0] = reward
-        self.packed[:, 1] = game_over.to(torch.float32)
+    def start(self, reward, game_over):
+        if self.pending is not None:
+            raise RuntimeError("ResultGather.start() called twice without finish()")
+        k = self.slot
+        self.slot ^= 1
+        packed, out = self.packed[k], self.out[k]
+        packed[:, 0] = reward
+        packed[:, 1] = game_over.to(torch.float32)
+        work = None
         if self.world == 1:
-            self.out.copy_(self.packed)
+            out.copy_(packed)
         elif self.equal:
             n = self.counts[0]
-            lst = [self.out[r * n:(r + 1) * n] for r in range(self.world)] if self.rank == self.dst else None
-            dist.gather(self.packed, lst, dst=self.dst, group=self.group)
+            lst = [out[r * n:(r + 1) * n] for r in range(self.world)] if self.rank == self.dst else None
+            work = dist.gather(packed, lst, dst=self.dst, group=self.group, async_op=True)
         else:
-            gather_slabs(self.packed, self.out, self.counts, self.rank, self.dst, self.group)
+            gather_slabs(packed, out, self.counts, self.rank, self.dst, self.group)
+        self.pending = (work, k)
+
+    def finish(self):
+        if self.pending is None:
+            return None, None
+        work, k = self.pending
+        self.pending = None
+        if work is not None:
+            work.wait()
         if self.rank != self.dst:
             return None, None
-        return self.out[:, 0], self.out[:, 1].to(torch.uint8)
+        out = self.out[k]
+        return out[:, 0], out[:, 1].to(torch.uint8)
+
+    def __call__(self, reward, game_over):
+        self.start(reward, game_over)
+        return self.finish()
 
 
 def gather_slabs(local, out_root, counts, rank, dst=0, group=None):
