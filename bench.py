@@ -65,6 +65,21 @@ def algorithmic_bytes(workload, sim):
     return 33 + 2 * d * d + obs, 2 * d * d + obs, "xw_render_all_kernel"
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs, gfx950 corrections applied by tools/summarize_prof.py); None if not profiled."""
+    best = None
+    for d in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        f = os.path.join(ROOT, "profiles", d, "traffic_%s.json" % workload)
+        if os.path.exists(f):
+            best = f
+    if not best:
+        return None, None
+    with open(best) as fh:
+        t = json.load(fh)
+    return t["traffic_bytes_per_launch"], os.path.relpath(best, ROOT)
+
+
 def cpu_baseline(workload, seconds_target=12.0):
     """The oracle (CPU restatement of the reference path, kind = "port") timed on this box's host cores,
     1 thread, on a bounded sample of the same workload (same loop: game_over? -> reset; get_state;
@@ -198,6 +213,7 @@ def main():
         total_envs = n_local * world
         value = total_envs * args.steps / dt_max
         achieved = n_local * per_launch / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
+        traffic, traffic_src = measured_traffic(args.workload) if n_local == WORKLOADS[args.workload][2] else (None, None)
         line = {
             "metric": "env-steps/sec (batched random policy)",
             "value": value,
@@ -217,7 +233,8 @@ def main():
                        "exchange": ("gather(reward,done)" + ("+gather(screens)" if args.gather_screens else ""))
                        if world > 1 else "none", "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel_name,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel_name,
                          "kernel_avg_us": kern_us, "kernel_launches": kern_n,
                          "algorithmic_bytes_per_launch": n_local * per_launch,
                          "algorithmic_bytes_per_env_step": per_step,

@@ -1,0 +1,92 @@
+"""The py_simulator-compatible surface on the GPU: the reference's example loops
+(python/examples/test_simple_game.py:15-30, test_simple_race.py:20-41, test_xworld.py:41-60) against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_simple_game_example_loop(oracle):
+    from xworld_amd.py_simulator import Simulator
+    game = Simulator.create("simple_game", {"array_size": 6})
+    ref = oracle.SimpleGame(6)
+    game.reset_game()
+    ref.reset_game()
+    assert game.get_num_actions() == 2 and game.get_screen_out_dimensions() == [1, 6, 1, 1]
+    rng = np.random.default_rng(1)
+    for _ in range(100):
+        over = game.game_over()
+        assert over == oracle.decode_game_over_code(ref.game_over())
+        if over != "alive":
+            game.reset_game()
+            ref.reset_game()
+            continue
+        state = game.get_state()
+        assert list(state.keys()) == ["screen"]
+        exp = (ref.state_screen().astype(np.float32) * np.float32(1 / 255.0)).tolist()   # float32 product, py_simulator.cpp:262-272
+        assert state["screen"] == exp
+        a = int(rng.integers(0, game.get_num_actions()))
+        r = game.take_actions({"action": a}, 1, False)
+        assert np.float32(r) == np.float32(ref.take_actions(a))
+        assert game.get_lives() == ref.get_lives() and game.get_num_steps() == ref.num_steps()
+    with pytest.raises(RuntimeError):
+        game.take_actions({}, 1, False)
+    with pytest.raises(RuntimeError):
+        game.take_actions({"action": 2}, 1, False)
+
+
+def test_simple_race_example_loop(oracle):
+    from xworld_amd.py_simulator import Simulator
+    opts = {"track_type": "straight", "track_width": 20.0, "track_length": 100.0, "track_radius": 30.0,
+            "race_full_manouver": False, "random": False, "difficulty": "easy", "pause_screen": False}
+    game = Simulator.create("simple_race", opts)
+    ref = oracle.SimpleRace()
+    game.reset_game()
+    ref.reset_game()
+    assert game.get_num_actions() == 2 and game.get_screen_out_dimensions() == [1, 4, 1, 1]
+    rng = np.random.default_rng(2)
+    for _ in range(150):
+        if game.game_over() != "alive":
+            assert game.game_over() == "dead" and ref.game_over() == 2 and game.get_lives() == 1
+            game.reset_game()
+            ref.reset_game()
+        state = game.get_state()
+        assert np.array_equal(np.float32(state["screen"]), ref.state_screen())
+        a = int(rng.integers(0, 2))
+        assert np.float32(game.take_actions({"action": a}, 1, False)) == np.float32(ref.take_actions(a))
+
+
+def test_xworld_example_loop(oracle):
+    from xworld_amd.py_simulator import Simulator
+    conf = os.path.join(ROOT, "xworld_amd", "confs", "navigation2d.json")
+    game = Simulator.create("xworld", {"xwd_conf_path": conf, "task_mode": "lang_acquisition", "context": 1,
+                                       "color": False, "seed": 4321})
+    pal = oracle.Palette(oracle.NAV_SUBTREES)
+    ref = oracle.XWorld(pal, render=True, map_kind=0, max_dim=8, dim=8, num_goals=4, num_blocks=16, color=0, seed=4321)
+    episode = 0
+    ref.reset_game(0, episode)
+    assert game.get_num_actions() == 4 and game.get_screen_out_dimensions() == [96, 96, 1, 1]
+    rng = np.random.default_rng(3)
+    for t in range(120):
+        over = game.game_over()
+        assert over == oracle.decode_game_over_code(ref.game_over())
+        if over != "alive":
+            game.reset_game()
+            episode += 1
+            ref.reset_game(0, episode)
+        state = game.get_state()
+        assert set(state.keys()) == {"screen", "sentence", "task", "event", "height", "width"}
+        assert state["height"] == "8" and state["width"] == "8" and state["sentence"] == "-"
+        exp = ref.state_screen().astype(np.float32).ravel() * np.float32(1 / 255.0)
+        assert np.array_equal(np.float32(state["screen"]), exp)
+        a = int(rng.integers(0, 4))
+        r = game.take_actions({"action": a}, 1, False)
+        assert np.float32(r) == np.float32(ref.take_actions(a))
+    # the Python default task_mode is "one_channel": the agent must also speak (xworld_simulator.cpp:211-212)
+    g2 = Simulator.create("xworld", {"xwd_conf_path": conf})
+    with pytest.raises(RuntimeError, match="speak"):
+        g2.take_actions({"action": 0}, 1, False)
+    assert g2.take_actions({"action": 0, "pred_sentence": "hello"}, 1, False) <= 0

@@ -1,41 +1,74 @@
 #!/usr/bin/env python3
-"""Condenses a tools/profile_gpu.sh output directory into a short text summary (kept under profiles/)."""
+"""Condenses a tools/profile_gpu.sh output directory into a short text summary + traffic.json (kept under profiles/)."""
 import csv
 import glob
+import json
 import os
 import sys
 
+FILL_BYTES = 693633024          # tools/hbm_write_ceiling.py buffer
 
-def main(out):
-    stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
-    print("== rocprofv3 --kernel-trace --stats (python bench.py --steps 100 --warmup 10) ==")
-    for f in stats:
+
+def counter_by_kernel(out, tag, counter):
+    agg = {}
+    for f in glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r.get("Counter_Name") != counter:
+                    continue
+                a = agg.setdefault(r.get("Kernel_Name", ""), [0, 0.0])
+                a[0] += 1
+                a[1] += float(r.get("Counter_Value", 0))
+    return agg
+
+
+def main(out, bench_args):
+    workload = "xworld7"
+    if "--workload" in bench_args:
+        workload = bench_args[bench_args.index("--workload") + 1]
+    print("== rocprofv3 --kernel-trace --stats (python bench.py --steps 100 --warmup 10 %s) ==" % " ".join(bench_args))
+    for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
         with open(f) as fh:
             rows = list(csv.DictReader(fh))
         print("%-70s %8s %14s %12s %8s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
         for r in rows[:12]:
             print("%-70s %8s %14s %12s %8s" % (r.get("Name", "")[:70], r.get("Calls"), r.get("TotalDurationNs"),
                                                r.get("AverageNs"), r.get("Percentage")))
+    per_kernel = {}
     for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-        files = glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True)
-        print("== rocprofv3 --pmc %s ==" % counter)
-        agg = {}
-        for f in files:
-            with open(f) as fh:
-                for r in csv.DictReader(fh):
-                    if r.get("Counter_Name") != counter:
-                        continue
-                    k = r.get("Kernel_Name", "")[:70]
-                    a = agg.setdefault(k, [0, 0.0])
-                    a[0] += 1
-                    a[1] += float(r.get("Counter_Value", 0))
+        agg = counter_by_kernel(out, tag, counter)
+        print("== rocprofv3 --pmc %s (raw counter, KiB per dispatch) ==" % counter)
         for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]:
-            print("%-70s dispatches %5d  %s per dispatch (raw counter units, KB): %.1f" % (k, n, counter, v / n))
+            print("%-70s dispatches %5d  %.1f" % (k[:70], n, v / n))
+            per_kernel.setdefault(k, {})[counter] = v / n * 1024.0
+    # calibration: bytes the counters report for a fill / copy of exactly FILL_BYTES
+    cal = {}
+    for tag, counter in (("cal_write", "WRITE_SIZE"), ("cal_fetch", "FETCH_SIZE")):
+        agg = counter_by_kernel(out, tag, counter)
+        print("== calibration: %s over tools/hbm_write_ceiling.py (buffers of %d B) ==" % (counter, FILL_BYTES))
+        for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:4]:
+            b = v / n * 1024.0
+            print("%-70s dispatches %5d  %.0f B per dispatch = %.3f x buffer" % (k[:70], n, b, b / FILL_BYTES))
+            cal.setdefault(counter, {})[k[:60]] = b / FILL_BYTES
+    dom = [k for k in per_kernel if "render_all" in k or "sg_kernel" in k or "race_kernel" in k]
+    if dom:
+        k = dom[0]
+        # write side: the fill kernels of the calibration report ~1.0 x -> WRITE_SIZE taken at face value;
+        # read side: FETCH_SIZE x 2 (gfx950 correction for 16 B/lane streaming reads, MI355X_MICROARCH.md "HBM")
+        w = per_kernel[k].get("WRITE_SIZE", 0.0)
+        f = per_kernel[k].get("FETCH_SIZE", 0.0)
+        traffic = {"workload": workload, "kernel": k[:80], "write_bytes_per_launch": w, "fetch_bytes_per_launch_raw": f,
+                   "fetch_bytes_per_launch_corrected": 2 * f, "traffic_bytes_per_launch": w + 2 * f,
+                   "calibration": cal, "source": os.path.basename(out)}
+        with open(os.path.join(out, "traffic.json"), "w") as fh:
+            json.dump(traffic, fh, indent=1)
+        print("== traffic ==")
+        print(json.dumps(traffic))
     log = os.path.join(out, "bench_under_rocprof.log")
     if os.path.exists(log):
         print("== bench line under rocprof ==")
-        print(open(log).read().strip().splitlines()[-1][:2000])
+        print(open(log).read().strip().splitlines()[-1][:2500])
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2:])

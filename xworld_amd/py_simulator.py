@@ -11,6 +11,8 @@ a batch exposes the tensor API through `.batch` (xworld_amd.batched.BatchedSimul
 """
 import os
 
+import numpy as np
+
 from . import lib
 from .batched import BatchedSimulator
 
@@ -78,8 +80,8 @@ class Simulator:
         d = {}
         obs = self.batch.env_obs(self._env)
         if obs.dtype.kind == "u":
-            scale = 1 / 255.0
-            d["screen"] = [float(x) * scale for x in obs.astype("float32")]
+            # `float scale = 1 / 255.0; l.append(x * scale)` with x a float: a float32 product (py_simulator.cpp:264-272)
+            d["screen"] = (obs.astype(np.float32) * np.float32(1 / 255.0)).tolist()
         else:
             d["screen"] = [float(x) for x in obs]
         if self.batch.name == "xworld":
