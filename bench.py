@@ -45,7 +45,7 @@ def make_sim(workload, n_envs, device, gid0):
     game, opts, _ = WORKLOADS[workload]
     opts = dict(opts)
     if game == "xworld":
-        opts["xwd_conf_path"] = os.path.join(ROOT, "xworld_amd", "confs", "navigation2d.json")
+        opts["xwd_conf_path"] = os.path.join(ROOT, "xworld_amd", "confs", "nav_target.json")
         opts["task_mode"] = "lang_acquisition"
     return BatchedSimulator(game, opts, num_envs=n_envs, device=device, env_gid0=gid0,
                             seed=0xC0FFEE, policy_seed=0x5EED)

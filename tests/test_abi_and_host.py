@@ -92,7 +92,7 @@ def test_palettes_and_conf():
     assert nav.icons64.shape == (347, 64, 64, 3)
     assert nav.names["block"] == ["brick"] and nav.names["agent"] == ["robot"]
     assert "shape" not in {m["subtree"] for m in nav.meta}
-    conf = assets.read_conf(os.path.join(ROOT, "xworld_amd", "confs", "navigation2d.json"))
+    conf = assets.read_conf(os.path.join(ROOT, "xworld_amd", "confs", "nav_target.json"))
     assert conf["map"] == "XWorldNav"
 
 

@@ -61,7 +61,7 @@ def test_simple_race_example_loop(oracle):
 
 def test_xworld_example_loop(oracle):
     from xworld_amd.py_simulator import Simulator
-    conf = os.path.join(ROOT, "xworld_amd", "confs", "navigation2d.json")
+    conf = os.path.join(ROOT, "xworld_amd", "confs", "nav_target.json")
     game = Simulator.create("xworld", {"xwd_conf_path": conf, "task_mode": "lang_acquisition", "context": 1,
                                        "color": False, "seed": 4321})
     pal = oracle.Palette(oracle.NAV_SUBTREES)

@@ -9,8 +9,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 CONF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xworld_amd", "confs")
-NAV = os.path.join(CONF, "navigation2d.json")
-WALLS = os.path.join(CONF, "walls7.json")
+NAV = os.path.join(CONF, "nav_target.json")
+WALLS = os.path.join(CONF, "walls_target.json")
 
 # (conf, options for the product, oracle cfg overrides)
 MAPS = {

@@ -7,7 +7,7 @@ import torch
 from xworld_amd.batched import BatchedSimulator
 
 n = 32768
-conf = os.path.join(ROOT, "xworld_amd", "confs", "navigation2d.json")
+conf = os.path.join(ROOT, "xworld_amd", "confs", "nav_target.json")
 sim = BatchedSimulator("xworld", {"xwd_conf_path": conf, "task_mode": "lang_acquisition", "max_dim": 7, "color": True}, num_envs=n)
 for k in (1, 2, 64, 115, 128, 1024, 8192, 32768):
     mask = torch.zeros(n, dtype=torch.uint8, device="cuda")

@@ -480,6 +480,53 @@ __global__ __launch_bounds__(1024) void lab_a9(XwParams p, int tile_envs, int n_
     }
 }
 
+// ---- variant J: S1-shaped render.  Short-lived workgroups in dispatch order, each owning EPB whole envs.  The
+// workgroup copies only the tiles its envs need (one slot per occupied cell + one white slot) from the L2-resident
+// table into LDS with 16-byte loads, then expands its envs' frames chunk-major exactly like the product kernel.
+template <int D, int CH, int BS, int EPB>
+__global__ __launch_bounds__(BS) void lab_j(XwParams p) {
+    constexpr int cells = D * D, cpf = CH * 9 * cells, TDW = CH * 36, RD = 3 * D, RH = 12 * D;
+    __shared__ uint4 s_tiles4[(EPB * cells + 1) * TDW / 4];      // slot 0 = white, slot 1 + le*cells + c = cell c of env le
+    __shared__ uint16_t s_code[EPB * cells];
+    uint32_t *s_tiles = reinterpret_cast<uint32_t *>(s_tiles4);
+    const int tid = threadIdx.x;
+    const int e0 = blockIdx.x * EPB;
+    const int ne = min(EPB, p.n - e0);
+    for (int i = tid; i < ne * cells; i += BS) s_code[i] = p.grid[(size_t)e0 * cells + i];
+    for (int i = tid; i < TDW / 4; i += BS) s_tiles4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    __syncthreads();
+    // tile copy: (cell, quad) items, 27 uint4 per tile for CH = 3
+    constexpr int QPT = TDW / 4;
+    const uint4 *atlas4 = reinterpret_cast<const uint4 *>(p.atlas);
+    for (int i = tid; i < ne * cells * QPT; i += BS) {
+        const int c = i / QPT, q = i - c * QPT;
+        const uint32_t code = s_code[c];
+        if (code) s_tiles4[(1 + c) * QPT + q] = atlas4[code * QPT + q];
+    }
+    __syncthreads();
+    const int total = ne * cpf;
+    uint4 *obs = reinterpret_cast<uint4 *>(p.obs) + (size_t)e0 * cpf;
+    for (int c0 = tid; c0 < total; c0 += BS) {
+        const int le = c0 / cpf, cc = c0 - le * cpf;
+        int d0 = cc * 4, ch = d0 / (RH * RD), rem = d0 - ch * (RH * RD), y = rem / RD, dx = rem - y * RD;
+        int cidx[4], aoff[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cy = y / 12, py = y - cy * 12, cx = dx / 3, kk = dx - cx * 3;
+            cidx[k] = le * cells + cy * D + cx;
+            aoff[k] = ch * 36 + py * 3 + kk;
+            dx += 1;
+            if (dx == RD) { dx = 0; y += 1; if (y == RH) { y = 0; ch += 1; } }
+        }
+        const uint32_t sa = s_code[cidx[0]] ? 1 + cidx[0] : 0, sb = s_code[cidx[3]] ? 1 + cidx[3] : 0;
+        uint32_t out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = s_tiles[(cidx[k] == cidx[0] ? sa : sb) * TDW + aoff[k]];
+        u32x4 nv = {out[0], out[1], out[2], out[3]};
+        __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(obs + c0));
+    }
+}
+
 int main() {
     const int N = 32768, D = 7, CH = 3, NI = 347;
     const int cells = D * D, cpf = CH * 9 * cells;
@@ -607,5 +654,11 @@ int main() {
     time_it("A9 pair codes, unroll 2", [&] { hipLaunchKernelGGL((lab_a9<7, 3, 2>), dim3(256), dim3(1024), r.lds + 2048, 0, p, r.tile_envs, r.n_tiles, r.atlas_dw); });
     cfg = 0; CK(allow_big_lds(lab_a9<7, 3, 3>, r.lds + 2048, cfg));
     time_it("A9 pair codes, unroll 3", [&] { hipLaunchKernelGGL((lab_a9<7, 3, 3>), dim3(256), dim3(1024), r.lds + 2048, 0, p, r.tile_envs, r.n_tiles, r.atlas_dw); });
+    printf("-- S1-shaped render with per-workgroup tile staging --\n");
+    time_it("J 256 thr, 1 env / group", [&] { hipLaunchKernelGGL((lab_j<7, 3, 256, 1>), dim3(N), dim3(256), 0, 0, p); });
+    time_it("J 256 thr, 2 envs / group", [&] { hipLaunchKernelGGL((lab_j<7, 3, 256, 2>), dim3(N / 2), dim3(256), 0, 0, p); });
+    time_it("J 512 thr, 2 envs / group", [&] { hipLaunchKernelGGL((lab_j<7, 3, 512, 2>), dim3(N / 2), dim3(512), 0, 0, p); });
+    time_it("J 512 thr, 1 env / group", [&] { hipLaunchKernelGGL((lab_j<7, 3, 512, 1>), dim3(N), dim3(512), 0, 0, p); });
+    time_it("J 1024 thr, 2 envs / group", [&] { hipLaunchKernelGGL((lab_j<7, 3, 1024, 2>), dim3(N / 2), dim3(1024), 0, 0, p); });
     return 0;
 }
