@@ -241,7 +241,7 @@ def main():
                          "step_loop_GBps": total_envs * per_step * args.steps / dt_max / 1e9},
             "timed_with_events_ms_per_step": dt / args.steps * 1e3,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # rank 0, N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(line))
     sim.close()

@@ -285,12 +285,12 @@ void timer_begin(xwb_sim *s, KernelTimer &t, hipStream_t st) {
         if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) return;
         t.pool.push_back(ep);
     }
-    hipEventRecord(t.pool[t.used].a, st);
+    (void)hipEventRecord(t.pool[t.used].a, st);
 }
 
 void timer_end(xwb_sim *s, KernelTimer &t, hipStream_t st) {
     if (!s->profiling || t.used >= t.pool.size()) return;
-    hipEventRecord(t.pool[t.used].b, st);
+    (void)hipEventRecord(t.pool[t.used].b, st);
     t.used++;
 }
 
