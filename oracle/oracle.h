@@ -119,6 +119,8 @@ enum { ORC_MAP_NAV = 0, ORC_MAP_WALLS = 1 };
 enum { ORC_EV_NONE = 0, ORC_EV_CORRECT = 1, ORC_EV_WRONG = 2, ORC_EV_TIMEUP = 3 };
 enum { ORC_STAGE_IDLE = 0, ORC_STAGE_NAV = 1, ORC_STAGE_TERMINAL = 2 };
 enum { ORC_TASKMODE_LANG_ACQ = 0, ORC_TASKMODE_ONE_CHANNEL = 1 };
+/* tasks of the XWorld3DNav group in confs/navigation2d.json order */
+enum { ORC_TASK_TARGET = 0, ORC_TASK_NEAR = 1, ORC_TASK_BETWEEN = 2, ORC_TASK_DIRECTION = 3, ORC_TASK_AVOID = 4 };
 
 typedef struct {
     int map_kind;            /* ORC_MAP_NAV | ORC_MAP_WALLS */
@@ -131,6 +133,8 @@ typedef struct {
     int color;               /* FLAGS_color */
     int context;
     uint32_t seed;           /* xwb-rng-v1 seed */
+    int n_tasks;             /* tasks of the group, sampled uniformly per episode (teaching_task.cpp:204-213); 0 = {TARGET} */
+    int tasks[8];            /* ORC_TASK_* in conf order */
 } orc_xw_cfg;
 
 typedef struct {
@@ -152,6 +156,9 @@ void    orc_xw_reset_game(orc_xworld *w, uint32_t env_gid, uint32_t episode);
  * with an explicit target pick (index into the reachable-goal list, or -1 to draw from the stream) */
 void    orc_xw_load_map(orc_xworld *w, int n_entities, const orc_entity *ents, int dim,
                         int target_pick, uint32_t env_gid, uint32_t episode);
+/* golden replay of any task: `decisions` are consumed, in order, wherever the idle stage would draw below(n) */
+void    orc_xw_load_map_ex(orc_xworld *w, int n_entities, const orc_entity *ents, int dim,
+                           const int *decisions, int n_decisions, uint32_t env_gid, uint32_t episode);
 float   orc_xw_take_actions(orc_xworld *w, int action, int act_rep);
 int     orc_xw_game_over(const orc_xworld *w);
 int     orc_xw_get_lives(const orc_xworld *w);
@@ -161,6 +168,9 @@ int     orc_xw_last_action_success(const orc_xworld *w);
 int     orc_xw_event(const orc_xworld *w);
 int     orc_xw_stage(const orc_xworld *w);
 int     orc_xw_target_name(const orc_xworld *w);
+int     orc_xw_task_kind(const orc_xworld *w);
+void    orc_xw_between_cell(const orc_xworld *w, int *x, int *y);
+void    orc_xw_get_target_cells(const orc_xworld *w, uint8_t *out);
 int     orc_xw_steps_in_task(const orc_xworld *w);
 int     orc_xw_n_entities(const orc_xworld *w);
 void    orc_xw_get_entities(const orc_xworld *w, orc_entity *out);

@@ -31,46 +31,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define MAXDIM   16
-#define MAXCELLS (MAXDIM * MAXDIM)
-#define MAXENT   (MAXCELLS + 8)
-#define MAXSTACK 4
-#define ITEM_SIZE 64          /* XItem::item_size_, xitem.h:151 */
-
-struct orc_xworld {
-    orc_xw_cfg cfg;
-    int n_icons;
-    orc_icon_info *info;
-    const uint8_t *icons64;          /* borrowed */
-    /* per type: names and their icon variants (xworld_env.py:247-255 set_goal_subtrees) */
-    int n_names[3];
-    int *name_variants[3];           /* flattened icon ids grouped by name */
-    int *name_first[3];              /* offsets, n_names+1 */
-    /* XWorld (xworld.h): item list, map */
-    orc_entity ents[MAXENT];
-    int n_ents;
-    int agent_idx;
-    int height, width;               /* max dims: what C++ sees (get_max_dims) */
-    int actual_h, actual_w, offset_h, offset_w;
-    int cube[MAXDIM][MAXDIM][MAXSTACK];   /* XMap::item_ptr_cube_ (entity indices) */
-    int cube_n[MAXDIM][MAXDIM];
-    int running_id;
-    /* XWorldSimulator */
-    int hits[MAXENT]; int n_hits;    /* ids in game_events_ ("collision:a|b\n" lines) */
-    int last_action_success;
-    /* TeachingEnvBuffer (simulator.h:265-292) */
-    double teacher_reward;
-    int event;
-    /* Task FSM (teaching_task.h:63-69) + XWorld3DTask fields */
-    int stage;
-    int steps_in_cur_task;
-    int target_name;
-    /* GameSimulator */
-    int64_t num_steps;
-    uint8_t *screens;
-    int img_h_out, img_w_out, channels;
-    orc_stream rs;
-};
+#include "xworld_internal.h"
 
 /* ------------------------------------------------------------- helpers ---- */
 static void cube_clear(orc_xworld *w) { memset(w->cube_n, 0, sizeof w->cube_n); }
@@ -384,7 +345,7 @@ static void gen_map_walls(orc_xworld *w) {
 
 /* --------------------------------------------------------------- teacher -- */
 /* XWorld3DTask._reachable, xworld3d_task.py:328-342 (coordinates in actual dims) */
-static int task_reachable(const orc_xworld *w, int goal_ent) {
+int orc_task_reachable(const orc_xworld *w, int goal_ent) {
     uint8_t obst[MAXCELLS];
     int X = w->actual_w, Y = w->actual_h;
     memset(obst, 0, sizeof obst);
@@ -401,24 +362,6 @@ static int task_reachable(const orc_xworld *w, int goal_ent) {
         if (e->type == 0 && !(ex == gx && ey == gy)) obst[ey * X + ex] = 1;
     }
     return orc_bfs_reachable(ax, ay, gx, gy, X, Y, obst);
-}
-
-/* XWorld3DNavTarget.idle, XWorld3DNavTarget.py:28-43 ; pick < 0 -> random.choice via stream */
-static void task_idle(orc_xworld *w, int pick) {
-    int cand[MAXENT], nc = 0;
-    for (int i = 0; i < w->n_ents; ++i)
-        if (w->ents[i].type == 0 && task_reachable(w, i)) cand[nc++] = i;
-    if (nc == 0) {
-        /* reference: `assert targets, "map too crowded?"` aborts the process.  The batched product
-         * cannot abort one env of a batch; both sides instead keep an untargeted episode (every goal
-         * reached counts as wrong).  Cannot happen on XWorldNav maps (the maze is connected). */
-        w->target_name = -1;
-    } else {
-        int k = pick >= 0 ? pick : (int)orc_stream_below(&w->rs, (uint32_t)nc);
-        w->target_name = w->ents[cand[k]].name_id;
-    }
-    w->teacher_reward += 0.0;
-    w->stage = ORC_STAGE_NAV;
 }
 
 /* XWorld3DTask._reach_object, xworld3d_task.py:451-454 with
@@ -461,8 +404,15 @@ static void task_navigation_reward(orc_xworld *w) {
             if (w->ents[i].type != 0) continue;
             if (task_reach_object(w, i)) {
                 any_reach = 1;
-                if (w->ents[i].name_id == w->target_name) target_reach = 1;
+                if (orc_task_is_target(w, i)) target_reach = 1;      /* t.id in objects_reach_test */
             }
+        }
+        if (w->task_kind == ORC_TASK_BETWEEN) {
+            /* XWorld3DNavTargetBetween.navigation_reward (XWorld3DNavTargetBetween.py:64-88): any reached goal
+             * fails; otherwise success when the agent stands within threshold/2 = 0.5 of the middle cell */
+            const orc_entity *a = &w->ents[w->agent_idx];
+            double ddx = a->x - w->between_x, ddy = a->y - w->between_y;
+            target_reach = !any_reach && sqrt(ddx * ddx + ddy * ddy) < 1.0 / 2;
         }
         if (target_reach) {
             w->event = ORC_EV_CORRECT;
@@ -480,12 +430,12 @@ static void task_navigation_reward(orc_xworld *w) {
     w->stage = next_stage;
 }
 
-/* Teacher::teach, teacher.cpp:207-230 (one group, one task fixed to NavTarget) */
+/* Teacher::teach, teacher.cpp:207-230 (one task group) */
 static void teacher_teach(orc_xworld *w, int idle_pick) {
     /* before_teach: clear_teacher_env_buffer */
     w->teacher_reward = 0; w->event = ORC_EV_NONE;
     switch (w->stage) {
-        case ORC_STAGE_IDLE: task_idle(w, idle_pick); break;
+        case ORC_STAGE_IDLE: (void)idle_pick; orc_task_idle(w); break;
         case ORC_STAGE_NAV: task_navigation_reward(w); break;
         default: w->teacher_reward += 0; break;   /* terminal(): ["terminal", 0, ""] */
     }
@@ -656,6 +606,25 @@ void orc_xw_destroy(orc_xworld *w) {
     free(w->info); free(w->screens); free(w);
 }
 
+void orc_xw_rebuild_map(orc_xworld *w) {
+    cube_clear(w);
+    w->agent_idx = -1;
+    for (int i = 0; i < w->n_ents; ++i) {
+        if (w->ents[i].type == 2 && w->agent_idx < 0) w->agent_idx = i;
+        map_add_item(w, i);
+    }
+}
+
+int orc_xw_draw_below(orc_xworld *w, int n) {
+    if (w->forced) {
+        if (w->forced_at >= w->n_forced) abort();
+        int v = w->forced[w->forced_at++];
+        if (n > 0 && (v < 0 || v >= n)) abort();
+        return v;
+    }
+    return (int)orc_stream_below(&w->rs, (uint32_t)n);
+}
+
 static void after_map(orc_xworld *w, int idle_pick) {
     /* XWorldSimulator::reset_game (:143-157), GameSimulator::reset_game */
     w->n_hits = 0;
@@ -675,8 +644,24 @@ void orc_xw_reset_game(orc_xworld *w, uint32_t env_gid, uint32_t episode) {
     after_map(w, -1);
 }
 
+void orc_xw_load_map_ex(orc_xworld *w, int n_entities, const orc_entity *ents, int dim,
+                        const int *decisions, int n_decisions, uint32_t env_gid, uint32_t episode) {
+    w->forced = decisions; w->n_forced = n_decisions; w->forced_at = 0;
+    orc_xw_load_map(w, n_entities, ents, dim, -1, env_gid, episode);
+    if (decisions && w->forced_at != n_decisions) abort();       /* every decision must have been consumed */
+    w->forced = NULL; w->n_forced = 0;
+}
+
 void orc_xw_load_map(orc_xworld *w, int n_entities, const orc_entity *ents, int dim,
                      int target_pick, uint32_t env_gid, uint32_t episode) {
+    /* target_pick >= 0: legacy form for a NavTarget-only config = decisions {task 0, pick} */
+    int legacy[2] = {0, target_pick};
+    if (target_pick >= 0 && !w->forced) {
+        w->forced = legacy; w->n_forced = 2; w->forced_at = 0;
+        orc_xw_load_map(w, n_entities, ents, dim, -1, env_gid, episode);
+        w->forced = NULL; w->n_forced = 0;
+        return;
+    }
     orc_stream_init(&w->rs, w->cfg.seed, env_gid, episode, 0);
     set_dims(w, dim, dim);
     w->n_ents = 0;
@@ -728,6 +713,16 @@ int orc_xw_last_action_success(const orc_xworld *w) { return w->last_action_succ
 int orc_xw_event(const orc_xworld *w) { return w->event; }
 int orc_xw_stage(const orc_xworld *w) { return w->stage; }
 int orc_xw_target_name(const orc_xworld *w) { return w->target_name; }
+int orc_xw_task_kind(const orc_xworld *w) { return w->task_kind; }
+void orc_xw_between_cell(const orc_xworld *w, int *x, int *y) { *x = w->between_x; *y = w->between_y; }
+/* 1 where the cell's top item is a target goal (self.target), max_dim*max_dim, row-major [y][x] */
+void orc_xw_get_target_cells(const orc_xworld *w, uint8_t *out) {
+    for (int y = 0; y < w->height; ++y)
+        for (int x = 0; x < w->width; ++x) {
+            int n = w->cube_n[y][x];
+            out[y * w->width + x] = (uint8_t)(n ? orc_task_is_target(w, w->cube[y][x][n - 1]) : 0);
+        }
+}
 int orc_xw_steps_in_task(const orc_xworld *w) { return w->steps_in_cur_task; }
 int orc_xw_n_entities(const orc_xworld *w) { return w->n_ents; }
 void orc_xw_get_entities(const orc_xworld *w, orc_entity *out) {

@@ -1,0 +1,58 @@
+/* oracle/xworld_internal.h -- TEST INFRASTRUCTURE ONLY: shared between xworld2d.c and xworld_tasks.c */
+#ifndef XW_ORACLE_INTERNAL_H
+#define XW_ORACLE_INTERNAL_H
+#include "oracle.h"
+
+#define MAXDIM   16
+#define MAXCELLS (MAXDIM * MAXDIM)
+#define MAXENT   (MAXCELLS + 8)
+#define MAXSTACK 4
+#define ITEM_SIZE 64          /* XItem::item_size_, xitem.h:151 */
+
+struct orc_xworld {
+    orc_xw_cfg cfg;
+    int n_icons;
+    orc_icon_info *info;
+    const uint8_t *icons64;          /* borrowed */
+    /* per type: names and their icon variants (xworld_env.py:247-255 set_goal_subtrees) */
+    int n_names[3];
+    int *name_variants[3];           /* flattened icon ids grouped by name */
+    int *name_first[3];              /* offsets, n_names+1 */
+    /* XWorld (xworld.h): item list, map */
+    orc_entity ents[MAXENT];
+    int n_ents;
+    int agent_idx;
+    int height, width;               /* max dims: what C++ sees (get_max_dims) */
+    int actual_h, actual_w, offset_h, offset_w;
+    int cube[MAXDIM][MAXDIM][MAXSTACK];   /* XMap::item_ptr_cube_ (entity indices) */
+    int cube_n[MAXDIM][MAXDIM];
+    int running_id;
+    /* XWorldSimulator */
+    int hits[MAXENT]; int n_hits;    /* ids in game_events_ ("collision:a|b\n" lines) */
+    int last_action_success;
+    /* TeachingEnvBuffer (simulator.h:265-292) */
+    double teacher_reward;
+    int event;
+    /* Task FSM (teaching_task.h:63-69) + XWorld3DTask fields */
+    int stage;
+    int steps_in_cur_task;
+    int target_name;                 /* NavTarget: name id of the picked goal (introspection) */
+    int task_kind;                   /* ORC_TASK_* of the busy task */
+    uint8_t target_ent[MAXENT];      /* self.target: entity is a target goal */
+    int between_x, between_y;        /* NavTargetBetween: the middle cell (C++ coordinates) */
+    const int *forced; int n_forced, forced_at;   /* golden replay: decisions instead of stream draws */
+    /* GameSimulator */
+    int64_t num_steps;
+    uint8_t *screens;
+    int img_h_out, img_w_out, channels;
+    orc_stream rs;
+};
+
+
+/* xworld2d.c */
+void orc_xw_rebuild_map(orc_xworld *w);                 /* XWorld::reset(false): rebuild the cube from the entity list */
+int  orc_xw_draw_below(orc_xworld *w, int n);           /* next decision: forced (golden replay) or stream draw */
+/* xworld_tasks.c */
+void orc_task_idle(orc_xworld *w);                      /* TaskGroup::run_stage: sample a task, run its idle stage */
+int  orc_task_is_target(const orc_xworld *w, int ent);
+#endif

@@ -41,7 +41,8 @@ class IconInfo(C.Structure):
 class XwCfg(C.Structure):
     _fields_ = [("map_kind", C.c_int), ("max_dim", C.c_int), ("dim", C.c_int), ("num_goals", C.c_int),
                 ("num_blocks", C.c_int), ("max_steps", C.c_int), ("max_steps_factor", C.c_int),
-                ("task_mode", C.c_int), ("color", C.c_int), ("context", C.c_int), ("seed", C.c_uint32)]
+                ("task_mode", C.c_int), ("color", C.c_int), ("context", C.c_int), ("seed", C.c_uint32),
+                ("n_tasks", C.c_int), ("tasks", C.c_int * 8)]
 
 
 class Entity(C.Structure):
@@ -132,6 +133,10 @@ def lib():
     sig("orc_xw_destroy", None, vp)
     sig("orc_xw_reset_game", None, vp, C.c_uint32, C.c_uint32)
     sig("orc_xw_load_map", None, vp, C.c_int, C.POINTER(Entity), C.c_int, C.c_int, C.c_uint32, C.c_uint32)
+    sig("orc_xw_load_map_ex", None, vp, C.c_int, C.POINTER(Entity), C.c_int, i32p, C.c_int, C.c_uint32, C.c_uint32)
+    sig("orc_xw_task_kind", C.c_int, vp)
+    sig("orc_xw_between_cell", None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
+    sig("orc_xw_get_target_cells", None, vp, u8p)
     sig("orc_xw_take_actions", C.c_float, vp, C.c_int, C.c_int)
     for n in ("game_over", "get_lives", "num_actions", "last_action_success", "event", "stage",
               "target_name", "steps_in_task", "n_entities"):
@@ -310,11 +315,20 @@ NAV_SUBTREES = ("animal", "fruit", "furniture", "vegetable")    # XWorldNav.py:1
 WALLS_SUBTREES = ("animal", "fruit", "shape")                   # XWorldWalls.py:16
 
 
+TASK_ID = {"XWorld3DNavTarget": 0, "XWorld3DNavTargetNear": 1, "XWorld3DNavTargetBetween": 2,
+           "XWorld3DNavTargetDirection": 3, "XWorld3DNavTargetAvoid": 4}
+
+
 def xw_cfg(**kw):
     c = XwCfg(map_kind=0, max_dim=8, dim=8, num_goals=4, num_blocks=16, max_steps=0,
               max_steps_factor=10, task_mode=0, color=0, context=1, seed=0xC0FFEE)
+    tasks = kw.pop("tasks", None)
     for k, v in kw.items():
         setattr(c, k, v)
+    if tasks is not None:
+        c.n_tasks = len(tasks)
+        for i, t in enumerate(tasks):
+            c.tasks[i] = TASK_ID.get(t, t)
     return c
 
 
@@ -343,6 +357,27 @@ class XWorld:
         for i, e in enumerate(ents):
             arr[i] = Entity(*e)
         self.L.orc_xw_load_map(self.h, len(ents), arr, dim, target_pick, env_gid, episode)
+
+    def load_map_ex(self, ents, dim, decisions, env_gid=0, episode=0):
+        arr = (Entity * len(ents))()
+        for i, e in enumerate(ents):
+            arr[i] = Entity(*e)
+        d = np.asarray(decisions, np.int32)
+        self.L.orc_xw_load_map_ex(self.h, len(ents), arr, dim, ptr(d, i32p), len(d), env_gid, episode)
+
+    def task_kind(self):
+        return self.L.orc_xw_task_kind(self.h)
+
+    def between_cell(self):
+        x, y = C.c_int(), C.c_int()
+        self.L.orc_xw_between_cell(self.h, C.byref(x), C.byref(y))
+        return x.value, y.value
+
+    def target_cells(self):
+        d = self.cfg.max_dim
+        out = np.zeros(d * d, np.uint8)
+        self.L.orc_xw_get_target_cells(self.h, ptr(out, u8p))
+        return out.reshape(d, d)
 
     def take_actions(self, a, act_rep=1):
         return self.L.orc_xw_take_actions(self.h, int(a), act_rep)

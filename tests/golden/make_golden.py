@@ -8,7 +8,8 @@ modules produced for them.  What is imported from /root/reference:
     python/maze2d.py                      spanning_tree_maze_generator, bfs
     python/py_util.py
     games/xworld/maps/xworld_env.py, XWorldNav.py, XWorldWalls.py
-    games/xworld3d/tasks/xworld3d_task.py, XWorld3DNavTarget.py
+    games/xworld3d/tasks/xworld3d_task.py, XWorld3DNavTarget.py, XWorld3DNavTargetNear.py,
+    XWorld3DNavTargetBetween.py, XWorld3DNavTargetDirection.py, XWorld3DNavTargetAvoid.py
 
 Harness shims (this file, clearly not reference code):
   * `py_gflags`: in the reference this module is provided by the embedding C++ program
@@ -33,6 +34,9 @@ Fixtures written:
   maps_walls.json  same for XWorldWalls
   teacher.json   XWorld3DNavTarget idle/navigation_reward run over random action strings on those maps:
                  per step action, reward, event, stage, agent cell, action success
+  tasks.json     all five tasks of the XWorld3DNav group (Target, Near, Between, Direction, Avoid): the idle stage
+                 driven by logged decisions (see DecisionRandom), the map after the teacher's rearrangement,
+                 the target cells, and a random-action trace as in teacher.json
 """
 import ctypes as C
 import json
@@ -287,6 +291,120 @@ def gen_teacher(cls, pal, n_maps, seed0, steps):
     return runs
 
 
+# ------------------------------------------------------ the five nav tasks ----
+class DecisionRandom(object):
+    """Stands in for the `random` module inside ONE task module.  Every call takes its decision(s) as
+    below(n) values from a seeded generator and logs them, so the oracle / product can be driven through the
+    same decisions ("xwb-taskgen-v1"):
+      shuffle(lst): the first two positions of a Fisher-Yates shuffle -- below(n), then below(n-1) -- because
+                    the tasks only ever use lst[:2] or lst[0] of a shuffled list;
+      choice(seq):  seq[below(n)]; a list of bare (x, y, 0) cells is first put in row-major order, since its
+                    order comes from the env's randomly shuffled available_grids list."""
+
+    def __init__(self, seed):
+        self.rnd = random.Random(seed)
+        self.log = []
+
+    def below(self, n):
+        v = self.rnd.randrange(n)
+        self.log.append(v)
+        return v
+
+    def shuffle(self, lst):
+        n = len(lst)
+        if n == 0:
+            return
+        lst.insert(0, lst.pop(self.below(n)))
+        if n >= 2:
+            lst.insert(1, lst.pop(1 + self.below(n - 1)))
+
+    def choice(self, seq):
+        seq = list(seq)
+        if seq and isinstance(seq[0], tuple) and len(seq[0]) == 3 and not isinstance(seq[0][0], tuple):
+            seq = sorted(seq, key=lambda c: (c[1], c[0]))
+        return seq[self.below(len(seq))]
+
+
+def gen_tasks(pal, n_maps, seed0, steps):
+    import importlib
+    names = ["XWorld3DNavTarget", "XWorld3DNavTargetNear", "XWorld3DNavTargetBetween",
+             "XWorld3DNavTargetDirection", "XWorld3DNavTargetAvoid"]
+    out = {}
+    env = XWorldNav(ITEM_PATH)
+    rnd = random.Random(4242)
+    for name in names:
+        mod = importlib.import_module(name)
+        cls = getattr(mod, name)
+        runs = []
+        k = 0
+        while len(runs) < n_maps and k < 4 * n_maps:
+            k += 1
+            random.seed(seed0 + k)
+            env.reset()
+            env.env_changed()
+            before = entity_records(env, pal)
+            h = Harness(env)
+            task = cls(env)
+            task.reset()
+            fake = DecisionRandom(seed0 * 7 + k)
+            real = mod.random
+            mod.random = fake
+            try:
+                h.env.update_entities_from_cpp([dict(e) for e in h.ents])
+                h.env.update_agent_sentence_from_cpp("")
+                h.env.update_agent_action_success_from_cpp(False)
+                h.env.update_game_event_from_cpp("")
+                try:
+                    ret = task.idle()
+                except AssertionError as err:                # "map too crowded?" -- the reference process would die
+                    continue
+            finally:
+                mod.random = real
+            assert ret[0] == "navigation_reward" and ret[1] == 0.0
+            task.get_event()
+            if env.env_changed():                            # Task::py_stage -> game_->update_environment()
+                h.ents = [dict(e) for e in env.cpp_get_entities()]
+                for e in h.ents:
+                    e["loc"] = tuple(int(v) for v in e["loc"])
+                h.agent = [e for e in h.ents if e["type"] == "agent"][0]
+            after = entity_records(env, pal)
+            goals = env.get_goals()
+            rec = {"py_seed": seed0 + k, "dim": env.get_dims()[0], "max_dim": env.get_max_dims()[0],
+                   "entities_before": before, "entities_after": after, "decisions": list(fake.log)}
+            if name == "XWorld3DNavTargetBetween":
+                l1, l2 = task.target
+                rec["between"] = [int((l1[0] + l2[0]) // 2), int((l1[1] + l2[1]) // 2)]
+                rec["target_cells"] = []
+            elif name == "XWorld3DNavTargetDirection":
+                referent, direction = task.target
+                agent = [e for e in env.get_entities() if e.type == "agent"][0]
+                fn = getattr(task, "_XWorld3DNavTargetDirection__compute_triple_direction")
+                cells = []
+                for g in goals:
+                    near = task._get_distance(g.loc, referent.loc) < 1.0 + 1e-3
+                    if near and fn(g, referent, agent.loc, agent.yaw) == direction:
+                        cells.append([int(g.loc[0]), int(g.loc[1])])
+                rec["target_cells"] = cells
+                rec["direction"] = direction
+            else:
+                rec["target_cells"] = [[int(t.loc[0]), int(t.loc[1])] for t in task.target]
+            stage = "navigation_reward"
+            trace, after_end = [], 0
+            for t in range(steps):
+                a = rnd.randrange(4)
+                h.act(a)
+                stage, reward, event = h.py_stage(task, stage)
+                trace.append([a, reward, event, stage, int(h.agent["loc"][0]), int(h.agent["loc"][1]), int(bool(h.success))])
+                if stage == "terminal":
+                    after_end += 1
+                    if after_end > 2:
+                        break
+            rec["trace"] = trace
+            runs.append(rec)
+        out[name] = runs
+    return out
+
+
 def main():
     nav_pal = O.Palette(O.NAV_SUBTREES)
     walls_pal = O.Palette(O.WALLS_SUBTREES)
@@ -297,6 +415,7 @@ def main():
         "maps_walls.json": gen_maps(XWorldWalls, walls_pal, 30, 500),
         "teacher.json": {"nav": gen_teacher(XWorldNav, nav_pal, 40, 2000, 700),
                          "walls": gen_teacher(XWorldWalls, walls_pal, 24, 3000, 500)},
+        "tasks.json": gen_tasks(nav_pal, 24, 9000, 660),
     }
     for name, data in out.items():
         with open(os.path.join(HERE, name), "w") as f:

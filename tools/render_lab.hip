@@ -527,6 +527,16 @@ __global__ __launch_bounds__(BS) void lab_j(XwParams p) {
     }
 }
 
+// one-shot workgroups of BS threads, PER adjacent 16-byte stores per lane (workgroup covers BS*PER*16 contiguous bytes)
+template <int BS, int PER>
+__global__ __launch_bounds__(BS) void lab_s6(uint4 *obs, size_t n) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const size_t i = ((size_t)blockIdx.x * PER + u) * BS + threadIdx.x;
+        if (i < n) { u32x4 nv = {(uint32_t)i, 1, 2, 3}; __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(obs + i)); }
+    }
+}
+
 int main() {
     const int N = 32768, D = 7, CH = 3, NI = 347;
     const int cells = D * D, cpf = CH * 9 * cells;
@@ -660,5 +670,11 @@ int main() {
     time_it("J 512 thr, 2 envs / group", [&] { hipLaunchKernelGGL((lab_j<7, 3, 512, 2>), dim3(N / 2), dim3(512), 0, 0, p); });
     time_it("J 512 thr, 1 env / group", [&] { hipLaunchKernelGGL((lab_j<7, 3, 512, 1>), dim3(N), dim3(512), 0, 0, p); });
     time_it("J 1024 thr, 2 envs / group", [&] { hipLaunchKernelGGL((lab_j<7, 3, 1024, 2>), dim3(N / 2), dim3(1024), 0, 0, p); });
+    printf("-- one-shot workgroups: size and stores per lane --\n");
+#define S6(BS, PER) { char nm[64]; snprintf(nm, sizeof nm, "S6 one-shot, %d thr, %d stores/lane", BS, PER); \
+    time_it(nm, [&] { hipLaunchKernelGGL((lab_s6<BS, PER>), dim3((unsigned)((nch + (size_t)BS * PER - 1) / ((size_t)BS * PER))), dim3(BS), 0, 0, reinterpret_cast<uint4 *>(d_obs), nch); }); }
+    S6(64, 1) S6(128, 1) S6(256, 1) S6(512, 1) S6(1024, 1)
+    S6(256, 2) S6(256, 4) S6(256, 8) S6(256, 16) S6(256, 64)
+    S6(1024, 2) S6(1024, 4) S6(1024, 8) S6(1024, 21)
     return 0;
 }
