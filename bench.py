@@ -45,7 +45,7 @@ def make_sim(workload, n_envs, device, gid0):
     game, opts, _ = WORKLOADS[workload]
     opts = dict(opts)
     if game == "xworld":
-        opts["xwd_conf_path"] = os.path.join(ROOT, "xworld_amd", "confs", "nav_target.json")
+        opts["xwd_conf_path"] = os.path.join(ROOT, "xworld_amd", "confs", "navigation2d.json")       # the five XWorld3DNav tasks
         opts["task_mode"] = "lang_acquisition"
     return BatchedSimulator(game, opts, num_envs=n_envs, device=device, env_gid0=gid0,
                             seed=0xC0FFEE, policy_seed=0x5EED)
@@ -100,7 +100,7 @@ def cpu_baseline(workload, seconds_target=12.0):
             d = sim_opts.get("max_dim", 8)
             pal = O.Palette(O.NAV_SUBTREES)
             cfg = O.xw_cfg(map_kind=0, max_dim=d, dim=d, num_goals=4, num_blocks=sim_opts.get("num_blocks", 16),
-                           color=1, seed=0xC0FFEE)
+                           color=1, seed=0xC0FFEE, tasks=[0, 1, 2, 3, 4])
             O.xw_rollout(n, cfg, pal, steps, 0x5EED, render=True)
         dt = time.perf_counter() - t0
         t_used += dt

@@ -52,6 +52,10 @@ enum { XWB_SIMPLE_GAME = 0, XWB_SIMPLE_RACE = 1, XWB_XWORLD2D = 2 };
 enum { XWB_ALIVE = 0, XWB_MAX_STEP = 1, XWB_DEAD = 2, XWB_SUCCESS = 4, XWB_LOST_LIFE = 8 };
 
 enum { XWB_MAP_NAV = 0, XWB_MAP_WALLS = 1 };             /* games/xworld/maps/XWorldNav.py, XWorldWalls.py */
+/* tasks of games/xworld3d/tasks/XWorld3DNav*.py (the full-observation 2-D game runs the same Python tasks) */
+enum { XWB_TASK_TARGET = 0, XWB_TASK_NEAR = 1, XWB_TASK_BETWEEN = 2, XWB_TASK_DIRECTION = 3, XWB_TASK_AVOID = 4 };
+#define XWB_CELL_ICON_MASK 0x7fff   /* cell code & mask = palette icon + 1 (0 = empty) */
+#define XWB_CELL_TARGET    0x8000   /* cell code bit: this goal belongs to the task's target set */
 enum { XWB_TASKMODE_LANG_ACQ = 0, XWB_TASKMODE_ONE_CHANNEL = 1 };   /* FLAGS_task_mode, xworld_simulator.cpp:33-37 */
 enum { XWB_EV_NONE = 0, XWB_EV_CORRECT_GOAL = 1, XWB_EV_WRONG_GOAL = 2, XWB_EV_TIME_UP = 3 };
 enum { XWB_ICON_GOAL = 0, XWB_ICON_BLOCK = 1, XWB_ICON_AGENT = 2 };  /* xworld_env.py:66 grid_types */
@@ -90,6 +94,9 @@ typedef struct xwb_config {
     int32_t  num_goals, num_blocks;
     int32_t  max_steps_factor;   /* FLAGS_max_steps_factor (10) */
     int32_t  task_mode;          /* XWB_TASKMODE_* */
+    int32_t  n_tasks;            /* tasks of the teacher's group (conf JSON "teacher"."task_groups", teacher.py:
+                                  * TaskGroup samples one per episode); 0 = { XWB_TASK_TARGET } */
+    int32_t  tasks[8];           /* XWB_TASK_* */
     int32_t  color;              /* FLAGS_color: 3-channel planar BGR when set, else 1-channel gray */
     int32_t  n_icons;            /* icons this map class can place (its "palette") */
     const uint8_t *icons64;      /* host, n_icons x 64 x 64 x 3, BGR as cv::imread(path, 1) (xitem.cpp:38) */
@@ -175,17 +182,23 @@ typedef struct xwb_env_state {
     float    race_x, race_y, race_angle;
     int32_t  xw_agent_x, xw_agent_y, xw_event, xw_stage, xw_target_name, xw_steps_in_task;
     uint32_t episode;
+    int32_t  xw_task;            /* XWB_TASK_* of this episode */
+    int32_t  xw_target;          /* TARGET: goal name id; BETWEEN: middle cell y * max_dim + x; else -1 */
 } xwb_env_state;
 int xwb_get_env_state(xwb_sim *sim, int32_t env, void *stream, xwb_env_state *out);
 /* copies env's "screen" (context frames) to host memory; bytes must equal bytes_per_env */
 int xwb_get_env_obs(xwb_sim *sim, int32_t env, void *stream, void *out_host, size_t bytes);
-/* xworld: cell codes (palette icon + 1, 0 = empty), max_dim*max_dim uint16, row-major [y][x] */
+/* xworld: cell codes (palette icon + 1, 0 = empty; | XWB_CELL_TARGET on the task's target goals),
+ * max_dim*max_dim uint16, row-major [y][x] */
 int xwb_get_env_grid(xwb_sim *sim, int32_t env, void *stream, uint16_t *out_host);
 
 /* replay an externally generated map into env (golden-map parity): grid cell codes, agent cell,
  * teacher target name id and actual dim; runs init_screen.  Synchronous. */
 int xwb_xw_load_map(xwb_sim *sim, int32_t env, const uint16_t *grid_host, int32_t agent_x, int32_t agent_y,
                     int32_t target_name, int32_t dim);
+/* the same for any task: grid codes carry XWB_CELL_TARGET on the target goals; `target` as xw_target above */
+int xwb_xw_load_map_task(xwb_sim *sim, int32_t env, const uint16_t *grid_host, int32_t agent_x, int32_t agent_y,
+                         int32_t dim, int32_t task, int32_t target);
 /* simple_race: overwrite the car state of env (test hook).  Synchronous. */
 int xwb_race_set_car(xwb_sim *sim, int32_t env, float x, float y, float angle);
 

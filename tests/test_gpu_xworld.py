@@ -194,7 +194,7 @@ def test_full_size_c4(oracle):
         assert np.array_equal(sim.game_over_codes.cpu().numpy(), ref.codes[t]), t
         if t % 8 == 0 or t == steps - 1:
             for lo in range(0, n, 8192):                                # every env, in slabs
-                G = sim.grid[lo:lo + 8192].to(torch.int64)
+                G = sim.grid[lo:lo + 8192].to(torch.int64) & 0x7fff            # bit 15 = target-set flag
                 exp = full[G]                                           # [m, D, D, C, 12, 12]
                 exp = exp.permute(0, 3, 1, 4, 2, 5).reshape(G.shape[0], 3, 12 * D, 12 * D)
                 assert torch.equal(sim.obs[lo:lo + 8192], exp), (t, lo)

@@ -53,3 +53,32 @@ def read_conf(path):
     if "map" not in conf or "item_path" not in conf:
         raise ValueError("world config needs 'item_path' and 'map' (xworld.cpp:71-72)")
     return conf
+
+
+# task class -> XWB_TASK_* (include/xwb.h); the 2-D game's navigation2d.json runs the XWorld3DNav* Python tasks
+TASK_IDS = {"XWorld3DNavTarget": 0, "XWorld3DNavTargetNear": 1, "XWorld3DNavTargetBetween": 2,
+            "XWorld3DNavTargetDirection": 3, "XWorld3DNavTargetAvoid": 4}
+TASK_NAMES = {v: k for k, v in TASK_IDS.items()}
+
+
+def conf_tasks(conf):
+    """Task ids of the conf's (single) task group, in the order the JSON lists them.
+
+    teacher.py: a TaskGroup with schedule "random" draws one of its tasks uniformly per episode; the
+    per-task numbers are weights only the "weighted" schedule reads."""
+    groups = conf.get("task_groups") or {}
+    if not groups:
+        return [0]
+    if len(groups) != 1:
+        raise RuntimeError("only one task group is built (confs/navigation2d.json has one): " + ", ".join(groups))
+    (gname, g), = groups.items()
+    if g.get("schedule", "random") != "random":
+        raise RuntimeError("task group schedule '%s' is not built (only 'random')" % g.get("schedule"))
+    out = []
+    for t in g.get("tasks", {}):
+        if t not in TASK_IDS:
+            raise RuntimeError("task %s of group %s is not built" % (t, gname))
+        out.append(TASK_IDS[t])
+    if not 1 <= len(out) <= 8:
+        raise RuntimeError("a task group needs 1..8 tasks")
+    return out

@@ -82,6 +82,12 @@ class BatchedSimulator:
                 raise RuntimeError("unsupported task mode: " + str(mode))  # xworld_simulator.cpp:194-196
             cfg.task_mode = 0 if mode == "lang_acquisition" else 1
             cfg.color = int(bool(opts.get("color", False)))
+            tasks = opts.get("tasks")                                     # override: list of task class names / ids
+            tasks = assets.conf_tasks(conf) if tasks is None else [assets.TASK_IDS.get(t, t) for t in tasks]
+            cfg.n_tasks = len(tasks)
+            for i, t in enumerate(tasks):
+                cfg.tasks[i] = int(t)
+            self.tasks = list(tasks)
             if int(opts.get("visible_radius", 0)) != 0:
                 raise RuntimeError("visible_radius > 0 (egocentric view) is not built yet (SURVEY 8(f) rank 2)")
             self.palette = assets.Palette(mc["subtrees"], opts.get("assets_dir", assets.ASSETS))
@@ -185,7 +191,8 @@ class BatchedSimulator:
 
     @property
     def grid(self):
-        """xworld: [num_envs, max_dim, max_dim] cell codes (palette icon + 1, 0 = empty), int16 view."""
+        """xworld: [num_envs, max_dim, max_dim] cell codes, int16 view: code & 0x7fff = palette icon + 1 (0 = empty);
+        the sign bit marks the goals in the task's target set."""
         d = self.cfg.max_dim
         return self._view("grid", self.L.xwb_xw_grid_dev, (self.num_envs, d, d), "<i2")
 
@@ -225,16 +232,31 @@ class BatchedSimulator:
         lib.check(self.L.xwb_get_env_obs(self.h, int(env), self._stream(stream), out.ctypes.data, self.obs_bytes_per_env))
         return out
 
-    def env_grid(self, env=0, stream=None):
+    def env_grid(self, env=0, stream=None, raw=False):
+        """Cell codes (palette icon + 1, 0 empty); raw=True keeps bit 15 = the goal is in the task's target set."""
         d = self.cfg.max_dim
         out = np.empty(d * d, np.uint16)
         lib.check(self.L.xwb_get_env_grid(self.h, int(env), self._stream(stream), out.ctypes.data))
-        return out.reshape(d, d)
+        out = out.reshape(d, d)
+        return out if raw else out & np.uint16(0x7fff)
 
-    def load_map(self, env, grid, agent_x, agent_y, target_name, dim=None):
+    def env_target_cells(self, env=0, stream=None):
+        """(x, y) cells (max_dim coordinates, row-major order) of the goals in the task's target set."""
+        g = self.env_grid(env, stream, raw=True)
+        ys, xs = np.nonzero(g & np.uint16(0x8000))
+        return [(int(x), int(y)) for x, y in zip(xs, ys)]
+
+    def load_map(self, env, grid, agent_x, agent_y, target_name=None, dim=None, task=None, target=-1):
+        """Replay a map.  task=None: XWorld3DNavTarget with `target_name`; else grid codes carry bit 15 on the
+        target goals and `target` is the middle cell (y * max_dim + x) for XWorld3DNavTargetBetween."""
         g = np.ascontiguousarray(grid, np.uint16)
-        lib.check(self.L.xwb_xw_load_map(self.h, int(env), g.ctypes.data, int(agent_x), int(agent_y),
-                                         int(target_name), int(self.cfg.dim if dim is None else dim)))
+        dim = int(self.cfg.dim if dim is None else dim)
+        if task is None:
+            lib.check(self.L.xwb_xw_load_map(self.h, int(env), g.ctypes.data, int(agent_x), int(agent_y),
+                                             int(target_name), dim))
+        else:
+            lib.check(self.L.xwb_xw_load_map_task(self.h, int(env), g.ctypes.data, int(agent_x), int(agent_y), dim,
+                                                  int(assets.TASK_IDS.get(task, task)), int(target)))
 
     def race_set_car(self, env, x, y, angle):
         lib.check(self.L.xwb_race_set_car(self.h, int(env), float(x), float(y), float(angle)))

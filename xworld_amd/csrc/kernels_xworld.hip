@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
             }
             // Teacher::teach -> Task stage (one group, task XWorld3DNavTarget)
             const int ts = p.task_state[e];
-            const int target = (int)(int16_t)(ts & 0xffff);
-            int stage = (ts >> 16) & 0xff;
+            const int target = task_target(ts), kind = task_kind(ts);
+            int stage = task_stage(ts);
             int tsteps = p.task_steps[e];
             int event = EV_NONE;
             double rew = 0.0;
@@ -92,11 +92,17 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
                 if (tsteps >= p.dim * p.dim * p.max_steps_factor) {
                     event = EV_TIMEUP;
                     stage = STAGE_TERMINAL;
-                } else if (hit != 0 && a == 1 && p.icon_type[hit - 1] == 0) {
+                } else if (hit != 0 && a == 1 && p.icon_type[(hit & CELL_ICON_MASK) - 1] == 0) {
                     // _reach_object: id in collisions and |theta| < pi/4.  Full-observation entities keep
                     // yaw = 1.5707963 (heading +y), so theta = 0 only for a goal hit by MOVE_DOWN.
-                    if ((int)p.icon_name[hit - 1] == target) { event = EV_CORRECT; rew += 1.0; }
+                    // Target / Near / Direction / Avoid: the reached goal is in self.target (cell bit 15, set by
+                    // the idle stage) -> correct, else wrong.  Between: any reached goal is wrong.
+                    if (kind != TASK_BETWEEN && (hit & CELL_TARGET_BIT)) { event = EV_CORRECT; rew += 1.0; }
                     else { event = EV_WRONG; rew += -1.0; }
+                    stage = STAGE_TERMINAL;
+                } else if (kind == TASK_BETWEEN && ay * D + ax == target) {
+                    // XWorld3DNavTargetBetween.navigation_reward: dist(agent, middle) < threshold / 2
+                    event = EV_CORRECT; rew += 1.0;
                     stage = STAGE_TERMINAL;
                 }
             }
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
             r = (float)((double)r + rew);                   // r += teacher_->give_reward() (double)
             const int code = done_code(p, steps, event);
             p.agent_xy[e] = ax | (ay << 16);
-            p.task_state[e] = pack_task(target, stage, event);
+            p.task_state[e] = pack_task(target, stage, event, kind);
             p.task_steps[e] = tsteps;
             p.num_steps[e] = steps;
             p.success[e] = success ? 1 : 0;
@@ -149,7 +155,7 @@ __device__ __forceinline__ uint4 xw_expand_chunk(const uint32_t *atlas, const ui
     for (int k = 0; k < 4; ++k) {
         const int cy = y / XW_TILE, py = y - cy * XW_TILE;
         const int cx = dx / XW_TILE_DW, kk = dx - cx * XW_TILE_DW;
-        const uint32_t code = g[cy * D + cx];
+        const uint32_t code = g[cy * D + cx] & CELL_ICON_MASK;
         out[k] = atlas[code * (CH * 36) + ch * 36 + py * 3 + kk];   // tile 0 = empty cell (white)
         dx += 1;
         if (dx == RD) { dx = 0; y += 1; if (y == RH) { y = 0; ch += 1; } }
@@ -199,7 +205,7 @@ __device__ __forceinline__ uint4 xw_expand_chunk2(const uint32_t *atlas, const u
         dx += 1;
         if (dx == RD) { dx = 0; y += 1; if (y == RH) { y = 0; ch += 1; } }
     }
-    const uint32_t ca = g[cidx[0]], cb = g[cidx[3]];
+    const uint32_t ca = g[cidx[0]] & CELL_ICON_MASK, cb = g[cidx[3]] & CELL_ICON_MASK;    // bit 15 = target flag
     uint32_t out[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -131,6 +131,7 @@ struct LaneLds {
     uint8_t *gcell;      // [XW_MAX_GOALS]
     uint16_t *ov_idx;    // [XW_MAX_GOALS]
     uint16_t *ov_val;    // [XW_MAX_GOALS]
+    uint16_t *gicon;     // [XW_MAX_GOALS] (aliases ov_idx: the name overrides are dead once the goals are placed)
     int lane;
     __device__ __forceinline__ int at(int i) const { return i * 64 + lane; }
 };
@@ -233,12 +234,13 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
             const int lx = x - off, ly = y - off;
             g[y * MD + x] = (lx >= 0 && ly >= 0 && lx < D && ly < D) ? (uint16_t)0 : brick;
         }
-    auto put = [&](int c, int icon) { g[(c / D + off) * MD + (c % D + off)] = (uint16_t)(icon + 1); };
+    auto put_code = [&](int c, uint16_t code) { g[(c / D + off) * MD + (c % D + off)] = code; };
+    auto put = [&](int c, int icon) { put_code(c, (uint16_t)(icon + 1)); };
 
     const int ng = p.num_goals;
     Mask<NW> avail, occupied;
     occupied.clear();
-    int na, agent_cell;
+    int na, agent_cell, agent_icon;
 
     if constexpr (KIND == 0) {
         // ---- XWorldNav: distinct goal names (shuffle + pop), maze, shuffled '#' list, placement ----
@@ -279,9 +281,11 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
             avail.reset(c); na--;
             const int nm = L.gname[L.at(i)];
             const int v = (int)s.below((uint32_t)T.nv(0, nm));
-            put(c, T.icon(0, nm, v));
+            const int ic = T.icon(0, nm, v);
+            put(c, ic);
             occupied.set(c);
             L.gcell[L.at(i)] = (uint8_t)c;
+            L.gicon[L.at(i)] = (uint16_t)ic;
         }
         for (int i = 0; i < p.num_blocks; ++i) {
             const int c = L.blk[L.at(--nb)];                   // blocks.pop()
@@ -295,7 +299,8 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
             avail.reset(c); na--;
             const int nm = (int)s.below((uint32_t)p.n_names[2]);
             const int v = (int)s.below((uint32_t)T.nv(2, nm));
-            put(c, T.icon(2, nm, v));
+            agent_icon = T.icon(2, nm, v);
+            put(c, agent_icon);
             agent_cell = c;
         }
     } else {
@@ -317,7 +322,8 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
             avail.reset(c); na--;
             const int nm = (int)s.below((uint32_t)p.n_names[2]);
             const int v = (int)s.below((uint32_t)T.nv(2, nm));
-            put(c, T.icon(2, nm, v));
+            agent_icon = T.icon(2, nm, v);
+            put(c, agent_icon);
             agent_cell = c;
         }
         for (int i = 0; i < ng; ++i) {
@@ -325,10 +331,12 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
             avail.reset(c); na--;
             const int nm = (int)s.below((uint32_t)p.n_names[0]);
             const int v = (int)s.below((uint32_t)T.nv(0, nm));
-            put(c, T.icon(0, nm, v));
+            const int ic = T.icon(0, nm, v);
+            put(c, ic);
             occupied.set(c);
             L.gcell[L.at(i)] = (uint8_t)c;
             L.gname[L.at(i)] = (uint16_t)nm;
+            L.gicon[L.at(i)] = (uint16_t)ic;
         }
         for (int i = 0; i < nb; ++i) {
             const int c = L.blk[L.at(i)];
@@ -339,37 +347,240 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
         }
     }
 
-    // ---- XWorld3DNavTarget.idle: goals reachable from the agent with blocks and the other goals as obstacles.
-    // Flood the empty cells from the agent by whole-board shifts; a goal is reachable iff one of its
-    // 4-neighbours is flooded (a path's interior holds neither blocks nor goals).
-    Mask<NW> free_cells = valid.andnot(occupied);          // agent cell included: it is the seed
-    Mask<NW> reach;
-    reach.clear();
-    reach.set(agent_cell);
-    for (int it = 0; it < D * D; ++it) {
-        const Mask<NW> grown = reach | (neighbours<NW>(reach, D, col0, colN, valid) & free_cells);
-        if (grown.equals(reach)) break;
-        reach = grown;
+    // ---- teacher idle stage (TaskGroup::run_stage samples one task of the group per episode, then its idle()):
+    // decision order "xwb-taskgen-v1" (DESIGN.md).  Nothing is written to the grid before the stage has
+    // succeeded, so the "map too crowded?" cases (the reference asserts) simply keep the generated map.
+    const int n_tasks = p.n_tasks > 0 ? p.n_tasks : 1;
+    const int tsel = (int)s.below((uint32_t)n_tasks);
+    const int kind = p.n_tasks > 0 ? p.tasks[tsel] : TASK_TARGET;
+    uint32_t target_bits = 0;                              // goal slot i belongs to self.target
+    int between = -1;                                      // NavTargetBetween: the middle cell (actual-dim index)
+    int target_field = -1;
+
+    if (kind == TASK_TARGET || kind == TASK_AVOID) {
+        // goals reachable from the agent with blocks and the other goals as obstacles: flood the empty cells from
+        // the agent by whole-board shifts; a goal is reachable iff one of its 4-neighbours is flooded
+        const Mask<NW> free_cells = valid.andnot(occupied);          // agent cell included: it is the seed
+        Mask<NW> reach;
+        reach.clear();
+        reach.set(agent_cell);
+        for (int it = 0; it < D * D; ++it) {
+            const Mask<NW> grown = reach | (neighbours<NW>(reach, D, col0, colN, valid) & free_cells);
+            if (grown.equals(reach)) break;
+            reach = grown;
+        }
+        int nc = 0;
+        uint32_t cand_bits = 0;
+        for (int i = 0; i < ng; ++i) {
+            Mask<NW> gm;
+            gm.clear();
+            gm.set(L.gcell[L.at(i)]);
+            if ((neighbours<NW>(gm, D, col0, colN, valid) & reach).any()) { cand_bits |= 1u << i; nc++; }
+        }
+        if (nc > 0) {                                                // else: assert targets, "map too crowded?"
+            int k = (int)s.below((uint32_t)nc);                      // sel_goal = random.choice(targets)
+            int pick = 0;
+            for (int i = 0; i < ng; ++i)
+                if ((cand_bits >> i) & 1u) { if (k == 0) { pick = i; break; } k--; }
+            const int selname = L.gname[L.at(pick)];
+            if (kind == TASK_TARGET) {
+                target_field = selname;
+                for (int i = 0; i < ng; ++i) if (L.gname[L.at(i)] == selname) target_bits |= 1u << i;
+            } else {
+                int nr = 0;
+                for (int i = 0; i < ng; ++i) if (L.gname[L.at(i)] != selname) nr++;
+                if (nr > 0) {                                        // else: assert referents
+                    int r = (int)s.below((uint32_t)nr);              // referent = random.choice(referents)
+                    int refname = 0;
+                    for (int i = 0; i < ng; ++i)
+                        if (L.gname[L.at(i)] != selname) { if (r == 0) { refname = L.gname[L.at(i)]; break; } r--; }
+                    for (int i = 0; i < ng; ++i) if (L.gname[L.at(i)] != refname) target_bits |= 1u << i;
+                }
+            }
+        }
+    } else if (ng >= 2) {
+        // ---- Near / Between / Direction: delete the agent and two goals, put the goals on a tile, re-place the agent
+        Mask<NW> A = valid.andnot(occupied);                         // available_grids after _delete_entity(agent)
+        const int d0 = (int)s.below((uint32_t)ng);                   // random.shuffle(goals); g1, g2 = goals[:2]
+        const int d1 = (int)s.below((uint32_t)(ng - 1));
+        const int g1 = d0, g2 = d1 < d0 ? d1 : d1 + 1;
+        const int c1o = L.gcell[L.at(g1)], c2o = L.gcell[L.at(g2)];
+        A.set(c1o); A.set(c2o);
+        auto from_right = [&](const Mask<NW> &m) { return m.andnot(col0).shr(1); };   // bit c = m[c+1], x < D-1
+        const Mask<NW> Nl = A.andnot(colN).shl(1) & valid, Nr = from_right(A), Nu = A.shl(D) & valid, Nd = A.shr(D);
+        Mask<NW> M[6];
+        int nm = 0;
+        if (kind == TASK_NEAR) {                                     // _get_p_tiles
+            const Mask<NW> C1 = Nl | Nr | Nu | Nd;
+            const Mask<NW> C2 = (Nl & Nr) | (Nl & Nu) | (Nl & Nd) | (Nr & Nu) | (Nr & Nd) | (Nu & Nd);
+            const Mask<NW> Hb = A & Nr, Vb = A & Nd, Db = A & from_right(A.shr(D));
+            M[0] = Hb & from_right(C2); M[1] = Hb & C2;
+            M[2] = Vb & C2.shr(D);      M[3] = Vb & C2;
+            M[4] = Db & from_right(C1.shr(D)); M[5] = Db & C1;
+            nm = 6;
+        } else if (kind == TASK_BETWEEN) {                           // _get_t_tiles
+            M[0] = A & Nl & Nr & (Nu | Nd);
+            M[1] = A & Nu & Nd & (Nl | Nr);
+            nm = 2;
+        } else {                                                     // _get_l_tiles
+            const Mask<NW> Tv = A & Nd & A.shr(2 * D);
+            const Mask<NW> Th = A & Nr & from_right(Nr);
+            M[0] = Tv; M[1] = Tv; M[2] = Th; M[3] = Th;
+            nm = 4;
+        }
+        int nt = 0;
+        for (int m = 0; m < 6; ++m) if (m < nm)
+#pragma unroll
+            for (int wi = 0; wi < NW; ++wi) nt += __popcll(M[m].w[wi]);
+        bool ok = nt > 0;                                            // assert tiles, "map too crowded?"
+        int l1 = 0, l2 = 0, al = 0, direction = 0, tgt = g1, ref = g2;
+        if (ok) {
+            int t0 = (int)s.below((uint32_t)nt);                     // random.shuffle(tiles); tiles[0]
+            if (nt >= 2) (void)s.below((uint32_t)(nt - 1));
+            // tiles are listed cell-major, the nm kinds in order inside a cell: find the cell, then the kind
+            int tc = 0, tm = 0;
+            {
+                int lo = 0, hi = D * D;                              // smallest c with prefix(c + 1) > t0
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    int pre = 0;
+                    for (int m = 0; m < 6; ++m) if (m < nm)
+#pragma unroll
+                        for (int wi = 0; wi < NW; ++wi) {
+                            const int b = mid + 1 - wi * 64;
+                            const uint64_t lowmask = b <= 0 ? 0ull : (b >= 64 ? ~0ull : ((1ull << b) - 1ull));
+                            pre += __popcll(M[m].w[wi] & lowmask);
+                        }
+                    if (pre > t0) hi = mid; else lo = mid + 1;
+                }
+                tc = lo;
+                int pre = 0;
+                for (int m = 0; m < 6; ++m) if (m < nm)
+#pragma unroll
+                    for (int wi = 0; wi < NW; ++wi) {
+                        const int b = tc - wi * 64;
+                        const uint64_t lowmask = b <= 0 ? 0ull : (b >= 64 ? ~0ull : ((1ull << b) - 1ull));
+                        pre += __popcll(M[m].w[wi] & lowmask);
+                    }
+                int r = t0 - pre;
+                for (int m = 0; m < 6; ++m) if (m < nm && M[m].test(tc)) { if (r == 0) { tm = m; break; } r--; }
+            }
+            if (kind == TASK_NEAR) {
+                const int other = tm < 2 ? tc + 1 : (tm < 4 ? tc + D : tc + D + 1);
+                l1 = (tm & 1) ? other : tc; l2 = (tm & 1) ? tc : other;
+            } else if (kind == TASK_BETWEEN) {
+                l1 = tm == 0 ? tc - 1 : tc - D; l2 = tm == 0 ? tc + 1 : tc + D;
+            } else {
+                const int st = tm < 2 ? D : 1;
+                l1 = (tm & 1) ? tc + st : tc; l2 = (tm & 1) ? tc + 2 * st : tc + st;
+            }
+            occupied.reset(c1o); occupied.reset(c2o);
+            occupied.set(l1); occupied.set(l2);                      // _set_entity_inst(g1), (g2)
+            A.reset(l1); A.reset(l2);
+            int seed = l2;
+            bool inclusive = false;
+            if (kind == TASK_BETWEEN) {
+                seed = (l1 + l2) / 2;                                // _middle_loc: same row or same column
+            } else if (kind == TASK_DIRECTION) {
+                Mask<NW> one;
+                one.clear(); one.set(l1);
+                Mask<NW> Ne = neighbours<NW>(one, D, col0, colN, valid) & A;   // empty 4-neighbours of g1 ...
+                if (!Ne.any()) { one.clear(); one.set(l2); Ne = neighbours<NW>(one, D, col0, colN, valid) & A; tgt = g2; ref = g1; }
+                int ne = 0;
+#pragma unroll
+                for (int wi = 0; wi < NW; ++wi) ne += __popcll(Ne.w[wi]);
+                if (ne == 0) ok = false;                             // assert empty_grids
+                else {
+                    const int ec = Ne.select((int)s.below((uint32_t)ne));    // random.choice(empty_grids), row-major
+                    const int tl = tgt == g1 ? l1 : l2, rl = ref == g1 ? l1 : l2;
+                    // __compute_triple_direction(target, referent, e): view = e -> target, v2 = target -> referent
+                    const int v1x = tl % D - ec % D, v1y = tl / D - ec / D;
+                    const int v2x = rl % D - tl % D, v2y = rl / D - tl / D;
+                    const int c = v1x * v2x + v1y * v2y, sn = v1y * v2x - v1x * v2y;
+                    direction = c > 0 ? DIR_FRONT : (c < 0 ? DIR_BEHIND : (sn > 0 ? DIR_RIGHT : DIR_LEFT));
+                    seed = ec; inclusive = true;                     // _propagate_agent([e], inclusive=True)
+                }
+            }
+            if (ok) {
+                // _propagate_agent: flood fill from the seed over cells that hold neither blocks nor goals
+                const Mask<NW> open = valid.andnot(occupied);
+                Mask<NW> fl;
+                fl.clear(); fl.set(seed);
+                for (int it = 0; it < D * D; ++it) {
+                    const Mask<NW> grown = fl | (neighbours<NW>(fl, D, col0, colN, valid) & open);
+                    if (grown.equals(fl)) break;
+                    fl = grown;
+                }
+                int na = inclusive ? 0 : -1;                         // the seed itself only counts when inclusive
+#pragma unroll
+                for (int wi = 0; wi < NW; ++wi) na += __popcll(fl.w[wi]);
+                if (na <= 0) ok = false;                             // assert new_a
+                else {
+                    int ka = (int)s.below((uint32_t)na);             // agent.loc, _ = random.choice(new_a)
+                    al = seed;
+                    if (!(inclusive && ka == 0)) {
+                        // new_a is in BFS discovery order (moves left, right, up, down): replay the BFS up to entry ka
+                        const int want = inclusive ? ka - 1 : ka;
+                        Mask<NW> seen;
+                        seen.clear(); seen.set(seed);
+                        int head = 0, tail = 0, count = 0;
+                        L.blk[L.at(tail++)] = (uint8_t)seed;
+                        bool found = false;
+                        while (head < tail && !found) {
+                            const int c = L.blk[L.at(head++)];
+                            const int cx = c % D, cy = c / D;
+                            for (int m = 0; m < 4 && !found; ++m) {
+                                const int nx = cx + (m == 0 ? -1 : (m == 1 ? 1 : 0)), ny = cy + (m == 2 ? -1 : (m == 3 ? 1 : 0));
+                                if (nx < 0 || ny < 0 || nx >= D || ny >= D) continue;
+                                const int nc2 = ny * D + nx;
+                                if (seen.test(nc2) || occupied.test(nc2)) continue;
+                                seen.set(nc2);
+                                L.blk[L.at(tail++)] = (uint8_t)nc2;
+                                if (count == want) { al = nc2; found = true; }
+                                count++;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (ok) {
+            // the env changed: XWorld::reset(false).  Clear the three old cells, then write the new ones.
+            auto clear_cell = [&](int c) { g[(c / D + off) * MD + (c % D + off)] = 0; };
+            clear_cell(c1o); clear_cell(c2o); clear_cell(agent_cell);
+            L.gcell[L.at(g1)] = (uint8_t)l1; L.gcell[L.at(g2)] = (uint8_t)l2;
+            put(al, agent_icon);
+            agent_cell = al;
+            if (kind == TASK_NEAR) {
+                // _get_surrounding_goals(refer=g1.loc): dist < 1.5 + 1e-3 = the 8-neighbourhood, goals AT g1.loc skipped
+                for (int i = 0; i < ng; ++i) {
+                    const int c = L.gcell[L.at(i)];
+                    const int ddx = c % D - l1 % D, ddy = c / D - l1 / D;
+                    if (c != l1 && ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1) target_bits |= 1u << i;
+                }
+            } else if (kind == TASK_BETWEEN) {
+                between = (l1 + l2) / 2;
+            } else {
+                // navigation_reward: a reached goal g wins iff direction(g, referent) seen along the agent's constant
+                // yaw 1.5707963 (heading +y) equals `direction` and g is within 1.0 + 1e-3 of the referent
+                const int rl = ref == g1 ? l1 : l2;
+                for (int i = 0; i < ng; ++i) {
+                    const int c = L.gcell[L.at(i)];
+                    const int v2x = rl % D - c % D, v2y = rl / D - c / D;
+                    if (v2x * v2x + v2y * v2y != 1) continue;         // dist == 0 -> False; dist > 1.001 -> far
+                    const int dir = v2y > 0 ? DIR_FRONT : (v2y < 0 ? DIR_BEHIND : (v2x > 0 ? DIR_RIGHT : DIR_LEFT));
+                    if (dir == direction) target_bits |= 1u << i;
+                }
+            }
+        }
     }
-    int nc = 0;
-    uint32_t cand_bits = 0;                                 // goal i is a candidate
-    for (int i = 0; i < ng; ++i) {
-        Mask<NW> gm;
-        gm.clear();
-        gm.set(L.gcell[L.at(i)]);
-        if ((neighbours<NW>(gm, D, col0, colN, valid) & reach).any()) { cand_bits |= 1u << i; nc++; }
-    }
-    int target = -1;                                        // reference asserts nc > 0 ("map too crowded?")
-    if (nc > 0) {
-        int k = (int)s.below((uint32_t)nc);                 // random.choice(targets)
-        int pick = 0;
-        for (int i = 0; i < ng; ++i)
-            if ((cand_bits >> i) & 1u) { if (k == 0) { pick = i; break; } k--; }
-        target = L.gname[L.at(pick)];
-    }
+    // goal cells carry bit 15 when the goal belongs to the target set (the step kernel's whole reward rule)
+    for (int i = 0; i < ng; ++i)
+        put_code(L.gcell[L.at(i)], (uint16_t)((L.gicon[L.at(i)] + 1) | (((target_bits >> i) & 1u) ? 0x8000u : 0u)));
+    if (kind == TASK_BETWEEN && between >= 0) target_field = (between / D + off) * MD + (between % D + off);
 
     p.agent_xy[e] = (agent_cell % D + off) | ((agent_cell / D + off) << 16);
-    p.task_state[e] = pack_task(target, STAGE_NAV, EV_NONE);
+    p.task_state[e] = pack_task(target_field, STAGE_NAV, EV_NONE, kind);
     p.task_steps[e] = 0;
     p.num_steps[e] = 0;
     p.fresh[e] = 2;                                       // render: init_screen (zero the older context frames)
@@ -390,6 +601,7 @@ __global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int 
     L.gname = reinterpret_cast<uint16_t *>(lds32 + 64 * 64);           // 16 x 64 x 2 B
     L.ov_idx = L.gname + XW_MAX_GOALS * 64;
     L.ov_val = L.ov_idx + XW_MAX_GOALS * 64;
+    L.gicon = L.ov_idx;
     L.gcell = reinterpret_cast<uint8_t *>(L.ov_val + XW_MAX_GOALS * 64);   // 16 x 64 B
     L.blk = L.gcell + XW_MAX_GOALS * 64;                               // D*D x 64 B
     // name -> icon-variant tables staged in LDS once per wavefront: every lookup afterwards is an LDS read

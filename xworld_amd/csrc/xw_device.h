@@ -7,9 +7,21 @@ namespace xwb {
 enum : int { STAGE_IDLE = 0, STAGE_NAV = 1, STAGE_TERMINAL = 2 };
 enum : int { EV_NONE = 0, EV_CORRECT = 1, EV_WRONG = 2, EV_TIMEUP = 3 };
 
-__device__ __forceinline__ int pack_task(int target, int stage, int event) {
-    return (target & 0xffff) | (stage << 16) | (event << 24);
+// tasks of the XWorld3DNav group (confs/navigation2d.json order) and the direction words of NavTargetDirection
+enum : int { TASK_TARGET = 0, TASK_NEAR = 1, TASK_BETWEEN = 2, TASK_DIRECTION = 3, TASK_AVOID = 4 };
+enum : int { DIR_FRONT = 1, DIR_BEHIND = 2, DIR_LEFT = 3, DIR_RIGHT = 4 };
+
+// task_state word: target (name id for NavTarget, middle cell for NavTargetBetween, else -1) | stage | event | task
+__device__ __forceinline__ int pack_task(int target, int stage, int event, int kind) {
+    return (target & 0xffff) | (stage << 16) | (event << 20) | (kind << 24);
 }
+__device__ __forceinline__ int task_target(int ts) { return (int)(int16_t)(ts & 0xffff); }
+__device__ __forceinline__ int task_stage(int ts) { return (ts >> 16) & 0xf; }
+__device__ __forceinline__ int task_event(int ts) { return (ts >> 20) & 0xf; }
+__device__ __forceinline__ int task_kind(int ts) { return (ts >> 24) & 0xf; }
+
+// cell code: bits 0..14 = palette icon + 1 (0 = empty), bit 15 = the goal belongs to the teacher's target set
+constexpr uint32_t CELL_ICON_MASK = 0x7fffu, CELL_TARGET_BIT = 0x8000u;
 
 __device__ __forceinline__ int done_code(const XwParams &p, int num_steps, int event) {
     // AgentSpecificSimulator::game_over = GameSimulator::game_over | XWorldSimulator::game_over

@@ -77,6 +77,7 @@ struct xwb_sim {
     int16_t *d_icon_name = nullptr, *d_name_first = nullptr, *d_name_variants = nullptr;
     uint32_t *d_atlas = nullptr;
     std::vector<uint8_t> tile_table;   // host copy, n_icons x c x 12 x 12
+    std::vector<int32_t> icon_type_h, icon_name_h;
     XwParams xw{};
     std::vector<void *> allocs;
 };
@@ -188,6 +189,9 @@ int xw_setup(xwb_sim *s) {
     if (c.n_icons < 1 || !c.icons64 || !c.icon_type || !c.icon_name)
         return fail(XWB_ERR_ARG, "xworld: icons64 / icon_type / icon_name are required (the reference loads item_path images)");
     if (c.n_icons > 4000) return fail(XWB_ERR_ARG, "xworld: too many icons");
+    if (c.n_tasks < 0 || c.n_tasks > 8) return fail(XWB_ERR_ARG, "xworld: need 0 <= n_tasks <= 8");
+    for (int i = 0; i < c.n_tasks; ++i)
+        if (c.tasks[i] < XWB_TASK_TARGET || c.tasks[i] > XWB_TASK_AVOID) return fail(XWB_ERR_ARG, "xworld: unknown task id");
     const int n = s->n, cells = c.max_dim * c.max_dim, ch = c.color ? 3 : 1;
     // name tables (xworld_env.py:247-255): per type, names -> icon variants (icon order = path order)
     int n_names[3] = {0, 0, 0};
@@ -234,6 +238,8 @@ int xw_setup(xwb_sim *s) {
     std::vector<uint8_t> types(c.n_icons);
     std::vector<int16_t> names(c.n_icons);
     for (int i = 0; i < c.n_icons; ++i) { types[i] = (uint8_t)c.icon_type[i]; names[i] = (int16_t)c.icon_name[i]; }
+    s->icon_type_h.assign(c.icon_type, c.icon_type + c.n_icons);
+    s->icon_name_h.assign(c.icon_name, c.icon_name + c.n_icons);
 
     int rc;
     if ((rc = dev_alloc(s, &s->d_grid, (size_t)n * cells))) return rc;
@@ -263,6 +269,8 @@ int xw_setup(xwb_sim *s) {
     p.map_kind = c.map_kind; p.max_dim = c.max_dim; p.dim = c.dim; p.num_goals = c.num_goals;
     p.num_blocks = c.num_blocks; p.max_steps_factor = c.max_steps_factor; p.task_mode = c.task_mode;
     p.channels = ch; p.n_icons = c.n_icons;
+    p.n_tasks = c.n_tasks;
+    for (int i = 0; i < 8; ++i) p.tasks[i] = i < c.n_tasks ? c.tasks[i] : 0;
     p.policy_seed = c.policy_seed; p.env_gid0 = c.env_gid0; p.policy_step = 0; p.seed = c.seed;
     p.icon_type = s->d_icon_type; p.icon_name = s->d_icon_name;
     p.name_first = s->d_name_first; p.name_variants = s->d_name_variants;
@@ -712,9 +720,11 @@ int xwb_get_env_state(xwb_sim *s, int32_t env, void *stream, xwb_env_state *o) {
     o->lives = s->cfg.game == XWB_SIMPLE_RACE ? 1 : (done ? 0 : 1);
     if (s->cfg.game == XWB_XWORLD2D) {
         o->xw_agent_x = axy & 0xffff; o->xw_agent_y = axy >> 16;
-        o->xw_target_name = (int16_t)(ts & 0xffff);
-        o->xw_stage = (ts >> 16) & 0xff;
-        o->xw_event = (ts >> 24) & 0xff;
+        o->xw_task = (ts >> 24) & 0xf;
+        o->xw_target = (int16_t)(ts & 0xffff);
+        o->xw_target_name = o->xw_task == XWB_TASK_TARGET ? o->xw_target : -1;
+        o->xw_stage = (ts >> 16) & 0xf;
+        o->xw_event = (ts >> 20) & 0xf;
         o->xw_steps_in_task = tsteps;
     }
     return XWB_OK;
@@ -741,9 +751,10 @@ int xwb_get_env_grid(xwb_sim *s, int32_t env, void *stream, uint16_t *out_host) 
     return XWB_OK;
 }
 
-int xwb_xw_load_map(xwb_sim *s, int32_t env, const uint16_t *grid_host, int32_t agent_x, int32_t agent_y,
-                    int32_t target_name, int32_t dim) {
+int xwb_xw_load_map_task(xwb_sim *s, int32_t env, const uint16_t *grid_host, int32_t agent_x, int32_t agent_y,
+                         int32_t dim, int32_t task, int32_t target) {
     if (!s || !grid_host) return fail(XWB_ERR_ARG, "NULL argument");
+    if (task < XWB_TASK_TARGET || task > XWB_TASK_AVOID) return fail(XWB_ERR_ARG, "unknown task id");
     if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
     if (dim != s->cfg.dim) return fail(XWB_ERR_ARG, "dim differs from the batch's dim");
@@ -752,7 +763,7 @@ int xwb_xw_load_map(xwb_sim *s, int32_t env, const uint16_t *grid_host, int32_t 
     HIP_TRY(hipDeviceSynchronize());
     const size_t cells = (size_t)D * D;
     int32_t axy = agent_x | (agent_y << 16);
-    int32_t ts = (target_name & 0xffff) | (1 << 16);
+    int32_t ts = (target & 0xffff) | (1 << 16) | (task << 24);          // stage NAV, no event (xw_device.h)
     int32_t zero = 0;
     uint8_t z8 = 0, one = 2;
     HIP_TRY(hipMemcpy(s->d_grid + (size_t)env * cells, grid_host, cells * 2, hipMemcpyHostToDevice));
@@ -772,6 +783,22 @@ int xwb_xw_load_map(xwb_sim *s, int32_t env, const uint16_t *grid_host, int32_t 
     HIP_TRY(hipMemset(p.done_count, 0, 4));
     s->list_valid = false;
     return XWB_OK;
+}
+
+int xwb_xw_load_map(xwb_sim *s, int32_t env, const uint16_t *grid_host, int32_t agent_x, int32_t agent_y,
+                    int32_t target_name, int32_t dim) {
+    if (!s || !grid_host) return fail(XWB_ERR_ARG, "NULL argument");
+    if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
+    // XWorld3DNavTarget: every goal named target_name is a target
+    const size_t cells = (size_t)s->cfg.max_dim * s->cfg.max_dim;
+    std::vector<uint16_t> g(grid_host, grid_host + cells);
+    for (auto &c : g) {
+        const int icon = (int)(c & XWB_CELL_ICON_MASK) - 1;
+        c &= XWB_CELL_ICON_MASK;
+        if (icon >= s->cfg.n_icons) return fail(XWB_ERR_ARG, "cell code beyond the palette");
+        if (icon >= 0 && s->icon_type_h[icon] == XWB_ICON_GOAL && s->icon_name_h[icon] == target_name) c |= XWB_CELL_TARGET;
+    }
+    return xwb_xw_load_map_task(s, env, g.data(), agent_x, agent_y, dim, XWB_TASK_TARGET, target_name);
 }
 
 int xwb_race_set_car(xwb_sim *s, int32_t env, float x, float y, float angle) {

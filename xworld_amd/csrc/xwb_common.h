@@ -129,6 +129,7 @@ struct XwParams {
     int n, context, max_steps, act_rep, auto_reset;
     int map_kind, max_dim, dim, num_goals, num_blocks, max_steps_factor, task_mode, channels;
     int n_icons;
+    int n_tasks, tasks[8];       // tasks of the teacher's group, sampled uniformly per episode
     uint32_t policy_seed, env_gid0, policy_step, seed;
     // icon tables (device)
     const uint8_t *icon_type;    // [n_icons]
@@ -143,10 +144,10 @@ struct XwParams {
     const uint8_t *mask;
     int32_t *actions_out;
     // state
-    uint16_t *grid;              // [n][max_dim*max_dim] cell code = icon + 1, 0 empty
+    uint16_t *grid;              // [n][max_dim*max_dim] cell code = icon + 1 (0 empty) | bit 15: target goal
     int32_t *agent_xy;           // x | y << 16
     int32_t *task_steps;         // steps_in_cur_task
-    int32_t *task_state;         // target name (low 16) | stage << 16 | event << 24
+    int32_t *task_state;         // target (low 16) | stage << 16 | event << 20 | task << 24  (xw_device.h)
     int32_t *num_steps;
     uint32_t *episode;
     uint8_t *success;            // last_action_success
