@@ -155,7 +155,7 @@ __device__ __forceinline__ uint4 xw_expand_chunk(const uint32_t *atlas, const ui
     for (int k = 0; k < 4; ++k) {
         const int cy = y / XW_TILE, py = y - cy * XW_TILE;
         const int cx = dx / XW_TILE_DW, kk = dx - cx * XW_TILE_DW;
-        const uint32_t code = g[cy * D + cx] & CELL_ICON_MASK;
+        const uint32_t code = g[cy * D + cx];
         out[k] = atlas[code * (CH * 36) + ch * 36 + py * 3 + kk];   // tile 0 = empty cell (white)
         dx += 1;
         if (dx == RD) { dx = 0; y += 1; if (y == RH) { y = 0; ch += 1; } }
@@ -205,7 +205,7 @@ __device__ __forceinline__ uint4 xw_expand_chunk2(const uint32_t *atlas, const u
         dx += 1;
         if (dx == RD) { dx = 0; y += 1; if (y == RH) { y = 0; ch += 1; } }
     }
-    const uint32_t ca = g[cidx[0]] & CELL_ICON_MASK, cb = g[cidx[3]] & CELL_ICON_MASK;    // bit 15 = target flag
+    const uint32_t ca = g[cidx[0]], cb = g[cidx[3]];     // staged codes: the target bit is already stripped
     uint32_t out[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(1024) void xw_render_all_kernel(XwParams p, int til
         const int ne = e_last - e_first + 1;                           // <= tile_envs + 1
         __syncthreads();
         const uint16_t *gsrc = p.grid + (size_t)e_first * cells;
-        for (int i = tid; i < ne * cells; i += 1024) s_grid[i] = gsrc[i];
+        for (int i = tid; i < ne * cells; i += 1024) s_grid[i] = gsrc[i] & CELL_ICON_MASK;   // drop the target bit
         if (!CTX1 && tid < ne) s_fresh[tid] = p.fresh[e_first + tid];  // rewritten by the next step kernel
         __syncthreads();
         const unsigned base = (unsigned)(w0 - (long long)e_first * cpf);   // chunk offset of w0 inside env e_first
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
     for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
         const int e = p.done_list[i];
         __syncthreads();
-        for (int k = threadIdx.x; k < cells; k += 256) s_grid[k] = p.grid[(size_t)e * cells + k];
+        for (int k = threadIdx.x; k < cells; k += 256) s_grid[k] = p.grid[(size_t)e * cells + k] & CELL_ICON_MASK;
         __syncthreads();
         uint4 *frame0 = reinterpret_cast<uint4 *>(p.obs) + (size_t)e * ctx * cpf;
         for (int cc = threadIdx.x; cc < cpf; cc += 256) {
