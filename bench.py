@@ -40,7 +40,7 @@ WORKLOADS = {
 }
 
 
-def make_sim(workload, n_envs, device, gid0):
+def make_sim(workload, n_envs, device, gid0, seed=0xC0FFEE):
     from xworld_amd.batched import BatchedSimulator
     game, opts, _ = WORKLOADS[workload]
     opts = dict(opts)
@@ -48,7 +48,7 @@ def make_sim(workload, n_envs, device, gid0):
         opts["xwd_conf_path"] = os.path.join(ROOT, "xworld_amd", "confs", "navigation2d.json")       # the five XWorld3DNav tasks
         opts["task_mode"] = "lang_acquisition"
     return BatchedSimulator(game, opts, num_envs=n_envs, device=device, env_gid0=gid0,
-                            seed=0xC0FFEE, policy_seed=0x5EED)
+                            seed=seed, policy_seed=0x5EED)
 
 
 def algorithmic_bytes(workload, sim):
@@ -119,7 +119,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--seed", type=lambda v: int(v, 0), default=0xC0FFEE, help="env RNG seed (xwb-rng-v1 key word 0)")
     ap.add_argument("--workload", default="xworld7", choices=list(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--gather-screens", action="store_true")
@@ -142,7 +143,7 @@ def main():
     n_gpus = world
     dev = torch.device("cuda", local_rank)
     n_local = args.envs_per_gpu or WORKLOADS[args.workload][2]
-    sim = make_sim(args.workload, n_local, local_rank, rank * n_local)
+    sim = make_sim(args.workload, n_local, local_rank, rank * n_local, args.seed)
     per_step, per_launch, kernel_name = algorithmic_bytes(args.workload, sim)
 
     # per-step exchange (xworld_amd/sharding.py): (reward, game_over) of every shard to rank 0 through one
@@ -228,7 +229,7 @@ def main():
             "dtype": "u8" if WORKLOADS[args.workload][0] != "simple_race" else "f32 (f64 trig)",
             "data": "synthetic",
             "config": {"workload": args.workload, "envs_per_gpu": n_local, "total_envs": total_envs,
-                       "obs": list(sim.obs.shape[1:]), "policy": "uniform random, drawn on device",
+                       "obs": list(sim.obs.shape[1:]), "seed": args.seed, "policy": "uniform random, drawn on device",
                        "loop": "step_autoreset" if args.autoreset else "step + reset_done",
                        "exchange": ("gather(reward,done)" + ("+gather(screens)" if args.gather_screens else ""))
                        if world > 1 else "none", "parallelism": "env-sharded x%d" % world},
