@@ -113,6 +113,7 @@ void    orc_race_get_state_screen(const orc_simple_race *g, float *out /* contex
 typedef struct {
     int type;      /* 0 goal, 1 block, 2 agent  (xworld_env.py grid_types) */
     int name_id;   /* index into the sorted list of names of that type     */
+    int colored;   /* properties.txt colour of this image != "na" (xworld_env.py:201-205) */
 } orc_icon_info;
 
 enum { ORC_MAP_NAV = 0, ORC_MAP_WALLS = 1 };
@@ -120,7 +121,9 @@ enum { ORC_EV_NONE = 0, ORC_EV_CORRECT = 1, ORC_EV_WRONG = 2, ORC_EV_TIMEUP = 3 
 enum { ORC_STAGE_IDLE = 0, ORC_STAGE_NAV = 1, ORC_STAGE_TERMINAL = 2 };
 enum { ORC_TASKMODE_LANG_ACQ = 0, ORC_TASKMODE_ONE_CHANNEL = 1 };
 /* tasks of the XWorld3DNav group in confs/navigation2d.json order */
-enum { ORC_TASK_TARGET = 0, ORC_TASK_NEAR = 1, ORC_TASK_BETWEEN = 2, ORC_TASK_DIRECTION = 3, ORC_TASK_AVOID = 4 };
+enum { ORC_TASK_TARGET = 0, ORC_TASK_NEAR = 1, ORC_TASK_BETWEEN = 2, ORC_TASK_DIRECTION = 3, ORC_TASK_AVOID = 4,
+       /* the 2-D-native group "XWorldNav" of confs/walls.json (games/xworld/tasks/XWorldNav*.py, rule D14b) */
+       ORC_TASK2D_TARGET = 5, ORC_TASK2D_NEAR = 6, ORC_TASK2D_COLOR = 7, ORC_TASK2D_BETWEEN = 8 };
 
 typedef struct {
     int map_kind;            /* ORC_MAP_NAV | ORC_MAP_WALLS */
@@ -159,6 +162,13 @@ void    orc_xw_load_map(orc_xworld *w, int n_entities, const orc_entity *ents, i
 /* golden replay of any task: `decisions` are consumed, in order, wherever the idle stage would draw below(n) */
 void    orc_xw_load_map_ex(orc_xworld *w, int n_entities, const orc_entity *ents, int dim,
                            const int *decisions, int n_decisions, uint32_t env_gid, uint32_t episode);
+/* the same, but `decisions` (kept by the caller) stay installed for the idle stages that run at step time
+ * (2-D-native tasks return to "idle"); orc_xw_forced_left tells how many are still unconsumed */
+void    orc_xw_load_map_forced(orc_xworld *w, int n_entities, const orc_entity *ents, int dim,
+                               const int *decisions, int n_decisions, uint32_t env_gid, uint32_t episode);
+int     orc_xw_forced_left(const orc_xworld *w);
+/* 2-D-native tasks: the recorded target cell (C++ coordinates), (-1,-1) when none */
+void    orc_xw_target2d(const orc_xworld *w, int *x, int *y);
 float   orc_xw_take_actions(orc_xworld *w, int action, int act_rep);
 int     orc_xw_game_over(const orc_xworld *w);
 int     orc_xw_get_lives(const orc_xworld *w);

@@ -345,7 +345,10 @@ static void gen_map_walls(orc_xworld *w) {
 
 /* --------------------------------------------------------------- teacher -- */
 /* XWorld3DTask._reachable, xworld3d_task.py:328-342 (coordinates in actual dims) */
-int orc_task_reachable(const orc_xworld *w, int goal_ent) {
+int orc_task_reachable(const orc_xworld *w, int goal_ent) { return orc_task_reachable_ex(w, goal_ent, 1); }
+
+/* goals_are_obstacles = 0: XWorldTask._reachable, games/xworld/tasks/xworld_task.py:347-357 (blocks only) */
+int orc_task_reachable_ex(const orc_xworld *w, int goal_ent, int goals_are_obstacles) {
     uint8_t obst[MAXCELLS];
     int X = w->actual_w, Y = w->actual_h;
     memset(obst, 0, sizeof obst);
@@ -359,7 +362,7 @@ int orc_task_reachable(const orc_xworld *w, int goal_ent) {
         int ex = e->x - w->offset_w, ey = e->y - w->offset_h;
         if (ex < 0 || ey < 0 || ex >= X || ey >= Y) continue;   /* padding blocks are dropped, xworld_env.py:393 */
         if (e->type == 1) obst[ey * X + ex] = 1;
-        if (e->type == 0 && !(ex == gx && ey == gy)) obst[ey * X + ex] = 1;
+        if (goals_are_obstacles && e->type == 0 && !(ex == gx && ey == gy)) obst[ey * X + ex] = 1;
     }
     return orc_bfs_reachable(ax, ay, gx, gy, X, Y, obst);
 }
@@ -435,8 +438,20 @@ static void teacher_teach(orc_xworld *w, int idle_pick) {
     /* before_teach: clear_teacher_env_buffer */
     w->teacher_reward = 0; w->event = ORC_EV_NONE;
     switch (w->stage) {
-        case ORC_STAGE_IDLE: (void)idle_pick; orc_task_idle(w); break;
-        case ORC_STAGE_NAV: task_navigation_reward(w); break;
+        case ORC_STAGE_IDLE:
+            (void)idle_pick;
+            /* an idle stage at step time (only the 2-D-native tasks come back to "idle"): its decisions are the
+             * words of stream 2, block = num_steps ("xwb-taskgen-v1") */
+            if (w->num_steps > 0) {
+                orc_stream_init(&w->rs, w->cfg.seed, w->env_gid, w->episode, 2);
+                w->rs.ctr[0] = (uint32_t)w->num_steps;
+            }
+            orc_task_idle(w);
+            break;
+        case ORC_STAGE_NAV:
+            if (w->task_kind >= ORC_TASK2D_TARGET) orc_task2d_navigation_reward(w);
+            else task_navigation_reward(w);
+            break;
         default: w->teacher_reward += 0; break;   /* terminal(): ["terminal", 0, ""] */
     }
     /* py_stage consumed game_events_ (get_events_of_game) */
@@ -633,11 +648,15 @@ static void after_map(orc_xworld *w, int idle_pick) {
     w->stage = ORC_STAGE_IDLE;
     w->steps_in_cur_task = 0;
     w->target_name = -1;
+    w->target2d_x = w->target2d_y = -1;
+    w->task_kind = ORC_TASK_TARGET;
     teacher_teach(w, idle_pick);
     init_screen(w);
 }
 
 void orc_xw_reset_game(orc_xworld *w, uint32_t env_gid, uint32_t episode) {
+    w->env_gid = env_gid; w->episode = episode;
+    w->forced = NULL; w->n_forced = 0;
     orc_stream_init(&w->rs, w->cfg.seed, env_gid, episode, 0);
     if (w->cfg.map_kind == ORC_MAP_WALLS) gen_map_walls(w);
     else gen_map_nav(w);
@@ -652,6 +671,15 @@ void orc_xw_load_map_ex(orc_xworld *w, int n_entities, const orc_entity *ents, i
     w->forced = NULL; w->n_forced = 0;
 }
 
+void orc_xw_load_map_forced(orc_xworld *w, int n_entities, const orc_entity *ents, int dim,
+                            const int *decisions, int n_decisions, uint32_t env_gid, uint32_t episode) {
+    w->forced = decisions; w->n_forced = n_decisions; w->forced_at = 0;
+    orc_xw_load_map(w, n_entities, ents, dim, -1, env_gid, episode);
+}
+
+int orc_xw_forced_left(const orc_xworld *w) { return w->forced ? w->n_forced - w->forced_at : 0; }
+void orc_xw_target2d(const orc_xworld *w, int *x, int *y) { *x = w->target2d_x; *y = w->target2d_y; }
+
 void orc_xw_load_map(orc_xworld *w, int n_entities, const orc_entity *ents, int dim,
                      int target_pick, uint32_t env_gid, uint32_t episode) {
     /* target_pick >= 0: legacy form for a NavTarget-only config = decisions {task 0, pick} */
@@ -662,6 +690,7 @@ void orc_xw_load_map(orc_xworld *w, int n_entities, const orc_entity *ents, int 
         w->forced = NULL; w->n_forced = 0;
         return;
     }
+    w->env_gid = env_gid; w->episode = episode;
     orc_stream_init(&w->rs, w->cfg.seed, env_gid, episode, 0);
     set_dims(w, dim, dim);
     w->n_ents = 0;

@@ -40,6 +40,9 @@ struct orc_xworld {
     int task_kind;                   /* ORC_TASK_* of the busy task */
     uint8_t target_ent[MAXENT];      /* self.target: entity is a target goal */
     int between_x, between_y;        /* NavTargetBetween: the middle cell (C++ coordinates) */
+    int target2d_x, target2d_y;      /* 2-D-native tasks: XWorldTask.target (C++ coordinates), -1 = none */
+    uint32_t env_gid, episode;       /* of the running episode: step-time idle stages draw from stream 2 */
+    int forced_sticky;
     const int *forced; int n_forced, forced_at;   /* golden replay: decisions instead of stream draws */
     /* GameSimulator */
     int64_t num_steps;
@@ -55,4 +58,6 @@ int  orc_xw_draw_below(orc_xworld *w, int n);           /* next decision: forced
 /* xworld_tasks.c */
 void orc_task_idle(orc_xworld *w);                      /* TaskGroup::run_stage: sample a task, run its idle stage */
 int  orc_task_is_target(const orc_xworld *w, int ent);
+void orc_task2d_navigation_reward(orc_xworld *w);       /* XWorldTask.simple_navigation_reward */
+int  orc_task_reachable_ex(const orc_xworld *w, int goal_ent, int goals_are_obstacles);
 #endif

@@ -296,6 +296,56 @@ crowded:
     orc_xw_rebuild_map(w);
 }
 
+/* ---- the 2-D-native group (confs/walls.json "XWorldNav"; rule D14b) -------------------------------------------
+ * XWorldNavTarget.idle (XWorldNavTarget.py:22-33), XWorldNavColorTarget.idle (:8-20): targets = [coloured] goals
+ * the agent can reach with only the BLOCKS as obstacles; random.choice -> self.target = that goal's loc.
+ * XWorldNavNear.idle / XWorldNavBetween.idle build their candidate cells as 2-tuples while entity locs are
+ * 3-tuples (xworld_task.py:327,341-342 vs xworld_env.py:362), so bfs() never meets its `end` and no target is
+ * ever found: both stay in "idle" with reward 0 (reproduced by tests/golden/tasks2d.json). */
+static void idle_2d(orc_xworld *w, penv *p) {
+    w->steps_in_cur_task = 0;                                            /* TaskGroup::run_stage: busy_task_->reset() */
+    w->target2d_x = w->target2d_y = -1;
+    w->teacher_reward += 0.0;
+    w->stage = ORC_STAGE_IDLE;
+    if (w->task_kind != ORC_TASK2D_TARGET && w->task_kind != ORC_TASK2D_COLOR) return;
+    int cand[MAXENT], nc = 0;
+    for (int k = 0; k < p->ng; ++k) {
+        int g = p->goals[k];
+        if (w->task_kind == ORC_TASK2D_COLOR && !w->info[w->ents[g].icon].colored) continue;   /* _get_colored_goals */
+        if (orc_task_reachable_ex(w, g, 0)) cand[nc++] = g;
+    }
+    if (nc == 0) return;                                                 /* ["idle", 0, ""] */
+    int sel = cand[orc_xw_draw_below(w, nc)];                            /* random.choice(targets) */
+    w->target2d_x = w->ents[sel].x; w->target2d_y = w->ents[sel].y;     /* self._record_target(sel_goal.loc) */
+    w->stage = ORC_STAGE_NAV;                                            /* ["simple_navigation_reward", 0.0, ...] */
+}
+
+/* XWorldTask.simple_navigation_reward, games/xworld/tasks/xworld_task.py:184-223 */
+void orc_task2d_navigation_reward(orc_xworld *w) {
+    double reward = -0.1;                                                /* time_penalty */
+    if (!w->last_action_success) reward += -0.2;                         /* failed_action_penalty */
+    const orc_entity *a = &w->ents[w->agent_idx];
+    int next_stage = ORC_STAGE_NAV;
+    w->steps_in_cur_task += 1;
+    int on_goal = 0;
+    for (int i = 0; i < w->n_ents; ++i)
+        if (w->ents[i].type == 0 && w->ents[i].x == a->x && w->ents[i].y == a->y) on_goal = 1;
+    if (w->cfg.task_mode == ORC_TASKMODE_ONE_CHANNEL &&
+        w->steps_in_cur_task >= w->height * w->width / 2) {             /* get_max_dims(); Python-2 int division */
+        w->steps_in_cur_task = 0;
+        next_stage = ORC_STAGE_IDLE;                                     /* _record_failure; "S -> timeup" */
+    } else if (a->x == w->target2d_x && a->y == w->target2d_y) {
+        w->steps_in_cur_task = 0;
+        w->event = ORC_EV_CORRECT;
+        reward += 1.0;
+        next_stage = ORC_STAGE_IDLE;
+    } else if (on_goal) {
+        reward += -1.0;
+    }
+    w->teacher_reward += reward;
+    w->stage = next_stage;
+}
+
 void orc_task_idle(orc_xworld *w) {
     penv p;
     penv_init(&p, w);
@@ -306,6 +356,7 @@ void orc_task_idle(orc_xworld *w) {
     int n_tasks = w->cfg.n_tasks > 0 ? w->cfg.n_tasks : 1;
     int t = orc_xw_draw_below(w, n_tasks);
     w->task_kind = w->cfg.n_tasks > 0 ? w->cfg.tasks[t] : ORC_TASK_TARGET;
+    if (w->task_kind >= ORC_TASK2D_TARGET) { idle_2d(w, &p); return; }
     if (w->task_kind == ORC_TASK_TARGET || w->task_kind == ORC_TASK_AVOID) {
         int cand[MAXENT];
         int nc = reachable_goals(w, &p, cand);

@@ -35,7 +35,7 @@ class RaceCfg(C.Structure):
 
 
 class IconInfo(C.Structure):
-    _fields_ = [("type", C.c_int), ("name_id", C.c_int)]
+    _fields_ = [("type", C.c_int), ("name_id", C.c_int), ("colored", C.c_int)]
 
 
 class XwCfg(C.Structure):
@@ -136,6 +136,9 @@ def lib():
     sig("orc_xw_load_map_ex", None, vp, C.c_int, C.POINTER(Entity), C.c_int, i32p, C.c_int, C.c_uint32, C.c_uint32)
     sig("orc_xw_task_kind", C.c_int, vp)
     sig("orc_xw_between_cell", None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
+    sig("orc_xw_load_map_forced", None, vp, C.c_int, C.POINTER(Entity), C.c_int, i32p, C.c_int, C.c_uint32, C.c_uint32)
+    sig("orc_xw_forced_left", C.c_int, vp)
+    sig("orc_xw_target2d", None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
     sig("orc_xw_get_target_cells", None, vp, u8p)
     sig("orc_xw_take_actions", C.c_float, vp, C.c_int, C.c_int)
     for n in ("game_over", "get_lives", "num_actions", "last_action_success", "event", "stage",
@@ -304,6 +307,7 @@ class Palette:
         for i, m in enumerate(self.meta):
             self.info[i].type = TYPE_ID[m["type"]]
             self.info[i].name_id = self.names[m["type"]].index(m["name"])
+            self.info[i].colored = int(m.get("color", "na") != "na")
             self.type_arr[i] = self.info[i].type
             self.name_arr[i] = self.info[i].name_id
 
@@ -316,7 +320,8 @@ WALLS_SUBTREES = ("animal", "fruit", "shape")                   # XWorldWalls.py
 
 
 TASK_ID = {"XWorld3DNavTarget": 0, "XWorld3DNavTargetNear": 1, "XWorld3DNavTargetBetween": 2,
-           "XWorld3DNavTargetDirection": 3, "XWorld3DNavTargetAvoid": 4}
+           "XWorld3DNavTargetDirection": 3, "XWorld3DNavTargetAvoid": 4,
+           "XWorldNavTarget": 5, "XWorldNavNear": 6, "XWorldNavColorTarget": 7, "XWorldNavBetween": 8}
 
 
 def xw_cfg(**kw):
@@ -364,6 +369,23 @@ class XWorld:
             arr[i] = Entity(*e)
         d = np.asarray(decisions, np.int32)
         self.L.orc_xw_load_map_ex(self.h, len(ents), arr, dim, ptr(d, i32p), len(d), env_gid, episode)
+
+    def load_map_forced(self, ents, dim, decisions, env_gid=0, episode=0):
+        """As load_map_ex, but the decisions stay installed for idle stages that run at step time."""
+        arr = (Entity * len(ents))()
+        for i, e in enumerate(ents):
+            arr[i] = Entity(*e)
+        self._forced = np.asarray(decisions, np.int32).copy()          # must outlive the episode
+        self.L.orc_xw_load_map_forced(self.h, len(ents), arr, dim, ptr(self._forced, i32p), len(self._forced),
+                                      env_gid, episode)
+
+    def forced_left(self):
+        return self.L.orc_xw_forced_left(self.h)
+
+    def target2d(self):
+        x, y = C.c_int(), C.c_int()
+        self.L.orc_xw_target2d(self.h, C.byref(x), C.byref(y))
+        return x.value, y.value
 
     def task_kind(self):
         return self.L.orc_xw_task_kind(self.h)

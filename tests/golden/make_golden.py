@@ -34,6 +34,8 @@ Fixtures written:
   maps_walls.json  same for XWorldWalls
   teacher.json   XWorld3DNavTarget idle/navigation_reward run over random action strings on those maps:
                  per step action, reward, event, stage, agent cell, action success
+  tasks2d.json   the 2-D-native group of confs/walls.json (XWorldNavTarget / Near / ColorTarget / Between, rule D14b)
+                 as a one-task group, both task modes, every teach() call of a 70-step episode
   tasks.json     all five tasks of the XWorld3DNav group (Target, Near, Between, Direction, Avoid): the idle stage
                  driven by logged decisions (see DecisionRandom), the map after the teacher's rearrangement,
                  the target cells, and a random-action trace as in teacher.json
@@ -405,18 +407,101 @@ def gen_tasks(pal, n_maps, seed0, steps):
     return out
 
 
+# ------------------------------------- the 2-D-native group (rule D14b) ----
+class _ItDict(dict):
+    """dict with the Python-2 iteritems() that XWorldTask._get_surrounding_empty_grids calls."""
+
+    def iteritems(self):
+        return iter(self.items())
+
+
+class _Py2Int(int):
+    """int whose `*` stays a _Py2Int and whose `/` floors, as Python 2's int / int does
+    (xworld_task.py:205: `self.steps_in_cur_task >= h*w / 2`)."""
+
+    def __mul__(self, o):
+        return _Py2Int(int(self) * int(o))
+
+    def __truediv__(self, o):
+        return _Py2Int(int(self) // int(o))
+
+
+def gen_tasks2d(pals, n_maps, seed0, steps):
+    """games/xworld/tasks/XWorldNav{Target,Near,ColorTarget,Between}.py (confs/walls.json group "XWorldNav")
+    run as a one-task TaskGroup (teaching_task.cpp:204-222: when the task is idle, Task::reset then its stage).
+    Per teach() call: was the task idle, the decisions its idle stage drew, reward, event, stage, target cell."""
+    import importlib
+    sys.path.insert(0, os.path.join(REF, "games", "xworld", "tasks"))
+    names = ["XWorldNavTarget", "XWorldNavNear", "XWorldNavColorTarget", "XWorldNavBetween"]
+    out = {}
+    rnd = random.Random(777)
+    for mode in ("lang_acquisition", "one_channel"):
+        FLAGS["task_mode"] = mode
+        for key, env_cls in (("nav", XWorldNav), ("walls", XWorldWalls)):
+            pal = pals[key]
+            env = env_cls(ITEM_PATH)
+            for name in names:
+                mod = importlib.import_module(name)
+                cls = getattr(mod, name)
+                runs = []
+                for k in range(n_maps):
+                    random.seed(seed0 + k)
+                    env.reset()
+                    env.env_changed()
+                    ents = entity_records(env, pal)
+                    h = Harness(env)
+                    mh, mw = env.get_max_dims()
+                    env.get_max_dims = lambda _h=mh, _w=mw: (_Py2Int(_h), _Py2Int(_w))
+                    task = cls(env)
+                    task.directions = _ItDict(task.directions)
+                    fake = DecisionRandom(seed0 * 11 + k)
+                    real = mod.random
+                    mod.random = fake
+                    state = {"stage": "idle"}
+
+                    def teach():
+                        was_idle = state["stage"] == "idle"
+                        if was_idle:
+                            task.reset()
+                        n0 = len(fake.log)
+                        stage, reward, event = h.py_stage(task, state["stage"])
+                        state["stage"] = stage
+                        tgt = task.target
+                        tx, ty = (int(tgt[0]) + env.offset_w, int(tgt[1]) + env.offset_h) if tgt[0] >= 0 else (-1, -1)
+                        return [int(was_idle), list(fake.log[n0:]), reward, event, stage, tx, ty]
+                    try:
+                        first = teach()
+                        trace = []
+                        for t in range(steps):
+                            a = rnd.randrange(4)
+                            h.act(a)
+                            rec = teach()
+                            trace.append([a, int(h.agent["loc"][0]), int(h.agent["loc"][1]), int(bool(h.success))] + rec)
+                    finally:
+                        mod.random = real
+                        del env.get_max_dims
+                    runs.append({"py_seed": seed0 + k, "dim": env.get_dims()[0], "max_dim": mh, "entities": ents,
+                                 "reset_teach": first, "trace": trace})
+                out["%s/%s/%s" % (mode, key, name)] = runs
+    FLAGS["task_mode"] = "lang_acquisition"
+    return out
+
+
 def main():
     nav_pal = O.Palette(O.NAV_SUBTREES)
     walls_pal = O.Palette(O.WALLS_SUBTREES)
-    out = {
-        "maze.json": gen_maze(),
-        "bfs.json": gen_bfs(),
-        "maps_nav.json": gen_maps(XWorldNav, nav_pal, 60, 100),
-        "maps_walls.json": gen_maps(XWorldWalls, walls_pal, 30, 500),
-        "teacher.json": {"nav": gen_teacher(XWorldNav, nav_pal, 40, 2000, 700),
-                         "walls": gen_teacher(XWorldWalls, walls_pal, 24, 3000, 500)},
-        "tasks.json": gen_tasks(nav_pal, 24, 9000, 660),
+    makers = {
+        "maze.json": lambda: gen_maze(),
+        "bfs.json": lambda: gen_bfs(),
+        "maps_nav.json": lambda: gen_maps(XWorldNav, nav_pal, 60, 100),
+        "maps_walls.json": lambda: gen_maps(XWorldWalls, walls_pal, 30, 500),
+        "teacher.json": lambda: {"nav": gen_teacher(XWorldNav, nav_pal, 40, 2000, 700),
+                                 "walls": gen_teacher(XWorldWalls, walls_pal, 24, 3000, 500)},
+        "tasks.json": lambda: gen_tasks(nav_pal, 24, 9000, 660),
+        "tasks2d.json": lambda: gen_tasks2d({"nav": nav_pal, "walls": walls_pal}, 6, 12000, 70),
     }
+    only = sys.argv[1:]                      # optional: the fixtures to (re)generate
+    out = {name: make() for name, make in makers.items() if not only or name in only}
     for name, data in out.items():
         with open(os.path.join(HERE, name), "w") as f:
             json.dump(data, f, separators=(",", ":"))
