@@ -53,7 +53,11 @@ enum { XWB_ALIVE = 0, XWB_MAX_STEP = 1, XWB_DEAD = 2, XWB_SUCCESS = 4, XWB_LOST_
 
 enum { XWB_MAP_NAV = 0, XWB_MAP_WALLS = 1 };             /* games/xworld/maps/XWorldNav.py, XWorldWalls.py */
 /* tasks of games/xworld3d/tasks/XWorld3DNav*.py (the full-observation 2-D game runs the same Python tasks) */
-enum { XWB_TASK_TARGET = 0, XWB_TASK_NEAR = 1, XWB_TASK_BETWEEN = 2, XWB_TASK_DIRECTION = 3, XWB_TASK_AVOID = 4 };
+enum { XWB_TASK_TARGET = 0, XWB_TASK_NEAR = 1, XWB_TASK_BETWEEN = 2, XWB_TASK_DIRECTION = 3, XWB_TASK_AVOID = 4,
+       /* the 2-D-native group "XWorldNav" of confs/walls.json: games/xworld/tasks/XWorldNav{Target,Near,ColorTarget,
+        * Between}.py with XWorldTask.simple_navigation_reward (xworld_task.py:184-223).  A group holds tasks of one
+        * family only. */
+       XWB_TASK2D_TARGET = 5, XWB_TASK2D_NEAR = 6, XWB_TASK2D_COLOR = 7, XWB_TASK2D_BETWEEN = 8 };
 #define XWB_CELL_ICON_MASK 0x7fff   /* cell code & mask = palette icon + 1 (0 = empty) */
 #define XWB_CELL_TARGET    0x8000   /* cell code bit: this goal belongs to the task's target set */
 enum { XWB_TASKMODE_LANG_ACQ = 0, XWB_TASKMODE_ONE_CHANNEL = 1 };   /* FLAGS_task_mode, xworld_simulator.cpp:33-37 */
@@ -102,6 +106,8 @@ typedef struct xwb_config {
     const uint8_t *icons64;      /* host, n_icons x 64 x 64 x 3, BGR as cv::imread(path, 1) (xitem.cpp:38) */
     const int32_t *icon_type;    /* host, n_icons, XWB_ICON_* */
     const int32_t *icon_name;    /* host, n_icons, index into the sorted names of that type */
+    const int32_t *icon_colored; /* host, n_icons or NULL: properties.txt colour != "na" (xworld_env.py:201-205);
+                                  * only XWB_TASK2D_COLOR reads it */
 } xwb_config;
 
 typedef struct xwb_sim xwb_sim;
@@ -183,7 +189,7 @@ typedef struct xwb_env_state {
     int32_t  xw_agent_x, xw_agent_y, xw_event, xw_stage, xw_target_name, xw_steps_in_task;
     uint32_t episode;
     int32_t  xw_task;            /* XWB_TASK_* of this episode */
-    int32_t  xw_target;          /* TARGET: goal name id; BETWEEN: middle cell y * max_dim + x; else -1 */
+    int32_t  xw_target;          /* TARGET: goal name id; BETWEEN and the 2-D-native tasks: cell y * max_dim + x; else -1 */
 } xwb_env_state;
 int xwb_get_env_state(xwb_sim *sim, int32_t env, void *stream, xwb_env_state *out);
 /* copies env's "screen" (context frames) to host memory; bytes must equal bytes_per_env */

@@ -162,3 +162,100 @@ def test_conf_navigation2d_lists_five_tasks():
     kinds = np.bincount([sim.env_state(e).xw_task for e in range(0, 4096, 4)], minlength=5)
     assert kinds.min() > 140 and kinds.max() < 270, kinds
     sim.close()
+
+
+# ------------------------------------------------------------------ rule D14b: the 2-D-native group of confs/walls.json
+from test_oracle_tasks2d import KINDS2D, STAGES2D, load2d   # noqa: E402
+
+
+@pytest.mark.parametrize("key,mode,tasks", [("nav8", "lang_acquisition", KINDS2D), ("nav8", "one_channel", KINDS2D),
+                                            ("walls7", "one_channel", KINDS2D), ("nav11", "one_channel", KINDS2D),
+                                            ("nav8_dim5", "one_channel", KINDS2D),
+                                            ("walls7", "one_channel", [KINDS2D[2]]), ("nav7", "lang_acquisition", [KINDS2D[0]])],
+                         ids=lambda v: v if isinstance(v, str) else str(len(v)))
+def test_rule_d14b_reset_and_rollout(oracle, key, mode, tasks):
+    """Task resampling whenever the group is idle (also at step time, stream 2), candidate tables, -0.1 / -0.3 rewards,
+    the one_channel time-up back to idle; episodes end by max_steps only."""
+    _torch()
+    n, steps = 1024, 150
+    sim, pal, cfg = _make(oracle, key, n, tasks, seed=31, policy_seed=6, gid0=3, task_mode=mode, max_steps=41)
+    cfg["task_mode"] = 0 if mode == "lang_acquisition" else 1
+    md = cfg["max_dim"]
+    ow = oracle.XWorld(pal, render=False, **cfg)
+    kinds = np.zeros(9, int)
+    for e in range(0, n, 3):
+        ow.reset_game(3 + e, 0)
+        st = sim.env_state(e)
+        assert st.xw_task == ow.task_kind() and st.xw_stage == ow.stage(), e
+        tx, ty = ow.target2d()
+        assert st.xw_target == (ty * md + tx if tx >= 0 else -1), e
+        assert not (sim.env_grid(e, raw=True) >> 15).any()
+        kinds[st.xw_task] += 1
+    assert all(kinds[oracle.TASK_ID[t]] > 0 for t in tasks)
+    ref = oracle.xw_rollout(n, oracle.xw_cfg(**cfg), pal, steps, policy_seed=6, env_gid0=3)
+    resets = 0
+    seen = set()
+    for t in range(steps):
+        sim.reset_done()
+        resets += sim.done_count()
+        sim.step()
+        r = sim.reward.cpu().numpy()
+        assert np.array_equal(r.view(np.uint32), ref.rewards[t].view(np.uint32)), t
+        assert np.array_equal(sim.game_over_codes.cpu().numpy(), ref.codes[t]), t
+        seen.update(np.unique(r).tolist())
+    assert resets == ref.stats.resets == n * (steps // 41)
+    assert seen - {0.0} == {float(np.float32(-0.1)), float(np.float32(-0.1 + -0.2))}, seen
+    assert (0.0 in seen) == (mode == "one_channel" or len(tasks) > 1)
+    sim.close()
+
+
+@pytest.mark.parametrize("key", [k for k in sorted(load2d())
+                                 if k.startswith("lang_acquisition") or k.endswith(("Near", "Between"))])
+def test_reference_2d_task_traces_through_product(oracle, key):
+    """tests/golden/tasks2d.json (the reference's Python tasks) replayed through the product.  The one_channel
+    Target / ColorTarget runs re-pick a target after each time-up with decisions only the oracle can be forced
+    through; they are covered by the oracle (test_oracle_tasks2d.py) + the oracle-vs-product rollouts above."""
+    torch = _torch()
+    from xworld_amd.batched import BatchedSimulator
+    mode, mapk, name = key.split("/")
+    runs = load2d()[key]
+    md, dim = runs[0]["max_dim"], runs[0]["dim"]
+    conf = os.path.join(CONF, "nav_target.json" if mapk == "nav" else "walls_target.json")
+    sim = BatchedSimulator("xworld", {"xwd_conf_path": conf, "max_dim": md, "dim": dim, "task_mode": mode,
+                                      "tasks": [name]}, num_envs=len(runs))
+    for e, run in enumerate(runs):
+        g = np.zeros((md, md), np.uint16)
+        agent = None
+        for t, x, y, icon, nm, serial in run["entities"]:
+            g[y, x] = icon + 1
+            if t == 2:
+                agent = (x, y)
+        tx, ty = run["reset_teach"][5:7]
+        sim.load_map(e, g, agent[0], agent[1], dim=dim, task=name, target=ty * md + tx if tx >= 0 else -1)
+        assert sim.env_state(e).xw_stage == STAGES2D[run["reset_teach"][4]]
+    for t in range(len(runs[0]["trace"])):
+        acts = np.array([run["trace"][t][0] for run in runs], np.int32)
+        sim.step(torch.from_numpy(acts).cuda())
+        rew = sim.reward.cpu().numpy()
+        for e, run in enumerate(runs):
+            a, ax, ay, success, was_idle, decs, reward, event, stage, tx, ty = run["trace"][t]
+            st = sim.env_state(e)
+            assert rew[e] == np.float32(reward), (run["py_seed"], t)
+            assert st.xw_stage == STAGES2D[stage] and st.xw_event == 0 and st.game_over == 0
+            assert (st.xw_agent_x, st.xw_agent_y) == (ax, ay) and st.last_action_success == success
+            assert st.xw_target == (ty * md + tx if tx >= 0 else -1)
+    sim.close()
+
+
+def test_conf_walls_json_navigation_group():
+    _torch()
+    from xworld_amd.batched import BatchedSimulator
+    with pytest.raises(RuntimeError):
+        BatchedSimulator("xworld", {"xwd_conf_path": os.path.join(CONF, "walls.json")}, num_envs=4)
+    sim = BatchedSimulator("xworld", {"xwd_conf_path": os.path.join(CONF, "walls.json"), "task_group": "XWorldNav"},
+                           num_envs=64, seed=2)
+    assert sim.tasks == [5, 6, 7, 8]
+    with pytest.raises(RuntimeError):
+        BatchedSimulator("xworld", {"xwd_conf_path": os.path.join(CONF, "nav_target.json"),
+                                    "tasks": ["XWorldNavTarget", "XWorld3DNavTarget"]}, num_envs=4)
+    sim.close()

@@ -38,6 +38,8 @@ class Palette:
         self.names = {t: sorted({m["name"] for m in self.meta if m["type"] == t}) for t in TYPE_ID}
         self.icon_type = np.array([TYPE_ID[m["type"]] for m in self.meta], np.int32)
         self.icon_name = np.array([self.names[m["type"]].index(m["name"]) for m in self.meta], np.int32)
+        # games/xworld/images/properties.txt: an image without a colour entry, or "na", has no colour
+        self.icon_colored = np.array([int(m.get("color", "na") != "na") for m in self.meta], np.int32)
 
     def __len__(self):
         return len(self.meta)
@@ -57,20 +59,27 @@ def read_conf(path):
 
 # task class -> XWB_TASK_* (include/xwb.h); the 2-D game's navigation2d.json runs the XWorld3DNav* Python tasks
 TASK_IDS = {"XWorld3DNavTarget": 0, "XWorld3DNavTargetNear": 1, "XWorld3DNavTargetBetween": 2,
-            "XWorld3DNavTargetDirection": 3, "XWorld3DNavTargetAvoid": 4}
+            "XWorld3DNavTargetDirection": 3, "XWorld3DNavTargetAvoid": 4,
+            # the 2-D-native group of confs/walls.json (games/xworld/tasks/, rule D14b)
+            "XWorldNavTarget": 5, "XWorldNavNear": 6, "XWorldNavColorTarget": 7, "XWorldNavBetween": 8}
 TASK_NAMES = {v: k for k, v in TASK_IDS.items()}
 
 
-def conf_tasks(conf):
-    """Task ids of the conf's (single) task group, in the order the JSON lists them.
+def conf_tasks(conf, group=None):
+    """Task ids of one task group of the conf, in the order the JSON lists them (`group` names it when the conf
+    has several: confs/walls.json also lists the language group XWorldRec, which is out of scope).
 
     teacher.py: a TaskGroup with schedule "random" draws one of its tasks uniformly per episode; the
     per-task numbers are weights only the "weighted" schedule reads."""
     groups = conf.get("task_groups") or {}
     if not groups:
         return [0]
+    if group is not None:
+        if group not in groups:
+            raise RuntimeError("task group %s is not in the conf" % group)
+        groups = {group: groups[group]}
     if len(groups) != 1:
-        raise RuntimeError("only one task group is built (confs/navigation2d.json has one): " + ", ".join(groups))
+        raise RuntimeError("one task group runs per batch; pick one with the 'task_group' option: " + ", ".join(groups))
     (gname, g), = groups.items()
     if g.get("schedule", "random") != "random":
         raise RuntimeError("task group schedule '%s' is not built (only 'random')" % g.get("schedule"))

@@ -83,7 +83,7 @@ class BatchedSimulator:
             cfg.task_mode = 0 if mode == "lang_acquisition" else 1
             cfg.color = int(bool(opts.get("color", False)))
             tasks = opts.get("tasks")                                     # override: list of task class names / ids
-            tasks = assets.conf_tasks(conf) if tasks is None else [assets.TASK_IDS.get(t, t) for t in tasks]
+            tasks = assets.conf_tasks(conf, opts.get("task_group")) if tasks is None else [assets.TASK_IDS.get(t, t) for t in tasks]
             cfg.n_tasks = len(tasks)
             for i, t in enumerate(tasks):
                 cfg.tasks[i] = int(t)
@@ -95,6 +95,7 @@ class BatchedSimulator:
             cfg.icons64 = self.palette.icons64.ctypes.data
             cfg.icon_type = self.palette.icon_type.ctypes.data
             cfg.icon_name = self.palette.icon_name.ctypes.data
+            cfg.icon_colored = self.palette.icon_colored.ctypes.data
         self.cfg = cfg
         h = C.c_void_p()
         lib.check(self.L.xwb_create(C.byref(cfg), C.byref(h)))

@@ -81,12 +81,38 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
             }
             // Teacher::teach -> Task stage (one group, task XWorld3DNavTarget)
             const int ts = p.task_state[e];
-            const int target = task_target(ts), kind = task_kind(ts);
+            int target = task_target(ts), kind = task_kind(ts);
             int stage = task_stage(ts);
             int tsteps = p.task_steps[e];
             int event = EV_NONE;
             double rew = 0.0;
-            if (stage == STAGE_NAV) {
+            if (p.group2d) {
+                // rule D14b (games/xworld/tasks/xworld_task.py:184-223): the group draws a task whenever its busy
+                // task is idle (teaching_task.cpp:204-222), also at step time
+                if (stage == STAGE_IDLE) {
+                    Stream s2;
+                    s2.init(p.seed, p.env_gid0 + (uint32_t)e, p.episode[e], 2u);
+                    s2.blk = (uint32_t)steps;
+                    const int k2 = p.tasks[s2.below((uint32_t)p.n_tasks)];
+                    kind = k2;
+                    idle_2d(kind, p.cand2d[e], p.goal_cells + (size_t)e * XW_MAX_GOALS,
+                            [&](uint32_t n) { return s2.below(n); }, target, stage, tsteps);
+                    rew = 0.0;
+                } else if (stage == STAGE_NAV) {
+                    rew = -0.1;                             // time_penalty
+                    if (!success) rew += -0.2;              // failed_action_penalty
+                    tsteps += 1;
+                    if (p.task_mode == 1 && tsteps >= D * D / 2) {           // one_channel: h*w / 2 (max dims)
+                        tsteps = 0;
+                        stage = STAGE_IDLE;                 // _record_failure, "S -> timeup"
+                    } else if (ay * D + ax == target) {     // agent.loc == self.target
+                        tsteps = 0;
+                        event = EV_CORRECT; rew += 1.0;
+                        stage = STAGE_IDLE;
+                    }
+                    // `agent.loc in goal_locs` (-1.0) cannot hold: XMap::move_item never enters an occupied cell
+                }
+            } else if (stage == STAGE_NAV) {
                 rew = -0.01;                                // time_penalty
                 tsteps += 1;
                 if (tsteps >= p.dim * p.dim * p.max_steps_factor) {

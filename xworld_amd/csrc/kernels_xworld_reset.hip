@@ -357,7 +357,39 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
     int between = -1;                                      // NavTargetBetween: the middle cell (actual-dim index)
     int target_field = -1;
 
-    if (kind == TASK_TARGET || kind == TASK_AVOID) {
+    int stage0 = STAGE_NAV;
+
+    if (p.group2d) {
+        // ---- the 2-D-native group (rule D14b).  XWorldTask._reachable: bfs with the BLOCKS as the only obstacles;
+        // the agent never leaves its component and nothing else moves, so the candidate sets of every later idle
+        // stage of this episode are fixed here: goal_cells + cand2d are what the step kernel's idle stage reads.
+        Mask<NW> goalm;
+        goalm.clear();
+        for (int i = 0; i < ng; ++i) goalm.set(L.gcell[L.at(i)]);
+        const Mask<NW> open2 = valid.andnot(occupied.andnot(goalm));
+        Mask<NW> r2;
+        r2.clear();
+        r2.set(agent_cell);
+        for (int it = 0; it < D * D; ++it) {
+            const Mask<NW> grown = r2 | (neighbours<NW>(r2, D, col0, colN, valid) & open2);
+            if (grown.equals(r2)) break;
+            r2 = grown;
+        }
+        uint32_t cand = 0;
+        uint8_t *gc = p.goal_cells + (size_t)e * XW_MAX_GOALS;
+        for (int i = 0; i < XW_MAX_GOALS; ++i) {
+            int cell = 0xff;
+            if (i < ng) {
+                const int c = L.gcell[L.at(i)];
+                cell = (c / D + off) * MD + (c % D + off);
+                if (r2.test(c)) cand |= (1u << i) | (p.icon_colored[L.gicon[L.at(i)]] ? (1u << (16 + i)) : 0u);
+            }
+            gc[i] = (uint8_t)cell;
+        }
+        p.cand2d[e] = cand;
+        int tsteps0;
+        idle_2d(kind, cand, gc, [&](uint32_t n) { return s.below(n); }, target_field, stage0, tsteps0);
+    } else if (kind == TASK_TARGET || kind == TASK_AVOID) {
         // goals reachable from the agent with blocks and the other goals as obstacles: flood the empty cells from
         // the agent by whole-board shifts; a goal is reachable iff one of its 4-neighbours is flooded
         const Mask<NW> free_cells = valid.andnot(occupied);          // agent cell included: it is the seed
@@ -580,7 +612,7 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
     if (kind == TASK_BETWEEN && between >= 0) target_field = (between / D + off) * MD + (between % D + off);
 
     p.agent_xy[e] = (agent_cell % D + off) | ((agent_cell / D + off) << 16);
-    p.task_state[e] = pack_task(target_field, STAGE_NAV, EV_NONE, kind);
+    p.task_state[e] = pack_task(target_field, stage0, EV_NONE, kind);
     p.task_steps[e] = 0;
     p.num_steps[e] = 0;
     p.fresh[e] = 2;                                       // render: init_screen (zero the older context frames)

@@ -73,11 +73,12 @@ struct xwb_sim {
     uint16_t *d_grid = nullptr;
     int32_t *d_agent = nullptr, *d_task_steps = nullptr, *d_task_state = nullptr, *d_done_list = nullptr,
             *d_done_count = nullptr;
-    uint8_t *d_fresh = nullptr, *d_icon_type = nullptr;
+    uint8_t *d_fresh = nullptr, *d_icon_type = nullptr, *d_icon_colored = nullptr, *d_goal_cells = nullptr;
+    uint32_t *d_cand2d = nullptr;
     int16_t *d_icon_name = nullptr, *d_name_first = nullptr, *d_name_variants = nullptr;
     uint32_t *d_atlas = nullptr;
     std::vector<uint8_t> tile_table;   // host copy, n_icons x c x 12 x 12
-    std::vector<int32_t> icon_type_h, icon_name_h;
+    std::vector<int32_t> icon_type_h, icon_name_h, icon_colored_h;
     XwParams xw{};
     std::vector<void *> allocs;
 };
@@ -191,7 +192,10 @@ int xw_setup(xwb_sim *s) {
     if (c.n_icons > 4000) return fail(XWB_ERR_ARG, "xworld: too many icons");
     if (c.n_tasks < 0 || c.n_tasks > 8) return fail(XWB_ERR_ARG, "xworld: need 0 <= n_tasks <= 8");
     for (int i = 0; i < c.n_tasks; ++i)
-        if (c.tasks[i] < XWB_TASK_TARGET || c.tasks[i] > XWB_TASK_AVOID) return fail(XWB_ERR_ARG, "xworld: unknown task id");
+        if (c.tasks[i] < XWB_TASK_TARGET || c.tasks[i] > XWB_TASK2D_BETWEEN) return fail(XWB_ERR_ARG, "xworld: unknown task id");
+    for (int i = 1; i < c.n_tasks; ++i)
+        if ((c.tasks[i] >= XWB_TASK2D_TARGET) != (c.tasks[0] >= XWB_TASK2D_TARGET))
+            return fail(XWB_ERR_ARG, "xworld: a task group holds XWorld3DNav* tasks or 2-D-native XWorldNav* tasks, not both");
     const int n = s->n, cells = c.max_dim * c.max_dim, ch = c.color ? 3 : 1;
     // name tables (xworld_env.py:247-255): per type, names -> icon variants (icon order = path order)
     int n_names[3] = {0, 0, 0};
@@ -240,6 +244,8 @@ int xw_setup(xwb_sim *s) {
     for (int i = 0; i < c.n_icons; ++i) { types[i] = (uint8_t)c.icon_type[i]; names[i] = (int16_t)c.icon_name[i]; }
     s->icon_type_h.assign(c.icon_type, c.icon_type + c.n_icons);
     s->icon_name_h.assign(c.icon_name, c.icon_name + c.n_icons);
+    s->icon_colored_h.assign(c.n_icons, 0);
+    if (c.icon_colored) s->icon_colored_h.assign(c.icon_colored, c.icon_colored + c.n_icons);
 
     int rc;
     if ((rc = dev_alloc(s, &s->d_grid, (size_t)n * cells))) return rc;
@@ -250,11 +256,19 @@ int xw_setup(xwb_sim *s) {
     if ((rc = dev_alloc(s, &s->d_done_count, 2))) return rc;
     if ((rc = dev_alloc(s, &s->d_fresh, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_icon_type, c.n_icons))) return rc;
+    if ((rc = dev_alloc(s, &s->d_icon_colored, c.n_icons))) return rc;
+    if ((rc = dev_alloc(s, &s->d_goal_cells, (size_t)n * XW_MAX_GOALS, 0xff))) return rc;
+    if ((rc = dev_alloc(s, &s->d_cand2d, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_icon_name, c.n_icons))) return rc;
     if ((rc = dev_alloc(s, &s->d_name_first, first.size()))) return rc;
     if ((rc = dev_alloc(s, &s->d_name_variants, variants.size()))) return rc;
     if ((rc = dev_alloc(s, &s->d_atlas, atlas.size() / 4))) return rc;
     HIP_TRY(hipMemcpy(s->d_icon_type, types.data(), types.size(), hipMemcpyHostToDevice));
+    if (c.icon_colored) {
+        std::vector<uint8_t> col(c.n_icons);
+        for (int i = 0; i < c.n_icons; ++i) col[i] = c.icon_colored[i] ? 1 : 0;
+        HIP_TRY(hipMemcpy(s->d_icon_colored, col.data(), col.size(), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemcpy(s->d_icon_name, names.data(), names.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_name_first, first.data(), first.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_name_variants, variants.data(), variants.size() * 2, hipMemcpyHostToDevice));
@@ -270,6 +284,8 @@ int xw_setup(xwb_sim *s) {
     p.num_blocks = c.num_blocks; p.max_steps_factor = c.max_steps_factor; p.task_mode = c.task_mode;
     p.channels = ch; p.n_icons = c.n_icons;
     p.n_tasks = c.n_tasks;
+    p.group2d = c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET;
+    p.goal_cells = s->d_goal_cells; p.cand2d = s->d_cand2d; p.icon_colored = s->d_icon_colored;
     for (int i = 0; i < 8; ++i) p.tasks[i] = i < c.n_tasks ? c.tasks[i] : 0;
     p.policy_seed = c.policy_seed; p.env_gid0 = c.env_gid0; p.policy_step = 0; p.seed = c.seed;
     p.icon_type = s->d_icon_type; p.icon_name = s->d_icon_name;
@@ -525,6 +541,7 @@ int xwb_create(const xwb_config *cfg, xwb_sim **out) {
     // the reference constructors leave a reset game behind (SimpleGame ctor cpp:82-85, SimpleRaceGame
     // ctor cpp:457, XWorld ctor xworld.cpp:106); screens_ stays empty until reset_game -> init_screen.
     s->cfg.icons64 = nullptr; s->cfg.icon_type = nullptr; s->cfg.icon_name = nullptr;   // not owned
+    s->cfg.icon_colored = nullptr;
     rc = xwb_reset(s, nullptr);
     if (rc) return bail(rc);
     HIP_TRY(hipDeviceSynchronize());
@@ -754,7 +771,7 @@ int xwb_get_env_grid(xwb_sim *s, int32_t env, void *stream, uint16_t *out_host) 
 int xwb_xw_load_map_task(xwb_sim *s, int32_t env, const uint16_t *grid_host, int32_t agent_x, int32_t agent_y,
                          int32_t dim, int32_t task, int32_t target) {
     if (!s || !grid_host) return fail(XWB_ERR_ARG, "NULL argument");
-    if (task < XWB_TASK_TARGET || task > XWB_TASK_AVOID) return fail(XWB_ERR_ARG, "unknown task id");
+    if (task < XWB_TASK_TARGET || task > XWB_TASK2D_BETWEEN) return fail(XWB_ERR_ARG, "unknown task id");
     if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
     if (dim != s->cfg.dim) return fail(XWB_ERR_ARG, "dim differs from the batch's dim");
@@ -763,7 +780,43 @@ int xwb_xw_load_map_task(xwb_sim *s, int32_t env, const uint16_t *grid_host, int
     HIP_TRY(hipDeviceSynchronize());
     const size_t cells = (size_t)D * D;
     int32_t axy = agent_x | (agent_y << 16);
-    int32_t ts = (target & 0xffff) | (1 << 16) | (task << 24);          // stage NAV, no event (xw_device.h)
+    const bool is2d = task >= XWB_TASK2D_TARGET;
+    if (is2d != (s->xw.group2d != 0)) return fail(XWB_ERR_ARG, "task is not of this batch's task family");
+    // stage NAV, no event (xw_device.h); a 2-D-native task without a target stays in its idle stage
+    const int stage = is2d && target < 0 ? 0 : 1;
+    int32_t ts = (target & 0xffff) | (stage << 16) | (task << 24);
+    if (is2d) {
+        // the per-episode candidate tables of the step-time idle stages: goal slots in row-major order; reachable =
+        // same component as the agent with the blocks as the only obstacles (xworld_task.py:347-357)
+        std::vector<uint8_t> gc(XW_MAX_GOALS, 0xff), seen(cells, 0);
+        std::vector<int> queue{agent_y * D + agent_x};
+        seen[queue[0]] = 1;
+        const int lo = (D - dim) / 2, hi = lo + dim;                     // XWorldEnv.set_dims offsets
+        for (size_t h = 0; h < queue.size(); ++h) {
+            const int c = queue[h], cx = c % D, cy = c / D;
+            const int nb[4][2] = {{cx - 1, cy}, {cx + 1, cy}, {cx, cy - 1}, {cx, cy + 1}};
+            for (auto &q : nb) {
+                if (q[0] < lo || q[1] < lo || q[0] >= hi || q[1] >= hi) continue;
+                const int nc = q[1] * D + q[0];
+                const int icon = (int)(grid_host[nc] & XWB_CELL_ICON_MASK) - 1;
+                if (icon >= s->cfg.n_icons) return fail(XWB_ERR_ARG, "cell code beyond the palette");
+                if (seen[nc] || (icon >= 0 && s->icon_type_h[icon] == XWB_ICON_BLOCK)) continue;
+                seen[nc] = 1;
+                queue.push_back(nc);
+            }
+        }
+        uint32_t cand = 0;
+        int slot = 0;
+        for (size_t c = 0; c < cells && slot < XW_MAX_GOALS; ++c) {
+            const int icon = (int)(grid_host[c] & XWB_CELL_ICON_MASK) - 1;
+            if (icon < 0 || icon >= s->cfg.n_icons || s->icon_type_h[icon] != XWB_ICON_GOAL) continue;
+            gc[slot] = (uint8_t)c;
+            if (seen[c]) cand |= (1u << slot) | (s->icon_colored_h[icon] ? (1u << (16 + slot)) : 0u);
+            slot++;
+        }
+        HIP_TRY(hipMemcpy(s->d_goal_cells + (size_t)env * XW_MAX_GOALS, gc.data(), XW_MAX_GOALS, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_cand2d + env, &cand, 4, hipMemcpyHostToDevice));
+    }
     int32_t zero = 0;
     uint8_t z8 = 0, one = 2;
     HIP_TRY(hipMemcpy(s->d_grid + (size_t)env * cells, grid_host, cells * 2, hipMemcpyHostToDevice));

@@ -129,7 +129,8 @@ struct XwParams {
     int n, context, max_steps, act_rep, auto_reset;
     int map_kind, max_dim, dim, num_goals, num_blocks, max_steps_factor, task_mode, channels;
     int n_icons;
-    int n_tasks, tasks[8];       // tasks of the teacher's group, sampled uniformly per episode
+    int n_tasks, tasks[8];       // tasks of the teacher's group, sampled uniformly whenever the group is idle
+    int group2d;                 // the group holds the 2-D-native tasks (rule D14b): idle stages also run at step time
     uint32_t policy_seed, env_gid0, policy_step, seed;
     // icon tables (device)
     const uint8_t *icon_type;    // [n_icons]
@@ -147,6 +148,10 @@ struct XwParams {
     uint16_t *grid;              // [n][max_dim*max_dim] cell code = icon + 1 (0 empty) | bit 15: target goal
     int32_t *agent_xy;           // x | y << 16
     int32_t *task_steps;         // steps_in_cur_task
+    uint8_t *goal_cells;         // [n][XW_MAX_GOALS] cell of goal slot i (entity order), 0xff = none  (2-D-native tasks)
+    uint32_t *cand2d;            // [n] goal slots the agent can reach, blocks as the only obstacles: bits 0..15
+                                 //     any goal (XWorldNavTarget), bits 16..31 coloured goals (XWorldNavColorTarget)
+    const uint8_t *icon_colored; // [n_icons] properties.txt colour != "na"
     int32_t *task_state;         // target (low 16) | stage << 16 | event << 20 | task << 24  (xw_device.h)
     int32_t *num_steps;
     uint32_t *episode;
