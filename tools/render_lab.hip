@@ -9,6 +9,179 @@
 using namespace xwb;
 
 namespace xwb {
+// device properties for the v1 launch plan
+static int g_num_cus = 0;
+static size_t g_max_lds = 0;
+
+hipError_t xw_render_prepare(int device) {
+    hipDeviceProp_t prop;
+    hipError_t err = hipGetDeviceProperties(&prop, device);
+    if (err != hipSuccess) return err;
+    g_num_cus = prop.multiProcessorCount;
+    g_max_lds = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : prop.sharedMemPerBlock;
+    return hipSuccess;
+}
+
+// ===== render_all v1 (the product's kernel until the one-shot kernel replaced it): persistent LDS-table workgroups =====
+// all envs: persistent 1024-thread workgroups (one per CU: the table fills the LDS), tile table resident in
+// LDS, env tiles staged in LDS.  Four consecutive dwords of a frame touch at most two cells -- the cell of
+// dword 0 and the cell of dword 3 (cells change every 3 dwords; a row or channel wrap coincides with a cell
+// change) -- so a chunk needs two cell-code reads, not four; two chunks are in flight per lane so that the
+// second chunk's LDS reads overlap the first one's.  tools/render_lab.hip holds the A/B history: this shape
+// is ~13 % faster than one code read per dword and beats the position-major / segment-major variants.
+template <int DIM_T, int CH>
+__device__ __forceinline__ uint4 xw_expand_chunk2(const uint32_t *atlas, const uint16_t *g, int cc, int dim_rt) {
+    const int D = DIM_T ? DIM_T : dim_rt;
+    const int RD = XW_TILE_DW * D, RH = XW_TILE * D;
+    const int d0 = cc * 4;
+    int ch = d0 / (RH * RD);
+    const int rem = d0 - ch * (RH * RD);
+    int y = rem / RD;
+    int dx = rem - y * RD;
+    int cidx[4], aoff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cy = y / XW_TILE, py = y - cy * XW_TILE;
+        const int cx = dx / XW_TILE_DW, kk = dx - cx * XW_TILE_DW;
+        cidx[k] = cy * D + cx;
+        aoff[k] = ch * 36 + py * 3 + kk;
+        dx += 1;
+        if (dx == RD) { dx = 0; y += 1; if (y == RH) { y = 0; ch += 1; } }
+    }
+    const uint32_t ca = g[cidx[0]], cb = g[cidx[3]];     // staged codes: the target bit is already stripped
+    uint32_t out[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t code = cidx[k] == cidx[0] ? ca : cb;
+        out[k] = atlas[code * (CH * 36) + aoff[k]];                 // tile 0 = empty cell (white)
+    }
+    return make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+template <int DIM_T, int CH, bool CTX1>
+__global__ __launch_bounds__(1024) void xw_render_all_v1_kernel(XwParams p, int tile_envs, int n_tiles, int atlas_dw) {
+    extern __shared__ uint4 smem4[];
+    uint32_t *s_atlas = reinterpret_cast<uint32_t *>(smem4);
+    uint16_t *s_grid = reinterpret_cast<uint16_t *>(s_atlas + atlas_dw);
+    const int D = DIM_T ? DIM_T : p.max_dim;
+    const int cells = D * D;
+    uint8_t *s_fresh = reinterpret_cast<uint8_t *>(s_grid + (tile_envs + 1) * cells);
+    const int tid = threadIdx.x;
+    const int ctx = CTX1 ? 1 : p.context;
+    const int cpf = CH * 9 * cells;                       // 16-byte chunks per frame: C*144*D*D/16
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.atlas);
+        for (int i = tid; i < atlas_dw / 4; i += 1024) smem4[i] = src[i];
+    }
+    // Each workgroup owns one contiguous range of the batch's 16-byte chunks [g_lo, g_hi), cut at 1 KiB
+    // boundaries (64 chunks = one wavefront store) and balanced to +-1 KiB for ANY workgroup count.  Ranges
+    // ignore env boundaries on purpose: an env frame is 16-byte but not 128-byte aligned (7x7x3: 21 168 B),
+    // and wave stores that straddle cache lines cost ~20 % of the write bandwidth (measured: 181 vs 148 us).
+    const long long total_chunks = (long long)p.n * cpf;
+    const long long units = (total_chunks + 63) / 64;
+    const long long g_lo = units * blockIdx.x / gridDim.x * 64;
+    long long g_hi = units * (blockIdx.x + 1) / gridDim.x * 64;
+    if (g_hi > total_chunks) g_hi = total_chunks;
+    const long long win = (long long)tile_envs * cpf;
+    for (long long w0 = g_lo; w0 < g_hi; w0 += win) {
+        const long long w1 = w0 + win < g_hi ? w0 + win : g_hi;
+        const int e_first = (int)(w0 / cpf), e_last = (int)((w1 - 1) / cpf);
+        const int ne = e_last - e_first + 1;                           // <= tile_envs + 1
+        __syncthreads();
+        const uint16_t *gsrc = p.grid + (size_t)e_first * cells;
+        for (int i = tid; i < ne * cells; i += 1024) s_grid[i] = gsrc[i] & CELL_ICON_MASK;   // drop the target bit
+        if (!CTX1 && tid < ne) s_fresh[tid] = p.fresh[e_first + tid];  // rewritten by the next step kernel
+        __syncthreads();
+        const unsigned base = (unsigned)(w0 - (long long)e_first * cpf);   // chunk offset of w0 inside env e_first
+        const int span = (int)(w1 - w0);
+        uint4 *win_obs = reinterpret_cast<uint4 *>(p.obs) + w0;             // CTX1: frames are back to back
+        for (int c0 = tid; c0 < span; c0 += 2048) {
+            const int c1 = c0 + 1024;
+            const bool has1 = c1 < span;
+            const unsigned a0 = base + (unsigned)c0, a1 = base + (unsigned)(has1 ? c1 : c0);
+            const int le0 = (int)(a0 / (unsigned)cpf), cc0 = (int)(a0 - (unsigned)le0 * (unsigned)cpf);
+            const int le1 = (int)(a1 / (unsigned)cpf), cc1 = (int)(a1 - (unsigned)le1 * (unsigned)cpf);
+            const uint4 v0 = xw_expand_chunk2<DIM_T, CH>(s_atlas, s_grid + le0 * cells, cc0, D);
+            const uint4 v1 = xw_expand_chunk2<DIM_T, CH>(s_atlas, s_grid + le1 * cells, cc1, D);
+            if (CTX1) {
+                u32x4 n0 = {v0.x, v0.y, v0.z, v0.w};
+                __builtin_nontemporal_store(n0, reinterpret_cast<u32x4 *>(win_obs + c0));
+                if (has1) {
+                    u32x4 n1 = {v1.x, v1.y, v1.z, v1.w};
+                    __builtin_nontemporal_store(n1, reinterpret_cast<u32x4 *>(win_obs + c1));
+                }
+            } else {
+                uint4 *obs4 = reinterpret_cast<uint4 *>(p.obs);
+                xw_store_chunk(obs4 + (size_t)(e_first + le0) * ctx * cpf, cc0, cpf, ctx, s_fresh[le0], v0);
+                if (has1) xw_store_chunk(obs4 + (size_t)(e_first + le1) * ctx * cpf, cc1, cpf, ctx, s_fresh[le1], v1);
+            }
+        }
+    }
+}
+
+// launch configuration shared by both render_all variants: how many grids fit next to the table in LDS,
+// and how many persistent workgroups the chip holds (LDS-limited: 1 per CU for the colour NAV palette)
+struct RenderPlan { int tile_envs, n_tiles, atlas_dw, n_blocks; size_t lds; };
+
+template <int CH>
+static hipError_t plan_render(const XwParams &p, int tile_cap, RenderPlan &r) {
+    const int cells = p.max_dim * p.max_dim;
+    r.atlas_dw = (p.n_icons + 1) * CH * 36;
+    const size_t atlas_bytes = (size_t)r.atlas_dw * 4;
+    const size_t lds_cap = g_max_lds ? g_max_lds : 65536;
+    const size_t per_env = (size_t)cells * 2 + 1;          // cell codes + fresh flag
+    if (atlas_bytes + per_env + 64 > lds_cap) return hipErrorInvalidValue;
+    r.tile_envs = (int)((lds_cap - atlas_bytes - 64) / per_env) - 1;
+    if (r.tile_envs > tile_cap) r.tile_envs = tile_cap;
+    r.n_tiles = (p.n + r.tile_envs - 1) / r.tile_envs;
+    r.lds = atlas_bytes + (size_t)(r.tile_envs + 1) * per_env + 16;      // a chunk window can overlap tile_envs + 1 envs
+    const int cus = g_num_cus ? g_num_cus : 256;
+    int per_cu = (int)(lds_cap / r.lds);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 1) per_cu = 1;                            // 1024-thread groups: one per CU keeps the tile split even
+    // Leave one CU per XCD without a render workgroup: the reset kernel's few latency-bound wavefronts run
+    // beside this kernel (side stream) and are 3.5x slower when they must share a CU with 16 render waves
+    // (workgroup b is placed on XCD b % 8, so cus - 8 groups leave exactly one free CU in every XCD).
+    int want = cus * per_cu;
+    if (want >= 64) want -= 8;
+    if (const char *ev = getenv("XWB_RENDER_BLOCKS")) { const int v = atoi(ev); if (v > 0) want = v; }
+    const int n_env_groups = (p.n + 3) / 4;                // at least ~4 envs per workgroup
+    r.n_blocks = n_env_groups < want ? n_env_groups : want;
+    return hipSuccess;
+}
+
+template <typename K>
+static hipError_t allow_big_lds(K kern, size_t lds, size_t &configured) {
+    if (lds > 65536 && configured < lds) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(g_max_lds ? g_max_lds : lds));
+        if (err != hipSuccess) return err;
+        configured = g_max_lds ? g_max_lds : lds;
+    }
+    return hipSuccess;
+}
+
+template <int DIM_T, int CH>
+static hipError_t render_all_v1(const XwParams &p, hipStream_t s) {
+    RenderPlan r;
+    hipError_t err = plan_render<CH>(p, 16, r);
+    if (err != hipSuccess) return err;
+    if (p.context == 1) {
+        auto kern = xw_render_all_v1_kernel<DIM_T, CH, true>;
+        static size_t configured = 0;
+        if ((err = allow_big_lds(kern, r.lds, configured)) != hipSuccess) return err;
+        hipLaunchKernelGGL(kern, dim3(r.n_blocks), dim3(1024), r.lds, s, p, r.tile_envs, r.n_tiles, r.atlas_dw);
+    } else {
+        auto kern = xw_render_all_v1_kernel<DIM_T, CH, false>;
+        static size_t configured = 0;
+        if ((err = allow_big_lds(kern, r.lds, configured)) != hipSuccess) return err;
+        hipLaunchKernelGGL(kern, dim3(r.n_blocks), dim3(1024), r.lds, s, p, r.tile_envs, r.n_tiles, r.atlas_dw);
+    }
+    return hipGetLastError();
+}
+
+
 // (moved out of the product after losing the A/B: position-major render)
 // ---- render_all, position-major variant (compile-time D) ------------------------------------------------
 // Where a 16-byte chunk sits inside a frame (channel, pixel row, the cells its 4 dwords fall in, the dword
@@ -527,6 +700,80 @@ __global__ __launch_bounds__(BS) void lab_j(XwParams p) {
     }
 }
 
+// ---- variant K: one-shot workgroups in dispatch order (the S1 store structure).  The span's bytes are assembled
+// in LDS in OUTPUT order from 12-byte tile rows gathered through L2 (one 12-byte load per tile row instead of H's four
+// dword gathers per chunk), then leave as one 1 KiB-aligned wavefront store of 16-byte chunks.
+template <int D, int CH, int BS, int PER, bool LOADS_FIRST = false>
+__global__ __launch_bounds__(BS) void lab_k(XwParams p, size_t n_chunks) {
+    constexpr int cells = D * D, FB = CH * 144 * cells, PB = 144 * cells, RB = 12 * D;
+    constexpr int SPAN = BS * PER;                                  // chunks per workgroup
+    __shared__ uint4 s_out4[SPAN + 2];
+    __shared__ uint16_t s_code[3 * cells];
+    uint32_t *s_out = reinterpret_cast<uint32_t *>(s_out4);
+    const int tid = threadIdx.x;
+    const size_t c_lo = (size_t)blockIdx.x * SPAN;
+    const size_t c_hi = c_lo + SPAN < n_chunks ? c_lo + SPAN : n_chunks;
+    const size_t b_lo = c_lo * 16, b_hi = c_hi * 16;
+    const int e0 = (int)(b_lo / FB), e1 = (int)((b_hi - 1) / FB);
+    const int ncode = (e1 - e0 + 1) * cells;
+    for (int i = tid; i < ncode; i += BS) s_code[i] = p.grid[(size_t)e0 * cells + i] & 0x7fff;
+    __syncthreads();
+    const size_t u0 = b_lo / 12, u1 = (b_hi + 11) / 12;
+    const int nu = (int)(u1 - u0);
+    const int shift = 4 - (int)(b_lo - u0 * 12) / 4;                // dword index of unit u0 (chunk 0 sits at dword 4)
+    if (LOADS_FIRST) {
+        constexpr int IT = ((SPAN * 16 + 11) / 12 + 1 + BS - 1) / BS;
+        uint32_t va[IT], vb[IT], vc[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = it * BS + tid;
+            const size_t B = (u0 + (i < nu ? i : 0)) * 12;
+            const int e = (int)(B / FB);
+            const int r = (int)(B - (size_t)e * FB);
+            const int ch = r / PB, r2 = r - ch * PB, y = r2 / RB, cx = (r2 - y * RB) / 12, cy = y / 12, py = y - cy * 12;
+            const uint32_t code = e < p.n ? s_code[(e - e0) * cells + cy * D + cx] : 0;
+            const uint32_t *src = p.atlas + code * (CH * 36) + ch * 36 + py * 3;
+            va[it] = src[0]; vb[it] = src[1]; vc[it] = src[2];
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = it * BS + tid;
+            if (i < nu) { const int o = shift + 3 * i; s_out[o] = va[it]; s_out[o + 1] = vb[it]; s_out[o + 2] = vc[it]; }
+        }
+    } else {
+    for (int i = tid; i < nu; i += BS) {
+        const size_t B = (u0 + i) * 12;
+        const int e = (int)(B / FB);
+        const int r = (int)(B - (size_t)e * FB);
+        const int ch = r / PB, r2 = r - ch * PB, y = r2 / RB, cx = (r2 - y * RB) / 12, cy = y / 12, py = y - cy * 12;
+        const uint32_t code = e < p.n ? s_code[(e - e0) * cells + cy * D + cx] : 0;
+        const uint32_t *src = p.atlas + code * (CH * 36) + ch * 36 + py * 3;
+        const uint32_t a = src[0], b = src[1], c = src[2];
+        const int o = shift + 3 * i;
+        s_out[o] = a; s_out[o + 1] = b; s_out[o + 2] = c;
+    }
+    }
+    __syncthreads();
+    const int nc = (int)(c_hi - c_lo);
+    uint4 *obs = reinterpret_cast<uint4 *>(p.obs) + c_lo;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int c = k * BS + tid;
+        if (c < nc) {
+            const uint4 v = s_out4[1 + c];
+            u32x4 nv = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(obs + c));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void lab_checksum(const uint32_t *obs, size_t n_dw, unsigned long long *out) {
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_dw; i += (size_t)gridDim.x * 256)
+        acc += (unsigned long long)obs[i] * (2 * i + 1);
+    atomicAdd(out, acc);
+}
+
 // one-shot workgroups of BS threads, PER adjacent 16-byte stores per lane (workgroup covers BS*PER*16 contiguous bytes)
 template <int BS, int PER>
 __global__ __launch_bounds__(BS) void lab_s6(uint4 *obs, size_t n) {
@@ -585,8 +832,8 @@ int main() {
     time_it("C store-only nt, 2048 x 1024 thr, small LDS", [&] { hipLaunchKernelGGL(lab_store_only, dim3(2048), dim3(1024), 1024, 0, reinterpret_cast<uint4 *>(d_obs), cpf, 16, r.n_tiles, N, 1); });
     cfg = 0; CK(allow_big_lds(lab_no_table<7, 3>, r.lds, cfg));
     time_it("B index math + grid reads, no table", [&] { hipLaunchKernelGGL((lab_no_table<7, 3>), dim3(256), dim3(1024), r.lds, 0, p, r.tile_envs, r.n_tiles, r.atlas_dw); });
-    cfg = 0; CK(allow_big_lds(xw_render_all_kernel<7, 3, true>, r.lds, cfg));
-    time_it("A product v1 (chunk-major)", [&] { hipLaunchKernelGGL((xw_render_all_kernel<7, 3, true>), dim3(256), dim3(1024), r.lds, 0, p, r.tile_envs, r.n_tiles, r.atlas_dw); });
+    cfg = 0; CK(allow_big_lds(xw_render_all_v1_kernel<7, 3, true>, r.lds, cfg));
+    time_it("A product v1 (chunk-major)", [&] { hipLaunchKernelGGL((xw_render_all_v1_kernel<7, 3, true>), dim3(256), dim3(1024), r.lds, 0, p, r.tile_envs, r.n_tiles, r.atlas_dw); });
     cfg = 0; CK(allow_big_lds(xw_render_all_v2_kernel<7, 3>, r.lds, cfg));
     time_it("D v2 (position-major, unroll 4)", [&] { hipLaunchKernelGGL((xw_render_all_v2_kernel<7, 3>), dim3(256), dim3(RenderGeom<7, 3>::NT), r.lds, 0, p, r.tile_envs, r.n_tiles, r.atlas_dw); });
     cfg = 0; CK(allow_big_lds(lab_v2_batched<7, 3, 16>, r.lds, cfg));
@@ -607,7 +854,7 @@ int main() {
         time_it(nm, [&] { hipLaunchKernelGGL(lab_store_only, dim3(256), dim3(1024), r.lds, 0, reinterpret_cast<uint4 *>(d_obs), cpf, te, ntl, N, 1); });
         if (te <= 16) {
             snprintf(nm, sizeof nm, "A product v1, tile %d envs", te);
-            time_it(nm, [&] { hipLaunchKernelGGL((xw_render_all_kernel<7, 3, true>), dim3(256), dim3(1024), r.lds, 0, p, te, ntl, r.atlas_dw); });
+            time_it(nm, [&] { hipLaunchKernelGGL((xw_render_all_v1_kernel<7, 3, true>), dim3(256), dim3(1024), r.lds, 0, p, te, ntl, r.atlas_dw); });
         }
     }
     printf("-- pure store structures --\n");
@@ -670,6 +917,31 @@ int main() {
     time_it("J 512 thr, 2 envs / group", [&] { hipLaunchKernelGGL((lab_j<7, 3, 512, 2>), dim3(N / 2), dim3(512), 0, 0, p); });
     time_it("J 512 thr, 1 env / group", [&] { hipLaunchKernelGGL((lab_j<7, 3, 512, 1>), dim3(N), dim3(512), 0, 0, p); });
     time_it("J 1024 thr, 2 envs / group", [&] { hipLaunchKernelGGL((lab_j<7, 3, 1024, 2>), dim3(N / 2), dim3(1024), 0, 0, p); });
+    time_it("PRODUCT one-shot render_all (256 x 4)", [&] { (void)launch_xw_render(p, 0, 0); });
+    printf("-- K: one-shot, 12-byte tile rows gathered through L2 into LDS in output order --\n");
+#define LABK(BS, PER) { char nm[64]; snprintf(nm, sizeof nm, "K one-shot, %d thr, %d chunks/lane", BS, PER); \
+    time_it(nm, [&] { hipLaunchKernelGGL((lab_k<7, 3, BS, PER>), dim3((unsigned)((nch + (size_t)BS * PER - 1) / ((size_t)BS * PER))), dim3(BS), 0, 0, p, nch); }); }
+    LABK(256, 1) LABK(256, 2) LABK(256, 4) LABK(512, 2) LABK(512, 4) LABK(1024, 1) LABK(1024, 2) LABK(128, 4) LABK(64, 4)
+    LABK(128, 2) LABK(128, 3) LABK(128, 6) LABK(128, 8) LABK(128, 16) LABK(192, 4) LABK(256, 3) LABK(256, 8) LABK(64, 8) LABK(64, 16)
+#define LABK2(BS, PER) { char nm[64]; snprintf(nm, sizeof nm, "K2 loads first, %d thr, %d chunks/lane", BS, PER); \
+    time_it(nm, [&] { hipLaunchKernelGGL((lab_k<7, 3, BS, PER, true>), dim3((unsigned)((nch + (size_t)BS * PER - 1) / ((size_t)BS * PER))), dim3(BS), 0, 0, p, nch); }); }
+    LABK2(128, 2) LABK2(128, 4) LABK2(128, 8) LABK2(256, 2) LABK2(256, 4) LABK2(64, 4) LABK2(64, 8)
+    {   // K against the product kernel: checksum of every output dword
+        unsigned long long *d_ck, ck[3] = {0, 0, 0};
+        CK(hipMalloc(&d_ck, 24)); CK(hipMemset(d_ck, 0, 24));
+        cfg = 0; CK(allow_big_lds(xw_render_all_v1_kernel<7, 3, true>, r.lds, cfg));
+        CK(hipMemset(d_obs, 0, obs_bytes));
+        hipLaunchKernelGGL((xw_render_all_v1_kernel<7, 3, true>), dim3(248), dim3(1024), r.lds, 0, p, r.tile_envs, r.n_tiles, r.atlas_dw);
+        hipLaunchKernelGGL(lab_checksum, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const uint32_t *>(d_obs), obs_bytes / 4, d_ck);
+        CK(hipMemset(d_obs, 0, obs_bytes));
+        hipLaunchKernelGGL((lab_k<7, 3, 128, 4>), dim3((unsigned)((nch + 511) / 512)), dim3(128), 0, 0, p, nch);
+        hipLaunchKernelGGL(lab_checksum, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const uint32_t *>(d_obs), obs_bytes / 4, d_ck + 1);
+        CK(hipMemset(d_obs, 0, obs_bytes));
+        hipLaunchKernelGGL((lab_k<7, 3, 256, 2, true>), dim3((unsigned)((nch + 511) / 512)), dim3(256), 0, 0, p, nch);
+        hipLaunchKernelGGL(lab_checksum, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const uint32_t *>(d_obs), obs_bytes / 4, d_ck + 2);
+        CK(hipMemcpy(ck, d_ck, 24, hipMemcpyDeviceToHost));
+        printf("checksum product %016llx  K %016llx  K2 %016llx  %s\n", ck[0], ck[1], ck[2], ck[0] == ck[1] && ck[0] == ck[2] ? "EQUAL" : "DIFFERENT");
+    }
     printf("-- one-shot workgroups: size and stores per lane --\n");
 #define S6(BS, PER) { char nm[64]; snprintf(nm, sizeof nm, "S6 one-shot, %d thr, %d stores/lane", BS, PER); \
     time_it(nm, [&] { hipLaunchKernelGGL((lab_s6<BS, PER>), dim3((unsigned)((nch + (size_t)BS * PER - 1) / ((size_t)BS * PER))), dim3(BS), 0, 0, reinterpret_cast<uint4 *>(d_obs), nch); }); }

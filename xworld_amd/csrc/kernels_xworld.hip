@@ -22,6 +22,7 @@
 // (n_icons+1) x C x 12 x 12 table that lives in LDS; HBM traffic is the output stream plus 2 B/cell.
 #include "xwb_common.h"
 #include <cstdlib>
+#include <cstring>
 #include "xw_device.h"
 
 namespace xwb {
@@ -206,98 +207,72 @@ __device__ __forceinline__ void xw_store_chunk(uint4 *frame0, int cc, int chunks
     __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(&q[(size_t)(ctx - 1) * chunks_per_frame]));
 }
 
-// all envs: persistent 1024-thread workgroups (one per CU: the table fills the LDS), tile table resident in
-// LDS, env tiles staged in LDS.  Four consecutive dwords of a frame touch at most two cells -- the cell of
-// dword 0 and the cell of dword 3 (cells change every 3 dwords; a row or channel wrap coincides with a cell
-// change) -- so a chunk needs two cell-code reads, not four; two chunks are in flight per lane so that the
-// second chunk's LDS reads overlap the first one's.  tools/render_lab.hip holds the A/B history: this shape
-// is ~13 % faster than one code read per dword and beats the position-major / segment-major variants.
-template <int DIM_T, int CH>
-__device__ __forceinline__ uint4 xw_expand_chunk2(const uint32_t *atlas, const uint16_t *g, int cc, int dim_rt) {
-    const int D = DIM_T ? DIM_T : dim_rt;
-    const int RD = XW_TILE_DW * D, RH = XW_TILE * D;
-    const int d0 = cc * 4;
-    int ch = d0 / (RH * RD);
-    const int rem = d0 - ch * (RH * RD);
-    int y = rem / RD;
-    int dx = rem - y * RD;
-    int cidx[4], aoff[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int cy = y / XW_TILE, py = y - cy * XW_TILE;
-        const int cx = dx / XW_TILE_DW, kk = dx - cx * XW_TILE_DW;
-        cidx[k] = cy * D + cx;
-        aoff[k] = ch * 36 + py * 3 + kk;
-        dx += 1;
-        if (dx == RD) { dx = 0; y += 1; if (y == RH) { y = 0; ch += 1; } }
-    }
-    const uint32_t ca = g[cidx[0]], cb = g[cidx[3]];     // staged codes: the target bit is already stripped
-    uint32_t out[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t code = cidx[k] == cidx[0] ? ca : cb;
-        out[k] = atlas[code * (CH * 36) + aoff[k]];                 // tile 0 = empty cell (white)
-    }
-    return make_uint4(out[0], out[1], out[2], out[3]);
-}
-
-template <int DIM_T, int CH, bool CTX1>
-__global__ __launch_bounds__(1024) void xw_render_all_kernel(XwParams p, int tile_envs, int n_tiles, int atlas_dw) {
-    extern __shared__ uint4 smem4[];
-    uint32_t *s_atlas = reinterpret_cast<uint32_t *>(smem4);
-    uint16_t *s_grid = reinterpret_cast<uint16_t *>(s_atlas + atlas_dw);
+// all envs: ONE-SHOT workgroups in dispatch order -- the store structure that reaches the write ceiling on this
+// chip (tools/render_lab.hip: one-shot 6.7 TB/s, every persistent / looping structure <= 5.7 TB/s; the persistent
+// LDS-table kernel this replaces ran at 4.4 TB/s).  Each workgroup owns SPAN = BS * PER consecutive 16-byte chunks
+// of the batch's frame bytes, cut at 1 KiB multiples of the global chunk index so every wavefront store is a whole
+// number of cache lines although env frames (7x7x3: 21 168 B) are not 128-byte aligned.  A frame row is a run of
+// 12-byte tile rows, so the span is assembled in LDS in OUTPUT order from 12-byte rows gathered from the tile table
+// through L2 (157 KB, resident in every XCD's L2; one 12-byte load per tile row -- a per-dword gather is TA-bound at
+// 3.2 TB/s) and leaves as one 16-byte non-temporal store per lane.  All of a lane's gathers are issued before its
+// first LDS write (loads-first: 119 -> 111 us on C4 in the lab; 104 us = 6.7 TB/s inside the step loop).
+template <int DIM_T, int CH, bool CTX1, int BS, int PER>
+__global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
+    constexpr int SPAN = BS * PER;
+    constexpr int IT = ((SPAN * 16 + 11) / 12 + 1 + BS - 1) / BS;          // tile rows per lane
+    __shared__ uint4 s_out4[SPAN + 2];
+    __shared__ uint16_t s_code[SPAN * 16 / (144 * CH) + 2 * XW_MAX_DIM * XW_MAX_DIM];
+    uint32_t *s_out = reinterpret_cast<uint32_t *>(s_out4);
     const int D = DIM_T ? DIM_T : p.max_dim;
     const int cells = D * D;
-    uint8_t *s_fresh = reinterpret_cast<uint8_t *>(s_grid + (tile_envs + 1) * cells);
+    const unsigned PB = 144u * cells, FB = CH * PB, RB = 12u * D;     // bytes per plane, frame, frame row
+    const int cpf = (int)(FB / 16);
     const int tid = threadIdx.x;
-    const int ctx = CTX1 ? 1 : p.context;
-    const int cpf = CH * 9 * cells;                       // 16-byte chunks per frame: C*144*D*D/16
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.atlas);
-        for (int i = tid; i < atlas_dw / 4; i += 1024) smem4[i] = src[i];
+    const unsigned long long n_chunks = (unsigned long long)p.n * cpf;
+    const unsigned long long c_lo = (unsigned long long)blockIdx.x * SPAN;
+    const unsigned long long c_hi = c_lo + SPAN < n_chunks ? c_lo + SPAN : n_chunks;
+    const unsigned long long b_lo = c_lo * 16, b_hi = c_hi * 16;
+    const int e0 = (int)(b_lo / FB), e1 = (int)((b_hi - 1) / FB);
+    const int ncode = (e1 - e0 + 1) * cells;
+    for (int i = tid; i < ncode; i += BS) s_code[i] = p.grid[(size_t)e0 * cells + i] & CELL_ICON_MASK;
+    __syncthreads();
+    // 12-byte units [u0, u1) cover the span; env and plane boundaries are multiples of 12, so flooring b_lo to a unit
+    // never leaves env e0
+    const unsigned long long u0 = b_lo / 12, u1 = (b_hi + 11) / 12;
+    const int nu = (int)(u1 - u0);
+    const unsigned r0 = (unsigned)(u0 * 12 - (unsigned long long)e0 * FB);   // byte offset of unit u0 inside env e0
+    const int shift = 4 - (int)(b_lo - u0 * 12) / 4;                          // dword index of unit u0: chunk 0 = dword 4
+    uint32_t va[IT], vb[IT], vc[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int i = it * BS + tid;
+        const unsigned rr = r0 + 12u * (unsigned)(i < nu ? i : 0);
+        const unsigned le = rr / FB, r = rr - le * FB;
+        const unsigned ch = r / PB, r2 = r - ch * PB, y = r2 / RB, cx = (r2 - y * RB) / 12u, cy = y / 12u, py = y - cy * 12u;
+        const uint32_t code = s_code[le * cells + cy * D + cx];
+        const uint32_t *src = p.atlas + code * (CH * 36) + ch * 36 + py * 3;   // tile 0 = empty cell (white)
+        va[it] = src[0]; vb[it] = src[1]; vc[it] = src[2];
     }
-    // Each workgroup owns one contiguous range of the batch's 16-byte chunks [g_lo, g_hi), cut at 1 KiB
-    // boundaries (64 chunks = one wavefront store) and balanced to +-1 KiB for ANY workgroup count.  Ranges
-    // ignore env boundaries on purpose: an env frame is 16-byte but not 128-byte aligned (7x7x3: 21 168 B),
-    // and wave stores that straddle cache lines cost ~20 % of the write bandwidth (measured: 181 vs 148 us).
-    const long long total_chunks = (long long)p.n * cpf;
-    const long long units = (total_chunks + 63) / 64;
-    const long long g_lo = units * blockIdx.x / gridDim.x * 64;
-    long long g_hi = units * (blockIdx.x + 1) / gridDim.x * 64;
-    if (g_hi > total_chunks) g_hi = total_chunks;
-    const long long win = (long long)tile_envs * cpf;
-    for (long long w0 = g_lo; w0 < g_hi; w0 += win) {
-        const long long w1 = w0 + win < g_hi ? w0 + win : g_hi;
-        const int e_first = (int)(w0 / cpf), e_last = (int)((w1 - 1) / cpf);
-        const int ne = e_last - e_first + 1;                           // <= tile_envs + 1
-        __syncthreads();
-        const uint16_t *gsrc = p.grid + (size_t)e_first * cells;
-        for (int i = tid; i < ne * cells; i += 1024) s_grid[i] = gsrc[i] & CELL_ICON_MASK;   // drop the target bit
-        if (!CTX1 && tid < ne) s_fresh[tid] = p.fresh[e_first + tid];  // rewritten by the next step kernel
-        __syncthreads();
-        const unsigned base = (unsigned)(w0 - (long long)e_first * cpf);   // chunk offset of w0 inside env e_first
-        const int span = (int)(w1 - w0);
-        uint4 *win_obs = reinterpret_cast<uint4 *>(p.obs) + w0;             // CTX1: frames are back to back
-        for (int c0 = tid; c0 < span; c0 += 2048) {
-            const int c1 = c0 + 1024;
-            const bool has1 = c1 < span;
-            const unsigned a0 = base + (unsigned)c0, a1 = base + (unsigned)(has1 ? c1 : c0);
-            const int le0 = (int)(a0 / (unsigned)cpf), cc0 = (int)(a0 - (unsigned)le0 * (unsigned)cpf);
-            const int le1 = (int)(a1 / (unsigned)cpf), cc1 = (int)(a1 - (unsigned)le1 * (unsigned)cpf);
-            const uint4 v0 = xw_expand_chunk2<DIM_T, CH>(s_atlas, s_grid + le0 * cells, cc0, D);
-            const uint4 v1 = xw_expand_chunk2<DIM_T, CH>(s_atlas, s_grid + le1 * cells, cc1, D);
-            if (CTX1) {
-                u32x4 n0 = {v0.x, v0.y, v0.z, v0.w};
-                __builtin_nontemporal_store(n0, reinterpret_cast<u32x4 *>(win_obs + c0));
-                if (has1) {
-                    u32x4 n1 = {v1.x, v1.y, v1.z, v1.w};
-                    __builtin_nontemporal_store(n1, reinterpret_cast<u32x4 *>(win_obs + c1));
-                }
-            } else {
-                uint4 *obs4 = reinterpret_cast<uint4 *>(p.obs);
-                xw_store_chunk(obs4 + (size_t)(e_first + le0) * ctx * cpf, cc0, cpf, ctx, s_fresh[le0], v0);
-                if (has1) xw_store_chunk(obs4 + (size_t)(e_first + le1) * ctx * cpf, cc1, cpf, ctx, s_fresh[le1], v1);
-            }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int i = it * BS + tid;
+        if (i < nu) { const int o = shift + 3 * i; s_out[o] = va[it]; s_out[o + 1] = vb[it]; s_out[o + 2] = vc[it]; }
+    }
+    __syncthreads();
+    const int nc = (int)(c_hi - c_lo);
+    uint4 *obs4 = reinterpret_cast<uint4 *>(p.obs);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int c = k * BS + tid;
+        if (c >= nc) break;
+        const uint4 v = s_out4[1 + c];
+        if (CTX1) {                                       // frames are back to back: the chunk index IS the address
+            u32x4 nv = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(obs4 + c_lo + c));
+        } else {
+            const unsigned long long gc = c_lo + c;
+            const int e = (int)(gc / cpf), cc = (int)(gc - (unsigned long long)e * cpf);
+            xw_store_chunk(obs4 + (size_t)e * p.context * cpf, cc, cpf, p.context, p.fresh[e], v);
         }
     }
 }
@@ -325,78 +300,30 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
     }
 }
 
-static int g_num_cus = 0;
-static size_t g_max_lds = 0;
-
-hipError_t xw_render_prepare(int device) {
-    hipDeviceProp_t prop;
-    hipError_t err = hipGetDeviceProperties(&prop, device);
-    if (err != hipSuccess) return err;
-    g_num_cus = prop.multiProcessorCount;
-    g_max_lds = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : prop.sharedMemPerBlock;
-    return hipSuccess;
-}
-
-// launch configuration shared by both render_all variants: how many grids fit next to the table in LDS,
-// and how many persistent workgroups the chip holds (LDS-limited: 1 per CU for the colour NAV palette)
-struct RenderPlan { int tile_envs, n_tiles, atlas_dw, n_blocks; size_t lds; };
-
-template <int CH>
-static hipError_t plan_render(const XwParams &p, int tile_cap, RenderPlan &r) {
-    const int cells = p.max_dim * p.max_dim;
-    r.atlas_dw = (p.n_icons + 1) * CH * 36;
-    const size_t atlas_bytes = (size_t)r.atlas_dw * 4;
-    const size_t lds_cap = g_max_lds ? g_max_lds : 65536;
-    const size_t per_env = (size_t)cells * 2 + 1;          // cell codes + fresh flag
-    if (atlas_bytes + per_env + 64 > lds_cap) return hipErrorInvalidValue;
-    r.tile_envs = (int)((lds_cap - atlas_bytes - 64) / per_env) - 1;
-    if (r.tile_envs > tile_cap) r.tile_envs = tile_cap;
-    r.n_tiles = (p.n + r.tile_envs - 1) / r.tile_envs;
-    r.lds = atlas_bytes + (size_t)(r.tile_envs + 1) * per_env + 16;      // a chunk window can overlap tile_envs + 1 envs
-    const int cus = g_num_cus ? g_num_cus : 256;
-    int per_cu = (int)(lds_cap / r.lds);
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 1) per_cu = 1;                            // 1024-thread groups: one per CU keeps the tile split even
-    // Leave one CU per XCD without a render workgroup: the reset kernel's few latency-bound wavefronts run
-    // beside this kernel (side stream) and are 3.5x slower when they must share a CU with 16 render waves
-    // (workgroup b is placed on XCD b % 8, so cus - 8 groups leave exactly one free CU in every XCD).
-    int want = cus * per_cu;
-    if (want >= 64) want -= 8;
-    if (const char *ev = getenv("XWB_RENDER_BLOCKS")) { const int v = atoi(ev); if (v > 0) want = v; }
-    const int n_env_groups = (p.n + 3) / 4;                // at least ~4 envs per workgroup
-    r.n_blocks = n_env_groups < want ? n_env_groups : want;
-    return hipSuccess;
-}
-
-template <typename K>
-static hipError_t allow_big_lds(K kern, size_t lds, size_t &configured) {
-    if (lds > 65536 && configured < lds) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)(g_max_lds ? g_max_lds : lds));
-        if (err != hipSuccess) return err;
-        configured = g_max_lds ? g_max_lds : lds;
-    }
-    return hipSuccess;
+// render_all launch shape: XWB_RENDER_SHAPE = "<threads>x<chunks per lane>" overrides the default (A/B hook)
+template <int DIM_T, int CH, int BS, int PER>
+static hipError_t render_all_shape(const XwParams &p, hipStream_t s) {
+    const unsigned long long n_chunks = (unsigned long long)p.n * (CH * 9 * p.max_dim * p.max_dim);
+    const unsigned blocks = (unsigned)((n_chunks + BS * PER - 1) / (BS * PER));
+    if (p.context == 1) hipLaunchKernelGGL((xw_render_all_kernel<DIM_T, CH, true, BS, PER>), dim3(blocks), dim3(BS), 0, s, p);
+    else hipLaunchKernelGGL((xw_render_all_kernel<DIM_T, CH, false, BS, PER>), dim3(blocks), dim3(BS), 0, s, p);
+    return hipGetLastError();
 }
 
 template <int DIM_T, int CH>
 static hipError_t render_all(const XwParams &p, hipStream_t s) {
-    RenderPlan r;
-    hipError_t err = plan_render<CH>(p, 16, r);
-    if (err != hipSuccess) return err;
-    if (p.context == 1) {
-        auto kern = xw_render_all_kernel<DIM_T, CH, true>;
-        static size_t configured = 0;
-        if ((err = allow_big_lds(kern, r.lds, configured)) != hipSuccess) return err;
-        hipLaunchKernelGGL(kern, dim3(r.n_blocks), dim3(1024), r.lds, s, p, r.tile_envs, r.n_tiles, r.atlas_dw);
-    } else {
-        auto kern = xw_render_all_kernel<DIM_T, CH, false>;
-        static size_t configured = 0;
-        if ((err = allow_big_lds(kern, r.lds, configured)) != hipSuccess) return err;
-        hipLaunchKernelGGL(kern, dim3(r.n_blocks), dim3(1024), r.lds, s, p, r.tile_envs, r.n_tiles, r.atlas_dw);
+    // measured on C4 / 8x8 / 11x11 (profiles/r1/render_shapes.txt): 128 x 2 is best everywhere (8 KiB spans, up to
+    // 16 two-wave groups per CU); one chunk per lane leaves too few bytes per barrier, four too few groups in flight
+    static int shape = -1;
+    if (shape < 0) {
+        shape = 0;
+        if (const char *ev = getenv("XWB_RENDER_SHAPE")) shape = !strcmp(ev, "64x2") ? 1 : (!strcmp(ev, "256x2") ? 2 : 0);
     }
-    return hipGetLastError();
+    switch (shape) {
+        case 1: return render_all_shape<DIM_T, CH, 64, 2>(p, s);
+        case 2: return render_all_shape<DIM_T, CH, 256, 2>(p, s);
+        default: return render_all_shape<DIM_T, CH, 128, 2>(p, s);
+    }
 }
 
 template <int DIM_T, int CH>

@@ -273,7 +273,6 @@ int xw_setup(xwb_sim *s) {
     HIP_TRY(hipMemcpy(s->d_name_first, first.data(), first.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_name_variants, variants.data(), variants.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_atlas, atlas.data(), atlas.size(), hipMemcpyHostToDevice));
-    HIP_TRY(xw_render_prepare(c.device));
     HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_step, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_reset, hipEventDisableTiming));

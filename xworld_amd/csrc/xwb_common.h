@@ -173,7 +173,6 @@ hipError_t launch_xw_compact(const XwParams &p, int mode, hipStream_t s);
 // render: indexed == 0 -> all envs (LDS-resident atlas, persistent workgroups);
 //         indexed == 1 -> envs in done_list (atlas through L2)
 hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s);
-hipError_t xw_render_prepare(int device);   // opt-in to > 64 KiB dynamic LDS once per process
 
 // host: builds the 12x12 tile table (OpenCV 3.2 fixed-point bilinear + BGR2GRAY) from 64x64 icons
 void build_tile_table(const uint8_t *icons64, int n_icons, int channels, uint8_t *out /* n*c*12*12 */);
