@@ -216,12 +216,15 @@ __device__ __forceinline__ void xw_store_chunk(uint4 *frame0, int cc, int chunks
 // through L2 (157 KB, resident in every XCD's L2; one 12-byte load per tile row -- a per-dword gather is TA-bound at
 // 3.2 TB/s) and leaves as one 16-byte non-temporal store per lane.  All of a lane's gathers are issued before its
 // first LDS write (loads-first: 119 -> 111 us on C4 in the lab; 104 us = 6.7 TB/s inside the step loop).
-template <int DIM_T, int CH, bool CTX1, int BS, int PER>
+// SKIP_DONE (xwb_step_autoreset): frames of finished envs are left to the list render that follows their reset on
+// the side stream, so that render runs beside this kernel instead of after it.
+template <int DIM_T, int CH, bool CTX1, int BS, int PER, bool SKIP_DONE>
 __global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
     constexpr int SPAN = BS * PER;
     constexpr int IT = ((SPAN * 16 + 11) / 12 + 1 + BS - 1) / BS;          // tile rows per lane
     __shared__ uint4 s_out4[SPAN + 2];
     __shared__ uint16_t s_code[SPAN * 16 / (144 * CH) + 2 * XW_MAX_DIM * XW_MAX_DIM];
+    __shared__ uint8_t s_done[SPAN * 16 / (144 * CH) + 2];
     uint32_t *s_out = reinterpret_cast<uint32_t *>(s_out4);
     const int D = DIM_T ? DIM_T : p.max_dim;
     const int cells = D * D;
@@ -235,6 +238,7 @@ __global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
     const int e0 = (int)(b_lo / FB), e1 = (int)((b_hi - 1) / FB);
     const int ncode = (e1 - e0 + 1) * cells;
     for (int i = tid; i < ncode; i += BS) s_code[i] = p.grid[(size_t)e0 * cells + i] & CELL_ICON_MASK;
+    if (SKIP_DONE) for (int i = tid; i <= e1 - e0; i += BS) s_done[i] = p.done[e0 + i];
     __syncthreads();
     // 12-byte units [u0, u1) cover the span; env and plane boundaries are multiples of 12, so flooring b_lo to a unit
     // never leaves env e0
@@ -266,6 +270,7 @@ __global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
         const int c = k * BS + tid;
         if (c >= nc) break;
         const uint4 v = s_out4[1 + c];
+        if (SKIP_DONE && s_done[((unsigned)(b_lo - (unsigned long long)e0 * FB) + 16u * (unsigned)c) / FB]) continue;
         if (CTX1) {                                       // frames are back to back: the chunk index IS the address
             u32x4 nv = {v.x, v.y, v.z, v.w};
             __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(obs4 + c_lo + c));
@@ -301,16 +306,16 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
 }
 
 // render_all launch shape: XWB_RENDER_SHAPE = "<threads>x<chunks per lane>" overrides the default (A/B hook)
-template <int DIM_T, int CH, int BS, int PER>
+template <int DIM_T, int CH, int BS, int PER, bool SKIP>
 static hipError_t render_all_shape(const XwParams &p, hipStream_t s) {
     const unsigned long long n_chunks = (unsigned long long)p.n * (CH * 9 * p.max_dim * p.max_dim);
     const unsigned blocks = (unsigned)((n_chunks + BS * PER - 1) / (BS * PER));
-    if (p.context == 1) hipLaunchKernelGGL((xw_render_all_kernel<DIM_T, CH, true, BS, PER>), dim3(blocks), dim3(BS), 0, s, p);
-    else hipLaunchKernelGGL((xw_render_all_kernel<DIM_T, CH, false, BS, PER>), dim3(blocks), dim3(BS), 0, s, p);
+    if (p.context == 1) hipLaunchKernelGGL((xw_render_all_kernel<DIM_T, CH, true, BS, PER, SKIP>), dim3(blocks), dim3(BS), 0, s, p);
+    else hipLaunchKernelGGL((xw_render_all_kernel<DIM_T, CH, false, BS, PER, SKIP>), dim3(blocks), dim3(BS), 0, s, p);
     return hipGetLastError();
 }
 
-template <int DIM_T, int CH>
+template <int DIM_T, int CH, bool SKIP>
 static hipError_t render_all(const XwParams &p, hipStream_t s) {
     // measured on C4 / 8x8 / 11x11 (profiles/r1/render_shapes.txt): 128 x 2 is best everywhere (8 KiB spans, up to
     // 16 two-wave groups per CU); one chunk per lane leaves too few bytes per barrier, four too few groups in flight
@@ -320,9 +325,9 @@ static hipError_t render_all(const XwParams &p, hipStream_t s) {
         if (const char *ev = getenv("XWB_RENDER_SHAPE")) shape = !strcmp(ev, "64x2") ? 1 : (!strcmp(ev, "256x2") ? 2 : 0);
     }
     switch (shape) {
-        case 1: return render_all_shape<DIM_T, CH, 64, 2>(p, s);
-        case 2: return render_all_shape<DIM_T, CH, 256, 2>(p, s);
-        default: return render_all_shape<DIM_T, CH, 128, 2>(p, s);
+        case 1: return render_all_shape<DIM_T, CH, 64, 2, SKIP>(p, s);
+        case 2: return render_all_shape<DIM_T, CH, 256, 2, SKIP>(p, s);
+        default: return render_all_shape<DIM_T, CH, 128, 2, SKIP>(p, s);
     }
 }
 
@@ -335,10 +340,10 @@ static hipError_t render_list(const XwParams &p, hipStream_t s) {
 
 template <int CH>
 static hipError_t render_dispatch(const XwParams &p, int indexed, hipStream_t s) {
-#define XW_CASE(DIMV) case DIMV: return indexed ? render_list<DIMV, CH>(p, s) : render_all<DIMV, CH>(p, s);
+#define XW_CASE(DIMV) case DIMV: return indexed == 1 ? render_list<DIMV, CH>(p, s) : (indexed == 2 ? render_all<DIMV, CH, true>(p, s) : render_all<DIMV, CH, false>(p, s));
     switch (p.max_dim) {
         XW_CASE(7) XW_CASE(8) XW_CASE(11)
-        default: return indexed ? render_list<0, CH>(p, s) : render_all<0, CH>(p, s);
+        default: return indexed == 1 ? render_list<0, CH>(p, s) : (indexed == 2 ? render_all<0, CH, true>(p, s) : render_all<0, CH, false>(p, s));
     }
 #undef XW_CASE
 }

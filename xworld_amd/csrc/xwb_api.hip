@@ -422,15 +422,23 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         HIP_TRY(launch_xw_step(p, st));
         timer_end(s, s->t_step, st);
         s->list_valid = true;
-        if (!autoreset) HIP_TRY(hipEventRecord(s->ev_step, st));
+        HIP_TRY(hipEventRecord(s->ev_step, st));
         if (autoreset) {
-            int rc = xw_reset_list(s, MODE_RESET_DONE, true, false, st);
-            if (rc) return rc;
+            // finished envs: reset + render of the list on the side stream, beside the render of everyone else
+            XwParams pr = xw_params(s);
+            pr.auto_reset = 1;
+            HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
+            timer_begin(s, s->t_reset, s->side);
+            HIP_TRY(launch_xw_reset(pr, MODE_RESET_DONE, s->side));
+            timer_end(s, s->t_reset, s->side);
+            HIP_TRY(launch_xw_render(pr, 1, s->side));
+            HIP_TRY(hipEventRecord(s->ev_reset, s->side));
             s->list_valid = false;
         }
         timer_begin(s, s->t_render, st);
-        HIP_TRY(launch_xw_render(p, 0, st));
+        HIP_TRY(launch_xw_render(p, autoreset ? 2 : 0, st));
         timer_end(s, s->t_render, st);
+        if (autoreset) HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
     }
     s->policy_step += 1;
     return XWB_OK;

@@ -172,6 +172,7 @@ hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s);
 hipError_t launch_xw_compact(const XwParams &p, int mode, hipStream_t s);
 // render: indexed == 0 -> all envs (LDS-resident atlas, persistent workgroups);
 //         indexed == 1 -> envs in done_list (atlas through L2)
+// indexed: 0 = every env, 1 = the compacted done list, 2 = every env whose done code is 0 (the rest follows as a list)
 hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s);
 
 // host: builds the 12x12 tile table (OpenCV 3.2 fixed-point bilinear + BGR2GRAY) from 64x64 icons
