@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the batched XWorld simulator on N MI355X (one process per GPU).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload xworld7|xworld8|xworld11|simple_game|simple_race]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload xworld7|xworld7_f32|xworld8|xworld11|simple_game|simple_race]
 
 N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -33,6 +33,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 
 WORKLOADS = {
     # name: (game, opts, envs per GPU, algorithmic bytes per env-step, bytes per env per render launch)
     "xworld7": ("xworld", {"max_dim": 7, "num_blocks": 16, "color": True}, 32768),
+    "xworld7_f32": ("xworld", {"max_dim": 7, "num_blocks": 16, "color": True, "obs_format": "float32"}, 32768),
     "xworld8": ("xworld", {"color": True}, 32768),
     "xworld11": ("xworld", {"max_dim": 11, "num_blocks": 30, "color": True}, 32768),
     "simple_game": ("simple_game", {"array_size": 64}, 65536),
@@ -61,7 +62,7 @@ def algorithmic_bytes(workload, sim):
         return 57, 57, "race_kernel"
     d = sim.cfg.max_dim
     c = sim.screen_dims[2]
-    obs = c * 144 * d * d
+    obs = c * 144 * d * d * (4 if sim.obs_is_float else 1)      # float32 variant: obs term x 4
     return 33 + 2 * d * d + obs, 2 * d * d + obs, "xw_render_all_kernel"
 
 
@@ -226,7 +227,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8" if WORKLOADS[args.workload][0] != "simple_race" else "f32 (f64 trig)",
+            "dtype": ("f32 (f64 trig)" if WORKLOADS[args.workload][0] == "simple_race" else
+                      ("u8 state, f32 frames (pixel * 1/255)" if sim.obs_is_float else "u8")),
             "data": "synthetic",
             "config": {"workload": args.workload, "envs_per_gpu": n_local, "total_envs": total_envs,
                        "obs": list(sim.obs.shape[1:]), "seed": args.seed, "policy": "uniform random, drawn on device",

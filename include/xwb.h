@@ -62,6 +62,7 @@ enum { XWB_TASK_TARGET = 0, XWB_TASK_NEAR = 1, XWB_TASK_BETWEEN = 2, XWB_TASK_DI
 #define XWB_CELL_TARGET    0x8000   /* cell code bit: this goal belongs to the task's target set */
 enum { XWB_TASKMODE_LANG_ACQ = 0, XWB_TASKMODE_ONE_CHANNEL = 1 };   /* FLAGS_task_mode, xworld_simulator.cpp:33-37 */
 enum { XWB_EV_NONE = 0, XWB_EV_CORRECT_GOAL = 1, XWB_EV_WRONG_GOAL = 2, XWB_EV_TIME_UP = 3 };
+enum { XWB_OBS_U8 = 0, XWB_OBS_F32 = 1 };
 enum { XWB_ICON_GOAL = 0, XWB_ICON_BLOCK = 1, XWB_ICON_AGENT = 2 };  /* xworld_env.py:66 grid_types */
 
 /*
@@ -102,6 +103,8 @@ typedef struct xwb_config {
                                   * TaskGroup samples one per episode); 0 = { XWB_TASK_TARGET } */
     int32_t  tasks[8];           /* XWB_TASK_* */
     int32_t  color;              /* FLAGS_color: 3-channel planar BGR when set, else 1-channel gray */
+    int32_t  obs_format;         /* XWB_OBS_U8 (the reference's screen bytes) | XWB_OBS_F32: float32 pixel * (1/255.0f),
+                                  * the scaling py_simulator.cpp:262-272 applies in get_state(), done on the device */
     int32_t  n_icons;            /* icons this map class can place (its "palette") */
     const uint8_t *icons64;      /* host, n_icons x 64 x 64 x 3, BGR as cv::imread(path, 1) (xitem.cpp:38) */
     const int32_t *icon_type;    /* host, n_icons, XWB_ICON_* */

@@ -347,3 +347,29 @@ def test_action_skip_and_reset_env(oracle):
     assert np.array_equal(sim.env_grid(5).astype(np.int32), w.grid())
     assert torch.equal(sim.obs[keep], before[keep])
     sim.close()
+
+
+@pytest.mark.parametrize("key,color,context", [("nav7", True, 1), ("nav8", False, 1), ("nav11", True, 1), ("walls7", True, 3),
+                                               ("nav8_dim5", False, 2)])
+def test_float32_observations(oracle, key, color, context):
+    """obs_format="float32" (SURVEY 8(d) variant): every frame equals the uint8 frame * float32(1/255), the product
+    py_simulator.cpp:262-272 computes in get_state(); same trajectories, resets and context ring."""
+    torch = _torch()
+    n = 700
+    a, _, _ = _make(oracle, key, n, seed=12, policy_seed=4, color=color, context=context)
+    b, _, _ = _make(oracle, key, n, seed=12, policy_seed=4, color=color, context=context, obs_format="float32")
+    assert b.obs.dtype == torch.float32 and b.obs.shape == a.obs.shape and b.obs_bytes_per_env == 4 * a.obs_bytes_per_env
+    scale = torch.tensor(1 / 255.0, dtype=torch.float32, device="cuda")
+    for t in range(60):
+        assert torch.equal(b.obs, a.obs.to(torch.float32) * scale), t
+        if t % 2:
+            a.step_autoreset(); b.step_autoreset()
+        else:
+            a.step(); b.step()
+            assert torch.equal(b.obs, a.obs.to(torch.float32) * scale), t
+            a.reset_done(); b.reset_done()
+        assert torch.equal(a.reward, b.reward) and torch.equal(a.game_over_codes, b.game_over_codes)
+    e = n // 2
+    assert np.array_equal(b.env_obs(e), a.env_obs(e).astype(np.float32) * np.float32(1 / 255.0))
+    a.close()
+    b.close()

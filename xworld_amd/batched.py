@@ -82,6 +82,10 @@ class BatchedSimulator:
                 raise RuntimeError("unsupported task mode: " + str(mode))  # xworld_simulator.cpp:194-196
             cfg.task_mode = 0 if mode == "lang_acquisition" else 1
             cfg.color = int(bool(opts.get("color", False)))
+            fmt = opts.get("obs_format", "uint8")
+            if fmt not in ("uint8", "float32"):
+                raise RuntimeError("obs_format must be 'uint8' or 'float32'")
+            cfg.obs_format = 1 if fmt == "float32" else 0
             tasks = opts.get("tasks")                                     # override: list of task class names / ids
             tasks = assets.conf_tasks(conf, opts.get("task_group")) if tasks is None else [assets.TASK_IDS.get(t, t) for t in tasks]
             cfg.n_tasks = len(tasks)
@@ -97,6 +101,7 @@ class BatchedSimulator:
             cfg.icon_name = self.palette.icon_name.ctypes.data
             cfg.icon_colored = self.palette.icon_colored.ctypes.data
         self.cfg = cfg
+        self.obs_is_float = name == "simple_race" or (name == "xworld" and cfg.obs_format == 1)
         h = C.c_void_p()
         lib.check(self.L.xwb_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -199,12 +204,13 @@ class BatchedSimulator:
 
     @property
     def obs(self):
-        """[num_envs, context*c, h, w]; uint8 (simple_game, xworld: planar B,G,R) or float32 (simple_race)."""
+        """[num_envs, context*c, h, w]; uint8 (simple_game, xworld: planar B,G,R) or float32 (simple_race; xworld
+        created with obs_format="float32": pixel * 1/255, the scaling of py_simulator's get_state)."""
         import torch
         if "obs" not in self._views:
             h, w, c = self.screen_dims
             ctx = self.cfg.context
-            if self.name == "simple_race":
+            if self.obs_is_float:
                 shape, ts = (self.num_envs, ctx * c, h, w), "<f4"
             else:
                 shape, ts = (self.num_envs, ctx * c, h, w), "|u1"
@@ -228,7 +234,7 @@ class BatchedSimulator:
         return st
 
     def env_obs(self, env=0, stream=None):
-        dt = np.float32 if self.name == "simple_race" else np.uint8
+        dt = np.float32 if self.obs_is_float else np.uint8
         out = np.empty(self.obs_bytes_per_env // np.dtype(dt).itemsize, dt)
         lib.check(self.L.xwb_get_env_obs(self.h, int(env), self._stream(stream), out.ctypes.data, self.obs_bytes_per_env))
         return out

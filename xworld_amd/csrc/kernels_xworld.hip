@@ -167,11 +167,21 @@ __global__ __launch_bounds__(256) void xw_compact_kernel(XwParams p, int mode, i
 // ----------------------------------------------------------------- render --
 // One output chunk = 16 consecutive bytes of an env's planar frame = 4 dwords, each of which lies
 // inside one tile row (12 px = 3 dwords, frame rows are 3*D dwords).
-template <int DIM_T, int CH>
+template <int DIM_T, int CH, int ES>
 __device__ __forceinline__ uint4 xw_expand_chunk(const uint32_t *atlas, const uint16_t *g, int cc, int dim_rt) {
     const int D = DIM_T ? DIM_T : dim_rt;
-    const int RD = XW_TILE_DW * D;      // dwords per frame row
+    const int RD = XW_TILE_DW * D;      // u8 dwords (4-pixel groups) per frame row
     const int RH = XW_TILE * D;         // rows per channel
+    if (ES == 4) {
+        // float32 frames: a 16-byte chunk is ONE 4-pixel group; the table holds it as one aligned uint4
+        int ch = cc / (RH * RD);
+        const int rem = cc - ch * (RH * RD);
+        const int y = rem / RD, dx = rem - y * RD;
+        const int cy = y / XW_TILE, py = y - cy * XW_TILE;
+        const int cx = dx / XW_TILE_DW, kk = dx - cx * XW_TILE_DW;
+        const uint32_t code = g[cy * D + cx];
+        return reinterpret_cast<const uint4 *>(atlas)[code * (CH * 36) + ch * 36 + py * 3 + kk];
+    }
     const int d0 = cc * 4;
     int ch = d0 / (RH * RD);
     const int rem = d0 - ch * (RH * RD);
@@ -218,17 +228,22 @@ __device__ __forceinline__ void xw_store_chunk(uint4 *frame0, int cc, int chunks
 // first LDS write (loads-first: 119 -> 111 us on C4 in the lab; 104 us = 6.7 TB/s inside the step loop).
 // SKIP_DONE (xwb_step_autoreset): frames of finished envs are left to the list render that follows their reset on
 // the side stream, so that render runs beside this kernel instead of after it.
-template <int DIM_T, int CH, bool CTX1, int BS, int PER, bool SKIP_DONE>
+// ES = bytes per pixel: 1 = uint8 frames; 4 = float32 frames (pixel * 1/255, py_simulator.cpp:262-272) expanded from
+// a float copy of the tile table (628 KB, still L2-resident): the same kernel with 48-byte tile rows.
+template <int DIM_T, int CH, bool CTX1, int BS, int PER, bool SKIP_DONE, int ES>
 __global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
     constexpr int SPAN = BS * PER;
-    constexpr int IT = ((SPAN * 16 + 11) / 12 + 1 + BS - 1) / BS;          // tile rows per lane
-    __shared__ uint4 s_out4[SPAN + 2];
-    __shared__ uint16_t s_code[SPAN * 16 / (144 * CH) + 2 * XW_MAX_DIM * XW_MAX_DIM];
-    __shared__ uint8_t s_done[SPAN * 16 / (144 * CH) + 2];
+    constexpr int TB = 12 * ES, TD = 3 * ES;                               // bytes / dwords per tile row
+    constexpr int PAD = (TD + 3) / 4 * 4;                                   // dword index of the span's first chunk
+    constexpr int IT = ((SPAN * 16 + TB - 1) / TB + 1 + BS - 1) / BS;       // tile rows per lane
+    constexpr int NE = SPAN * 16 / (144 * CH * ES) + 2;                     // envs a span can touch
+    __shared__ uint4 s_out4[SPAN + PAD / 4 + TD / 4 + 1];
+    __shared__ uint16_t s_code[SPAN * 16 / (144 * CH * ES) + 2 * XW_MAX_DIM * XW_MAX_DIM];
+    __shared__ uint8_t s_done[NE];
     uint32_t *s_out = reinterpret_cast<uint32_t *>(s_out4);
     const int D = DIM_T ? DIM_T : p.max_dim;
     const int cells = D * D;
-    const unsigned PB = 144u * cells, FB = CH * PB, RB = 12u * D;     // bytes per plane, frame, frame row
+    const unsigned PB = 144u * ES * cells, FB = CH * PB, RB = 12u * ES * D;   // bytes per plane, frame, frame row
     const int cpf = (int)(FB / 16);
     const int tid = threadIdx.x;
     const unsigned long long n_chunks = (unsigned long long)p.n * cpf;
@@ -240,27 +255,46 @@ __global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
     for (int i = tid; i < ncode; i += BS) s_code[i] = p.grid[(size_t)e0 * cells + i] & CELL_ICON_MASK;
     if (SKIP_DONE) for (int i = tid; i <= e1 - e0; i += BS) s_done[i] = p.done[e0 + i];
     __syncthreads();
-    // 12-byte units [u0, u1) cover the span; env and plane boundaries are multiples of 12, so flooring b_lo to a unit
+    // TB-byte units [u0, u1) cover the span; env and plane boundaries are multiples of TB, so flooring b_lo to a unit
     // never leaves env e0
-    const unsigned long long u0 = b_lo / 12, u1 = (b_hi + 11) / 12;
+    const unsigned long long u0 = b_lo / TB, u1 = (b_hi + TB - 1) / TB;
     const int nu = (int)(u1 - u0);
-    const unsigned r0 = (unsigned)(u0 * 12 - (unsigned long long)e0 * FB);   // byte offset of unit u0 inside env e0
-    const int shift = 4 - (int)(b_lo - u0 * 12) / 4;                          // dword index of unit u0: chunk 0 = dword 4
-    uint32_t va[IT], vb[IT], vc[IT];
+    const unsigned r0 = (unsigned)(u0 * TB - (unsigned long long)e0 * FB);   // byte offset of unit u0 inside env e0
+    const int shift = PAD - (int)(b_lo - u0 * TB) / 4;                        // dword index of unit u0: chunk 0 = dword PAD
+    uint32_t v[IT][TD];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int i = it * BS + tid;
-        const unsigned rr = r0 + 12u * (unsigned)(i < nu ? i : 0);
+        const unsigned rr = r0 + (unsigned)TB * (unsigned)(i < nu ? i : 0);
         const unsigned le = rr / FB, r = rr - le * FB;
-        const unsigned ch = r / PB, r2 = r - ch * PB, y = r2 / RB, cx = (r2 - y * RB) / 12u, cy = y / 12u, py = y - cy * 12u;
+        const unsigned ch = r / PB, r2 = r - ch * PB, y = r2 / RB, cx = (r2 - y * RB) / (unsigned)TB, cy = y / 12u, py = y - cy * 12u;
         const uint32_t code = s_code[le * cells + cy * D + cx];
-        const uint32_t *src = p.atlas + code * (CH * 36) + ch * 36 + py * 3;   // tile 0 = empty cell (white)
-        va[it] = src[0]; vb[it] = src[1]; vc[it] = src[2];
+        const uint32_t *src = p.atlas + (code * (CH * 36) + ch * 36 + py * 3) * ES;   // tile 0 = empty cell (white)
+        if (ES == 4) {
+#pragma unroll
+            for (int q = 0; q < TD / 4; ++q) {
+                const uint4 t = reinterpret_cast<const uint4 *>(src)[q];
+                v[it][4 * q] = t.x; v[it][4 * q + 1] = t.y; v[it][4 * q + 2] = t.z; v[it][4 * q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < TD; ++d) v[it][d] = src[d];
+        }
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int i = it * BS + tid;
-        if (i < nu) { const int o = shift + 3 * i; s_out[o] = va[it]; s_out[o + 1] = vb[it]; s_out[o + 2] = vc[it]; }
+        if (i < nu) {
+            const int o = shift + TD * i;
+            if (ES == 4) {
+#pragma unroll
+                for (int q = 0; q < TD / 4; ++q)
+                    s_out4[o / 4 + q] = make_uint4(v[it][4 * q], v[it][4 * q + 1], v[it][4 * q + 2], v[it][4 * q + 3]);
+            } else {
+#pragma unroll
+                for (int d = 0; d < TD; ++d) s_out[o + d] = v[it][d];
+            }
+        }
     }
     __syncthreads();
     const int nc = (int)(c_hi - c_lo);
@@ -269,27 +303,27 @@ __global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
     for (int k = 0; k < PER; ++k) {
         const int c = k * BS + tid;
         if (c >= nc) break;
-        const uint4 v = s_out4[1 + c];
+        const uint4 val = s_out4[PAD / 4 + c];
         if (SKIP_DONE && s_done[((unsigned)(b_lo - (unsigned long long)e0 * FB) + 16u * (unsigned)c) / FB]) continue;
         if (CTX1) {                                       // frames are back to back: the chunk index IS the address
-            u32x4 nv = {v.x, v.y, v.z, v.w};
+            u32x4 nv = {val.x, val.y, val.z, val.w};
             __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(obs4 + c_lo + c));
         } else {
             const unsigned long long gc = c_lo + c;
             const int e = (int)(gc / cpf), cc = (int)(gc - (unsigned long long)e * cpf);
-            xw_store_chunk(obs4 + (size_t)e * p.context * cpf, cc, cpf, p.context, p.fresh[e], v);
+            xw_store_chunk(obs4 + (size_t)e * p.context * cpf, cc, cpf, p.context, p.fresh[e], val);
         }
     }
 }
 
 // the compacted list of freshly reset envs: one env per workgroup pass, tile table through L1/L2
-template <int DIM_T, int CH>
+template <int DIM_T, int CH, int ES>
 __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const int32_t *count_now) {
     __shared__ uint16_t s_grid[XW_MAX_DIM * XW_MAX_DIM];
     const int D = DIM_T ? DIM_T : p.max_dim;
     const int cells = D * D;
     const int ctx = p.context;
-    const int cpf = CH * 9 * cells;
+    const int cpf = CH * 9 * cells * ES;
     const int cnt = *count_now;
     for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
         const int e = p.done_list[i];
@@ -298,7 +332,7 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
         __syncthreads();
         uint4 *frame0 = reinterpret_cast<uint4 *>(p.obs) + (size_t)e * ctx * cpf;
         for (int cc = threadIdx.x; cc < cpf; cc += 256) {
-            const uint4 v = xw_expand_chunk<DIM_T, CH>(p.atlas, s_grid, cc, D);
+            const uint4 v = xw_expand_chunk<DIM_T, CH, ES>(p.atlas, s_grid, cc, D);
             xw_store_chunk(frame0, cc, cpf, ctx, 2, v);
         }
         if (threadIdx.x == 0) p.fresh[e] = 0;
@@ -306,16 +340,16 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
 }
 
 // render_all launch shape: XWB_RENDER_SHAPE = "<threads>x<chunks per lane>" overrides the default (A/B hook)
-template <int DIM_T, int CH, int BS, int PER, bool SKIP>
+template <int DIM_T, int CH, int BS, int PER, bool SKIP, int ES>
 static hipError_t render_all_shape(const XwParams &p, hipStream_t s) {
-    const unsigned long long n_chunks = (unsigned long long)p.n * (CH * 9 * p.max_dim * p.max_dim);
+    const unsigned long long n_chunks = (unsigned long long)p.n * (CH * 9 * ES * p.max_dim * p.max_dim);
     const unsigned blocks = (unsigned)((n_chunks + BS * PER - 1) / (BS * PER));
-    if (p.context == 1) hipLaunchKernelGGL((xw_render_all_kernel<DIM_T, CH, true, BS, PER, SKIP>), dim3(blocks), dim3(BS), 0, s, p);
-    else hipLaunchKernelGGL((xw_render_all_kernel<DIM_T, CH, false, BS, PER, SKIP>), dim3(blocks), dim3(BS), 0, s, p);
+    if (p.context == 1) hipLaunchKernelGGL((xw_render_all_kernel<DIM_T, CH, true, BS, PER, SKIP, ES>), dim3(blocks), dim3(BS), 0, s, p);
+    else hipLaunchKernelGGL((xw_render_all_kernel<DIM_T, CH, false, BS, PER, SKIP, ES>), dim3(blocks), dim3(BS), 0, s, p);
     return hipGetLastError();
 }
 
-template <int DIM_T, int CH, bool SKIP>
+template <int DIM_T, int CH, bool SKIP, int ES>
 static hipError_t render_all(const XwParams &p, hipStream_t s) {
     // measured on C4 / 8x8 / 11x11 (profiles/r1/render_shapes.txt): 128 x 2 is best everywhere (8 KiB spans, up to
     // 16 two-wave groups per CU); one chunk per lane leaves too few bytes per barrier, four too few groups in flight
@@ -325,31 +359,32 @@ static hipError_t render_all(const XwParams &p, hipStream_t s) {
         if (const char *ev = getenv("XWB_RENDER_SHAPE")) shape = !strcmp(ev, "64x2") ? 1 : (!strcmp(ev, "256x2") ? 2 : 0);
     }
     switch (shape) {
-        case 1: return render_all_shape<DIM_T, CH, 64, 2, SKIP>(p, s);
-        case 2: return render_all_shape<DIM_T, CH, 256, 2, SKIP>(p, s);
-        default: return render_all_shape<DIM_T, CH, 128, 2, SKIP>(p, s);
+        case 1: return render_all_shape<DIM_T, CH, 64, 2, SKIP, ES>(p, s);
+        case 2: return render_all_shape<DIM_T, CH, 256, 2, SKIP, ES>(p, s);
+        default: return render_all_shape<DIM_T, CH, 128, 2, SKIP, ES>(p, s);
     }
 }
 
-template <int DIM_T, int CH>
+template <int DIM_T, int CH, int ES>
 static hipError_t render_list(const XwParams &p, hipStream_t s) {
     dim3 grid(512), block(256);
-    hipLaunchKernelGGL((xw_render_list_kernel<DIM_T, CH>), grid, block, 0, s, p, (const int32_t *)p.done_count);
+    hipLaunchKernelGGL((xw_render_list_kernel<DIM_T, CH, ES>), grid, block, 0, s, p, (const int32_t *)p.done_count);
     return hipGetLastError();
 }
 
-template <int CH>
+template <int CH, int ES>
 static hipError_t render_dispatch(const XwParams &p, int indexed, hipStream_t s) {
-#define XW_CASE(DIMV) case DIMV: return indexed == 1 ? render_list<DIMV, CH>(p, s) : (indexed == 2 ? render_all<DIMV, CH, true>(p, s) : render_all<DIMV, CH, false>(p, s));
+#define XW_CASE(DIMV) case DIMV: return indexed == 1 ? render_list<DIMV, CH, ES>(p, s) : (indexed == 2 ? render_all<DIMV, CH, true, ES>(p, s) : render_all<DIMV, CH, false, ES>(p, s));
     switch (p.max_dim) {
         XW_CASE(7) XW_CASE(8) XW_CASE(11)
-        default: return indexed == 1 ? render_list<0, CH>(p, s) : (indexed == 2 ? render_all<0, CH, true>(p, s) : render_all<0, CH, false>(p, s));
+        default: return indexed == 1 ? render_list<0, CH, ES>(p, s) : (indexed == 2 ? render_all<0, CH, true, ES>(p, s) : render_all<0, CH, false, ES>(p, s));
     }
 #undef XW_CASE
 }
 
 hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s) {
-    return p.channels == 3 ? render_dispatch<3>(p, indexed, s) : render_dispatch<1>(p, indexed, s);
+    if (p.obs_f32) return p.channels == 3 ? render_dispatch<3, 4>(p, indexed, s) : render_dispatch<1, 4>(p, indexed, s);
+    return p.channels == 3 ? render_dispatch<3, 1>(p, indexed, s) : render_dispatch<1, 1>(p, indexed, s);
 }
 
 hipError_t launch_xw_compact(const XwParams &p, int mode, hipStream_t s) {

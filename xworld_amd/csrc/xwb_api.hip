@@ -262,7 +262,8 @@ int xw_setup(xwb_sim *s) {
     if ((rc = dev_alloc(s, &s->d_icon_name, c.n_icons))) return rc;
     if ((rc = dev_alloc(s, &s->d_name_first, first.size()))) return rc;
     if ((rc = dev_alloc(s, &s->d_name_variants, variants.size()))) return rc;
-    if ((rc = dev_alloc(s, &s->d_atlas, atlas.size() / 4))) return rc;
+    const bool f32 = c.obs_format == XWB_OBS_F32;
+    if ((rc = dev_alloc(s, &s->d_atlas, f32 ? atlas.size() : atlas.size() / 4))) return rc;
     HIP_TRY(hipMemcpy(s->d_icon_type, types.data(), types.size(), hipMemcpyHostToDevice));
     if (c.icon_colored) {
         std::vector<uint8_t> col(c.n_icons);
@@ -272,7 +273,15 @@ int xw_setup(xwb_sim *s) {
     HIP_TRY(hipMemcpy(s->d_icon_name, names.data(), names.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_name_first, first.data(), first.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_name_variants, variants.data(), variants.size() * 2, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(s->d_atlas, atlas.data(), atlas.size(), hipMemcpyHostToDevice));
+    if (f32) {
+        // py_simulator.cpp:262-272: `float scale = 1 / 255.0` then pixel * scale, a float32 product
+        std::vector<float> af(atlas.size());
+        const float scale = (float)(1 / 255.0);
+        for (size_t i = 0; i < atlas.size(); ++i) af[i] = (float)atlas[i] * scale;
+        HIP_TRY(hipMemcpy(s->d_atlas, af.data(), af.size() * 4, hipMemcpyHostToDevice));
+    } else {
+        HIP_TRY(hipMemcpy(s->d_atlas, atlas.data(), atlas.size(), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_step, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_reset, hipEventDisableTiming));
@@ -282,6 +291,7 @@ int xw_setup(xwb_sim *s) {
     p.map_kind = c.map_kind; p.max_dim = c.max_dim; p.dim = c.dim; p.num_goals = c.num_goals;
     p.num_blocks = c.num_blocks; p.max_steps_factor = c.max_steps_factor; p.task_mode = c.task_mode;
     p.channels = ch; p.n_icons = c.n_icons;
+    p.obs_f32 = f32 ? 1 : 0;
     p.n_tasks = c.n_tasks;
     p.group2d = c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET;
     p.goal_cells = s->d_goal_cells; p.cand2d = s->d_cand2d; p.icon_colored = s->d_icon_colored;
@@ -514,7 +524,8 @@ int xwb_create(const xwb_config *cfg, xwb_sim **out) {
             break;
         case XWB_XWORLD2D:
             s->out_h = cfg->max_dim * 12; s->out_w = cfg->max_dim * 12; s->out_c = cfg->color ? 3 : 1;   // xworld_simulator.cpp:53-61,106-112
-            s->obs_bytes_per_env = (size_t)cfg->context * s->out_c * s->out_h * s->out_w;
+            if (cfg->obs_format != XWB_OBS_U8 && cfg->obs_format != XWB_OBS_F32) return bail(fail(XWB_ERR_ARG, "xworld: unknown obs_format"));
+            s->obs_bytes_per_env = (size_t)cfg->context * s->out_c * s->out_h * s->out_w * (cfg->obs_format == XWB_OBS_F32 ? 4 : 1);
             s->num_actions = 4;                                           // xitem.cpp:82-83
             break;
         default:
@@ -877,7 +888,8 @@ int xwb_get_state_packet(xwb_sim *s, int32_t env, float reward, void *stream, ui
     if (!s || !need) return fail(XWB_ERR_ARG, "NULL argument");
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
     const bool xw = s->cfg.game == XWB_XWORLD2D;
-    const bool is_float = s->cfg.game == XWB_SIMPLE_RACE;
+    // float32 frames (SimpleRace; XWorld2D with XWB_OBS_F32) travel as a reals buffer, uint8 frames as pixels
+    const bool is_float = s->cfg.game == XWB_SIMPLE_RACE || (xw && s->cfg.obs_format == XWB_OBS_F32);
     const size_t n_screen = is_float ? s->obs_bytes_per_env / 4 : s->obs_bytes_per_env;
     // sizes first
     size_t total = 8;

@@ -128,6 +128,7 @@ constexpr int XW_TILE_DW = 3;         // dwords per tile row (12 bytes)
 struct XwParams {
     int n, context, max_steps, act_rep, auto_reset;
     int map_kind, max_dim, dim, num_goals, num_blocks, max_steps_factor, task_mode, channels;
+    int obs_f32;                 // frames are float32 (pixel * 1/255), the tile table too
     int n_icons;
     int n_tasks, tasks[8];       // tasks of the teacher's group, sampled uniformly whenever the group is idle
     int group2d;                 // the group holds the 2-D-native tasks (rule D14b): idle stages also run at step time
@@ -140,7 +141,8 @@ struct XwParams {
     int n_names[3];
     int name_first_off[3];       // start of each type's offset table inside name_first
     int name_first_len, name_variants_len;
-    const uint32_t *atlas;       // [n_icons][channels][12][3] dwords (tile table)
+    const uint32_t *atlas;       // [n_icons + 1][channels][12][3] dwords (tile table; entry 0 = empty cell), or
+                                 // [n_icons + 1][channels][12][12] floats when obs_f32
     const int32_t *actions;
     const uint8_t *mask;
     int32_t *actions_out;

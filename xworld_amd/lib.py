@@ -30,7 +30,7 @@ class XwbConfig(C.Structure):
         ("map_kind", C.c_int32), ("max_dim", C.c_int32), ("dim", C.c_int32), ("num_goals", C.c_int32),
         ("num_blocks", C.c_int32), ("max_steps_factor", C.c_int32), ("task_mode", C.c_int32),
         ("n_tasks", C.c_int32), ("tasks", C.c_int32 * 8),
-        ("color", C.c_int32), ("n_icons", C.c_int32),
+        ("color", C.c_int32), ("obs_format", C.c_int32), ("n_icons", C.c_int32),
         ("icons64", C.c_void_p), ("icon_type", C.c_void_p), ("icon_name", C.c_void_p), ("icon_colored", C.c_void_p),
     ]
 

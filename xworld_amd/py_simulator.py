@@ -13,6 +13,8 @@ import os
 
 import numpy as np
 
+from . import assets
+
 from . import lib
 from .batched import BatchedSimulator
 
@@ -88,7 +90,7 @@ class Simulator:
             st = self.batch.env_state(self._env)
             d["sentence"] = "-"                                       # teacher language is out of scope
             events = {0: "", 1: "correct_goal", 2: "wrong_goal", 3: "time_up"}
-            d["task"] = "XWorld3DNavTarget"
+            d["task"] = assets.TASK_NAMES[st.xw_task]
             d["event"] = events[st.xw_event]
             d["height"] = str(self.batch.cfg.dim)                     # get_extra_info, xworld_simulator.cpp:495-504
             d["width"] = str(self.batch.cfg.dim)
