@@ -136,6 +136,7 @@ typedef struct {
     int color;               /* FLAGS_color */
     int context;
     uint32_t seed;           /* xwb-rng-v1 seed */
+    int visible_radius;      /* FLAGS_visible_radius: 0 = full observation; odd r > 0 = egocentric r x r view, 6 actions */
     int n_tasks;             /* tasks of the group, sampled uniformly per episode (teaching_task.cpp:204-213); 0 = {TARGET} */
     int tasks[8];            /* ORC_TASK_* in conf order */
 } orc_xw_cfg;
@@ -169,6 +170,16 @@ void    orc_xw_load_map_forced(orc_xworld *w, int n_entities, const orc_entity *
 int     orc_xw_forced_left(const orc_xworld *w);
 /* 2-D-native tasks: the recorded target cell (C++ coordinates), (-1,-1) when none */
 void    orc_xw_target2d(const orc_xworld *w, int *x, int *y);
+/* egocentric mode: per-entity pose (xworld_env.py:207-223): yaw, scale, offset; entity index = order of orc_xw_get_entities */
+void    orc_xw_set_pose(orc_xworld *w, int ent, double yaw, double scale, double offset);
+void    orc_xw_get_pose(const orc_xworld *w, int ent, double *yaw, double *scale, double *offset);
+double  orc_xw_agent_yaw(const orc_xworld *w);
+/* poses (yaw, scale, offset per entity, in entity order) the NEXT orc_xw_load_map* applies before the teacher's idle stage */
+void    orc_xw_stage_poses(orc_xworld *w, const double *poses, int n_entities);
+/* XMap::image_masking for the agent: ROI origin (padded coordinates) and the r*r shadow flags */
+void    orc_xw_agent_masking(const orc_xworld *w, int *x_st, int *y_st, uint8_t *shadow);
+/* re-render after poses were set by hand (load_map draws no poses): init_screen */
+void    orc_xw_refresh_screen(orc_xworld *w);
 float   orc_xw_take_actions(orc_xworld *w, int action, int act_rep);
 int     orc_xw_game_over(const orc_xworld *w);
 int     orc_xw_get_lives(const orc_xworld *w);
@@ -200,6 +211,9 @@ void    orc_maze_generate(orc_stream *s, int X, char *maze);
 int     orc_bfs_reachable(int sx, int sy, int ex, int ey, int X, int Y, const uint8_t *obstacle);
 
 /* OpenCV 3.2 restatements (third-party, version pinned by cmake/opencv.cmake:5-6) */
+void    orc_cv_get_rotation_matrix_2d(double cx, double cy, double angle_deg, double scale, double M[6]);
+void    orc_cv_warp_affine_8uc3(const uint8_t *src, int sh, int sw, uint8_t *dst, int dh, int dw, const double M[6],
+                                const uint8_t border[3]);
 void    orc_cv_resize_linear_8u(const uint8_t *src, int sh, int sw, int cn, uint8_t *dst, int dh, int dw);
 void    orc_cv_bgr2gray_8u(const uint8_t *src, int n_pixels, uint8_t *dst);
 

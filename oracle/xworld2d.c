@@ -77,15 +77,41 @@ static int map_move_item(orc_xworld *w, int item, int tx, int ty, int *contact, 
     return 0;
 }
 
-/* XAgent::act, xitem.cpp:89-101 (FLAGS_visible_radius == 0: MOVE_UP/DOWN/LEFT/RIGHT) */
-static void agent_act(const orc_xworld *w, int action_id, int *tx, int *ty) {
+/* XAgent::act, xitem.cpp:89-155.  FLAGS_visible_radius == 0: MOVE_UP / DOWN / LEFT / RIGHT; otherwise
+ * MOVE_FORWARD, MOVE_BACKWARD, MOVE_LEFT_FPV, MOVE_RIGHT_FPV, TURN_LEFT, TURN_RIGHT relative to the facing direction;
+ * a turn changes e_.yaw and returns the current cell (which XMap::move_item then refuses: the action "fails"). */
+static void agent_act(orc_xworld *w, int action_id, int *tx, int *ty) {
     int cx = w->ents[w->agent_idx].x, cy = w->ents[w->agent_idx].y;
-    if (action_id < 0 || action_id >= 4) abort();
+    if (w->cfg.visible_radius == 0) {
+        if (action_id < 0 || action_id >= 4) abort();
+        switch (action_id) {
+            case 0: *tx = cx;     *ty = cy - 1; break;   /* MOVE_UP    */
+            case 1: *tx = cx;     *ty = cy + 1; break;   /* MOVE_DOWN  */
+            case 2: *tx = cx - 1; *ty = cy;     break;   /* MOVE_LEFT  */
+            default:*tx = cx + 1; *ty = cy;     break;   /* MOVE_RIGHT */
+        }
+        return;
+    }
+    if (action_id < 0 || action_id >= 6) abort();
+    const double PI = 3.14159265358979323846;                       /* M_PI */
+    double *yaw = &w->e_yaw[w->agent_idx];
+    int dir = orc_facing_dir(*yaw);                                 /* 0 right, 1 down, 2 left, 3 up */
+    static const int fwd[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};
+    static const int left[4][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}};    /* MOVE_LEFT_FPV per facing dir */
+    *tx = cx; *ty = cy;
     switch (action_id) {
-        case 0: *tx = cx;     *ty = cy - 1; break;   /* MOVE_UP    */
-        case 1: *tx = cx;     *ty = cy + 1; break;   /* MOVE_DOWN  */
-        case 2: *tx = cx - 1; *ty = cy;     break;   /* MOVE_LEFT  */
-        default:*tx = cx + 1; *ty = cy;     break;   /* MOVE_RIGHT */
+        case 0: *tx = cx + fwd[dir][0];  *ty = cy + fwd[dir][1];  break;   /* MOVE_FORWARD   */
+        case 1: *tx = cx - fwd[dir][0];  *ty = cy - fwd[dir][1];  break;   /* MOVE_BACKWARD  */
+        case 2: *tx = cx + left[dir][0]; *ty = cy + left[dir][1]; break;   /* MOVE_LEFT_FPV  */
+        case 3: *tx = cx - left[dir][0]; *ty = cy - left[dir][1]; break;   /* MOVE_RIGHT_FPV */
+        case 4:                                                             /* TURN_LEFT      */
+            *yaw -= PI / 2;
+            if (*yaw < -PI / 2 - 1e-4) *yaw += 2 * PI;
+            break;
+        default:                                                            /* TURN_RIGHT     */
+            *yaw += PI / 2;
+            if (*yaw > PI + 1e-4) *yaw -= 2 * PI;
+            break;
     }
 }
 
@@ -200,6 +226,8 @@ static int cell_list_find(const cell *list, int n, int x, int y) {
 static void add_entity(orc_xworld *w, int type, int x, int y, int name, int icon, int serial) {
     orc_entity *e = &w->ents[w->n_ents++];
     e->type = type; e->x = x; e->y = y; e->name_id = name; e->icon = icon; e->serial = serial;
+    int k = w->n_ents - 1;
+    w->e_yaw[k] = 1.5707963; w->e_scale[k] = 1.0; w->e_offset[k] = 0.0;      /* Entity.__init__ defaults */
 }
 
 /* xworld_env.py:464-493 __padding_walls + :376-384 cpp_get_entities (offset shift) */
@@ -276,6 +304,15 @@ static void gen_map_nav(orc_xworld *w) {
         cell c = avail[k]; na = cell_list_remove_at(avail, na, k);
         int v = (int)orc_stream_below(&w->rs, (uint32_t)n_variants(w, 0, goal_name[i]));
         add_entity(w, 0, c.x, c.y, goal_name[i], variant_icon(w, 0, goal_name[i], v), w->running_id++);
+        if (w->cfg.visible_radius) {
+            /* xworld_env.py:211-223: yaw ~ U[0, 4*PI_2), scale ~ U[0.5, 1], offset ~ U[0, 1 - scale]; random.uniform(a, b)
+             * = a + (b - a) * random(); here random() = the stream's unit() ("xwb-mapgen-v1", egocentric extension) */
+            int k = w->n_ents - 1;
+            double u0 = (double)orc_stream_unit(&w->rs), u1 = (double)orc_stream_unit(&w->rs), u2 = (double)orc_stream_unit(&w->rs);
+            w->e_yaw[k] = 0 + (1.5707963 * 4 - 0) * u0;
+            w->e_scale[k] = 0.5 + (1 - 0.5) * u1;
+            w->e_offset[k] = 0 + ((1 - w->e_scale[k]) - 0) * u2;
+        }
     }
     for (int i = 0; i < w->cfg.num_blocks; ++i) {
         cell c = blocks[--nb];
@@ -289,6 +326,8 @@ static void gen_map_nav(orc_xworld *w) {
         int nm = (int)orc_stream_below(&w->rs, (uint32_t)w->n_names[2]);
         int v = (int)orc_stream_below(&w->rs, (uint32_t)n_variants(w, 2, nm));
         add_entity(w, 2, c.x, c.y, nm, variant_icon(w, 2, nm, v), w->running_id++);
+        if (w->cfg.visible_radius)                      /* xworld_env.py:208-210: random.choice(range(-1, 3)) * PI_2 */
+            w->e_yaw[w->n_ents - 1] = (double)(-1 + (int)orc_stream_below(&w->rs, 4)) * 1.5707963;
     }
     finish_map(w);
 }
@@ -298,6 +337,9 @@ static void gen_map_nav(orc_xworld *w) {
  * order agent, goals, blocks: loc (if unset) = avail[below(n_avail)], name below(#names of type),
  * variant below(nv).  avail is the row-major cell list minus the wall cells.          */
 static void gen_map_walls(orc_xworld *w) {
+    /* without maze generation set_property() keeps the Entity default yaw 1.5707963, which check_or_get_value
+     * rejects for the agent when visible_radius > 0 (xworld_env.py:210, py_util.py:27-29): the reference asserts */
+    if (w->cfg.visible_radius) abort();
     int D = w->cfg.dim;
     set_dims(w, D, D);
     w->n_ents = 0;
@@ -374,7 +416,7 @@ static int task_reach_object(const orc_xworld *w, int goal_ent) {
     for (int i = 0; i < w->n_hits; ++i) if (w->hits[i] == goal_ent) in_hits = 1;
     const orc_entity *a = &w->ents[w->agent_idx];
     const orc_entity *g = &w->ents[goal_ent];
-    double yaw = 1.5707963;                       /* xworld_env.py:42 Entity default; full observation */
+    double yaw = w->e_yaw[w->agent_idx];          /* xworld_env.py:42 Entity default 1.5707963 under full observation */
     double dx = g->x - a->x, dy = g->y - a->y;
     double dist = sqrt(dx * dx + dy * dy);
     double theta;
@@ -538,6 +580,14 @@ void orc_xw_get_screen(const orc_xworld *w, uint8_t *out) {
     int ih = H * ITEM_SIZE, iw = W * ITEM_SIZE;
     /* XMap::to_image, xmap.cpp:125-146: canvas filled with 255, items copied in stack order */
     uint8_t *world = (uint8_t *)malloc((size_t)ih * iw * 3);
+    if (w->cfg.visible_radius > 0) {
+        /* egocentric: the r*64-pixel view (xworld_ego.c), then get_screen_rgb's resize to img_height_ x img_width_ */
+        int r = w->cfg.visible_radius, S = r * ITEM_SIZE;
+        uint8_t *view = (uint8_t *)malloc((size_t)S * S * 3);
+        orc_xw_ego_view(w, r, view);
+        orc_cv_resize_linear_8u(view, S, S, 3, world, ih, iw);
+        free(view);
+    } else {
     memset(world, 255, (size_t)ih * iw * 3);
     for (int i = 0; i < H; ++i)
         for (int j = 0; j < W; ++j)
@@ -547,6 +597,7 @@ void orc_xw_get_screen(const orc_xworld *w, uint8_t *out) {
                     memcpy(world + ((size_t)(i * ITEM_SIZE + r) * iw + (size_t)j * ITEM_SIZE) * 3,
                            icon + (size_t)r * ITEM_SIZE * 3, ITEM_SIZE * 3);
             }
+    }
     /* get_screen_rgb (:287-307): same-size resize, then interleaved BGR -> planar */
     uint8_t *rgbs = (uint8_t *)malloc((size_t)ih * iw * 3);
     for (int i = 0; i < ih; ++i)
@@ -609,6 +660,11 @@ orc_xworld *orc_xw_create(const orc_xw_cfg *cfg, int n_icons, const orc_icon_inf
     w->height = w->width = w->cfg.max_dim;
     w->img_h_out = w->height * 12;
     w->img_w_out = w->width * 12;
+    if (w->cfg.visible_radius > 0) {                                /* :62-68 */
+        if (w->cfg.visible_radius > w->cfg.max_dim) w->cfg.visible_radius = w->cfg.max_dim;
+        int block_size = 84 / w->cfg.visible_radius;
+        w->img_h_out = w->img_w_out = w->cfg.visible_radius * block_size;
+    }
     w->channels = w->cfg.color ? 3 : 1;
     w->screens = (uint8_t *)calloc(screen_size(w) * (size_t)w->cfg.context, 1);
     w->last_action_success = 1;       /* GameSimulator ctor default, simulator.cpp:33-34 */
@@ -677,6 +733,21 @@ void orc_xw_load_map_forced(orc_xworld *w, int n_entities, const orc_entity *ent
     orc_xw_load_map(w, n_entities, ents, dim, -1, env_gid, episode);
 }
 
+void orc_xw_set_pose(orc_xworld *w, int ent, double yaw, double scale, double offset) {
+    if (ent < 0 || ent >= w->n_ents) abort();
+    w->e_yaw[ent] = yaw; w->e_scale[ent] = scale; w->e_offset[ent] = offset;
+}
+void orc_xw_get_pose(const orc_xworld *w, int ent, double *yaw, double *scale, double *offset) {
+    *yaw = w->e_yaw[ent]; *scale = w->e_scale[ent]; *offset = w->e_offset[ent];
+}
+double orc_xw_agent_yaw(const orc_xworld *w) { return w->e_yaw[w->agent_idx]; }
+void orc_xw_agent_masking(const orc_xworld *w, int *x_st, int *y_st, uint8_t *shadow) {
+    const orc_entity *a = &w->ents[w->agent_idx];
+    orc_xw_image_masking(w, a->x, a->y, w->e_yaw[w->agent_idx], w->cfg.visible_radius, x_st, y_st, shadow);
+}
+void orc_xw_refresh_screen(orc_xworld *w) { init_screen(w); }
+void orc_xw_stage_poses(orc_xworld *w, const double *poses, int n_entities) { w->staged_poses = poses; w->n_staged_poses = n_entities; }
+
 int orc_xw_forced_left(const orc_xworld *w) { return w->forced ? w->n_forced - w->forced_at : 0; }
 void orc_xw_target2d(const orc_xworld *w, int *x, int *y) { *x = w->target2d_x; *y = w->target2d_y; }
 
@@ -696,6 +767,13 @@ void orc_xw_load_map(orc_xworld *w, int n_entities, const orc_entity *ents, int 
     w->n_ents = 0;
     for (int i = 0; i < n_entities; ++i)
         add_entity(w, ents[i].type, ents[i].x, ents[i].y, ents[i].name_id, ents[i].icon, ents[i].serial);
+    if (w->staged_poses) {
+        if (w->n_staged_poses != n_entities) abort();
+        for (int i = 0; i < n_entities; ++i) {
+            w->e_yaw[i] = w->staged_poses[3 * i]; w->e_scale[i] = w->staged_poses[3 * i + 1]; w->e_offset[i] = w->staged_poses[3 * i + 2];
+        }
+        w->staged_poses = NULL;
+    }
     finish_map(w);
     after_map(w, target_pick);
 }
@@ -736,7 +814,7 @@ int orc_xw_game_over(const orc_xworld *w) {
 }
 
 int orc_xw_get_lives(const orc_xworld *w) { return orc_xw_game_over(w) ? 0 : 1; }   /* :506 */
-int orc_xw_num_actions(const orc_xworld *w) { (void)w; return 4; }
+int orc_xw_num_actions(const orc_xworld *w) { return w->cfg.visible_radius ? 6 : 4; }   /* xitem.cpp:80-87 */
 int64_t orc_xw_num_steps(const orc_xworld *w) { return w->num_steps; }
 int orc_xw_last_action_success(const orc_xworld *w) { return w->last_action_success; }
 int orc_xw_event(const orc_xworld *w) { return w->event; }

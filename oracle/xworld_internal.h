@@ -20,6 +20,7 @@ struct orc_xworld {
     int *name_first[3];              /* offsets, n_names+1 */
     /* XWorld (xworld.h): item list, map */
     orc_entity ents[MAXENT];
+    double e_yaw[MAXENT], e_scale[MAXENT], e_offset[MAXENT];   /* Entity.yaw / scale / offset (xworld_env.py:42) */
     int n_ents;
     int agent_idx;
     int height, width;               /* max dims: what C++ sees (get_max_dims) */
@@ -40,9 +41,11 @@ struct orc_xworld {
     int task_kind;                   /* ORC_TASK_* of the busy task */
     uint8_t target_ent[MAXENT];      /* self.target: entity is a target goal */
     int between_x, between_y;        /* NavTargetBetween: the middle cell (C++ coordinates) */
+    int dir_ref_ent, dir_word;       /* NavTargetDirection: self.target = (referent, direction) */
     int target2d_x, target2d_y;      /* 2-D-native tasks: XWorldTask.target (C++ coordinates), -1 = none */
     uint32_t env_gid, episode;       /* of the running episode: step-time idle stages draw from stream 2 */
     int forced_sticky;
+    const double *staged_poses; int n_staged_poses;
     const int *forced; int n_forced, forced_at;   /* golden replay: decisions instead of stream draws */
     /* GameSimulator */
     int64_t num_steps;
@@ -53,6 +56,10 @@ struct orc_xworld {
 
 
 /* xworld2d.c */
+/* xworld_ego.c */
+int  orc_facing_dir(double yaw);                        /* XItem::get_item_facing_dir: 0 right 1 down 2 left 3 up */
+void orc_xw_image_masking(const orc_xworld *w, int ax, int ay, double yaw, int r, int *x_st, int *y_st, uint8_t *shadow);
+void orc_xw_ego_view(const orc_xworld *w, int r, uint8_t *view);
 void orc_xw_rebuild_map(orc_xworld *w);                 /* XWorld::reset(false): rebuild the cube from the entity list */
 int  orc_xw_draw_below(orc_xworld *w, int n);           /* next decision: forced (golden replay) or stream draw */
 /* xworld_tasks.c */

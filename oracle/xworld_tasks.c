@@ -186,15 +186,30 @@ static int triple_direction(pcell target, pcell referent, double view_yaw) {
     return 0;
 }
 
-int orc_task_is_target(const orc_xworld *w, int ent) { return w->target_ent[ent]; }
+/* t in self.target.  NavTargetDirection evaluates (direction(g, referent, agent.yaw), near) when g is reached
+ * (XWorld3DNavTargetDirection.py:74-89): with the egocentric agent the yaw -- and so the answer -- changes over time */
+int orc_task_is_target(const orc_xworld *w, int ent) {
+    if (w->task_kind == ORC_TASK_DIRECTION && w->dir_word != 0 && w->dir_ref_ent >= 0 && w->ents[ent].type == 0) {
+        pcell gl = {w->ents[ent].x, w->ents[ent].y}, rl = {w->ents[w->dir_ref_ent].x, w->ents[w->dir_ref_ent].y};
+        double ddx = gl.x - rl.x, ddy = gl.y - rl.y;
+        int near = sqrt(ddx * ddx + ddy * ddy) < 1.0 + 1e-3;
+        return near && triple_direction(gl, rl, w->e_yaw[w->agent_idx]) == w->dir_word;
+    }
+    return w->target_ent[ent];
+}
 
 /* env.entities order after delete_entity(x) ... set_entity_inst(x): x moves to the end of the list */
 static void move_to_end(orc_xworld *w, int *tracked, int n_tracked, int e) {
     orc_entity tmp = w->ents[e];
     uint8_t flag = w->target_ent[e];
-    for (int i = e; i + 1 < w->n_ents; ++i) { w->ents[i] = w->ents[i + 1]; w->target_ent[i] = w->target_ent[i + 1]; }
+    double pose[3] = {w->e_yaw[e], w->e_scale[e], w->e_offset[e]};
+    for (int i = e; i + 1 < w->n_ents; ++i) {
+        w->ents[i] = w->ents[i + 1]; w->target_ent[i] = w->target_ent[i + 1];
+        w->e_yaw[i] = w->e_yaw[i + 1]; w->e_scale[i] = w->e_scale[i + 1]; w->e_offset[i] = w->e_offset[i + 1];
+    }
     w->ents[w->n_ents - 1] = tmp;
     w->target_ent[w->n_ents - 1] = flag;
+    w->e_yaw[w->n_ents - 1] = pose[0]; w->e_scale[w->n_ents - 1] = pose[1]; w->e_offset[w->n_ents - 1] = pose[2];
     for (int k = 0; k < n_tracked; ++k) {
         if (tracked[k] == e) tracked[k] = w->n_ents - 1;
         else if (tracked[k] > e) tracked[k] -= 1;
@@ -276,7 +291,7 @@ static void idle_rearranging(orc_xworld *w, penv *p, int kind) {
                 pcell gl = {px(p, g), py_(p, g)};
                 double ddx = gl.x - rl.x, ddy = gl.y - rl.y;
                 int near = sqrt(ddx * ddx + ddy * ddy) < 1.0 + 1e-3;
-                if (near && direction != 0 && triple_direction(gl, rl, 1.5707963) == direction) w->target_ent[g] = 1;
+                if (near && direction != 0 && triple_direction(gl, rl, w->e_yaw[agent]) == direction) w->target_ent[g] = 1;
             }
         }
         /* env.entities: g1, g2, agent were deleted and re-added -> they move to the end, in that order */
@@ -284,6 +299,7 @@ static void idle_rearranging(orc_xworld *w, penv *p, int kind) {
         move_to_end(w, tr, 3, tr[0]);
         move_to_end(w, tr, 3, tr[1]);
         move_to_end(w, tr, 3, tr[2]);
+        if (kind == ORC_TASK_DIRECTION) { w->dir_ref_ent = referent == g1 ? tr[0] : tr[1]; w->dir_word = direction; }
         orc_xw_rebuild_map(w);                                           /* env_changed -> XWorld::reset(false) */
         return;
     }
@@ -352,6 +368,7 @@ void orc_task_idle(orc_xworld *w) {
     memset(w->target_ent, 0, sizeof w->target_ent);
     w->between_x = w->between_y = -1;
     w->target_name = -1;
+    w->dir_ref_ent = -1; w->dir_word = 0;
     /* TaskGroup::run_stage: idx = get_rand_ind(task_list_.size()) */
     int n_tasks = w->cfg.n_tasks > 0 ? w->cfg.n_tasks : 1;
     int t = orc_xw_draw_below(w, n_tasks);

@@ -42,7 +42,7 @@ class XwCfg(C.Structure):
     _fields_ = [("map_kind", C.c_int), ("max_dim", C.c_int), ("dim", C.c_int), ("num_goals", C.c_int),
                 ("num_blocks", C.c_int), ("max_steps", C.c_int), ("max_steps_factor", C.c_int),
                 ("task_mode", C.c_int), ("color", C.c_int), ("context", C.c_int), ("seed", C.c_uint32),
-                ("n_tasks", C.c_int), ("tasks", C.c_int * 8)]
+                ("visible_radius", C.c_int), ("n_tasks", C.c_int), ("tasks", C.c_int * 8)]
 
 
 class Entity(C.Structure):
@@ -136,6 +136,15 @@ def lib():
     sig("orc_xw_load_map_ex", None, vp, C.c_int, C.POINTER(Entity), C.c_int, i32p, C.c_int, C.c_uint32, C.c_uint32)
     sig("orc_xw_task_kind", C.c_int, vp)
     sig("orc_xw_between_cell", None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
+    sig("orc_xw_set_pose", None, vp, C.c_int, C.c_double, C.c_double, C.c_double)
+    sig("orc_xw_get_pose", None, vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+    sig("orc_xw_agent_yaw", C.c_double, vp)
+    sig("orc_xw_num_actions", C.c_int, vp)
+    sig("orc_xw_stage_poses", None, vp, C.POINTER(C.c_double), C.c_int)
+    sig("orc_xw_agent_masking", None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), u8p)
+    sig("orc_xw_refresh_screen", None, vp)
+    sig("orc_cv_get_rotation_matrix_2d", None, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double))
+    sig("orc_cv_warp_affine_8uc3", None, u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int, C.POINTER(C.c_double), u8p)
     sig("orc_xw_load_map_forced", None, vp, C.c_int, C.POINTER(Entity), C.c_int, i32p, C.c_int, C.c_uint32, C.c_uint32)
     sig("orc_xw_forced_left", C.c_int, vp)
     sig("orc_xw_target2d", None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
@@ -326,7 +335,7 @@ TASK_ID = {"XWorld3DNavTarget": 0, "XWorld3DNavTargetNear": 1, "XWorld3DNavTarge
 
 def xw_cfg(**kw):
     c = XwCfg(map_kind=0, max_dim=8, dim=8, num_goals=4, num_blocks=16, max_steps=0,
-              max_steps_factor=10, task_mode=0, color=0, context=1, seed=0xC0FFEE)
+              max_steps_factor=10, task_mode=0, color=0, context=1, seed=0xC0FFEE, visible_radius=0)
     tasks = kw.pop("tasks", None)
     for k, v in kw.items():
         setattr(c, k, v)
@@ -386,6 +395,35 @@ class XWorld:
         x, y = C.c_int(), C.c_int()
         self.L.orc_xw_target2d(self.h, C.byref(x), C.byref(y))
         return x.value, y.value
+
+    def set_pose(self, ent, yaw, scale=1.0, offset=0.0):
+        self.L.orc_xw_set_pose(self.h, int(ent), float(yaw), float(scale), float(offset))
+
+    def get_pose(self, ent):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self.L.orc_xw_get_pose(self.h, int(ent), C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def stage_poses(self, poses):
+        """[[yaw, scale, offset], ...] in entity order, applied by the next load_map* before the idle stage."""
+        self._poses = np.ascontiguousarray(poses, np.float64)
+        self.L.orc_xw_stage_poses(self.h, self._poses.ctypes.data_as(C.POINTER(C.c_double)), len(self._poses))
+
+    def num_actions(self):
+        return self.L.orc_xw_num_actions(self.h)
+
+    def agent_yaw(self):
+        return self.L.orc_xw_agent_yaw(self.h)
+
+    def agent_masking(self):
+        r = self.cfg.visible_radius
+        x, y = C.c_int(), C.c_int()
+        sh = np.zeros(r * r, np.uint8)
+        self.L.orc_xw_agent_masking(self.h, C.byref(x), C.byref(y), ptr(sh, u8p))
+        return x.value, y.value, sh.reshape(r, r)
+
+    def refresh_screen(self):
+        self.L.orc_xw_refresh_screen(self.h)
 
     def task_kind(self):
         return self.L.orc_xw_task_kind(self.h)

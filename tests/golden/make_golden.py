@@ -34,6 +34,8 @@ Fixtures written:
   maps_walls.json  same for XWorldWalls
   teacher.json   XWorld3DNavTarget idle/navigation_reward run over random action strings on those maps:
                  per step action, reward, event, stage, agent cell, action success
+  tasks_ego.json the five tasks with FLAGS_visible_radius = 3: entity poses (yaw, scale, offset) as the reference's
+                 map generator drew them, six first-person actions, the agent's yaw after every step
   tasks2d.json   the 2-D-native group of confs/walls.json (XWorldNavTarget / Near / ColorTarget / Between, rule D14b)
                  as a one-task group, both task modes, every teach() call of a 70-step episode
   tasks.json     all five tasks of the XWorld3DNav group (Target, Near, Between, Direction, Avoid): the idle stage
@@ -42,6 +44,7 @@ Fixtures written:
 """
 import ctypes as C
 import json
+import math
 import os
 import random
 import sys
@@ -327,8 +330,66 @@ class DecisionRandom(object):
         return seq[self.below(len(seq))]
 
 
-def gen_tasks(pal, n_maps, seed0, steps):
+class EgoHarness(Harness):
+    """Harness for FLAGS_visible_radius > 0: XAgent::act with the six first-person actions (xitem.cpp:103-155)
+    and XMap::move_item, for which a turn is a failed move onto the agent's own cell (xmap.cpp:76-101)."""
+
+    @staticmethod
+    def facing(yaw):                                   # XItem::get_item_facing_dir, xitem.cpp:65-78
+        eps = 1e-4
+        if abs(yaw) < eps:
+            return 0                                   # right
+        if abs(yaw - math.pi / 2) < eps:
+            return 1                                   # down
+        if abs(yaw - math.pi) < eps:
+            return 2                                   # left
+        return 3                                       # up
+
+    def act(self, a):
+        x, y = self.agent["loc"][0], self.agent["loc"][1]
+        d = self.facing(self.agent["yaw"])
+        fwd = [(1, 0), (0, 1), (-1, 0), (0, -1)][d]
+        left = [(0, -1), (1, 0), (0, 1), (-1, 0)][d]
+        tx, ty = x, y
+        if a == 0:
+            tx, ty = x + fwd[0], y + fwd[1]
+        elif a == 1:
+            tx, ty = x - fwd[0], y - fwd[1]
+        elif a == 2:
+            tx, ty = x + left[0], y + left[1]
+        elif a == 3:
+            tx, ty = x - left[0], y - left[1]
+        elif a == 4:
+            self.agent["yaw"] -= math.pi / 2
+            if self.agent["yaw"] < -math.pi / 2 - 1e-4:
+                self.agent["yaw"] += 2 * math.pi
+        else:
+            self.agent["yaw"] += math.pi / 2
+            if self.agent["yaw"] > math.pi + 1e-4:
+                self.agent["yaw"] -= 2 * math.pi
+        contact = []
+        ok = False
+        if 0 <= tx < self.W and 0 <= ty < self.H:
+            items = self.cell(tx, ty)
+            contact = [i["id"] for i in items if i["id"] != self.agent["id"]]
+            ok = len(items) == 0
+        if ok:
+            self.agent["loc"] = (tx, ty, 0)
+        if contact:
+            self.game_events += "collision:" + "|".join(contact) + "\n"
+        self.success = ok
+
+
+def gen_tasks(pal, n_maps, seed0, steps, ego=0):
     import importlib
+    FLAGS["visible_radius"] = ego
+    try:
+        return _gen_tasks(pal, n_maps, seed0, steps, ego, importlib)
+    finally:
+        FLAGS["visible_radius"] = 0
+
+
+def _gen_tasks(pal, n_maps, seed0, steps, ego, importlib):
     names = ["XWorld3DNavTarget", "XWorld3DNavTargetNear", "XWorld3DNavTargetBetween",
              "XWorld3DNavTargetDirection", "XWorld3DNavTargetAvoid"]
     out = {}
@@ -345,7 +406,8 @@ def gen_tasks(pal, n_maps, seed0, steps):
             env.reset()
             env.env_changed()
             before = entity_records(env, pal)
-            h = Harness(env)
+            poses = [[float(e["yaw"]), float(e["scale"]), float(e["offset"])] for e in env.cpp_get_entities()]
+            h = EgoHarness(env) if ego else Harness(env)
             task = cls(env)
             task.reset()
             fake = DecisionRandom(seed0 * 7 + k)
@@ -373,6 +435,8 @@ def gen_tasks(pal, n_maps, seed0, steps):
             goals = env.get_goals()
             rec = {"py_seed": seed0 + k, "dim": env.get_dims()[0], "max_dim": env.get_max_dims()[0],
                    "entities_before": before, "entities_after": after, "decisions": list(fake.log)}
+            if ego:
+                rec["poses"] = poses
             if name == "XWorld3DNavTargetBetween":
                 l1, l2 = task.target
                 rec["between"] = [int((l1[0] + l2[0]) // 2), int((l1[1] + l2[1]) // 2)]
@@ -393,10 +457,11 @@ def gen_tasks(pal, n_maps, seed0, steps):
             stage = "navigation_reward"
             trace, after_end = [], 0
             for t in range(steps):
-                a = rnd.randrange(4)
+                a = rnd.randrange(6 if ego else 4)
                 h.act(a)
                 stage, reward, event = h.py_stage(task, stage)
-                trace.append([a, reward, event, stage, int(h.agent["loc"][0]), int(h.agent["loc"][1]), int(bool(h.success))])
+                trace.append([a, reward, event, stage, int(h.agent["loc"][0]), int(h.agent["loc"][1]), int(bool(h.success))]
+                             + ([float(h.agent["yaw"])] if ego else []))
                 if stage == "terminal":
                     after_end += 1
                     if after_end > 2:
@@ -498,6 +563,7 @@ def main():
         "teacher.json": lambda: {"nav": gen_teacher(XWorldNav, nav_pal, 40, 2000, 700),
                                  "walls": gen_teacher(XWorldWalls, walls_pal, 24, 3000, 500)},
         "tasks.json": lambda: gen_tasks(nav_pal, 24, 9000, 660),
+        "tasks_ego.json": lambda: gen_tasks(nav_pal, 16, 15000, 900, ego=3),
         "tasks2d.json": lambda: gen_tasks2d({"nav": nav_pal, "walls": walls_pal}, 6, 12000, 70),
     }
     only = sys.argv[1:]                      # optional: the fixtures to (re)generate
