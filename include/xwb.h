@@ -103,6 +103,9 @@ typedef struct xwb_config {
                                   * TaskGroup samples one per episode); 0 = { XWB_TASK_TARGET } */
     int32_t  tasks[8];           /* XWB_TASK_* */
     int32_t  color;              /* FLAGS_color: 3-channel planar BGR when set, else 1-channel gray */
+    int32_t  visible_radius;     /* FLAGS_visible_radius: 0 = full observation (4 actions, 12 px per cell); odd r > 0 =
+                                  * egocentric r x r view, 6 first-person actions, frame edge r * (84 / r)
+                                  * (xworld_simulator.cpp:62-68, xitem.cpp:80-87); XWorldNav maps only */
     int32_t  obs_format;         /* XWB_OBS_U8 (the reference's screen bytes) | XWB_OBS_F32: float32 pixel * (1/255.0f),
                                   * the scaling py_simulator.cpp:262-272 applies in get_state(), done on the device */
     int32_t  n_icons;            /* icons this map class can place (its "palette") */
@@ -192,7 +195,9 @@ typedef struct xwb_env_state {
     int32_t  xw_agent_x, xw_agent_y, xw_event, xw_stage, xw_target_name, xw_steps_in_task;
     uint32_t episode;
     int32_t  xw_task;            /* XWB_TASK_* of this episode */
-    int32_t  xw_target;          /* TARGET: goal name id; BETWEEN and the 2-D-native tasks: cell y * max_dim + x; else -1 */
+    int32_t  xw_target;          /* TARGET: goal name id; BETWEEN and the 2-D-native tasks: cell y * max_dim + x;
+                                  * DIRECTION: referent cell | direction word << 8 (1 front 2 behind 3 left 4 right); else -1 */
+    int32_t  xw_agent_dir;       /* egocentric heading: 0 right, 1 down, 2 left, 3 up; 1 under full observation */
 } xwb_env_state;
 int xwb_get_env_state(xwb_sim *sim, int32_t env, void *stream, xwb_env_state *out);
 /* copies env's "screen" (context frames) to host memory; bytes must equal bytes_per_env */
@@ -208,6 +213,12 @@ int xwb_xw_load_map(xwb_sim *sim, int32_t env, const uint16_t *grid_host, int32_
 /* the same for any task: grid codes carry XWB_CELL_TARGET on the target goals; `target` as xw_target above */
 int xwb_xw_load_map_task(xwb_sim *sim, int32_t env, const uint16_t *grid_host, int32_t agent_x, int32_t agent_y,
                          int32_t dim, int32_t task, int32_t target);
+/* egocentric replays: the agent's heading, and the pose (xworld_env.py:207-223: yaw, scale, offset) of the goal at a
+ * cell; the warp matrix is derived on the host exactly as XItem::get_item_image does.  Synchronous; call
+ * xwb_xw_refresh_obs afterwards to re-render the env. */
+int xwb_xw_set_agent_dir(xwb_sim *sim, int32_t env, int32_t dir);
+int xwb_xw_set_goal_pose(xwb_sim *sim, int32_t env, int32_t cell_x, int32_t cell_y, double yaw, double scale, double offset);
+int xwb_xw_refresh_obs(xwb_sim *sim, int32_t env);
 /* simple_race: overwrite the car state of env (test hook).  Synchronous. */
 int xwb_race_set_car(xwb_sim *sim, int32_t env, float x, float y, float angle);
 

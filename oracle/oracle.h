@@ -191,6 +191,8 @@ int     orc_xw_stage(const orc_xworld *w);
 int     orc_xw_target_name(const orc_xworld *w);
 int     orc_xw_task_kind(const orc_xworld *w);
 void    orc_xw_between_cell(const orc_xworld *w, int *x, int *y);
+/* NavTargetDirection: self.target = (referent, direction): the referent's cell and the word (1 front 2 behind 3 left 4 right; 0 none) */
+void    orc_xw_direction_target(const orc_xworld *w, int *x, int *y, int *word);
 void    orc_xw_get_target_cells(const orc_xworld *w, uint8_t *out);
 int     orc_xw_steps_in_task(const orc_xworld *w);
 int     orc_xw_n_entities(const orc_xworld *w);

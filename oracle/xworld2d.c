@@ -748,6 +748,11 @@ void orc_xw_agent_masking(const orc_xworld *w, int *x_st, int *y_st, uint8_t *sh
 void orc_xw_refresh_screen(orc_xworld *w) { init_screen(w); }
 void orc_xw_stage_poses(orc_xworld *w, const double *poses, int n_entities) { w->staged_poses = poses; w->n_staged_poses = n_entities; }
 
+void orc_xw_direction_target(const orc_xworld *w, int *x, int *y, int *word) {
+    *x = *y = -1; *word = 0;
+    if (w->task_kind == ORC_TASK_DIRECTION && w->dir_ref_ent >= 0) { *x = w->ents[w->dir_ref_ent].x; *y = w->ents[w->dir_ref_ent].y; *word = w->dir_word; }
+}
+
 int orc_xw_forced_left(const orc_xworld *w) { return w->forced ? w->n_forced - w->forced_at : 0; }
 void orc_xw_target2d(const orc_xworld *w, int *x, int *y) { *x = w->target2d_x; *y = w->target2d_y; }
 
@@ -871,7 +876,7 @@ uint64_t orc_xw_rollout(int n_envs, const orc_xw_cfg *cfg, int n_icons, const or
                 s.resets++;
             }
             if (render) orc_xw_get_state_screen(w, obs);
-            int a = orc_policy_action(policy_seed, env_gid0 + (uint32_t)e, (uint32_t)t, 4);
+            int a = orc_policy_action(policy_seed, env_gid0 + (uint32_t)e, (uint32_t)t, orc_xw_num_actions(w));
             float r = orc_xw_take_actions(w, a, 1);
             int code = orc_xw_game_over(w);
             s.reward_sum += r;

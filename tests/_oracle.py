@@ -139,6 +139,7 @@ def lib():
     sig("orc_xw_set_pose", None, vp, C.c_int, C.c_double, C.c_double, C.c_double)
     sig("orc_xw_get_pose", None, vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
     sig("orc_xw_agent_yaw", C.c_double, vp)
+    sig("orc_xw_direction_target", None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
     sig("orc_xw_num_actions", C.c_int, vp)
     sig("orc_xw_stage_poses", None, vp, C.POINTER(C.c_double), C.c_int)
     sig("orc_xw_agent_masking", None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), u8p)
@@ -411,6 +412,11 @@ class XWorld:
 
     def num_actions(self):
         return self.L.orc_xw_num_actions(self.h)
+
+    def direction_target(self):
+        x, y, wd = C.c_int(), C.c_int(), C.c_int()
+        self.L.orc_xw_direction_target(self.h, C.byref(x), C.byref(y), C.byref(wd))
+        return x.value, y.value, wd.value
 
     def agent_yaw(self):
         return self.L.orc_xw_agent_yaw(self.h)

@@ -1,0 +1,185 @@
+"""GPU parity for the egocentric mode (visible_radius > 0): six first-person actions, headings, the teacher's rule
+along the heading, and the egocentric frames (shadow casting, goal warps, view rotation, the two resizes) -- through
+the C ABI against the CPU oracle and the reference's own task traces (tests/golden/tasks_ego.json)."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_xworld import MAPS, _torch
+from test_oracle_ego import ego_runs
+from test_oracle_tasks import EVENTS, KINDS, STAGES
+
+pytestmark = pytest.mark.gpu
+
+CONF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xworld_amd", "confs")
+FACING = {0: 0.0, 1: np.pi / 2, 2: np.pi, 3: -np.pi / 2}
+
+
+def _facing(yaw):
+    eps = 1e-4
+    return 0 if abs(yaw) < eps else (1 if abs(yaw - np.pi / 2) < eps else (2 if abs(yaw - np.pi) < eps else 3))
+
+
+def _make(oracle, key, n, r, tasks=KINDS, seed=0xC0FFEE, policy_seed=0x5EED, gid0=0, **opts):
+    from xworld_amd.batched import BatchedSimulator
+    conf, popts, ocfg = MAPS[key]
+    o = {"xwd_conf_path": conf, "task_mode": "lang_acquisition", "tasks": list(tasks), "visible_radius": r}
+    o.update(popts)
+    o.update(opts)
+    sim = BatchedSimulator("xworld", o, num_envs=n, seed=seed, policy_seed=policy_seed, env_gid0=gid0)
+    pal = oracle.Palette(oracle.NAV_SUBTREES)
+    cfg = dict(ocfg)
+    cfg.update(seed=seed, tasks=list(tasks), visible_radius=r, color=int(bool(opts.get("color", False))),
+               context=int(opts.get("context", 1)), max_steps=int(opts.get("max_steps", 0)))
+    return sim, pal, cfg
+
+
+@pytest.mark.parametrize("key,r", [("nav8", 3), ("nav7", 5), ("nav11", 7), ("nav8_dim5", 3), ("nav7", 1)])
+def test_ego_reset_and_rollout(oracle, key, r):
+    """Reset parity (map, heading, task, target sets) and random-policy rollouts with resets: reward bits and codes."""
+    _torch()
+    n, steps = 768, 200
+    sim, pal, cfg = _make(oracle, key, n, r, seed=17, policy_seed=3, gid0=40)
+    assert sim.num_actions == 6 and sim.screen_dims[:2] == (r * (84 // r), r * (84 // r))
+    ow = oracle.XWorld(pal, render=False, **cfg)
+    dirs = np.zeros(4, int)
+    for e in range(0, n, 2):
+        ow.reset_game(40 + e, 0)
+        st = sim.env_state(e)
+        raw = sim.env_grid(e, raw=True)
+        assert np.array_equal((raw & 0x7fff).astype(np.int32), ow.grid()), e
+        assert (st.xw_agent_x, st.xw_agent_y) == ow.agent_xy() and st.xw_task == ow.task_kind(), e
+        assert st.xw_agent_dir == _facing(ow.agent_yaw()), e
+        if st.xw_task != 3:
+            assert np.array_equal((raw >> 15).astype(np.uint8), ow.target_cells()), (e, st.xw_task)
+        dirs[st.xw_agent_dir] += 1
+    assert dirs.min() > 50
+    ref = oracle.xw_rollout(n, oracle.xw_cfg(**cfg), pal, steps, policy_seed=3, env_gid0=40)
+    resets = 0
+    for t in range(steps):
+        sim.reset_done()
+        resets += sim.done_count()
+        sim.step()
+        assert np.array_equal(sim.reward.cpu().numpy().view(np.uint32), ref.rewards[t].view(np.uint32)), t
+        assert np.array_equal(sim.game_over_codes.cpu().numpy(), ref.codes[t]), t
+    assert resets == ref.stats.resets and resets > 0
+    sim.close()
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_reference_ego_traces_through_product(oracle, kind):
+    """tests/golden/tasks_ego.json: the reference's Python tasks with visible_radius = 3, replayed through the product's
+    step kernel (map after the idle stage, heading and target set loaded)."""
+    torch = _torch()
+    from xworld_amd.batched import BatchedSimulator
+    runs = ego_runs(kind)
+    md, dim = runs[0]["max_dim"], runs[0]["dim"]
+    assert all(r["max_dim"] == md and r["dim"] == dim for r in runs)
+    n = len(runs)
+    sim = BatchedSimulator("xworld", {"xwd_conf_path": os.path.join(CONF, "nav_target.json"), "max_dim": md, "dim": dim,
+                                      "task_mode": "lang_acquisition", "tasks": [kind], "visible_radius": 3}, num_envs=n)
+    pal = oracle.Palette(oracle.NAV_SUBTREES)
+    for e, run in enumerate(runs):
+        # the oracle replays the idle stage (pinned to the same file by test_oracle_ego.py) and tells what Direction's
+        # (referent, direction) is
+        w = oracle.XWorld(pal, render=False, map_kind=0, max_dim=md, dim=dim, num_goals=4, tasks=[kind], visible_radius=3)
+        w.stage_poses(run["poses"])
+        w.load_map_ex([tuple(x) for x in run["entities_before"]], dim, [0] + run["decisions"])
+        g = np.zeros((md, md), np.uint16)
+        agent = None
+        for t, x, y, icon, name, serial in run["entities_after"]:
+            g[y, x] = icon + 1
+            if t == 2:
+                agent = (x, y)
+        if kind != "XWorld3DNavTargetDirection":
+            for x, y in run["target_cells"]:
+                g[y, x] |= 0x8000
+        target = -1
+        if kind == "XWorld3DNavTargetBetween":
+            target = run["between"][1] * md + run["between"][0]
+        elif kind == "XWorld3DNavTargetDirection":
+            rx, ry, word = w.direction_target()
+            target = (ry * md + rx) | (word << 8)
+        sim.load_map(e, g, agent[0], agent[1], dim=dim, task=kind, target=target)
+        sim.set_agent_dir(e, _facing(w.agent_yaw()))
+    seen = set()
+    T = max(len(r["trace"]) for r in runs)
+    for t in range(T):
+        acts = np.full(n, -1, np.int32)
+        for e, run in enumerate(runs):
+            if t < len(run["trace"]):
+                acts[e] = run["trace"][t][0]
+        sim.step(torch.from_numpy(acts).cuda())
+        rew = sim.reward.cpu().numpy()
+        for e, run in enumerate(runs):
+            if t >= len(run["trace"]):
+                continue
+            a, reward, event, stage, ax, ay, success, yaw = run["trace"][t]
+            st = sim.env_state(e)
+            assert rew[e] == np.float32(reward), (run["py_seed"], t)
+            assert st.xw_event == EVENTS[event] and st.xw_stage == STAGES[stage], (run["py_seed"], t)
+            assert (st.xw_agent_x, st.xw_agent_y) == (ax, ay) and st.last_action_success == success
+            assert st.xw_agent_dir == _facing(yaw), (run["py_seed"], t)
+            seen.add(event)
+    assert {"correct_goal", "wrong_goal"} <= seen
+    sim.close()
+
+
+@pytest.mark.parametrize("key,r,color,context", [("nav7", 3, True, 1), ("nav8", 5, False, 1), ("nav7", 7, True, 2),
+                                                 ("nav11", 3, True, 1), ("nav8_dim5", 1, True, 1)])
+def test_ego_frames_with_host_poses(oracle, key, r, color, context):
+    """Frames bit for bit: maps from the oracle's generator are loaded into the product with the goal poses set through
+    the host (same libm as the oracle), then both run the same action strings."""
+    torch = _torch()
+    n, steps = 48, 14
+    sim, pal, cfg = _make(oracle, key, n, r, tasks=[KINDS[0]], seed=5, color=color, context=context)
+    md = cfg["max_dim"]
+    envs = []
+    for e in range(n):
+        w = oracle.XWorld(pal, render=True, **cfg)
+        w.reset_game(e, 0)
+        envs.append(w)
+        g = w.grid().astype(np.uint16)
+        ax, ay = w.agent_xy()
+        tc = w.target_cells()
+        g[tc != 0] |= 0x8000
+        sim.load_map(e, g, ax, ay, dim=cfg["dim"], task=KINDS[0], target=w.target_name())
+        sim.set_agent_dir(e, _facing(w.agent_yaw()))
+        for i, ent in enumerate(w.entities()):
+            if ent[0] == 0:
+                yaw, scale, offset = w.get_pose(i)
+                sim.set_goal_pose(e, ent[1], ent[2], yaw, scale, offset)
+        sim.refresh_obs(e)
+    rng = np.random.default_rng(1)
+    for t in range(steps):
+        obs = sim.obs.cpu().numpy()
+        for e, w in enumerate(envs):
+            exp = w.state_screen()
+            assert np.array_equal(obs[e], exp), (t, e, int((obs[e] != exp).sum()))
+        acts = rng.integers(0, 6, n).astype(np.int32)
+        sim.step(torch.from_numpy(acts).cuda())
+        for e, w in enumerate(envs):
+            w.take_actions(int(acts[e]))
+    sim.close()
+
+
+def test_ego_frames_device_poses(oracle):
+    """The same with poses drawn by the reset kernel (device cos / sin): an env's frame may differ from the oracle's in
+    a few goal pixels by one level when the two libms round an inverse-warp coefficient differently."""
+    _torch()
+    n = 256
+    sim, pal, cfg = _make(oracle, "nav7", n, 3, seed=23, color=True)
+    ow = oracle.XWorld(pal, render=True, **cfg)
+    obs = sim.obs.cpu().numpy()
+    bad_px = bad_env = 0
+    for e in range(n):
+        ow.reset_game(e, 0)
+        exp = ow.state_screen()
+        d = np.abs(obs[e].astype(int) - exp.astype(int))
+        assert d.max() <= 1, (e, d.max())
+        bad_px += int((d != 0).sum())
+        bad_env += int(d.any())
+    print("device-pose frames: %d of %d envs differ, %d pixel values" % (bad_env, n, bad_px))
+    assert bad_env <= n // 50
+    sim.close()

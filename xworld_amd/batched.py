@@ -92,8 +92,7 @@ class BatchedSimulator:
             for i, t in enumerate(tasks):
                 cfg.tasks[i] = int(t)
             self.tasks = list(tasks)
-            if int(opts.get("visible_radius", 0)) != 0:
-                raise RuntimeError("visible_radius > 0 (egocentric view) is not built yet (SURVEY 8(f) rank 2)")
+            cfg.visible_radius = int(opts.get("visible_radius", 0))         # py_simulator.cpp:133
             self.palette = assets.Palette(mc["subtrees"], opts.get("assets_dir", assets.ASSETS))
             cfg.n_icons = len(self.palette)
             cfg.icons64 = self.palette.icons64.ctypes.data
@@ -264,6 +263,16 @@ class BatchedSimulator:
         else:
             lib.check(self.L.xwb_xw_load_map_task(self.h, int(env), g.ctypes.data, int(agent_x), int(agent_y), dim,
                                                   int(assets.TASK_IDS.get(task, task)), int(target)))
+
+    def set_agent_dir(self, env, d):
+        """egocentric heading: 0 right, 1 down, 2 left, 3 up"""
+        lib.check(self.L.xwb_xw_set_agent_dir(self.h, int(env), int(d)))
+
+    def set_goal_pose(self, env, x, y, yaw, scale=1.0, offset=0.0):
+        lib.check(self.L.xwb_xw_set_goal_pose(self.h, int(env), int(x), int(y), float(yaw), float(scale), float(offset)))
+
+    def refresh_obs(self, env):
+        lib.check(self.L.xwb_xw_refresh_obs(self.h, int(env)))
 
     def race_set_car(self, env, x, y, angle):
         lib.check(self.L.xwb_race_set_car(self.h, int(env), float(x), float(y), float(angle)))

@@ -46,13 +46,14 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
     if (e == 0) *p.done_count_next = 0;        // double-buffered done counter: zero the next step's
     bool is_done = false;
     if (e < p.n) {
-        int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step, 4);
+        const int NA = p.visible_radius ? 6 : 4;           // XAgent legal_actions_, xitem.cpp:80-87
+        int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step, NA);
         p.actions_out[e] = a;
         // render hand-off flag: 0 = env untouched (leave its context ring alone), 1 = stepped, 2 = fresh (reset)
-        p.fresh[e] = (unsigned)a < 4u ? 1 : 0;
+        p.fresh[e] = (unsigned)a < (unsigned)NA ? 1 : 0;
         if (a == ACTION_SKIP) {
             // XWB_ACTION_SKIP: this env does not take part in the call (per-slot SimulatorInterface views)
-        } else if ((unsigned)a >= 4u) {        // CHECK_LT(action_idx, get_num_actions())
+        } else if ((unsigned)a >= (unsigned)NA) {   // CHECK_LT(action_idx, get_num_actions())
             atomicAdd(p.err_count, 1);
         } else {
             const int D = p.max_dim;
@@ -61,13 +62,29 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
             int ax = axy & 0xffff, ay = axy >> 16;
             const int steps = p.num_steps[e] + 1;          // GameSimulator::take_actions: once per call
             const uint16_t agent_code = g[ay * D + ax];
-            const int ddx = a == 2 ? -1 : (a == 3 ? 1 : 0);   // MOVE_LEFT / MOVE_RIGHT
-            const int ddy = a == 0 ? -1 : (a == 1 ? 1 : 0);   // MOVE_UP / MOVE_DOWN
-            int hit = 0;
+            int ddx = a == 2 ? -1 : (a == 3 ? 1 : 0);         // MOVE_LEFT / MOVE_RIGHT
+            int ddy = a == 0 ? -1 : (a == 1 ? 1 : 0);         // MOVE_UP / MOVE_DOWN
+            int vx = 0, vy = 1;                                // heading: entities keep yaw 1.5707963 (+y) under full observation
+            int hit = 0, hit_cell = 0;
             bool success = false;
             for (int i = 0; i < p.act_rep; ++i) {
+                if (p.visible_radius) {
+                    // XAgent::act, xitem.cpp:103-155: MOVE_FORWARD, MOVE_BACKWARD, MOVE_LEFT_FPV, MOVE_RIGHT_FPV relative to
+                    // the heading; TURN_LEFT / TURN_RIGHT change the yaw and "move" onto the agent's own cell, which
+                    // XMap::move_item refuses (xmap.cpp:76-101): a turn is an unsuccessful action without contacts
+                    int dir = p.agent_dir[e];
+                    if (a == 4) dir = (dir + 3) & 3;
+                    else if (a == 5) dir = (dir + 1) & 3;
+                    p.agent_dir[e] = (uint8_t)dir;
+                    vx = dir == 0 ? 1 : (dir == 2 ? -1 : 0);
+                    vy = dir == 1 ? 1 : (dir == 3 ? -1 : 0);
+                    const int lx = vy, ly = -vx;               // MOVE_LEFT_FPV: right->up, down->right, left->down, up->left
+                    ddx = a == 0 ? vx : (a == 1 ? -vx : (a == 2 ? lx : (a == 3 ? -lx : 0)));
+                    ddy = a == 0 ? vy : (a == 1 ? -vy : (a == 2 ? ly : (a == 3 ? -ly : 0)));
+                }
                 const int tx = ax + ddx, ty = ay + ddy;
                 success = false;
+                if (p.visible_radius && a >= 4) continue;      // a turn
                 if (tx >= 0 && ty >= 0 && tx < D && ty < D) {
                     const int code = g[ty * D + tx];
                     if (code == 0) {                        // XMap::move_item: empty cell -> move
@@ -77,6 +94,7 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
                         success = true;
                     } else {
                         hit = code;                         // contact_list -> "collision:<id>" event
+                        hit_cell = ty * D + tx;
                     }
                 }
             }
@@ -119,12 +137,21 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
                 if (tsteps >= p.dim * p.dim * p.max_steps_factor) {
                     event = EV_TIMEUP;
                     stage = STAGE_TERMINAL;
-                } else if (hit != 0 && a == 1 && p.icon_type[(hit & CELL_ICON_MASK) - 1] == 0) {
-                    // _reach_object: id in collisions and |theta| < pi/4.  Full-observation entities keep
-                    // yaw = 1.5707963 (heading +y), so theta = 0 only for a goal hit by MOVE_DOWN.
-                    // Target / Near / Direction / Avoid: the reached goal is in self.target (cell bit 15, set by
-                    // the idle stage) -> correct, else wrong.  Between: any reached goal is wrong.
-                    if (kind != TASK_BETWEEN && (hit & CELL_TARGET_BIT)) { event = EV_CORRECT; rew += 1.0; }
+                } else if (hit != 0 && ddx == vx && ddy == vy && p.icon_type[(hit & CELL_ICON_MASK) - 1] == 0) {
+                    // _reach_object: id in collisions and |theta| < pi/4, i.e. the goal was bumped into along the
+                    // heading: MOVE_DOWN under full observation (yaw stays 1.5707963), MOVE_FORWARD in egocentric mode.
+                    // Target / Near / Avoid: the reached goal is in self.target (cell bit 15, set by the idle stage)
+                    // -> correct, else wrong.  Between: any reached goal is wrong.  Direction: (direction(g, referent,
+                    // agent.yaw), near) is evaluated now, the yaw being the current heading.
+                    bool good = kind != TASK_BETWEEN && (hit & CELL_TARGET_BIT);
+                    if (kind == TASK_DIRECTION) {
+                        const int rc = target & 0xff, word = (target >> 8) & 7;
+                        const int v2x = rc % D - hit_cell % D, v2y = rc / D - hit_cell / D;
+                        const int cs = vx * v2x + vy * v2y, sn = vy * v2x - vx * v2y;
+                        const int dirw = cs > 0 ? DIR_FRONT : (cs < 0 ? DIR_BEHIND : (sn > 0 ? DIR_RIGHT : DIR_LEFT));
+                        good = target >= 0 && v2x * v2x + v2y * v2y == 1 && dirw == word;
+                    }
+                    if (good) { event = EV_CORRECT; rew += 1.0; }
                     else { event = EV_WRONG; rew += -1.0; }
                     stage = STAGE_TERMINAL;
                 } else if (kind == TASK_BETWEEN && ay * D + ax == target) {
@@ -200,32 +227,6 @@ __device__ __forceinline__ uint4 xw_expand_chunk(const uint32_t *atlas, const ui
     return make_uint4(out[0], out[1], out[2], out[3]);
 }
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// flag: 0 = env untouched by this call (nothing to do), 1 = stepped (ring shift), 2 = fresh (init_screen)
-__device__ __forceinline__ void xw_store_chunk(uint4 *frame0, int cc, int chunks_per_frame, int ctx, int flag, uint4 v) {
-    uint4 *q = frame0 + cc;
-    if (ctx > 1) {
-        if (flag == 0) return;
-        const bool fresh = flag == 2;
-        // shift_context: oldest first; init_screen: zeros.  The same lane owns offset cc in every frame.
-        if (fresh) for (int f = 0; f + 1 < ctx; ++f) q[(size_t)f * chunks_per_frame] = make_uint4(0, 0, 0, 0);
-        else for (int f = 0; f + 1 < ctx; ++f) q[(size_t)f * chunks_per_frame] = q[(size_t)(f + 1) * chunks_per_frame];
-    }
-    // streamed once, never re-read by this kernel: one non-temporal global_store_dwordx4 per lane
-    u32x4 nv = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(&q[(size_t)(ctx - 1) * chunks_per_frame]));
-}
-
-// all envs: ONE-SHOT workgroups in dispatch order -- the store structure that reaches the write ceiling on this
-// chip (tools/render_lab.hip: one-shot 6.7 TB/s, every persistent / looping structure <= 5.7 TB/s; the persistent
-// LDS-table kernel this replaces ran at 4.4 TB/s).  Each workgroup owns SPAN = BS * PER consecutive 16-byte chunks
-// of the batch's frame bytes, cut at 1 KiB multiples of the global chunk index so every wavefront store is a whole
-// number of cache lines although env frames (7x7x3: 21 168 B) are not 128-byte aligned.  A frame row is a run of
-// 12-byte tile rows, so the span is assembled in LDS in OUTPUT order from 12-byte rows gathered from the tile table
-// through L2 (157 KB, resident in every XCD's L2; one 12-byte load per tile row -- a per-dword gather is TA-bound at
-// 3.2 TB/s) and leaves as one 16-byte non-temporal store per lane.  All of a lane's gathers are issued before its
-// first LDS write (loads-first: 119 -> 111 us on C4 in the lab; 104 us = 6.7 TB/s inside the step loop).
 // SKIP_DONE (xwb_step_autoreset): frames of finished envs are left to the list render that follows their reset on
 // the side stream, so that render runs beside this kernel instead of after it.
 // ES = bytes per pixel: 1 = uint8 frames; 4 = float32 frames (pixel * 1/255, py_simulator.cpp:262-272) expanded from
@@ -383,6 +384,7 @@ static hipError_t render_dispatch(const XwParams &p, int indexed, hipStream_t s)
 }
 
 hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s) {
+    if (p.visible_radius) return launch_xw_render_ego(p, indexed, s);
     if (p.obs_f32) return p.channels == 3 ? render_dispatch<3, 4>(p, indexed, s) : render_dispatch<1, 4>(p, indexed, s);
     return p.channels == 3 ? render_dispatch<3, 1>(p, indexed, s) : render_dispatch<1, 1>(p, indexed, s);
 }

@@ -286,6 +286,30 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
             occupied.set(c);
             L.gcell[L.at(i)] = (uint8_t)c;
             L.gicon[L.at(i)] = (uint16_t)ic;
+            if (p.visible_radius) {
+                // xworld_env.py:211-223: yaw ~ U[0, 4 * PI_2), scale ~ U[0.5, 1], offset ~ U[0, 1 - scale]; random.uniform
+                // (a, b) = a + (b - a) * random() with random() = unit().  XItem::get_item_image (xitem.cpp:33-63) then
+                // warps the icon by getRotationMatrix2D(centre, 90 - yaw * 180 / M_PI, scale) plus the translation
+                // (offset + scale / 2 - 0.5) * 64; cv::warpAffine inverts that matrix: the inverse is what the
+                // egocentric render needs, so it is stored.
+                const double u0 = (double)s.unit(), u1 = (double)s.unit(), u2 = (double)s.unit();
+                const double yaw = 0 + (1.5707963 * 4 - 0) * u0;
+                const double scale = 0.5 + (1 - 0.5) * u1;
+                const double offset = 0 + ((1 - scale) - 0) * u2;
+                const double angle = (90 - yaw * 180 / 3.14159265358979323846) * 3.1415926535897932384626433832795 / 180;
+                const double alpha = cos(angle) * scale, beta = sin(angle) * scale;
+                double M[6] = {alpha, beta, (1 - alpha) * 32.0 - beta * 32.0, -beta, alpha, beta * 32.0 + (1 - alpha) * 32.0};
+                M[2] += (offset + scale / 2 - 0.5) * 64;
+                M[5] += (offset + scale / 2 - 0.5) * 64;
+                double Dt = M[0] * M[4] - M[1] * M[3];
+                Dt = Dt != 0 ? 1. / Dt : 0;
+                const double A11 = M[4] * Dt, A22 = M[0] * Dt;
+                M[0] = A11; M[1] *= -Dt; M[3] *= -Dt; M[4] = A22;
+                const double b1 = -M[0] * M[2] - M[1] * M[5], b2 = -M[3] * M[2] - M[4] * M[5];
+                M[2] = b1; M[5] = b2;
+                double *gw = p.goal_warp + ((size_t)e * XW_MAX_GOALS + i) * 6;
+                for (int k = 0; k < 6; ++k) gw[k] = M[k];
+            }
         }
         for (int i = 0; i < p.num_blocks; ++i) {
             const int c = L.blk[L.at(--nb)];                   // blocks.pop()
@@ -302,6 +326,8 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
             agent_icon = T.icon(2, nm, v);
             put(c, agent_icon);
             agent_cell = c;
+            // xworld_env.py:208-210: yaw = random.choice(range(-1, 3)) * PI_2 -> heading up, right, down, left
+            if (p.visible_radius) p.agent_dir[e] = (uint8_t)((s.below(4u) + 3u) & 3u);
         }
     } else {
         // ---- XWorldWalls: one full brick row, a partial brick column, then agent, goals, blocks ----
@@ -376,15 +402,14 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
             r2 = grown;
         }
         uint32_t cand = 0;
+        for (int i = 0; i < ng; ++i) {
+            const int c = L.gcell[L.at(i)];
+            if (r2.test(c)) cand |= (1u << i) | (p.icon_colored[L.gicon[L.at(i)]] ? (1u << (16 + i)) : 0u);
+        }
         uint8_t *gc = p.goal_cells + (size_t)e * XW_MAX_GOALS;
         for (int i = 0; i < XW_MAX_GOALS; ++i) {
-            int cell = 0xff;
-            if (i < ng) {
-                const int c = L.gcell[L.at(i)];
-                cell = (c / D + off) * MD + (c % D + off);
-                if (r2.test(c)) cand |= (1u << i) | (p.icon_colored[L.gicon[L.at(i)]] ? (1u << (16 + i)) : 0u);
-            }
-            gc[i] = (uint8_t)cell;
+            const int c = i < ng ? L.gcell[L.at(i)] : 0;
+            gc[i] = i < ng ? (uint8_t)((c / D + off) * MD + (c % D + off)) : (uint8_t)0xff;
         }
         p.cand2d[e] = cand;
         int tsteps0;
@@ -595,14 +620,20 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
             } else {
                 // navigation_reward: a reached goal g wins iff direction(g, referent) seen along the agent's constant
                 // yaw 1.5707963 (heading +y) equals `direction` and g is within 1.0 + 1e-3 of the referent
+                // (the step kernel evaluates the same test with the heading at that time -- it changes in egocentric
+                // mode; the bits below are the answer for the heading at reset)
                 const int rl = ref == g1 ? l1 : l2;
+                const int hd = p.visible_radius ? p.agent_dir[e] : 1;
+                const int hx = hd == 0 ? 1 : (hd == 2 ? -1 : 0), hy = hd == 1 ? 1 : (hd == 3 ? -1 : 0);
                 for (int i = 0; i < ng; ++i) {
                     const int c = L.gcell[L.at(i)];
                     const int v2x = rl % D - c % D, v2y = rl / D - c / D;
                     if (v2x * v2x + v2y * v2y != 1) continue;         // dist == 0 -> False; dist > 1.001 -> far
-                    const int dir = v2y > 0 ? DIR_FRONT : (v2y < 0 ? DIR_BEHIND : (v2x > 0 ? DIR_RIGHT : DIR_LEFT));
+                    const int cs = hx * v2x + hy * v2y, sn = hy * v2x - hx * v2y;
+                    const int dir = cs > 0 ? DIR_FRONT : (cs < 0 ? DIR_BEHIND : (sn > 0 ? DIR_RIGHT : DIR_LEFT));
                     if (dir == direction) target_bits |= 1u << i;
                 }
+                target_field = ((rl / D + off) * MD + (rl % D + off)) | (direction << 8);
             }
         }
     }
@@ -610,6 +641,13 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
     for (int i = 0; i < ng; ++i)
         put_code(L.gcell[L.at(i)], (uint16_t)((L.gicon[L.at(i)] + 1) | (((target_bits >> i) & 1u) ? 0x8000u : 0u)));
     if (kind == TASK_BETWEEN && between >= 0) target_field = (between / D + off) * MD + (between % D + off);
+    if (!p.group2d) {                                     // goal slot -> cell (the egocentric render finds a goal's pose by it)
+        uint8_t *gc = p.goal_cells + (size_t)e * XW_MAX_GOALS;
+        for (int i = 0; i < XW_MAX_GOALS; ++i) {
+            const int c = i < ng ? L.gcell[L.at(i)] : 0;
+            gc[i] = i < ng ? (uint8_t)((c / D + off) * MD + (c % D + off)) : (uint8_t)0xff;
+        }
+    }
 
     p.agent_xy[e] = (agent_cell % D + off) | ((agent_cell / D + off) << 16);
     p.task_state[e] = pack_task(target_field, stage0, EV_NONE, kind);

@@ -58,4 +58,32 @@ __device__ __forceinline__ int done_code(const XwParams &p, int num_steps, int e
 }
 
 
+// ---- shared by the render kernels ----
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// flag: 0 = env untouched by this call (nothing to do), 1 = stepped (ring shift), 2 = fresh (init_screen)
+__device__ __forceinline__ void xw_store_chunk(uint4 *frame0, int cc, int chunks_per_frame, int ctx, int flag, uint4 v) {
+    uint4 *q = frame0 + cc;
+    if (ctx > 1) {
+        if (flag == 0) return;
+        const bool fresh = flag == 2;
+        // shift_context: oldest first; init_screen: zeros.  The same lane owns offset cc in every frame.
+        if (fresh) for (int f = 0; f + 1 < ctx; ++f) q[(size_t)f * chunks_per_frame] = make_uint4(0, 0, 0, 0);
+        else for (int f = 0; f + 1 < ctx; ++f) q[(size_t)f * chunks_per_frame] = q[(size_t)(f + 1) * chunks_per_frame];
+    }
+    // streamed once, never re-read by this kernel: one non-temporal global_store_dwordx4 per lane
+    u32x4 nv = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(&q[(size_t)(ctx - 1) * chunks_per_frame]));
+}
+
+// all envs: ONE-SHOT workgroups in dispatch order -- the store structure that reaches the write ceiling on this
+// chip (tools/render_lab.hip: one-shot 6.7 TB/s, every persistent / looping structure <= 5.7 TB/s; the persistent
+// LDS-table kernel this replaces ran at 4.4 TB/s).  Each workgroup owns SPAN = BS * PER consecutive 16-byte chunks
+// of the batch's frame bytes, cut at 1 KiB multiples of the global chunk index so every wavefront store is a whole
+// number of cache lines although env frames (7x7x3: 21 168 B) are not 128-byte aligned.  A frame row is a run of
+// 12-byte tile rows, so the span is assembled in LDS in OUTPUT order from 12-byte rows gathered from the tile table
+// through L2 (157 KB, resident in every XCD's L2; one 12-byte load per tile row -- a per-dword gather is TA-bound at
+// 3.2 TB/s) and leaves as one 16-byte non-temporal store per lane.  All of a lane's gathers are issued before its
+// first LDS write (loads-first: 119 -> 111 us on C4 in the lab; 104 us = 6.7 TB/s inside the step loop).
+
 }  // namespace xwb

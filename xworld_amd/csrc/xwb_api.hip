@@ -75,6 +75,9 @@ struct xwb_sim {
             *d_done_count = nullptr;
     uint8_t *d_fresh = nullptr, *d_icon_type = nullptr, *d_icon_colored = nullptr, *d_goal_cells = nullptr;
     uint32_t *d_cand2d = nullptr;
+    uint8_t *d_agent_dir = nullptr, *d_atlas64 = nullptr;
+    EgoTap *d_ego_taps = nullptr;
+    double *d_goal_warp = nullptr;
     int16_t *d_icon_name = nullptr, *d_name_first = nullptr, *d_name_variants = nullptr;
     uint32_t *d_atlas = nullptr;
     std::vector<uint8_t> tile_table;   // host copy, n_icons x c x 12 x 12
@@ -259,6 +262,14 @@ int xw_setup(xwb_sim *s) {
     if ((rc = dev_alloc(s, &s->d_icon_colored, c.n_icons))) return rc;
     if ((rc = dev_alloc(s, &s->d_goal_cells, (size_t)n * XW_MAX_GOALS, 0xff))) return rc;
     if ((rc = dev_alloc(s, &s->d_cand2d, n))) return rc;
+    if ((rc = dev_alloc(s, &s->d_agent_dir, n, 1))) return rc;                 // heading "down": yaw 1.5707963
+    if (c.visible_radius > 0) {
+        if ((rc = dev_alloc(s, &s->d_goal_warp, (size_t)n * XW_MAX_GOALS * 6))) return rc;
+        if ((rc = dev_alloc(s, &s->d_atlas64, (size_t)c.n_icons * 64 * 64 * 3))) return rc;
+        HIP_TRY(hipMemcpy(s->d_atlas64, c.icons64, (size_t)c.n_icons * 64 * 64 * 3, hipMemcpyHostToDevice));
+        HIP_TRY(xw_ego_tables(c.visible_radius, c.max_dim, s->out_h, &s->d_ego_taps));
+        s->allocs.push_back(s->d_ego_taps);
+    }
     if ((rc = dev_alloc(s, &s->d_icon_name, c.n_icons))) return rc;
     if ((rc = dev_alloc(s, &s->d_name_first, first.size()))) return rc;
     if ((rc = dev_alloc(s, &s->d_name_variants, variants.size()))) return rc;
@@ -295,6 +306,8 @@ int xw_setup(xwb_sim *s) {
     p.n_tasks = c.n_tasks;
     p.group2d = c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET;
     p.goal_cells = s->d_goal_cells; p.cand2d = s->d_cand2d; p.icon_colored = s->d_icon_colored;
+    p.visible_radius = c.visible_radius; p.out_dim = s->out_h;
+    p.agent_dir = s->d_agent_dir; p.goal_warp = s->d_goal_warp; p.atlas64 = s->d_atlas64; p.ego_taps = s->d_ego_taps;
     for (int i = 0; i < 8; ++i) p.tasks[i] = i < c.n_tasks ? c.tasks[i] : 0;
     p.policy_seed = c.policy_seed; p.env_gid0 = c.env_gid0; p.policy_step = 0; p.seed = c.seed;
     p.icon_type = s->d_icon_type; p.icon_name = s->d_icon_name;
@@ -525,8 +538,22 @@ int xwb_create(const xwb_config *cfg, xwb_sim **out) {
         case XWB_XWORLD2D:
             s->out_h = cfg->max_dim * 12; s->out_w = cfg->max_dim * 12; s->out_c = cfg->color ? 3 : 1;   // xworld_simulator.cpp:53-61,106-112
             if (cfg->obs_format != XWB_OBS_U8 && cfg->obs_format != XWB_OBS_F32) return bail(fail(XWB_ERR_ARG, "xworld: unknown obs_format"));
-            s->obs_bytes_per_env = (size_t)cfg->context * s->out_c * s->out_h * s->out_w * (cfg->obs_format == XWB_OBS_F32 ? 4 : 1);
             s->num_actions = 4;                                           // xitem.cpp:82-83
+            if (cfg->visible_radius < 0) return bail(fail(XWB_ERR_ARG, "xworld: visible_radius must be >= 0"));
+            if (cfg->visible_radius > 0) {
+                // xworld_simulator.cpp:62-68: clamp to the map, frame edge r * (84 / r); xmap.cpp:277: r must be odd
+                if (s->cfg.visible_radius > cfg->max_dim) s->cfg.visible_radius = cfg->max_dim;
+                const int r = s->cfg.visible_radius;
+                if (r % 2 != 1) return bail(fail(XWB_ERR_ARG, "xworld: visible_radius must be an odd int (xmap.cpp:277)"));
+                if (cfg->map_kind != XWB_MAP_NAV)
+                    return bail(fail(XWB_ERR_ARG, "xworld: visible_radius > 0 needs a maze map (XWorldNav): without maze "
+                                                  "generation the reference's set_property rejects the agent's default yaw "
+                                                  "(xworld_env.py:208-210, py_util.py:27-29)"));
+                if (cfg->obs_format != XWB_OBS_U8) return bail(fail(XWB_ERR_ARG, "xworld: egocentric frames are uint8 only"));
+                s->out_h = s->out_w = r * (84 / r);
+                s->num_actions = 6;                                       // xitem.cpp:84-86
+            }
+            s->obs_bytes_per_env = (size_t)cfg->context * s->out_c * s->out_h * s->out_w * (cfg->obs_format == XWB_OBS_F32 ? 4 : 1);
             break;
         default:
             return bail(fail(XWB_ERR_ARG, "Unrecognized game type"));     // simulator_interface.cpp:82
@@ -761,6 +788,9 @@ int xwb_get_env_state(xwb_sim *s, int32_t env, void *stream, xwb_env_state *o) {
         o->xw_stage = (ts >> 16) & 0xf;
         o->xw_event = (ts >> 20) & 0xf;
         o->xw_steps_in_task = tsteps;
+        uint8_t dir = 1;
+        HIP_TRY(hipMemcpy(&dir, s->d_agent_dir + env, 1, hipMemcpyDeviceToHost));
+        o->xw_agent_dir = dir;
     }
     return XWB_OK;
 }
@@ -834,6 +864,20 @@ int xwb_xw_load_map_task(xwb_sim *s, int32_t env, const uint16_t *grid_host, int
         }
         HIP_TRY(hipMemcpy(s->d_goal_cells + (size_t)env * XW_MAX_GOALS, gc.data(), XW_MAX_GOALS, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s->d_cand2d + env, &cand, 4, hipMemcpyHostToDevice));
+    } else {
+        // goal slot -> cell table (slots in row-major order): the egocentric render finds a goal's pose through it
+        std::vector<uint8_t> gc(XW_MAX_GOALS, 0xff);
+        int slot = 0;
+        for (size_t c = 0; c < cells && slot < XW_MAX_GOALS; ++c) {
+            const int icon = (int)(grid_host[c] & XWB_CELL_ICON_MASK) - 1;
+            if (icon >= 0 && icon < s->cfg.n_icons && s->icon_type_h[icon] == XWB_ICON_GOAL) gc[slot++] = (uint8_t)c;
+        }
+        HIP_TRY(hipMemcpy(s->d_goal_cells + (size_t)env * XW_MAX_GOALS, gc.data(), XW_MAX_GOALS, hipMemcpyHostToDevice));
+        if (s->d_goal_warp) {                               // default pose: yaw 1.5707963, scale 1, offset 0 = the identity warp
+            const double ident[6] = {1, 0, 0, 0, 1, 0};
+            for (int i = 0; i < XW_MAX_GOALS; ++i)
+                HIP_TRY(hipMemcpy(s->d_goal_warp + ((size_t)env * XW_MAX_GOALS + i) * 6, ident, sizeof ident, hipMemcpyHostToDevice));
+        }
     }
     int32_t zero = 0;
     uint8_t z8 = 0, one = 2;
@@ -870,6 +914,61 @@ int xwb_xw_load_map(xwb_sim *s, int32_t env, const uint16_t *grid_host, int32_t 
         if (icon >= 0 && s->icon_type_h[icon] == XWB_ICON_GOAL && s->icon_name_h[icon] == target_name) c |= XWB_CELL_TARGET;
     }
     return xwb_xw_load_map_task(s, env, g.data(), agent_x, agent_y, dim, XWB_TASK_TARGET, target_name);
+}
+
+int xwb_xw_set_agent_dir(xwb_sim *s, int32_t env, int32_t dir) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    if (s->cfg.game != XWB_XWORLD2D || s->cfg.visible_radius == 0) return fail(XWB_ERR_STATE, "not an egocentric xworld batch");
+    if (env < 0 || env >= s->n || dir < 0 || dir > 3) return fail(XWB_ERR_ARG, "env or dir out of range");
+    HIP_TRY(hipDeviceSynchronize());
+    const uint8_t d = (uint8_t)dir;
+    HIP_TRY(hipMemcpy(s->d_agent_dir + env, &d, 1, hipMemcpyHostToDevice));
+    return XWB_OK;
+}
+
+int xwb_xw_set_goal_pose(xwb_sim *s, int32_t env, int32_t cell_x, int32_t cell_y, double yaw, double scale, double offset) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    if (s->cfg.game != XWB_XWORLD2D || s->cfg.visible_radius == 0) return fail(XWB_ERR_STATE, "not an egocentric xworld batch");
+    const int D = s->cfg.max_dim;
+    if (env < 0 || env >= s->n || cell_x < 0 || cell_y < 0 || cell_x >= D || cell_y >= D) return fail(XWB_ERR_ARG, "env or cell out of range");
+    HIP_TRY(hipDeviceSynchronize());
+    uint8_t gc[XW_MAX_GOALS];
+    HIP_TRY(hipMemcpy(gc, s->d_goal_cells + (size_t)env * XW_MAX_GOALS, XW_MAX_GOALS, hipMemcpyDeviceToHost));
+    int slot = -1;
+    for (int i = 0; i < XW_MAX_GOALS; ++i) if (gc[i] == cell_y * D + cell_x) slot = i;
+    if (slot < 0) return fail(XWB_ERR_ARG, "no goal at that cell");
+    // XItem::get_item_image (xitem.cpp:46-60) + the inversion cv::warpAffine performs
+    const double angle = (90 - yaw * 180 / 3.14159265358979323846) * 3.1415926535897932384626433832795 / 180;
+    const double alpha = std::cos(angle) * scale, beta = std::sin(angle) * scale;
+    double M[6] = {alpha, beta, (1 - alpha) * 32.0 - beta * 32.0, -beta, alpha, beta * 32.0 + (1 - alpha) * 32.0};
+    M[2] += (offset + scale / 2 - 0.5) * 64;
+    M[5] += (offset + scale / 2 - 0.5) * 64;
+    double Dt = M[0] * M[4] - M[1] * M[3];
+    Dt = Dt != 0 ? 1. / Dt : 0;
+    const double A11 = M[4] * Dt, A22 = M[0] * Dt;
+    M[0] = A11; M[1] *= -Dt; M[3] *= -Dt; M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5], b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+    HIP_TRY(hipMemcpy(s->d_goal_warp + ((size_t)env * XW_MAX_GOALS + slot) * 6, M, sizeof M, hipMemcpyHostToDevice));
+    return XWB_OK;
+}
+
+int xwb_xw_refresh_obs(xwb_sim *s, int32_t env) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
+    if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
+    HIP_TRY(hipDeviceSynchronize());
+    XwParams p = xw_params(s);
+    const int32_t cnt = 1;
+    const uint8_t two = 2;
+    HIP_TRY(hipMemcpy(p.done_list, &env, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p.done_count, &cnt, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_fresh + env, &two, 1, hipMemcpyHostToDevice));
+    HIP_TRY(launch_xw_render(p, 1, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(p.done_count, 0, 4));
+    s->list_valid = false;
+    return XWB_OK;
 }
 
 int xwb_race_set_car(xwb_sim *s, int32_t env, float x, float y, float angle) {

@@ -128,6 +128,8 @@ constexpr int XW_TILE_DW = 3;         // dwords per tile row (12 bytes)
 struct XwParams {
     int n, context, max_steps, act_rep, auto_reset;
     int map_kind, max_dim, dim, num_goals, num_blocks, max_steps_factor, task_mode, channels;
+    int visible_radius;          // FLAGS_visible_radius: 0 = full observation; odd r > 0 = egocentric r x r view, 6 actions
+    int out_dim;                 // egocentric frame edge: r * (84 / r)
     int obs_f32;                 // frames are float32 (pixel * 1/255), the tile table too
     int n_icons;
     int n_tasks, tasks[8];       // tasks of the teacher's group, sampled uniformly whenever the group is idle
@@ -150,7 +152,11 @@ struct XwParams {
     uint16_t *grid;              // [n][max_dim*max_dim] cell code = icon + 1 (0 empty) | bit 15: target goal
     int32_t *agent_xy;           // x | y << 16
     int32_t *task_steps;         // steps_in_cur_task
-    uint8_t *goal_cells;         // [n][XW_MAX_GOALS] cell of goal slot i (entity order), 0xff = none  (2-D-native tasks)
+    uint8_t *goal_cells;         // [n][XW_MAX_GOALS] cell of goal slot i (entity order), 0xff = none
+    uint8_t *agent_dir;          // [n] egocentric heading: 0 right, 1 down, 2 left, 3 up (XItem::get_item_facing_dir)
+    double *goal_warp;           // [n][XW_MAX_GOALS][6] egocentric: inverse affine map of the goal's icon warp
+    const uint8_t *atlas64;      // egocentric: [n_icons][64][64][3] BGR item images (XItem::item_size_ = 64)
+    const void *ego_taps;        // egocentric: cv::resize taps of the two resizes (kernels_xworld_ego.hip)
     uint32_t *cand2d;            // [n] goal slots the agent can reach, blocks as the only obstacles: bits 0..15
                                  //     any goal (XWorldNavTarget), bits 16..31 coloured goals (XWorldNavColorTarget)
     const uint8_t *icon_colored; // [n_icons] properties.txt colour != "na"
@@ -176,6 +182,9 @@ hipError_t launch_xw_compact(const XwParams &p, int mode, hipStream_t s);
 //         indexed == 1 -> envs in done_list (atlas through L2)
 // indexed: 0 = every env, 1 = the compacted done list, 2 = every env whose done code is 0 (the rest follows as a list)
 hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s);
+hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s);
+struct EgoTap;
+hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out);
 
 // host: builds the 12x12 tile table (OpenCV 3.2 fixed-point bilinear + BGR2GRAY) from 64x64 icons
 void build_tile_table(const uint8_t *icons64, int n_icons, int channels, uint8_t *out /* n*c*12*12 */);

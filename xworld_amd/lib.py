@@ -30,7 +30,7 @@ class XwbConfig(C.Structure):
         ("map_kind", C.c_int32), ("max_dim", C.c_int32), ("dim", C.c_int32), ("num_goals", C.c_int32),
         ("num_blocks", C.c_int32), ("max_steps_factor", C.c_int32), ("task_mode", C.c_int32),
         ("n_tasks", C.c_int32), ("tasks", C.c_int32 * 8),
-        ("color", C.c_int32), ("obs_format", C.c_int32), ("n_icons", C.c_int32),
+        ("color", C.c_int32), ("visible_radius", C.c_int32), ("obs_format", C.c_int32), ("n_icons", C.c_int32),
         ("icons64", C.c_void_p), ("icon_type", C.c_void_p), ("icon_name", C.c_void_p), ("icon_colored", C.c_void_p),
     ]
 
@@ -43,7 +43,7 @@ class XwbEnvState(C.Structure):
         ("race_x", C.c_float), ("race_y", C.c_float), ("race_angle", C.c_float),
         ("xw_agent_x", C.c_int32), ("xw_agent_y", C.c_int32), ("xw_event", C.c_int32), ("xw_stage", C.c_int32),
         ("xw_target_name", C.c_int32), ("xw_steps_in_task", C.c_int32),
-        ("episode", C.c_uint32), ("xw_task", C.c_int32), ("xw_target", C.c_int32),
+        ("episode", C.c_uint32), ("xw_task", C.c_int32), ("xw_target", C.c_int32), ("xw_agent_dir", C.c_int32),
     ]
 
 
@@ -79,6 +79,9 @@ _SIGS = [
     ("xwb_get_env_obs", C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_size_t]),
     ("xwb_get_env_grid", C.c_int, [_vp, C.c_int32, _vp, _vp]),
     ("xwb_xw_load_map", C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    ("xwb_xw_set_agent_dir", C.c_int, [_vp, C.c_int32, C.c_int32]),
+    ("xwb_xw_set_goal_pose", C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
+    ("xwb_xw_refresh_obs", C.c_int, [_vp, C.c_int32]),
     ("xwb_xw_load_map_task", C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     ("xwb_race_set_car", C.c_int, [_vp, C.c_int32, C.c_float, C.c_float, C.c_float]),
     ("xwb_get_state_packet", C.c_int, [_vp, C.c_int32, C.c_float, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
