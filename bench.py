@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the batched XWorld simulator on N MI355X (one process per GPU).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload xworld7|xworld7_f32|xworld8|xworld11|simple_game|simple_race]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload xworld7|xworld7_f32|xworld7_ego3|xworld8|xworld11|simple_game|simple_race]
 
 N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -34,6 +34,7 @@ WORKLOADS = {
     # name: (game, opts, envs per GPU, algorithmic bytes per env-step, bytes per env per render launch)
     "xworld7": ("xworld", {"max_dim": 7, "num_blocks": 16, "color": True}, 32768),
     "xworld7_f32": ("xworld", {"max_dim": 7, "num_blocks": 16, "color": True, "obs_format": "float32"}, 32768),
+    "xworld7_ego3": ("xworld", {"max_dim": 7, "num_blocks": 16, "color": True, "visible_radius": 3}, 32768),
     "xworld8": ("xworld", {"color": True}, 32768),
     "xworld11": ("xworld", {"max_dim": 11, "num_blocks": 30, "color": True}, 32768),
     "simple_game": ("simple_game", {"array_size": 64}, 65536),
@@ -62,6 +63,11 @@ def algorithmic_bytes(workload, sim):
         return 57, 57, "race_kernel"
     d = sim.cfg.max_dim
     c = sim.screen_dims[2]
+    if sim.cfg.visible_radius:
+        # egocentric: the frame is (r * (84 / r))^2 pixels; the render is compute-bound (16 view-pixel evaluations per
+        # output pixel), its algorithmic bytes are the frame written + the grid read
+        obs = c * sim.screen_dims[0] * sim.screen_dims[1]
+        return 33 + 2 * d * d + obs, 2 * d * d + obs, "xw_render_ego_kernel"
     obs = c * 144 * d * d * (4 if sim.obs_is_float else 1)      # float32 variant: obs term x 4
     return 33 + 2 * d * d + obs, 2 * d * d + obs, "xw_render_all_kernel"
 
@@ -101,7 +107,7 @@ def cpu_baseline(workload, seconds_target=12.0):
             d = sim_opts.get("max_dim", 8)
             pal = O.Palette(O.NAV_SUBTREES)
             cfg = O.xw_cfg(map_kind=0, max_dim=d, dim=d, num_goals=4, num_blocks=sim_opts.get("num_blocks", 16),
-                           color=1, seed=0xC0FFEE, tasks=[0, 1, 2, 3, 4])
+                           color=1, seed=0xC0FFEE, tasks=[0, 1, 2, 3, 4], visible_radius=sim_opts.get("visible_radius", 0))
             O.xw_rollout(n, cfg, pal, steps, 0x5EED, render=True)
         dt = time.perf_counter() - t0
         t_used += dt

@@ -144,12 +144,12 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
                     // -> correct, else wrong.  Between: any reached goal is wrong.  Direction: (direction(g, referent,
                     // agent.yaw), near) is evaluated now, the yaw being the current heading.
                     bool good = kind != TASK_BETWEEN && (hit & CELL_TARGET_BIT);
-                    if (kind == TASK_DIRECTION) {
+                    if (kind == TASK_DIRECTION && target >= 0) {        // (a replayed map may carry the bits only)
                         const int rc = target & 0xff, word = (target >> 8) & 7;
                         const int v2x = rc % D - hit_cell % D, v2y = rc / D - hit_cell / D;
                         const int cs = vx * v2x + vy * v2y, sn = vy * v2x - vx * v2y;
                         const int dirw = cs > 0 ? DIR_FRONT : (cs < 0 ? DIR_BEHIND : (sn > 0 ? DIR_RIGHT : DIR_LEFT));
-                        good = target >= 0 && v2x * v2x + v2y * v2y == 1 && dirw == word;
+                        good = v2x * v2x + v2y * v2y == 1 && dirw == word;
                     }
                     if (good) { event = EV_CORRECT; rew += 1.0; }
                     else { event = EV_WRONG; rew += -1.0; }
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
             const uint4 v = xw_expand_chunk<DIM_T, CH, ES>(p.atlas, s_grid, cc, D);
             xw_store_chunk(frame0, cc, cpf, ctx, 2, v);
         }
-        if (threadIdx.x == 0) p.fresh[e] = 0;
+        if (threadIdx.x == 0) { p.fresh[e] = 0; if (p.auto_reset == 2) p.done[e] = 0; }
     }
 }
 

@@ -32,36 +32,22 @@ namespace {
 struct EgoCell { uint8_t kind; uint8_t aux; uint16_t icon; };       // kind: 0 black, 1 white, 2 block icon, 3 agent (aux = heading), 4 goal (aux = slot)
 
 struct EgoCtx {
-    const uint8_t *atlas64;
+    const uint32_t *atlas4;      // [n_icons * 4096 + 2] pixels B | G << 8 | R << 16; the last two are white and black
     const EgoCell *cells;        // LDS, r * r
-    const double *warp;          // LDS, [slot][6]
     int r, S, dir;
+    uint32_t white, black;       // pixel indices of the two constant pixels
 };
 
-__device__ __forceinline__ void icon_px(const uint8_t *atlas64, int icon, int x, int y, int &b, int &g, int &rr) {
-    const uint8_t *q = atlas64 + (((size_t)icon * 64 + y) * 64 + x) * 3;
-    b = q[0]; g = q[1]; rr = q[2];
-}
-
-// one pixel of the rotated view: BGR
-__device__ __forceinline__ void view_px(const EgoCtx &c, int vy, int vx, int &b, int &g, int &rr) {
-    // undo cv::warpAffine(view, rot(centre S/2, 90 + yaw deg)): quarter turns are exact integer maps; the source index S
-    // falls outside, which leaves one black row / column (borderValue 0)
-    const int S = c.S;
-    int sx, sy;
-    switch (c.dir) {
-        case 3: sx = vx; sy = vy; break;                   // heading up: 0 deg
-        case 0: sx = S - vy; sy = vx; break;               // right: 90 deg
-        case 1: sx = S - vx; sy = S - vy; break;           // down: 180 deg
-        default: sx = vy; sy = S - vx; break;              // left: 270 deg
-    }
-    b = g = rr = 0;
-    if ((unsigned)sx >= (unsigned)S || (unsigned)sy >= (unsigned)S) return;
+// Where one pixel of the rotated view comes from: an index into atlas4, or (goal cells) into this env's warped goal
+// images, which xw_warp_goals_kernel renders once per episode.  sx / sy are the un-rotated view coordinates.
+__device__ __forceinline__ uint32_t view_idx(const EgoCtx &c, int sx, int sy, bool &goal) {
+    goal = false;
+    if ((unsigned)sx >= (unsigned)c.S || (unsigned)sy >= (unsigned)c.S) return c.black;   // border row / column of the rotation
     const EgoCell cell = c.cells[(sy >> 6) * c.r + (sx >> 6)];
     const int px = sx & 63, py = sy & 63;
-    if (cell.kind == 0) return;
-    if (cell.kind == 1) { b = g = rr = 255; return; }
-    if (cell.kind == 2) { icon_px(c.atlas64, cell.icon, px, py, b, g, rr); return; }
+    if (cell.kind == 0) return c.black;
+    if (cell.kind == 1) return c.white;
+    if (cell.kind == 2) return (uint32_t)cell.icon * 4096u + (uint32_t)(py * 64 + px);
     if (cell.kind == 3) {
         // XItem::get_item_image for the agent: rotation by 90 - yaw deg about (32, 32), border white
         int ix, iy;
@@ -71,67 +57,39 @@ __device__ __forceinline__ void view_px(const EgoCtx &c, int vy, int vx, int &b,
             case 3: ix = 64 - px; iy = 64 - py; break;     // up: 180 deg
             default: ix = py; iy = 64 - px; break;         // left: -90 deg
         }
-        if ((unsigned)ix >= 64u || (unsigned)iy >= 64u) { b = g = rr = 255; return; }
-        icon_px(c.atlas64, cell.icon, ix, iy, b, g, rr);
-        return;
+        if ((unsigned)ix >= 64u || (unsigned)iy >= 64u) return c.white;
+        return (uint32_t)cell.icon * 4096u + (uint32_t)(iy * 64 + ix);
     }
-    // goal: cv::warpAffine with the stored inverse matrix, INTER_LINEAR, BORDER_CONSTANT white
-    const double *M = c.warp + cell.aux * 6;
-    const int X0 = __double2int_rn((M[1] * py + M[2]) * 1024) + 16, Y0 = __double2int_rn((M[4] * py + M[5]) * 1024) + 16;
-    const int X = (X0 + __double2int_rn(M[0] * px * 1024)) >> 5, Y = (Y0 + __double2int_rn(M[3] * px * 1024)) >> 5;
-    const int ix = X >> 5, iy = Y >> 5, fx = X & 31, fy = Y & 31;
-    if (ix >= 64 || ix + 1 < 0 || iy >= 64 || iy + 1 < 0) { b = g = rr = 255; return; }
-    int w0 = (32 - fx) * (32 - fy) * 32, w1 = fx * (32 - fy) * 32, w2 = (32 - fx) * fy * 32, w3 = fx * fy * 32;
-    if (w0 == 32768) { w0 = 32767; w3 = 1; }               // BilinearTab_i: saturated entry and its compensation
-    int pb[4], pg[4], pr[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int qx = ix + (k & 1), qy = iy + (k >> 1);
-        if ((unsigned)qx < 64u && (unsigned)qy < 64u) icon_px(c.atlas64, cell.icon, qx, qy, pb[k], pg[k], pr[k]);
-        else pb[k] = pg[k] = pr[k] = 255;
-    }
-    b = (pb[0] * w0 + pb[1] * w1 + pb[2] * w2 + pb[3] * w3 + (1 << 14)) >> 15;
-    g = (pg[0] * w0 + pg[1] * w1 + pg[2] * w2 + pg[3] * w3 + (1 << 14)) >> 15;
-    rr = (pr[0] * w0 + pr[1] * w1 + pr[2] * w2 + pr[3] * w3 + (1 << 14)) >> 15;
+    goal = true;
+    return (uint32_t)cell.aux * 4096u + (uint32_t)(py * 64 + px);
 }
 
-// cv::resize INTER_LINEAR on 8-bit data, one output pixel: HResizeLinear (11-bit) then VResizeLinear<uchar>
+// cv::resize INTER_LINEAR on 8-bit data, one output value: HResizeLinear (11-bit) then VResizeLinear<uchar>
 __device__ __forceinline__ int vresize(int b0, int h0, int b1, int h1) {
     return ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
-}
-
-// one pixel of the intermediate (canvas-sized) image
-__device__ __forceinline__ void mid_px(const EgoCtx &c, const EgoTap &ty, const EgoTap &tx, int &b, int &g, int &rr) {
-    int hb[2], hg[2], hr[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int row = k ? ty.s1 : ty.s0;
-        int b0, g0, r0, b1, g1, r1;
-        view_px(c, row, tx.s0, b0, g0, r0);
-        if (tx.s1 != tx.s0) view_px(c, row, tx.s1, b1, g1, r1); else { b1 = b0; g1 = g0; r1 = r0; }
-        hb[k] = b0 * tx.w0 + b1 * tx.w1; hg[k] = g0 * tx.w0 + g1 * tx.w1; hr[k] = r0 * tx.w0 + r1 * tx.w1;
-    }
-    b = vresize(ty.w0, hb[0], ty.w1, hb[1]);
-    g = vresize(ty.w0, hg[0], ty.w1, hg[1]);
-    rr = vresize(ty.w0, hr[0], ty.w1, hr[1]);
 }
 
 }  // namespace
 
 // MODE 0: every env; 1: the compacted done list; 2: every env whose done code is 0 (step_autoreset)
 template <int CH, int MODE>
-__global__ __launch_bounds__(256) void xw_render_ego_kernel(XwParams p, const uint8_t *atlas64, const EgoTap *tap_h1,
+__global__ __launch_bounds__(256) void xw_render_ego_kernel(XwParams p, const uint32_t *atlas4, const EgoTap *tap_h1,
                                                             const EgoTap *tap_v1, const EgoTap *tap_h2, const EgoTap *tap_v2,
                                                             const int32_t *count_now) {
     extern __shared__ uint4 smem4[];
     const int r = p.visible_radius, S = 64 * r, D = p.max_dim, O = p.out_dim;
     uint8_t *s_frame = reinterpret_cast<uint8_t *>(smem4);                       // CH * O * O, planar
-    double *s_warp = reinterpret_cast<double *>(s_frame + ((CH * O * O + 15) & ~15));
-    EgoCell *s_cells = reinterpret_cast<EgoCell *>(s_warp + XW_MAX_GOALS * 6);
+    EgoCell *s_cells = reinterpret_cast<EgoCell *>(s_frame + ((CH * O * O + 15) & ~15));
     uint8_t *s_shadow = reinterpret_cast<uint8_t *>(s_cells + r * r);
     uint8_t *s_ray = s_shadow + r * r;
     uint8_t *s_gc = s_ray + ((r + 3) & ~3);
-    __shared__ int s_geo[4];
+    // composed taps of one output row / column: the two intermediate indices' taps and the output tap (static: O <= 84)
+    __shared__ EgoTap s_row[84][3], s_col[84][3];
+    for (int i = threadIdx.x; i < O; i += 256) {
+        const EgoTap ty = tap_v2[i], tx = tap_h2[i];
+        s_row[i][0] = tap_v1[ty.s0]; s_row[i][1] = tap_v1[ty.s1]; s_row[i][2] = ty;
+        s_col[i][0] = tap_h1[tx.s0]; s_col[i][1] = tap_h1[tx.s1]; s_col[i][2] = tx;
+    }
     const int tid = threadIdx.x;
     const int cells = D * D;
     const int cpf = CH * O * O / 16;
@@ -144,7 +102,6 @@ __global__ __launch_bounds__(256) void xw_render_ego_kernel(XwParams p, const ui
         const int dir = p.agent_dir[e];
         __syncthreads();
         if (tid < XW_MAX_GOALS) s_gc[tid] = p.goal_cells[(size_t)e * XW_MAX_GOALS + tid];
-        if (tid < XW_MAX_GOALS * 6) s_warp[tid] = p.goal_warp[(size_t)e * XW_MAX_GOALS * 6 + tid];
         auto is_block = [&](int x, int y) {
             if ((unsigned)x >= (unsigned)D || (unsigned)y >= (unsigned)D) return false;
             const int code = grid[y * D + x] & CELL_ICON_MASK;
@@ -203,34 +160,118 @@ __global__ __launch_bounds__(256) void xw_render_ego_kernel(XwParams p, const ui
             s_cells[k] = c;
         }
         __syncthreads();
-        EgoCtx ctx{atlas64, s_cells, s_warp, r, S, dir};
+        const uint32_t n_px = (uint32_t)p.n_icons * 4096u;
+        EgoCtx ctx{atlas4, s_cells, r, S, dir, n_px, n_px + 1};
+        const uint32_t *gimg = p.goal_img + (size_t)e * p.num_goals * 4096;
         for (int o = tid; o < O * O; o += 256) {
             const int oy = o / O, ox = o - oy * O;
-            const EgoTap ty = tap_v2[oy], tx = tap_h2[ox];
-            int hb[2], hg[2], hr[2];
+            // the 2 x 2 intermediate pixels this output pixel blends, and the 4 x 4 view pixels behind them
+            const EgoTap ty = s_row[oy][2], tx = s_col[ox][2];
+            const EgoTap my[2] = {s_row[oy][0], s_row[oy][1]}, mx[2] = {s_col[ox][0], s_col[ox][1]};
+            const int R[4] = {my[0].s0, my[0].s1, my[1].s0, my[1].s1}, C[4] = {mx[0].s0, mx[0].s1, mx[1].s0, mx[1].s1};
+            // cv::warpAffine(view, rot(centre S/2, 90 + yaw deg)) undone: quarter turns are exact integer maps, the source
+            // index S falls outside and leaves one black row / column (borderValue 0)
+            int sxs[16], sys[16];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const EgoTap my = tap_v1[k ? ty.s1 : ty.s0];
-                int b0, g0, r0, b1, g1, r1;
-                mid_px(ctx, my, tap_h1[tx.s0], b0, g0, r0);
-                if (tx.s1 != tx.s0) mid_px(ctx, my, tap_h1[tx.s1], b1, g1, r1); else { b1 = b0; g1 = g0; r1 = r0; }
-                hb[k] = b0 * tx.w0 + b1 * tx.w1; hg[k] = g0 * tx.w0 + g1 * tx.w1; hr[k] = r0 * tx.w0 + r1 * tx.w1;
+            for (int k = 0; k < 16; ++k) {
+                const int vy = R[k >> 2], vx = C[k & 3];
+                sxs[k] = dir == 3 ? vx : (dir == 0 ? S - vy : (dir == 1 ? S - vx : vy));
+                sys[k] = dir == 3 ? vy : (dir == 0 ? vx : (dir == 1 ? S - vy : S - vx));
             }
-            const int b = vresize(ty.w0, hb[0], ty.w1, hb[1]);
-            const int g = vresize(ty.w0, hg[0], ty.w1, hg[1]);
-            const int rr = vresize(ty.w0, hr[0], ty.w1, hr[1]);
+            const uint32_t *src[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                bool gl;
+                const uint32_t ix = view_idx(ctx, sxs[k], sys[k], gl);
+                src[k] = (gl ? gimg : atlas4) + ix;
+            }
+            uint32_t v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = *src[k];
+            int out[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                int hB[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {              // intermediate row a
+                    int A[2];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {          // intermediate column b
+                        const int h0 = (int)((v[(2 * a) * 4 + 2 * b] >> (8 * ch)) & 255u) * mx[b].w0 +
+                                       (int)((v[(2 * a) * 4 + 2 * b + 1] >> (8 * ch)) & 255u) * mx[b].w1;
+                        const int h1 = (int)((v[(2 * a + 1) * 4 + 2 * b] >> (8 * ch)) & 255u) * mx[b].w0 +
+                                       (int)((v[(2 * a + 1) * 4 + 2 * b + 1] >> (8 * ch)) & 255u) * mx[b].w1;
+                        A[b] = vresize(my[a].w0, h0, my[a].w1, h1);
+                    }
+                    hB[a] = A[0] * tx.w0 + A[1] * tx.w1;
+                }
+                out[ch] = vresize(ty.w0, hB[0], ty.w1, hB[1]);
+            }
             if (CH == 3) {
-                s_frame[o] = (uint8_t)b; s_frame[O * O + o] = (uint8_t)g; s_frame[2 * O * O + o] = (uint8_t)rr;
+                s_frame[o] = (uint8_t)out[0]; s_frame[O * O + o] = (uint8_t)out[1]; s_frame[2 * O * O + o] = (uint8_t)out[2];
             } else {
-                s_frame[o] = (uint8_t)((b * 1868 + g * 9617 + rr * 4899 + (1 << 13)) >> 14);   // cvtColor BGR2GRAY
+                s_frame[o] = (uint8_t)((out[0] * 1868 + out[1] * 9617 + out[2] * 4899 + (1 << 13)) >> 14);   // cvtColor BGR2GRAY
             }
         }
         __syncthreads();
         const int flag = MODE == 1 ? 2 : p.fresh[e];
         uint4 *frame0 = reinterpret_cast<uint4 *>(p.obs) + (size_t)e * p.context * cpf;
         for (int cc = tid; cc < cpf; cc += 256) xw_store_chunk(frame0, cc, cpf, p.context, p.context > 1 ? flag : 1, smem4[cc]);
-        if (MODE == 1 && tid == 0) p.fresh[e] = 0;
+        if (MODE == 1 && tid == 0) { p.fresh[e] = 0; if (p.auto_reset == 2) p.done[e] = 0; }
     }
+}
+
+// The warped 64x64 image of every goal of the listed envs (XItem::get_item_image, xitem.cpp:46-60): cv::warpAffine with
+// the goal's inverse matrix, INTER_LINEAR, BORDER_CONSTANT white.  A goal keeps its pose for the whole episode, so this
+// runs once per reset (~0.4 % of the envs per step) and the render reads goal pixels like any other icon.
+template <bool LIST>
+__global__ __launch_bounds__(256) void xw_warp_goals_kernel(XwParams p, const uint32_t *atlas4, const int32_t *count_now) {
+    const int G = p.num_goals, D = p.max_dim;
+    const int n_items = (LIST ? *count_now : p.n) * G;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int ei = item / G, slot = item - ei * G;
+        const int e = LIST ? p.done_list[ei] : ei;
+        const int cell = p.goal_cells[(size_t)e * XW_MAX_GOALS + slot];
+        uint32_t *out = p.goal_img + ((size_t)e * G + slot) * 4096;
+        if (cell == 0xff) continue;
+        const int icon = (int)(p.grid[(size_t)e * D * D + cell] & CELL_ICON_MASK) - 1;
+        if (icon < 0) continue;
+        const double *M = p.goal_warp + ((size_t)e * XW_MAX_GOALS + slot) * 6;
+        const double m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3], m4 = M[4], m5 = M[5];
+        for (int q = threadIdx.x; q < 4096; q += 256) {
+            const int px = q & 63, py = q >> 6;
+            const int X0 = __double2int_rn((m1 * py + m2) * 1024) + 16, Y0 = __double2int_rn((m4 * py + m5) * 1024) + 16;
+            const int X = (X0 + __double2int_rn(m0 * px * 1024)) >> 5, Y = (Y0 + __double2int_rn(m3 * px * 1024)) >> 5;
+            const int ix = X >> 5, iy = Y >> 5, fx = X & 31, fy = Y & 31;
+            uint32_t res = 0xffffffu;
+            if (!(ix >= 64 || ix + 1 < 0 || iy >= 64 || iy + 1 < 0)) {
+                int w[4] = {(32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32};
+                if (w[0] == 32768) { w[0] = 32767; w[3] = 1; }     // BilinearTab_i: saturated entry and its compensation
+                uint32_t t[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int qx = ix + (k & 1), qy = iy + (k >> 1);
+                    t[k] = ((unsigned)qx < 64u && (unsigned)qy < 64u) ? atlas4[(uint32_t)icon * 4096u + (uint32_t)(qy * 64 + qx)] : 0xffffffu;
+                }
+                res = 0;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    int acc = 1 << 14;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc += (int)((t[k] >> (8 * ch)) & 255u) * w[k];
+                    res |= (uint32_t)(acc >> 15) << (8 * ch);
+                }
+            }
+            out[q] = res;
+        }
+    }
+}
+
+hipError_t launch_xw_warp_goals(const XwParams &p, bool list, hipStream_t s) {
+    const uint32_t *a4 = reinterpret_cast<const uint32_t *>(p.atlas64);
+    if (list) hipLaunchKernelGGL((xw_warp_goals_kernel<true>), dim3(1024), dim3(256), 0, s, p, a4, (const int32_t *)p.done_count);
+    else hipLaunchKernelGGL((xw_warp_goals_kernel<false>), dim3(8192), dim3(256), 0, s, p, a4, (const int32_t *)p.done_count);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------- host side ----
@@ -281,11 +322,11 @@ hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s) {
     const int r = p.visible_radius, O = p.out_dim, P = 64 * p.max_dim;
     const EgoTap *h1 = reinterpret_cast<const EgoTap *>(p.ego_taps), *v1 = h1 + P, *h2 = v1 + P, *v2 = h2 + O;
     const int CH = p.channels;
-    const size_t lds = (size_t)((CH * O * O + 15) & ~15) + XW_MAX_GOALS * 6 * sizeof(double) + (size_t)r * r * (sizeof(EgoCell) + 1) +
+    const size_t lds = (size_t)((CH * O * O + 15) & ~15) + (size_t)r * r * (sizeof(EgoCell) + 1) +
                        (size_t)((r + 3) & ~3) + XW_MAX_GOALS + 16;
     const unsigned blocks = indexed == 1 ? 2048u : (unsigned)(p.n < 16384 ? p.n : 16384);
     const int32_t *cnt = (const int32_t *)p.done_count;
-#define EGO_LAUNCH(CHV, MODEV) hipLaunchKernelGGL((xw_render_ego_kernel<CHV, MODEV>), dim3(blocks), dim3(256), lds, s, p, p.atlas64, h1, v1, h2, v2, cnt)
+#define EGO_LAUNCH(CHV, MODEV) hipLaunchKernelGGL((xw_render_ego_kernel<CHV, MODEV>), dim3(blocks), dim3(256), lds, s, p, reinterpret_cast<const uint32_t *>(p.atlas64), h1, v1, h2, v2, cnt)
     if (CH == 3) { if (indexed == 1) EGO_LAUNCH(3, 1); else if (indexed == 2) EGO_LAUNCH(3, 2); else EGO_LAUNCH(3, 0); }
     else { if (indexed == 1) EGO_LAUNCH(1, 1); else if (indexed == 2) EGO_LAUNCH(1, 2); else EGO_LAUNCH(1, 0); }
 #undef EGO_LAUNCH

@@ -707,7 +707,11 @@ hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s) {
     if (cells <= 64) launch_reset_nw<1>(p, mode, grid, lds, s);
     else if (cells <= 128) launch_reset_nw<2>(p, mode, grid, lds, s);
     else launch_reset_nw<4>(p, mode, grid, lds, s);
-    return hipGetLastError();
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    // egocentric: the goals of the reset envs got new poses; render their warped images once
+    if (p.visible_radius) return launch_xw_warp_goals(p, mode != MODE_RESET_ALL, s);
+    return hipSuccess;
 }
 
 }  // namespace xwb

@@ -76,6 +76,7 @@ struct xwb_sim {
     uint8_t *d_fresh = nullptr, *d_icon_type = nullptr, *d_icon_colored = nullptr, *d_goal_cells = nullptr;
     uint32_t *d_cand2d = nullptr;
     uint8_t *d_agent_dir = nullptr, *d_atlas64 = nullptr;
+    uint32_t *d_goal_img = nullptr;
     EgoTap *d_ego_taps = nullptr;
     double *d_goal_warp = nullptr;
     int16_t *d_icon_name = nullptr, *d_name_first = nullptr, *d_name_variants = nullptr;
@@ -265,8 +266,13 @@ int xw_setup(xwb_sim *s) {
     if ((rc = dev_alloc(s, &s->d_agent_dir, n, 1))) return rc;                 // heading "down": yaw 1.5707963
     if (c.visible_radius > 0) {
         if ((rc = dev_alloc(s, &s->d_goal_warp, (size_t)n * XW_MAX_GOALS * 6))) return rc;
-        if ((rc = dev_alloc(s, &s->d_atlas64, (size_t)c.n_icons * 64 * 64 * 3))) return rc;
-        HIP_TRY(hipMemcpy(s->d_atlas64, c.icons64, (size_t)c.n_icons * 64 * 64 * 3, hipMemcpyHostToDevice));
+        if ((rc = dev_alloc(s, &s->d_goal_img, (size_t)n * c.num_goals * 4096))) return rc;
+        const size_t npx = (size_t)c.n_icons * 64 * 64;
+        std::vector<uint8_t> a4((npx + 2) * 4, 0);
+        for (size_t i = 0; i < npx; ++i) for (int k = 0; k < 3; ++k) a4[i * 4 + k] = c.icons64[i * 3 + k];
+        for (int k = 0; k < 3; ++k) a4[npx * 4 + k] = 255;            // white pixel, then a black one
+        if ((rc = dev_alloc(s, &s->d_atlas64, a4.size()))) return rc;
+        HIP_TRY(hipMemcpy(s->d_atlas64, a4.data(), a4.size(), hipMemcpyHostToDevice));
         HIP_TRY(xw_ego_tables(c.visible_radius, c.max_dim, s->out_h, &s->d_ego_taps));
         s->allocs.push_back(s->d_ego_taps);
     }
@@ -307,7 +313,7 @@ int xw_setup(xwb_sim *s) {
     p.group2d = c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET;
     p.goal_cells = s->d_goal_cells; p.cand2d = s->d_cand2d; p.icon_colored = s->d_icon_colored;
     p.visible_radius = c.visible_radius; p.out_dim = s->out_h;
-    p.agent_dir = s->d_agent_dir; p.goal_warp = s->d_goal_warp; p.atlas64 = s->d_atlas64; p.ego_taps = s->d_ego_taps;
+    p.agent_dir = s->d_agent_dir; p.goal_warp = s->d_goal_warp; p.atlas64 = s->d_atlas64; p.ego_taps = s->d_ego_taps; p.goal_img = s->d_goal_img;
     for (int i = 0; i < 8; ++i) p.tasks[i] = i < c.n_tasks ? c.tasks[i] : 0;
     p.policy_seed = c.policy_seed; p.env_gid0 = c.env_gid0; p.policy_step = 0; p.seed = c.seed;
     p.icon_type = s->d_icon_type; p.icon_name = s->d_icon_name;
@@ -399,7 +405,10 @@ XwParams xw_params(xwb_sim *s) {
 // regenerated; those envs' frames are rewritten in full by render(list) below, which waits for both.
 int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t st, bool beside_render = false) {
     XwParams p = xw_params(s);
-    p.auto_reset = keep_done ? 1 : 0;
+    // 0: the reset kernel clears the done codes; 1: they are kept (step_autoreset); 2: the reset runs on the side stream
+    // beside work already queued on `st` that may still read this step's codes -> the list render, which is ordered
+    // on `st` after that work, clears them instead
+    p.auto_reset = keep_done ? 1 : (beside_render && render ? 2 : 0);
     hipStream_t rs = beside_render ? s->side : st;
     if (beside_render) HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
     timer_begin(s, s->t_reset, rs);
@@ -893,6 +902,7 @@ int xwb_xw_load_map_task(xwb_sim *s, int32_t env, const uint16_t *grid_host, int
     int32_t cnt = 1;
     HIP_TRY(hipMemcpy(p.done_list, &env, 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p.done_count, &cnt, 4, hipMemcpyHostToDevice));
+    if (p.visible_radius) HIP_TRY(launch_xw_warp_goals(p, true, nullptr));
     HIP_TRY(launch_xw_render(p, 1, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(p.done_count, 0, 4));
@@ -964,6 +974,7 @@ int xwb_xw_refresh_obs(xwb_sim *s, int32_t env) {
     HIP_TRY(hipMemcpy(p.done_list, &env, 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p.done_count, &cnt, 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_fresh + env, &two, 1, hipMemcpyHostToDevice));
+    if (p.visible_radius) HIP_TRY(launch_xw_warp_goals(p, true, nullptr));
     HIP_TRY(launch_xw_render(p, 1, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(p.done_count, 0, 4));

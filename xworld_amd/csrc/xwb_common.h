@@ -155,7 +155,9 @@ struct XwParams {
     uint8_t *goal_cells;         // [n][XW_MAX_GOALS] cell of goal slot i (entity order), 0xff = none
     uint8_t *agent_dir;          // [n] egocentric heading: 0 right, 1 down, 2 left, 3 up (XItem::get_item_facing_dir)
     double *goal_warp;           // [n][XW_MAX_GOALS][6] egocentric: inverse affine map of the goal's icon warp
-    const uint8_t *atlas64;      // egocentric: [n_icons][64][64][3] BGR item images (XItem::item_size_ = 64)
+    const uint8_t *atlas64;      // egocentric: [n_icons * 4096 + 2] x 4 bytes (B, G, R, 0): the 64x64 item images
+                                 // (XItem::item_size_ = 64), then one white and one black pixel
+    uint32_t *goal_img;          // egocentric: [n][num_goals][64 * 64] warped goal images (B | G << 8 | R << 16)
     const void *ego_taps;        // egocentric: cv::resize taps of the two resizes (kernels_xworld_ego.hip)
     uint32_t *cand2d;            // [n] goal slots the agent can reach, blocks as the only obstacles: bits 0..15
                                  //     any goal (XWorldNavTarget), bits 16..31 coloured goals (XWorldNavColorTarget)
@@ -183,6 +185,7 @@ hipError_t launch_xw_compact(const XwParams &p, int mode, hipStream_t s);
 // indexed: 0 = every env, 1 = the compacted done list, 2 = every env whose done code is 0 (the rest follows as a list)
 hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s);
 hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s);
+hipError_t launch_xw_warp_goals(const XwParams &p, bool list, hipStream_t s);
 struct EgoTap;
 hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out);
 
