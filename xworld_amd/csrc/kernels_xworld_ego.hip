@@ -29,44 +29,97 @@ struct EgoTap { int16_t s0, s1, w0, w1; };        // cv::resize: source indices 
 
 namespace {
 
-struct EgoCell { uint8_t kind; uint8_t aux; uint16_t icon; };       // kind: 0 black, 1 white, 2 block icon, 3 agent (aux = heading), 4 goal (aux = slot)
-
-struct EgoCtx {
-    const uint32_t *atlas4;      // [n_icons * 4096 + 2] pixels B | G << 8 | R << 16; the last two are white and black
-    const EgoCell *cells;        // LDS, r * r
-    int r, S, dir;
-    uint32_t white, black;       // pixel indices of the two constant pixels
+// What one cell of the view shows: a 64 x 64 image (block icon, this env's warped goal image, the agent icon turned for
+// its heading -- the three turned copies of every agent icon are appended to the atlas at create time) or one constant
+// pixel (mask = 0).  The table makes the per-pixel lookup branch-free: one 16-byte LDS read, an AND and an add.
+struct EgoCell {
+    const uint32_t *img;
+    int mask;                    // -1: index the image; 0: a constant pixel
+    int pad;
 };
 
-// Where one pixel of the rotated view comes from: an index into atlas4, or (goal cells) into this env's warped goal
-// images, which xw_warp_goals_kernel renders once per episode.  sx / sy are the un-rotated view coordinates.
-__device__ __forceinline__ uint32_t view_idx(const EgoCtx &c, int sx, int sy, bool &goal) {
-    goal = false;
-    if ((unsigned)sx >= (unsigned)c.S || (unsigned)sy >= (unsigned)c.S) return c.black;   // border row / column of the rotation
-    const EgoCell cell = c.cells[(sy >> 6) * c.r + (sx >> 6)];
-    const int px = sx & 63, py = sy & 63;
-    if (cell.kind == 0) return c.black;
-    if (cell.kind == 1) return c.white;
-    if (cell.kind == 2) return (uint32_t)cell.icon * 4096u + (uint32_t)(py * 64 + px);
-    if (cell.kind == 3) {
-        // XItem::get_item_image for the agent: rotation by 90 - yaw deg about (32, 32), border white
-        int ix, iy;
-        switch (cell.aux) {
-            case 1: ix = px; iy = py; break;               // down: 0 deg
-            case 0: ix = 64 - py; iy = px; break;          // right: 90 deg
-            case 3: ix = 64 - px; iy = 64 - py; break;     // up: 180 deg
-            default: ix = py; iy = 64 - px; break;         // left: -90 deg
-        }
-        if ((unsigned)ix >= 64u || (unsigned)iy >= 64u) return c.white;
-        return (uint32_t)cell.icon * 4096u + (uint32_t)(iy * 64 + ix);
-    }
-    goal = true;
-    return (uint32_t)cell.aux * 4096u + (uint32_t)(py * 64 + px);
-}
+struct EgoCtx {
+    const EgoCell *cells;        // LDS, r * r
+    const uint32_t *white, *black;
+    int r, S;
+};
 
 // cv::resize INTER_LINEAR on 8-bit data, one output value: HResizeLinear (11-bit) then VResizeLinear<uchar>
 __device__ __forceinline__ int vresize(int b0, int h0, int b1, int h1) {
-    return ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    // operands < 2^24 and products < 2^31: v_mul_u32_u24 is exact and full rate
+    return (int)((((__umul24((unsigned)b0, (unsigned)(h0 >> 4))) >> 16) + ((__umul24((unsigned)b1, (unsigned)(h1 >> 4))) >> 16) + 2u) >> 2);
+}
+
+// All pixels of one frame.  DIR = the agent's heading: cv::warpAffine(view, rot(centre S/2, 90 + yaw deg)) is undone
+// per tap row / column -- quarter turns are exact integer maps, separable in x and y; the source index S falls outside
+// and leaves one black row / column (borderValue 0).
+template <int CH, int DIR>
+__device__ __forceinline__ void ego_pixels(const EgoCtx &c, const EgoTap (*s_row)[3], const EgoTap (*s_col)[3],
+                                           uint8_t *s_frame, int O, int tid) {
+    const int S = c.S;
+    for (int o = tid; o < O * O; o += 256) {
+        const int oy = o / O, ox = o - oy * O;
+        // the 2 x 2 intermediate pixels this output pixel blends, and the 4 x 4 view pixels behind them
+        const EgoTap ty = s_row[oy][2], tx = s_col[ox][2];
+        const EgoTap my[2] = {s_row[oy][0], s_row[oy][1]}, mx[2] = {s_col[ox][0], s_col[ox][1]};
+        const int R[4] = {my[0].s0, my[0].s1, my[1].s0, my[1].s1}, C[4] = {mx[0].s0, mx[0].s1, mx[1].s0, mx[1].s1};
+        // source coordinate contributed by a view row (vr) and by a view column (vc):
+        //   up (3): sx = vc, sy = vr;  right (0): sx = S - vr, sy = vc;  down (1): sx = S - vc, sy = S - vr;  left (2): sx = vr, sy = S - vc
+        int fr[4], fc[4];                                   // coordinate from the row index, from the column index
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fr[i] = (DIR == 3 || DIR == 2) ? R[i] : S - R[i];
+            fc[i] = (DIR == 3 || DIR == 0) ? C[i] : S - C[i];
+        }
+        // fr is sy for headings up / down and sx for right / left (and fc the other one)
+        constexpr bool ROW_IS_Y = DIR == 3 || DIR == 1;
+        int cr[4], cc[4], pr[4], pc[4];
+        bool okr[4], okc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            okr[i] = (unsigned)fr[i] < (unsigned)S; okc[i] = (unsigned)fc[i] < (unsigned)S;
+            cr[i] = ROW_IS_Y ? __mul24(fr[i] >> 6, c.r) : (fr[i] >> 6);
+            cc[i] = ROW_IS_Y ? (fc[i] >> 6) : __mul24(fc[i] >> 6, c.r);
+            pr[i] = fr[i] & 63; pc[i] = fc[i] & 63;
+        }
+        const uint32_t *src[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = k >> 2, j = k & 3;
+            const bool inview = okr[i] && okc[j];
+            const EgoCell cell = c.cells[inview ? cr[i] + cc[j] : 0];
+            const int px = ROW_IS_Y ? pc[j] : pr[i], py = ROW_IS_Y ? pr[i] : pc[j];
+            const uint32_t *q = cell.img + ((py * 64 + px) & cell.mask);
+            src[k] = inview ? q : c.black;
+        }
+        uint32_t v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = *src[k];
+        int out[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            int hB[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {                  // intermediate row a
+                int A[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {              // intermediate column b
+                    const int h0 = __mul24((int)((v[(2 * a) * 4 + 2 * b] >> (8 * ch)) & 255u), mx[b].w0) +
+                                   __mul24((int)((v[(2 * a) * 4 + 2 * b + 1] >> (8 * ch)) & 255u), mx[b].w1);
+                    const int h1 = __mul24((int)((v[(2 * a + 1) * 4 + 2 * b] >> (8 * ch)) & 255u), mx[b].w0) +
+                                   __mul24((int)((v[(2 * a + 1) * 4 + 2 * b + 1] >> (8 * ch)) & 255u), mx[b].w1);
+                    A[b] = vresize(my[a].w0, h0, my[a].w1, h1);
+                }
+                hB[a] = __mul24(A[0], tx.w0) + __mul24(A[1], tx.w1);
+            }
+            out[ch] = vresize(ty.w0, hB[0], ty.w1, hB[1]);
+        }
+        if (CH == 3) {
+            s_frame[o] = (uint8_t)out[0]; s_frame[O * O + o] = (uint8_t)out[1]; s_frame[2 * O * O + o] = (uint8_t)out[2];
+        } else {
+            s_frame[o] = (uint8_t)((out[0] * 1868 + out[1] * 9617 + out[2] * 4899 + (1 << 13)) >> 14);   // cvtColor BGR2GRAY
+        }
+    }
 }
 
 }  // namespace
@@ -138,80 +191,36 @@ __global__ __launch_bounds__(256) void xw_render_ego_kernel(XwParams p, const ui
             }
         }
         __syncthreads();
+        const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
+        const uint32_t *gimg = p.goal_img + (size_t)e * p.num_goals * 4096;
         for (int k = tid; k < r * r; k += 256) {                // what each view cell shows
             const int gx = x_st - r + k % r, gy = y_st - r + k / r;
-            EgoCell c{0, 0, 0};
+            EgoCell c{black, 0, 0};                             // outside the map, or in a wall's shadow
             if ((unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && !s_shadow[k]) {
                 const int code = grid[gy * D + gx] & CELL_ICON_MASK;
-                if (code == 0) c.kind = 1;
+                if (code == 0) c.img = white;
                 else {
-                    c.icon = (uint16_t)(code - 1);
                     const int t = p.icon_type[code - 1];
-                    if (t == 1) c.kind = 2;
-                    else if (t == 2) { c.kind = 3; c.aux = (uint8_t)dir; }
-                    else {
-                        c.kind = 4;
+                    c.img = atlas4 + (size_t)(code - 1) * 4096;
+                    c.mask = -1;
+                    if (t == 2) {                               // the agent: XItem::get_item_image turns its icon by 90 - yaw deg
+                        if (dir != 1) c.img = atlas4 + p.ego_agent_rot[code - 1] + (size_t)(dir == 0 ? 0 : (dir == 2 ? 1 : 2)) * 4096;
+                    } else if (t == 0) {
                         int slot = 0;
                         for (int i = 0; i < XW_MAX_GOALS; ++i) if (s_gc[i] == gy * D + gx) slot = i;
-                        c.aux = (uint8_t)slot;
+                        c.img = gimg + slot * 4096;
                     }
                 }
             }
             s_cells[k] = c;
         }
         __syncthreads();
-        const uint32_t n_px = (uint32_t)p.n_icons * 4096u;
-        EgoCtx ctx{atlas4, s_cells, r, S, dir, n_px, n_px + 1};
-        const uint32_t *gimg = p.goal_img + (size_t)e * p.num_goals * 4096;
-        for (int o = tid; o < O * O; o += 256) {
-            const int oy = o / O, ox = o - oy * O;
-            // the 2 x 2 intermediate pixels this output pixel blends, and the 4 x 4 view pixels behind them
-            const EgoTap ty = s_row[oy][2], tx = s_col[ox][2];
-            const EgoTap my[2] = {s_row[oy][0], s_row[oy][1]}, mx[2] = {s_col[ox][0], s_col[ox][1]};
-            const int R[4] = {my[0].s0, my[0].s1, my[1].s0, my[1].s1}, C[4] = {mx[0].s0, mx[0].s1, mx[1].s0, mx[1].s1};
-            // cv::warpAffine(view, rot(centre S/2, 90 + yaw deg)) undone: quarter turns are exact integer maps, the source
-            // index S falls outside and leaves one black row / column (borderValue 0)
-            int sxs[16], sys[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int vy = R[k >> 2], vx = C[k & 3];
-                sxs[k] = dir == 3 ? vx : (dir == 0 ? S - vy : (dir == 1 ? S - vx : vy));
-                sys[k] = dir == 3 ? vy : (dir == 0 ? vx : (dir == 1 ? S - vy : S - vx));
-            }
-            const uint32_t *src[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                bool gl;
-                const uint32_t ix = view_idx(ctx, sxs[k], sys[k], gl);
-                src[k] = (gl ? gimg : atlas4) + ix;
-            }
-            uint32_t v[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = *src[k];
-            int out[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                int hB[2];
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {              // intermediate row a
-                    int A[2];
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {          // intermediate column b
-                        const int h0 = (int)((v[(2 * a) * 4 + 2 * b] >> (8 * ch)) & 255u) * mx[b].w0 +
-                                       (int)((v[(2 * a) * 4 + 2 * b + 1] >> (8 * ch)) & 255u) * mx[b].w1;
-                        const int h1 = (int)((v[(2 * a + 1) * 4 + 2 * b] >> (8 * ch)) & 255u) * mx[b].w0 +
-                                       (int)((v[(2 * a + 1) * 4 + 2 * b + 1] >> (8 * ch)) & 255u) * mx[b].w1;
-                        A[b] = vresize(my[a].w0, h0, my[a].w1, h1);
-                    }
-                    hB[a] = A[0] * tx.w0 + A[1] * tx.w1;
-                }
-                out[ch] = vresize(ty.w0, hB[0], ty.w1, hB[1]);
-            }
-            if (CH == 3) {
-                s_frame[o] = (uint8_t)out[0]; s_frame[O * O + o] = (uint8_t)out[1]; s_frame[2 * O * O + o] = (uint8_t)out[2];
-            } else {
-                s_frame[o] = (uint8_t)((out[0] * 1868 + out[1] * 9617 + out[2] * 4899 + (1 << 13)) >> 14);   // cvtColor BGR2GRAY
-            }
+        EgoCtx ctx{s_cells, white, black, r, S};
+        switch (dir) {
+            case 0: ego_pixels<CH, 0>(ctx, s_row, s_col, s_frame, O, tid); break;
+            case 1: ego_pixels<CH, 1>(ctx, s_row, s_col, s_frame, O, tid); break;
+            case 2: ego_pixels<CH, 2>(ctx, s_row, s_col, s_frame, O, tid); break;
+            default: ego_pixels<CH, 3>(ctx, s_row, s_col, s_frame, O, tid); break;
         }
         __syncthreads();
         const int flag = MODE == 1 ? 2 : p.fresh[e];

@@ -76,7 +76,7 @@ struct xwb_sim {
     uint8_t *d_fresh = nullptr, *d_icon_type = nullptr, *d_icon_colored = nullptr, *d_goal_cells = nullptr;
     uint32_t *d_cand2d = nullptr;
     uint8_t *d_agent_dir = nullptr, *d_atlas64 = nullptr;
-    uint32_t *d_goal_img = nullptr;
+    uint32_t *d_goal_img = nullptr, *d_agent_rot = nullptr;
     EgoTap *d_ego_taps = nullptr;
     double *d_goal_warp = nullptr;
     int16_t *d_icon_name = nullptr, *d_name_first = nullptr, *d_name_variants = nullptr;
@@ -271,8 +271,25 @@ int xw_setup(xwb_sim *s) {
         std::vector<uint8_t> a4((npx + 2) * 4, 0);
         for (size_t i = 0; i < npx; ++i) for (int k = 0; k < 3; ++k) a4[i * 4 + k] = c.icons64[i * 3 + k];
         for (int k = 0; k < 3; ++k) a4[npx * 4 + k] = 255;            // white pixel, then a black one
+        // XItem::get_item_image turns the agent's icon by 90 - yaw degrees about (32, 32) with a white border: the three
+        // quarter turns are exact integer maps (source index 64 falls outside): heading right, left, up
+        std::vector<uint32_t> rot_off(c.n_icons, 0);
+        for (int ic = 0; ic < c.n_icons; ++ic) {
+            if (c.icon_type[ic] != XWB_ICON_AGENT) continue;
+            rot_off[ic] = (uint32_t)(a4.size() / 4);
+            for (int h = 0; h < 3; ++h)
+                for (int py = 0; py < 64; ++py)
+                    for (int px = 0; px < 64; ++px) {
+                        const int ix = h == 0 ? 64 - py : (h == 1 ? py : 64 - px), iy = h == 0 ? px : (h == 1 ? 64 - px : 64 - py);
+                        const bool in = ix >= 0 && ix < 64 && iy >= 0 && iy < 64;
+                        for (int k = 0; k < 3; ++k) a4.push_back(in ? c.icons64[(((size_t)ic * 64 + iy) * 64 + ix) * 3 + k] : 255);
+                        a4.push_back(0);
+                    }
+        }
         if ((rc = dev_alloc(s, &s->d_atlas64, a4.size()))) return rc;
         HIP_TRY(hipMemcpy(s->d_atlas64, a4.data(), a4.size(), hipMemcpyHostToDevice));
+        if ((rc = dev_alloc(s, &s->d_agent_rot, (size_t)c.n_icons))) return rc;
+        HIP_TRY(hipMemcpy(s->d_agent_rot, rot_off.data(), rot_off.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(xw_ego_tables(c.visible_radius, c.max_dim, s->out_h, &s->d_ego_taps));
         s->allocs.push_back(s->d_ego_taps);
     }
@@ -313,7 +330,7 @@ int xw_setup(xwb_sim *s) {
     p.group2d = c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET;
     p.goal_cells = s->d_goal_cells; p.cand2d = s->d_cand2d; p.icon_colored = s->d_icon_colored;
     p.visible_radius = c.visible_radius; p.out_dim = s->out_h;
-    p.agent_dir = s->d_agent_dir; p.goal_warp = s->d_goal_warp; p.atlas64 = s->d_atlas64; p.ego_taps = s->d_ego_taps; p.goal_img = s->d_goal_img;
+    p.agent_dir = s->d_agent_dir; p.goal_warp = s->d_goal_warp; p.atlas64 = s->d_atlas64; p.ego_taps = s->d_ego_taps; p.goal_img = s->d_goal_img; p.ego_agent_rot = s->d_agent_rot;
     for (int i = 0; i < 8; ++i) p.tasks[i] = i < c.n_tasks ? c.tasks[i] : 0;
     p.policy_seed = c.policy_seed; p.env_gid0 = c.env_gid0; p.policy_step = 0; p.seed = c.seed;
     p.icon_type = s->d_icon_type; p.icon_name = s->d_icon_name;

@@ -155,8 +155,10 @@ struct XwParams {
     uint8_t *goal_cells;         // [n][XW_MAX_GOALS] cell of goal slot i (entity order), 0xff = none
     uint8_t *agent_dir;          // [n] egocentric heading: 0 right, 1 down, 2 left, 3 up (XItem::get_item_facing_dir)
     double *goal_warp;           // [n][XW_MAX_GOALS][6] egocentric: inverse affine map of the goal's icon warp
-    const uint8_t *atlas64;      // egocentric: [n_icons * 4096 + 2] x 4 bytes (B, G, R, 0): the 64x64 item images
-                                 // (XItem::item_size_ = 64), then one white and one black pixel
+    const uint8_t *atlas64;      // egocentric: 4 bytes per pixel (B, G, R, 0): [n_icons][64][64] item images (XItem::item_size_
+                                 // = 64), one white and one black pixel, then the turned copies of the agent icons
+    const uint32_t *ego_agent_rot;   // egocentric: [n_icons] pixel offset in atlas64 of an agent icon's three turned copies
+                                 // (heading right, left, up; heading down is the icon itself)
     uint32_t *goal_img;          // egocentric: [n][num_goals][64 * 64] warped goal images (B | G << 8 | R << 16)
     const void *ego_taps;        // egocentric: cv::resize taps of the two resizes (kernels_xworld_ego.hip)
     uint32_t *cand2d;            // [n] goal slots the agent can reach, blocks as the only obstacles: bits 0..15
