@@ -233,6 +233,16 @@ int xwb_race_set_car(xwb_sim *sim, int32_t env, float x, float y, float angle);
 int xwb_get_state_packet(xwb_sim *sim, int32_t env, float reward, void *stream,
                          uint8_t *out_host, size_t cap, size_t *need);
 
+/* ---- checkpoint / resume of a batch (replaces the reference's --curriculum_stamp style restarts) ----
+ * The whole dynamic state of the batch -- SoA arrays, episode counters (= the RNG stream positions: every draw is a
+ * pure function of (seed, global env id, episode / step counters)), the built-in policy's step counter and, when
+ * `include_obs` is set, the observation buffer (needed for bit-exact context rings; without it the frames are
+ * re-rendered from the state on load and the older context frames start black) -- as one host blob.  A blob loads into
+ * any batch created with the same configuration.  Both calls synchronise. */
+int xwb_state_bytes(xwb_sim *sim, int32_t include_obs, size_t *bytes);
+int xwb_save_state(xwb_sim *sim, int32_t include_obs, uint8_t *out_host, size_t cap);
+int xwb_load_state(xwb_sim *sim, const uint8_t *in_host, size_t bytes);
+
 /* GameSimulator::decode_game_over_code, simulator.cpp:125-144 ("alive" | "max_step|dead|...") */
 int xwb_decode_game_over_code(int32_t code, char *out, size_t cap);
 

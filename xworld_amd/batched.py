@@ -274,6 +274,18 @@ class BatchedSimulator:
     def refresh_obs(self, env):
         lib.check(self.L.xwb_xw_refresh_obs(self.h, int(env)))
 
+    def save_state(self, include_obs=True):
+        """The batch's whole dynamic state as one numpy uint8 blob (checkpoint); load_state() resumes bit for bit."""
+        n = C.c_size_t()
+        lib.check(self.L.xwb_state_bytes(self.h, int(include_obs), C.byref(n)))
+        buf = np.empty(n.value, np.uint8)
+        lib.check(self.L.xwb_save_state(self.h, int(include_obs), buf.ctypes.data, n.value))
+        return buf
+
+    def load_state(self, blob):
+        blob = np.ascontiguousarray(blob, np.uint8)
+        lib.check(self.L.xwb_load_state(self.h, blob.ctypes.data, blob.size))
+
     def race_set_car(self, env, x, y, angle):
         lib.check(self.L.xwb_race_set_car(self.h, int(env), float(x), float(y), float(angle)))
 

@@ -334,9 +334,9 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
         uint4 *frame0 = reinterpret_cast<uint4 *>(p.obs) + (size_t)e * ctx * cpf;
         for (int cc = threadIdx.x; cc < cpf; cc += 256) {
             const uint4 v = xw_expand_chunk<DIM_T, CH, ES>(p.atlas, s_grid, cc, D);
-            xw_store_chunk(frame0, cc, cpf, ctx, 2, v);
+            xw_store_chunk(frame0, cc, cpf, ctx, p.list_flag, v);
         }
-        if (threadIdx.x == 0) { p.fresh[e] = 0; if (p.auto_reset == 2) p.done[e] = 0; }
+        if (threadIdx.x == 0 && p.list_flag == 2) { p.fresh[e] = 0; if (p.auto_reset == 2) p.done[e] = 0; }
     }
 }
 

@@ -223,10 +223,10 @@ __global__ __launch_bounds__(256) void xw_render_ego_kernel(XwParams p, const ui
             default: ego_pixels<CH, 3>(ctx, s_row, s_col, s_frame, O, tid); break;
         }
         __syncthreads();
-        const int flag = MODE == 1 ? 2 : p.fresh[e];
+        const int flag = MODE == 1 ? p.list_flag : p.fresh[e];
         uint4 *frame0 = reinterpret_cast<uint4 *>(p.obs) + (size_t)e * p.context * cpf;
         for (int cc = tid; cc < cpf; cc += 256) xw_store_chunk(frame0, cc, cpf, p.context, p.context > 1 ? flag : 1, smem4[cc]);
-        if (MODE == 1 && tid == 0) { p.fresh[e] = 0; if (p.auto_reset == 2) p.done[e] = 0; }
+        if (MODE == 1 && tid == 0 && p.list_flag == 2) { p.fresh[e] = 0; if (p.auto_reset == 2) p.done[e] = 0; }
     }
 }
 

@@ -410,6 +410,7 @@ XwParams xw_params(xwb_sim *s) {
     XwParams p = s->xw;
     p.obs = static_cast<uint8_t *>(s->d_obs);
     p.policy_step = s->policy_step;
+    p.list_flag = 2;
     p.done_count = s->d_done_count + s->count_sel;
     p.done_count_next = s->d_done_count + (1 - s->count_sel);
     return p;
@@ -471,21 +472,28 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         HIP_TRY(launch_xw_step(p, st));
         timer_end(s, s->t_step, st);
         s->list_valid = true;
-        HIP_TRY(hipEventRecord(s->ev_step, st));
+        XwParams pr = xw_params(s);
         if (autoreset) {
-            // finished envs: reset + render of the list on the side stream, beside the render of everyone else
-            XwParams pr = xw_params(s);
-            pr.auto_reset = 1;
+            // finished envs: reset + first frame of the new episode on the side stream, beside the render of everyone
+            // else; their terminal frames are not materialised
+            HIP_TRY(hipEventRecord(s->ev_step, st));
             HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
+            pr.auto_reset = 1;
             timer_begin(s, s->t_reset, s->side);
             HIP_TRY(launch_xw_reset(pr, MODE_RESET_DONE, s->side));
             timer_end(s, s->t_reset, s->side);
             HIP_TRY(launch_xw_render(pr, 1, s->side));
             HIP_TRY(hipEventRecord(s->ev_reset, s->side));
             s->list_valid = false;
+        } else {
+            // finished envs: their terminal frames are rendered from the (short) list first; everything a following
+            // xwb_reset_done regenerates beside the big render has then been read (ev_step marks that point)
+            pr.list_flag = 1;
+            HIP_TRY(launch_xw_render(pr, 1, st));
+            HIP_TRY(hipEventRecord(s->ev_step, st));
         }
         timer_begin(s, s->t_render, st);
-        HIP_TRY(launch_xw_render(p, autoreset ? 2 : 0, st));
+        HIP_TRY(launch_xw_render(p, 2, st));                // every env that is still alive
         timer_end(s, s->t_render, st);
         if (autoreset) HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
     }
@@ -1007,6 +1015,112 @@ int xwb_race_set_car(xwb_sim *s, int32_t env, float x, float y, float angle) {
     HIP_TRY(hipMemcpy(s->d_x + env, &x, 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_y + env, &y, 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_angle + env, &angle, 4, hipMemcpyHostToDevice));
+    return XWB_OK;
+}
+
+// ---- checkpoint ----
+namespace {
+struct StateArray { void *ptr; size_t bytes; };
+
+std::vector<StateArray> state_arrays(xwb_sim *s, bool include_obs) {
+    const size_t n = (size_t)s->n;
+    std::vector<StateArray> a;
+    auto add = [&](void *p, size_t bytes) { if (p) a.push_back(StateArray{p, bytes}); };
+    add(s->d_actions, n * 4); add(s->d_num_steps, n * 4); add(s->d_episode, n * 4); add(s->d_reward, n * 4);
+    add(s->d_done, n); add(s->d_success, n); add(s->d_err, 4); add(s->d_reset_count, 4);
+    add(s->d_pos, n * 4); add(s->d_flags, n);
+    add(s->d_x, n * 4); add(s->d_y, n * 4); add(s->d_angle, n * 4);
+    if (s->cfg.game == XWB_XWORLD2D) {
+        const size_t cells = (size_t)s->cfg.max_dim * s->cfg.max_dim;
+        add(s->d_grid, n * cells * 2); add(s->d_agent, n * 4); add(s->d_task_steps, n * 4); add(s->d_task_state, n * 4);
+        add(s->d_done_list, n * 4); add(s->d_done_count, 8); add(s->d_fresh, n);
+        add(s->d_goal_cells, n * XW_MAX_GOALS); add(s->d_cand2d, n * 4); add(s->d_agent_dir, n);
+        add(s->d_goal_warp, n * XW_MAX_GOALS * 6 * sizeof(double));     // goal images are re-warped from these on load
+    }
+    if (include_obs) add(s->d_obs, n * s->obs_bytes_per_env);
+    return a;
+}
+
+struct StateHeader {
+    char magic[8];
+    uint32_t version, game, num_envs, include_obs, n_arrays, policy_step, count_sel, list_valid;
+    uint64_t obs_bytes_per_env, cfg_hash;
+};
+
+uint64_t config_hash(const xwb_config &c) {            // everything that shapes the state; pointers excluded
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+    const int32_t v[] = {c.game, c.num_envs, c.context, c.max_steps, c.array_size, c.track_type, c.race_full_manouver, c.random,
+                         c.difficulty_hard, c.map_kind, c.max_dim, c.dim, c.num_goals, c.num_blocks, c.max_steps_factor, c.task_mode,
+                         c.n_tasks, c.color, c.visible_radius, c.obs_format, c.n_icons};
+    mix(v, sizeof v); mix(c.tasks, sizeof c.tasks);
+    mix(&c.seed, 4); mix(&c.policy_seed, 4); mix(&c.env_gid0, 4);
+    return h;
+}
+}  // namespace
+
+int xwb_state_bytes(xwb_sim *s, int32_t include_obs, size_t *bytes) {
+    if (!s || !bytes) return fail(XWB_ERR_ARG, "NULL argument");
+    size_t total = sizeof(StateHeader);
+    for (auto &a : state_arrays(s, include_obs != 0)) total += 8 + a.bytes;
+    *bytes = total;
+    return XWB_OK;
+}
+
+int xwb_save_state(xwb_sim *s, int32_t include_obs, uint8_t *out_host, size_t cap) {
+    if (!s || !out_host) return fail(XWB_ERR_ARG, "NULL argument");
+    size_t need = 0;
+    xwb_state_bytes(s, include_obs, &need);
+    if (cap < need) return fail(XWB_ERR_ARG, "buffer smaller than xwb_state_bytes");
+    HIP_TRY(hipDeviceSynchronize());
+    const auto arrays = state_arrays(s, include_obs != 0);
+    StateHeader h{};
+    memcpy(h.magic, "XWBSTATE", 8);
+    h.version = 1; h.game = (uint32_t)s->cfg.game; h.num_envs = (uint32_t)s->n; h.include_obs = include_obs ? 1u : 0u;
+    h.n_arrays = (uint32_t)arrays.size(); h.policy_step = s->policy_step; h.count_sel = (uint32_t)s->count_sel;
+    h.list_valid = s->list_valid ? 1u : 0u; h.obs_bytes_per_env = s->obs_bytes_per_env; h.cfg_hash = config_hash(s->cfg);
+    uint8_t *w = out_host;
+    memcpy(w, &h, sizeof h); w += sizeof h;
+    for (auto &a : arrays) {
+        const uint64_t b = a.bytes;
+        memcpy(w, &b, 8); w += 8;
+        HIP_TRY(hipMemcpy(w, a.ptr, a.bytes, hipMemcpyDeviceToHost));
+        w += a.bytes;
+    }
+    return XWB_OK;
+}
+
+int xwb_load_state(xwb_sim *s, const uint8_t *in_host, size_t bytes) {
+    if (!s || !in_host) return fail(XWB_ERR_ARG, "NULL argument");
+    if (bytes < sizeof(StateHeader)) return fail(XWB_ERR_ARG, "not a state blob");
+    StateHeader h;
+    memcpy(&h, in_host, sizeof h);
+    if (memcmp(h.magic, "XWBSTATE", 8) != 0 || h.version != 1) return fail(XWB_ERR_ARG, "not a state blob of this version");
+    if (h.game != (uint32_t)s->cfg.game || h.num_envs != (uint32_t)s->n || h.obs_bytes_per_env != s->obs_bytes_per_env ||
+        h.cfg_hash != config_hash(s->cfg))
+        return fail(XWB_ERR_ARG, "state blob was saved from a batch with another configuration");
+    const auto arrays = state_arrays(s, h.include_obs != 0);
+    if (arrays.size() != h.n_arrays) return fail(XWB_ERR_ARG, "state blob layout mismatch");
+    HIP_TRY(hipDeviceSynchronize());
+    const uint8_t *r = in_host + sizeof h, *end = in_host + bytes;
+    for (auto &a : arrays) {
+        uint64_t b;
+        if (r + 8 > end) return fail(XWB_ERR_ARG, "truncated state blob");
+        memcpy(&b, r, 8); r += 8;
+        if (b != a.bytes || r + b > end) return fail(XWB_ERR_ARG, "state blob layout mismatch");
+        HIP_TRY(hipMemcpy(a.ptr, r, a.bytes, hipMemcpyHostToDevice));
+        r += b;
+    }
+    s->policy_step = h.policy_step; s->count_sel = (int)h.count_sel; s->list_valid = h.list_valid != 0;
+    if (s->cfg.game == XWB_XWORLD2D) {
+        XwParams p = xw_params(s);
+        if (p.visible_radius) HIP_TRY(launch_xw_warp_goals(p, false, nullptr));
+        if (!h.include_obs) {                           // frames from the state; older context frames start black
+            HIP_TRY(hipMemset(s->d_fresh, 2, (size_t)s->n));
+            HIP_TRY(launch_xw_render(p, 0, nullptr));
+        }
+    }
+    HIP_TRY(hipDeviceSynchronize());
     return XWB_OK;
 }
 

@@ -133,6 +133,8 @@ struct XwParams {
     int obs_f32;                 // frames are float32 (pixel * 1/255), the tile table too
     int n_icons;
     int n_tasks, tasks[8];       // tasks of the teacher's group, sampled uniformly whenever the group is idle
+    int list_flag;               // list render: 2 = first frame of a new episode (init_screen: older context frames zeroed,
+                                 // fresh / done flags cleared); 1 = the terminal frame of a finished env (ring shift only)
     int group2d;                 // the group holds the 2-D-native tasks (rule D14b): idle stages also run at step time
     uint32_t policy_seed, env_gid0, policy_step, seed;
     // icon tables (device)

@@ -79,6 +79,9 @@ _SIGS = [
     ("xwb_get_env_obs", C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_size_t]),
     ("xwb_get_env_grid", C.c_int, [_vp, C.c_int32, _vp, _vp]),
     ("xwb_xw_load_map", C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    ("xwb_state_bytes", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_size_t)]),
+    ("xwb_save_state", C.c_int, [_vp, C.c_int32, _vp, C.c_size_t]),
+    ("xwb_load_state", C.c_int, [_vp, _vp, C.c_size_t]),
     ("xwb_xw_set_agent_dir", C.c_int, [_vp, C.c_int32, C.c_int32]),
     ("xwb_xw_set_goal_pose", C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
     ("xwb_xw_refresh_obs", C.c_int, [_vp, C.c_int32]),
