@@ -203,6 +203,8 @@ typedef struct xwb_env_state {
     int32_t  xw_target;          /* TARGET: goal name id; BETWEEN and the 2-D-native tasks: cell y * max_dim + x;
                                   * DIRECTION: referent cell | direction word << 8 (1 front 2 behind 3 left 4 right); else -1 */
     int32_t  xw_agent_dir;       /* egocentric heading: 0 right, 1 down, 2 left, 3 up; 1 under full observation */
+    uint32_t xw_sentence_names;  /* goal-name ids the idle stage binds into the teacher's sentence: a | b << 16 (0xffff none):
+                                  * TARGET G = the picked goal; NEAR G = g1; BETWEEN G1, G2; DIRECTION, AVOID G = the referent */
 } xwb_env_state;
 int xwb_get_env_state(xwb_sim *sim, int32_t env, void *stream, xwb_env_state *out);
 /* copies env's "screen" (context frames) to host memory; bytes must equal bytes_per_env */

@@ -192,6 +192,8 @@ int     orc_xw_target_name(const orc_xworld *w);
 int     orc_xw_task_kind(const orc_xworld *w);
 void    orc_xw_between_cell(const orc_xworld *w, int *x, int *y);
 /* NavTargetDirection: self.target = (referent, direction): the referent's cell and the word (1 front 2 behind 3 left 4 right; 0 none) */
+/* goal-name ids bound into the teacher's sentence by the idle stage (self._bind("G -> ...")); -1 = none */
+void    orc_xw_sentence_names(const orc_xworld *w, int *a, int *b);
 void    orc_xw_direction_target(const orc_xworld *w, int *x, int *y, int *word);
 void    orc_xw_get_target_cells(const orc_xworld *w, uint8_t *out);
 int     orc_xw_steps_in_task(const orc_xworld *w);

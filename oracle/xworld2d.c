@@ -748,6 +748,8 @@ void orc_xw_agent_masking(const orc_xworld *w, int *x_st, int *y_st, uint8_t *sh
 void orc_xw_refresh_screen(orc_xworld *w) { init_screen(w); }
 void orc_xw_stage_poses(orc_xworld *w, const double *poses, int n_entities) { w->staged_poses = poses; w->n_staged_poses = n_entities; }
 
+void orc_xw_sentence_names(const orc_xworld *w, int *a, int *b) { *a = w->sent_a; *b = w->sent_b; }
+
 void orc_xw_direction_target(const orc_xworld *w, int *x, int *y, int *word) {
     *x = *y = -1; *word = 0;
     if (w->task_kind == ORC_TASK_DIRECTION && w->dir_ref_ent >= 0) { *x = w->ents[w->dir_ref_ent].x; *y = w->ents[w->dir_ref_ent].y; *word = w->dir_word; }

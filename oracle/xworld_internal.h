@@ -41,6 +41,7 @@ struct orc_xworld {
     int task_kind;                   /* ORC_TASK_* of the busy task */
     uint8_t target_ent[MAXENT];      /* self.target: entity is a target goal */
     int between_x, between_y;        /* NavTargetBetween: the middle cell (C++ coordinates) */
+    int sent_a, sent_b;              /* goal-name ids the idle stage binds into the task's grammar (G / G1, G2); -1 none */
     int dir_ref_ent, dir_word;       /* NavTargetDirection: self.target = (referent, direction) */
     int target2d_x, target2d_y;      /* 2-D-native tasks: XWorldTask.target (C++ coordinates), -1 = none */
     uint32_t env_gid, episode;       /* of the running episode: step-time idle stages draw from stream 2 */

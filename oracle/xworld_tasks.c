@@ -300,6 +300,9 @@ static void idle_rearranging(orc_xworld *w, penv *p, int kind) {
         move_to_end(w, tr, 3, tr[1]);
         move_to_end(w, tr, 3, tr[2]);
         if (kind == ORC_TASK_DIRECTION) { w->dir_ref_ent = referent == g1 ? tr[0] : tr[1]; w->dir_word = direction; }
+        /* Near: G -> g1.name; Between: G1 -> g1.name, G2 -> g2.name; Direction: G -> referent.name */
+        w->sent_a = w->ents[kind == ORC_TASK_DIRECTION ? (referent == g1 ? tr[0] : tr[1]) : tr[0]].name_id;
+        if (kind == ORC_TASK_BETWEEN) w->sent_b = w->ents[tr[1]].name_id;
         orc_xw_rebuild_map(w);                                           /* env_changed -> XWorld::reset(false) */
         return;
     }
@@ -369,6 +372,7 @@ void orc_task_idle(orc_xworld *w) {
     w->between_x = w->between_y = -1;
     w->target_name = -1;
     w->dir_ref_ent = -1; w->dir_word = 0;
+    w->sent_a = w->sent_b = -1;
     /* TaskGroup::run_stage: idx = get_rand_ind(task_list_.size()) */
     int n_tasks = w->cfg.n_tasks > 0 ? w->cfg.n_tasks : 1;
     int t = orc_xw_draw_below(w, n_tasks);
@@ -381,6 +385,7 @@ void orc_task_idle(orc_xworld *w) {
             int sel = cand[orc_xw_draw_below(w, nc)];                    /* sel_goal = random.choice(targets) */
             if (w->task_kind == ORC_TASK_TARGET) {
                 w->target_name = w->ents[sel].name_id;
+                w->sent_a = w->target_name;                               /* _bind("G -> '" + sel_goal.name + "'") */
                 for (int k = 0; k < p.ng; ++k)
                     if (w->ents[p.goals[k]].name_id == w->target_name) w->target_ent[p.goals[k]] = 1;
             } else {
@@ -389,6 +394,7 @@ void orc_task_idle(orc_xworld *w) {
                     if (w->ents[p.goals[k]].name_id != w->ents[sel].name_id) refs[nr++] = p.goals[k];
                 if (nr > 0) {                                            /* else: assert referents, "Identical object names?" */
                     int referent = refs[orc_xw_draw_below(w, nr)];
+                    w->sent_a = w->ents[referent].name_id;                   /* _bind("G -> '" + referent.name + "'") */
                     for (int k = 0; k < p.ng; ++k)
                         if (w->ents[p.goals[k]].name_id != w->ents[referent].name_id) w->target_ent[p.goals[k]] = 1;
                 }

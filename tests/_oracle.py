@@ -139,6 +139,7 @@ def lib():
     sig("orc_xw_set_pose", None, vp, C.c_int, C.c_double, C.c_double, C.c_double)
     sig("orc_xw_get_pose", None, vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
     sig("orc_xw_agent_yaw", C.c_double, vp)
+    sig("orc_xw_sentence_names", None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
     sig("orc_xw_direction_target", None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
     sig("orc_xw_num_actions", C.c_int, vp)
     sig("orc_xw_stage_poses", None, vp, C.POINTER(C.c_double), C.c_int)
@@ -412,6 +413,11 @@ class XWorld:
 
     def num_actions(self):
         return self.L.orc_xw_num_actions(self.h)
+
+    def sentence_names(self):
+        a, b = C.c_int(), C.c_int()
+        self.L.orc_xw_sentence_names(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def direction_target(self):
         x, y, wd = C.c_int(), C.c_int(), C.c_int()

@@ -36,6 +36,7 @@ Fixtures written:
                  per step action, reward, event, stage, agent cell, action success
   tasks_ego.json the five tasks with FLAGS_visible_radius = 3: entity poses (yaw, scale, offset) as the reference's
                  map generator drew them, six first-person actions, the agent's yaw after every step
+  sentences.json the reference's CFG with each task's grammar: sentences for random bindings + the choices behind them
   tasks2d.json   the 2-D-native group of confs/walls.json (XWorldNavTarget / Near / ColorTarget / Between, rule D14b)
                  as a one-task group, both task modes, every teach() call of a 70-step episode
   tasks.json     all five tasks of the XWorld3DNav group (Target, Near, Between, Direction, Avoid): the idle stage
@@ -552,6 +553,53 @@ def gen_tasks2d(pals, n_maps, seed0, steps):
     return out
 
 
+# ------------------------------------------------------------ teacher sentences ----
+def gen_sentences(n_per_task, seed0):
+    """The reference's context_free_grammar.CFG (the real module, not the no-op stand-in above) fed with each task's own
+    _define_grammar(): sentences for random bindings, with the random.choice decisions that produced them."""
+    import importlib
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("real_cfg", os.path.join(REF, "python", "context_free_grammar.py"))
+    real = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(real)
+    real.CFG._CFG__unbind_all = lambda self: [rhs.unbind() for rhs in self.productions.values()]   # py2 iteritems
+    env = XWorldNav(ITEM_PATH)
+    random.seed(seed0)
+    env.reset()
+    names = sorted(_orig_names(env, "goal"))
+    rnd = random.Random(seed0)
+    out = {"goal_names": names, "tasks": {}}
+    for name in ["XWorld3DNavTarget", "XWorld3DNavTargetNear", "XWorld3DNavTargetBetween", "XWorld3DNavTargetDirection",
+                 "XWorld3DNavTargetAvoid"]:
+        mod = importlib.import_module(name)
+        task = getattr(mod, name)(env)
+        grammar, start = task._define_grammar()
+        cfg = real.CFG(grammar, start)
+        recs = []
+        for k in range(n_per_task):
+            what = ["start", "correct", "wrong", "timeup"][0 if k % 4 else rnd.randrange(1, 4)] if k % 7 == 0 else "start"
+            binds = {"S": what}
+            if what == "start":
+                if name == "XWorld3DNavTargetBetween":
+                    binds["G1"] = "'%s'" % rnd.choice(names)
+                    binds["G2"] = "'%s'" % rnd.choice(names)
+                else:
+                    binds["G"] = "'%s'" % rnd.choice(names)
+                if name == "XWorld3DNavTargetDirection":
+                    binds["P"] = rnd.choice(["LEFT", "RIGHT", "FRONT", "BEHIND"])
+            fake = DecisionRandom(seed0 * 3 + k)
+            real.random = fake
+            try:
+                for lhs, rhs in binds.items():
+                    cfg.bind("%s -> %s" % (lhs, rhs))
+                sent = cfg.generate()
+            finally:
+                real.random = random
+            recs.append({"bind": binds, "decisions": list(fake.log), "sentence": sent})
+        out["tasks"][name] = recs
+    return out
+
+
 def main():
     nav_pal = O.Palette(O.NAV_SUBTREES)
     walls_pal = O.Palette(O.WALLS_SUBTREES)
@@ -564,6 +612,7 @@ def main():
                                  "walls": gen_teacher(XWorldWalls, walls_pal, 24, 3000, 500)},
         "tasks.json": lambda: gen_tasks(nav_pal, 24, 9000, 660),
         "tasks_ego.json": lambda: gen_tasks(nav_pal, 16, 15000, 900, ego=3),
+        "sentences.json": lambda: gen_sentences(60, 31000),
         "tasks2d.json": lambda: gen_tasks2d({"nav": nav_pal, "walls": walls_pal}, 6, 12000, 70),
     }
     only = sys.argv[1:]                      # optional: the fixtures to (re)generate

@@ -259,3 +259,57 @@ def test_conf_walls_json_navigation_group():
         BatchedSimulator("xworld", {"xwd_conf_path": os.path.join(CONF, "nav_target.json"),
                                     "tasks": ["XWorldNavTarget", "XWorld3DNavTarget"]}, num_envs=4)
     sim.close()
+
+
+# ------------------------------------------------------------------------------------------ the teacher's sentences
+def test_sentences_follow_the_episode(oracle):
+    """The names the idle stage binds (vs the oracle), one instruction per episode that contains them, the closing
+    message on the step that ends the episode, silence afterwards, a new instruction after the reset."""
+    torch = _torch()
+    from xworld_amd import language
+    n = 384
+    sim, pal, cfg = _make(oracle, "nav8", n, KINDS, seed=77, policy_seed=1, gid0=500)
+    names = sim.palette.names["goal"]
+    assert names == pal.names["goal"]
+    ow = oracle.XWorld(pal, render=False, **cfg)
+    first = {}
+    starts = set()
+    for e in range(n):
+        ow.reset_game(500 + e, 0)
+        st = sim.env_state(e)
+        a, b = ow.sentence_names()
+        assert (st.xw_sentence_names & 0xffff, st.xw_sentence_names >> 16) == (a & 0xffff, b & 0xffff), (e, st.xw_task)
+        s = sim.sentence(e)
+        first[e] = s
+        if a >= 0:
+            assert names[a] in s.split() and (b < 0 or names[b] in s.split()), (e, s)
+            starts.add(s.split()[0])
+        else:
+            assert s == ""
+    assert len(starts) >= 6 and len(set(first.values())) > n // 2       # the grammar's variety shows
+    closing = {1: "Well done !", 2: "Wrong !", 3: "Time up ."}
+    seen = set()
+    for t in range(120):
+        sim.step()
+        for e in range(0, n, 7):
+            st = sim.env_state(e)
+            s = sim.sentence(e)
+            if st.xw_event:
+                assert s == closing[st.xw_event]
+                seen.add(st.xw_event)
+            elif st.xw_stage == 2:
+                assert s == ""
+            else:
+                assert s == first[e]                              # the instruction is repeated every step
+        sim.reset_done()
+        for e in range(0, n, 7):
+            st = sim.env_state(e)
+            if st.num_steps == 0 and st.episode > 0:
+                first[e] = sim.sentence(e)
+    assert {1, 2} <= seen
+    # the py_simulator surface shows it under "sentence"
+    from xworld_amd.py_simulator import Simulator
+    g = Simulator.create("xworld", {"xwd_conf_path": os.path.join(CONF, "navigation2d.json"), "task_mode": "lang_acquisition"})
+    g.reset_game()
+    assert g.get_state()["sentence"] == g.batch.sentence(0) != ""
+    sim.close()

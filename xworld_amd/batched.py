@@ -274,6 +274,15 @@ class BatchedSimulator:
     def refresh_obs(self, env):
         lib.check(self.L.xwb_xw_refresh_obs(self.h, int(env)))
 
+    def sentence(self, env=0, stream=None):
+        """The teacher's sentence of one env after the last call (language.py); "" where the reference shows "-"."""
+        from . import language
+        st = self.env_state(env, stream)
+        sn = st.xw_sentence_names
+        return language.sentence(st.xw_task, st.xw_stage, st.xw_event, self.palette.names["goal"], sn & 0xffff, sn >> 16,
+                                 (st.xw_target >> 8) & 7 if st.xw_task == 3 and st.xw_target >= 0 else 0,
+                                 self.cfg.seed, self.cfg.env_gid0 + int(env), st.episode)
+
     def save_state(self, include_obs=True):
         """The batch's whole dynamic state as one numpy uint8 blob (checkpoint); load_state() resumes bit for bit."""
         n = C.c_size_t()

@@ -380,6 +380,7 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
     const int tsel = (int)s.below((uint32_t)n_tasks);
     const int kind = p.n_tasks > 0 ? p.tasks[tsel] : TASK_TARGET;
     uint32_t target_bits = 0;                              // goal slot i belongs to self.target
+    int sent_a = 0xffff, sent_b = 0xffff;                  // names bound into the teacher's grammar (G / G1, G2)
     int between = -1;                                      // NavTargetBetween: the middle cell (actual-dim index)
     int target_field = -1;
 
@@ -442,6 +443,7 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
             const int selname = L.gname[L.at(pick)];
             if (kind == TASK_TARGET) {
                 target_field = selname;
+                sent_a = selname;
                 for (int i = 0; i < ng; ++i) if (L.gname[L.at(i)] == selname) target_bits |= 1u << i;
             } else {
                 int nr = 0;
@@ -452,6 +454,7 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
                     for (int i = 0; i < ng; ++i)
                         if (L.gname[L.at(i)] != selname) { if (r == 0) { refname = L.gname[L.at(i)]; break; } r--; }
                     for (int i = 0; i < ng; ++i) if (L.gname[L.at(i)] != refname) target_bits |= 1u << i;
+                    sent_a = refname;
                 }
             }
         }
@@ -608,6 +611,8 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
             L.gcell[L.at(g1)] = (uint8_t)l1; L.gcell[L.at(g2)] = (uint8_t)l2;
             put(al, agent_icon);
             agent_cell = al;
+            sent_a = L.gname[L.at(kind == TASK_DIRECTION ? ref : g1)];
+            if (kind == TASK_BETWEEN) sent_b = L.gname[L.at(g2)];
             if (kind == TASK_NEAR) {
                 // _get_surrounding_goals(refer=g1.loc): dist < 1.5 + 1e-3 = the 8-neighbourhood, goals AT g1.loc skipped
                 for (int i = 0; i < ng; ++i) {
@@ -651,6 +656,7 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
 
     p.agent_xy[e] = (agent_cell % D + off) | ((agent_cell / D + off) << 16);
     p.task_state[e] = pack_task(target_field, stage0, EV_NONE, kind);
+    p.sent_names[e] = (uint32_t)sent_a | ((uint32_t)sent_b << 16);
     p.task_steps[e] = 0;
     p.num_steps[e] = 0;
     p.fresh[e] = 2;                                       // render: init_screen (zero the older context frames)

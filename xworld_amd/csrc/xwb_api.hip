@@ -74,7 +74,7 @@ struct xwb_sim {
     int32_t *d_agent = nullptr, *d_task_steps = nullptr, *d_task_state = nullptr, *d_done_list = nullptr,
             *d_done_count = nullptr;
     uint8_t *d_fresh = nullptr, *d_icon_type = nullptr, *d_icon_colored = nullptr, *d_goal_cells = nullptr;
-    uint32_t *d_cand2d = nullptr;
+    uint32_t *d_cand2d = nullptr, *d_sent_names = nullptr;
     uint8_t *d_agent_dir = nullptr, *d_atlas64 = nullptr;
     uint32_t *d_goal_img = nullptr, *d_agent_rot = nullptr;
     EgoTap *d_ego_taps = nullptr;
@@ -263,6 +263,7 @@ int xw_setup(xwb_sim *s) {
     if ((rc = dev_alloc(s, &s->d_icon_colored, c.n_icons))) return rc;
     if ((rc = dev_alloc(s, &s->d_goal_cells, (size_t)n * XW_MAX_GOALS, 0xff))) return rc;
     if ((rc = dev_alloc(s, &s->d_cand2d, n))) return rc;
+    if ((rc = dev_alloc(s, &s->d_sent_names, n, 0xff))) return rc;
     if ((rc = dev_alloc(s, &s->d_agent_dir, n, 1))) return rc;                 // heading "down": yaw 1.5707963
     if (c.visible_radius > 0) {
         if ((rc = dev_alloc(s, &s->d_goal_warp, (size_t)n * XW_MAX_GOALS * 6))) return rc;
@@ -328,6 +329,7 @@ int xw_setup(xwb_sim *s) {
     p.obs_f32 = f32 ? 1 : 0;
     p.n_tasks = c.n_tasks;
     p.group2d = c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET;
+    p.sent_names = s->d_sent_names;
     p.goal_cells = s->d_goal_cells; p.cand2d = s->d_cand2d; p.icon_colored = s->d_icon_colored;
     p.visible_radius = c.visible_radius; p.out_dim = s->out_h;
     p.agent_dir = s->d_agent_dir; p.goal_warp = s->d_goal_warp; p.atlas64 = s->d_atlas64; p.ego_taps = s->d_ego_taps; p.goal_img = s->d_goal_img; p.ego_agent_rot = s->d_agent_rot;
@@ -825,6 +827,9 @@ int xwb_get_env_state(xwb_sim *s, int32_t env, void *stream, xwb_env_state *o) {
         uint8_t dir = 1;
         HIP_TRY(hipMemcpy(&dir, s->d_agent_dir + env, 1, hipMemcpyDeviceToHost));
         o->xw_agent_dir = dir;
+        uint32_t sn = 0xffffffffu;
+        HIP_TRY(hipMemcpy(&sn, s->d_sent_names + env, 4, hipMemcpyDeviceToHost));
+        o->xw_sentence_names = sn;
     }
     return XWB_OK;
 }
@@ -1034,7 +1039,7 @@ std::vector<StateArray> state_arrays(xwb_sim *s, bool include_obs) {
         const size_t cells = (size_t)s->cfg.max_dim * s->cfg.max_dim;
         add(s->d_grid, n * cells * 2); add(s->d_agent, n * 4); add(s->d_task_steps, n * 4); add(s->d_task_state, n * 4);
         add(s->d_done_list, n * 4); add(s->d_done_count, 8); add(s->d_fresh, n);
-        add(s->d_goal_cells, n * XW_MAX_GOALS); add(s->d_cand2d, n * 4); add(s->d_agent_dir, n);
+        add(s->d_goal_cells, n * XW_MAX_GOALS); add(s->d_cand2d, n * 4); add(s->d_agent_dir, n); add(s->d_sent_names, n * 4);
         add(s->d_goal_warp, n * XW_MAX_GOALS * 6 * sizeof(double));     // goal images are re-warped from these on load
     }
     if (include_obs) add(s->d_obs, n * s->obs_bytes_per_env);

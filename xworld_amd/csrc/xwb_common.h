@@ -155,6 +155,7 @@ struct XwParams {
     int32_t *agent_xy;           // x | y << 16
     int32_t *task_steps;         // steps_in_cur_task
     uint8_t *goal_cells;         // [n][XW_MAX_GOALS] cell of goal slot i (entity order), 0xff = none
+    uint32_t *sent_names;        // [n] goal-name ids the idle stage binds into the teacher's sentence: a | b << 16 (0xffff none)
     uint8_t *agent_dir;          // [n] egocentric heading: 0 right, 1 down, 2 left, 3 up (XItem::get_item_facing_dir)
     double *goal_warp;           // [n][XW_MAX_GOALS][6] egocentric: inverse affine map of the goal's icon warp
     const uint8_t *atlas64;      // egocentric: 4 bytes per pixel (B, G, R, 0): [n_icons][64][64] item images (XItem::item_size_

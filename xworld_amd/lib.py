@@ -43,7 +43,7 @@ class XwbEnvState(C.Structure):
         ("race_x", C.c_float), ("race_y", C.c_float), ("race_angle", C.c_float),
         ("xw_agent_x", C.c_int32), ("xw_agent_y", C.c_int32), ("xw_event", C.c_int32), ("xw_stage", C.c_int32),
         ("xw_target_name", C.c_int32), ("xw_steps_in_task", C.c_int32),
-        ("episode", C.c_uint32), ("xw_task", C.c_int32), ("xw_target", C.c_int32), ("xw_agent_dir", C.c_int32),
+        ("episode", C.c_uint32), ("xw_task", C.c_int32), ("xw_target", C.c_int32), ("xw_agent_dir", C.c_int32), ("xw_sentence_names", C.c_uint32),
     ]
 
 

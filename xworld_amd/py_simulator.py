@@ -88,7 +88,7 @@ class Simulator:
             d["screen"] = [float(x) for x in obs]
         if self.batch.name == "xworld":
             st = self.batch.env_state(self._env)
-            d["sentence"] = "-"                                       # teacher language is out of scope
+            d["sentence"] = self.batch.sentence(self._env) or "-"     # get_teacher_sentence_for_agent: "" -> "-"
             events = {0: "", 1: "correct_goal", 2: "wrong_goal", 3: "time_up"}
             d["task"] = assets.TASK_NAMES[st.xw_task]
             d["event"] = events[st.xw_event]
