@@ -245,6 +245,10 @@ int xwb_state_bytes(xwb_sim *sim, int32_t include_obs, size_t *bytes);
 int xwb_save_state(xwb_sim *sim, int32_t include_obs, uint8_t *out_host, size_t cap);
 int xwb_load_state(xwb_sim *sim, const uint8_t *in_host, size_t bytes);
 
+/* SimulatorInterface::get_extra_info of one env.  XWorld2D (xworld_simulator.cpp:495-504):
+ * "<pid>|task:<task class>,event:<event>,height:<actual h>,width:<actual w>"; the other games: "". */
+int xwb_get_extra_info(xwb_sim *sim, int32_t env, void *stream, char *out, size_t cap);
+
 /* GameSimulator::decode_game_over_code, simulator.cpp:125-144 ("alive" | "max_step|dead|...") */
 int xwb_decode_game_over_code(int32_t code, char *out, size_t cap);
 

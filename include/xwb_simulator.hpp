@@ -205,7 +205,11 @@ class SimulatorInterface {
         p.decode(buf);
         return p;
     }
-    virtual void get_extra_info(std::string &info) { info = ""; }
+    virtual void get_extra_info(std::string &info) {
+        char buf[256];
+        check(xwb_get_extra_info(batch_->handle(), env_, nullptr, buf, sizeof buf));
+        info = buf;
+    }
     virtual bool last_action_success() { return batch_->env_state(env_).last_action_success != 0; }
     virtual std::string last_action() {
         const int a = batch_->env_state(env_).last_action;

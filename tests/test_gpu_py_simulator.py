@@ -79,7 +79,7 @@ def test_xworld_example_loop(oracle):
             ref.reset_game(0, episode)
         state = game.get_state()
         assert set(state.keys()) == {"screen", "sentence", "task", "event", "height", "width"}
-        assert state["height"] == "8" and state["width"] == "8" and state["sentence"] == "-"
+        assert state["height"] == "8" and state["width"] == "8"
         exp = ref.state_screen().astype(np.float32).ravel() * np.float32(1 / 255.0)
         assert np.array_equal(np.float32(state["screen"]), exp)
         a = int(rng.integers(0, 4))
@@ -90,3 +90,21 @@ def test_xworld_example_loop(oracle):
     with pytest.raises(RuntimeError, match="speak"):
         g2.take_actions({"action": 0}, 1, False)
     assert g2.take_actions({"action": 0, "pred_sentence": "hello"}, 1, False) <= 0
+
+
+def test_extra_info_string():
+    """xworld_simulator.cpp:495-504: "<pid>|task:<class>,event:<event>,height:<h>,width:<w>"; other games: ""."""
+    import ctypes as C
+    import os
+    import torch
+    assert torch.cuda.is_available()
+    from xworld_amd.batched import BatchedSimulator
+    conf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xworld_amd", "confs", "nav_target.json")
+    sim = BatchedSimulator("xworld", {"xwd_conf_path": conf}, num_envs=4)
+    buf = C.create_string_buffer(256)
+    assert sim.L.xwb_get_extra_info(sim.h, 2, None, buf, 256) == 0
+    assert buf.value.decode() == "%d|task:XWorld3DNavTarget,event:,height:8,width:8" % os.getpid()
+    sim.close()
+    sim = BatchedSimulator("simple_game", {"array_size": 8}, num_envs=2)
+    assert sim.L.xwb_get_extra_info(sim.h, 0, None, buf, 256) == 0 and buf.value == b""
+    sim.close()

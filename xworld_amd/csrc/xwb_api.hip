@@ -15,6 +15,8 @@
 #include <string>
 #include <vector>
 
+#include <unistd.h>
+
 using namespace xwb;
 
 namespace {
@@ -1020,6 +1022,22 @@ int xwb_race_set_car(xwb_sim *s, int32_t env, float x, float y, float angle) {
     HIP_TRY(hipMemcpy(s->d_x + env, &x, 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_y + env, &y, 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_angle + env, &angle, 4, hipMemcpyHostToDevice));
+    return XWB_OK;
+}
+
+int xwb_get_extra_info(xwb_sim *s, int32_t env, void *stream, char *out, size_t cap) {
+    if (!s || !out || cap == 0) return fail(XWB_ERR_ARG, "NULL argument");
+    out[0] = 0;
+    if (s->cfg.game != XWB_XWORLD2D) return XWB_OK;
+    xwb_env_state st;
+    int rc = xwb_get_env_state(s, env, stream, &st);
+    if (rc) return rc;
+    static const char *tasks[] = {"XWorld3DNavTarget", "XWorld3DNavTargetNear", "XWorld3DNavTargetBetween", "XWorld3DNavTargetDirection",
+                                  "XWorld3DNavTargetAvoid", "XWorldNavTarget", "XWorldNavNear", "XWorldNavColorTarget", "XWorldNavBetween"};
+    static const char *events[] = {"", "correct_goal", "wrong_goal", "time_up"};
+    const char *task = st.xw_task >= 0 && st.xw_task < 9 ? tasks[st.xw_task] : "";
+    const char *event = st.xw_event >= 0 && st.xw_event < 4 ? events[st.xw_event] : "";
+    snprintf(out, cap, "%d|task:%s,event:%s,height:%d,width:%d", (int)getpid(), task, event, s->cfg.dim, s->cfg.dim);
     return XWB_OK;
 }
 

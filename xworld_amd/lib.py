@@ -79,6 +79,7 @@ _SIGS = [
     ("xwb_get_env_obs", C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_size_t]),
     ("xwb_get_env_grid", C.c_int, [_vp, C.c_int32, _vp, _vp]),
     ("xwb_xw_load_map", C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    ("xwb_get_extra_info", C.c_int, [_vp, C.c_int32, _vp, C.c_char_p, C.c_size_t]),
     ("xwb_state_bytes", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_size_t)]),
     ("xwb_save_state", C.c_int, [_vp, C.c_int32, _vp, C.c_size_t]),
     ("xwb_load_state", C.c_int, [_vp, _vp, C.c_size_t]),
