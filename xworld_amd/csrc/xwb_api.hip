@@ -1042,6 +1042,7 @@ int xwb_get_extra_info(xwb_sim *s, int32_t env, void *stream, char *out, size_t 
 }
 
 // ---- checkpoint ----
+extern "C++" {
 namespace {
 struct StateArray { void *ptr; size_t bytes; };
 
@@ -1081,6 +1082,7 @@ uint64_t config_hash(const xwb_config &c) {            // everything that shapes
     return h;
 }
 }  // namespace
+}  // extern "C++"
 
 int xwb_state_bytes(xwb_sim *s, int32_t include_obs, size_t *bytes) {
     if (!s || !bytes) return fail(XWB_ERR_ARG, "NULL argument");
