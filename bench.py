@@ -163,22 +163,29 @@ def main():
         screens_all = torch.empty((world * n_local,) + tuple(sim.obs.shape[1:]), dtype=sim.obs.dtype, device=dev)
         sim.bind_obs(screens_all[:n_local])              # rank 0 renders straight into its slice
 
-    def exchange():
+    def exchange_results():
         if world == 1:
             return
-        # finish the gather of the previous step (it ran beside this step's kernels), start this step's
+        # finish the gather of the previous step (it ran beside this step's kernels), start this step's: the step
+        # kernel wrote (reward, code) straight into the buffer, no packing kernels
         results.finish()
-        results.start(sim.reward, sim.game_over_codes)
-        if args.gather_screens:
+        results.start()
+
+    def exchange_screens():
+        if world > 1 and args.gather_screens:
             sharding.gather_slabs(sim.obs, screens_all, counts, rank)
 
     def one_step():
+        if results is not None:
+            sim.bind_results(results.next_buffer())
         if args.autoreset:
             sim.step_autoreset()
+            exchange_results()
         else:
             sim.step()
+            exchange_results()                           # this step's results, before reset_done clears the codes
             sim.reset_done()
-        exchange()
+        exchange_screens()                               # the frames the next policy step would see
 
     def fence():
         if results is not None:

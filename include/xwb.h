@@ -169,6 +169,10 @@ int xwb_check_errors(xwb_sim *sim, void *stream, int32_t *n_bad);
 /* "screen" of get_state(): [num_envs][context][c][h][w]; uint8 for simple_game / xworld (planar B,G,R),
  * float32 for simple_race (simple_race_simulator.cpp:412-430).  Newest frame last (simulator.cpp:51-60). */
 int xwb_obs_dev(xwb_sim *sim, void **ptr, size_t *bytes_per_env);
+/* Optional second output of every step: packed_dev[e] = (reward, game_over code as float) for every env the call steps,
+ * float[num_envs][2] in caller-owned device memory (NULL = off) -- one buffer to ship per step (sharding.ResultGather). */
+int xwb_bind_results(xwb_sim *sim, float *packed_dev);
+
 /* redirect the observation output to caller-owned device memory (e.g. a shard of a gathered tensor) */
 int xwb_bind_obs(xwb_sim *sim, void *obs_dev);
 int xwb_reward_dev(xwb_sim *sim, float **ptr);          /* float[num_envs]: return value of take_actions */

@@ -152,3 +152,31 @@ def test_user_stream_and_state_packet(oracle):
     assert scr.has_pixels and scr.n_pixels == 16
     assert [scr.pixels[i] for i in range(16)] == sim.env_obs(7).tolist()
     sim.close()
+
+
+@pytest.mark.parametrize("game,opts", [("simple_game", {"array_size": 16}),
+                                        ("simple_race", {"track_width": 20.0, "track_length": 100.0, "track_radius": 30.0}),
+                                        ("xworld", None)])
+def test_bind_results_packed_output(game, opts):
+    """xwb_bind_results: every step also writes (reward, game_over code) of the stepped envs into one caller buffer."""
+    import os
+    import torch
+    assert torch.cuda.is_available()
+    from xworld_amd.batched import BatchedSimulator
+    if opts is None:
+        conf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xworld_amd", "confs", "navigation2d.json")
+        opts = {"xwd_conf_path": conf, "task_mode": "lang_acquisition"}
+    n = 2048
+    sim = BatchedSimulator(game, opts, num_envs=n, policy_seed=3)
+    bufs = [torch.full((n, 2), -7.0, device="cuda") for _ in range(2)]
+    for t in range(60):
+        sim.bind_results(bufs[t & 1])
+        sim.step()
+        assert torch.equal(bufs[t & 1][:, 0], sim.reward) and torch.equal(bufs[t & 1][:, 1], sim.game_over_codes.float()), t
+        sim.reset_done()
+        assert torch.equal(bufs[t & 1][:, 1] != 0, bufs[t & 1][:, 1] != 0)
+    sim.bind_results(None)
+    keep = bufs[1].clone()
+    sim.step()
+    assert torch.equal(bufs[1], keep)
+    sim.close()

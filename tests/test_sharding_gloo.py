@@ -56,6 +56,21 @@ def _worker(rank, world, port, total, q):
                 assert torch.equal(got, exp) and got.is_contiguous()
             else:
                 assert r_all is None and got is None
+        # pipelined form with the simulator writing straight into the exchange buffer (bind_results): the gather of
+        # step t is finished only after step t + 1 was produced
+        prev = None
+        for step in range(4):
+            buf = rg.next_buffer()                      # what BatchedSimulator.bind_results would be given
+            buf[:, 0] = reward + 10 * step
+            buf[:, 1] = done.to(torch.float32)
+            got_prev = rg.finish()
+            rg.start()
+            if rank == 0 and prev is not None:
+                g = torch.arange(total)
+                assert torch.equal(got_prev[0], g.to(torch.float32) * 0.5 - 3.0 + 10 * prev)
+                assert torch.equal(got_prev[1], (g % 5 == 0).to(torch.uint8) * 4)
+            prev = step
+        rg.finish()
         dist.barrier()
         q.put((rank, "ok"))
     except Exception as e:                               # pragma: no cover

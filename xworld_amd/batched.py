@@ -217,6 +217,15 @@ class BatchedSimulator:
                                                  device="cuda:%d" % self.device)
         return self._views["obs"]
 
+    def bind_results(self, tensor):
+        """float32 [num_envs, 2] device tensor (or None): every step also writes (reward, game_over code) there."""
+        if tensor is None:
+            lib.check(self.L.xwb_bind_results(self.h, None))
+        else:
+            assert tensor.is_contiguous() and tensor.dtype.itemsize == 4 and tensor.numel() == 2 * self.num_envs
+            lib.check(self.L.xwb_bind_results(self.h, C.c_void_p(tensor.data_ptr())))
+        self._results = tensor
+
     def bind_obs(self, tensor):
         """Redirect the observation output into caller-owned device memory (e.g. a shard of a gathered tensor)."""
         assert tensor.is_contiguous() and tensor.numel() * tensor.element_size() == self.num_envs * self.obs_bytes_per_env

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void sg_kernel(SgParams p) {
                            (sg_over(pos, A) ? SUCCESS : ALIVE);
                 p.reward[e] = rr;
                 p.done[e] = (uint8_t)code;
+                if (p.packed) p.packed[e] = make_float2(rr, (float)code);
                 obs_pos = pos;
                 if (p.auto_reset && code != ALIVE) do_reset = true;
             }
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(256) void race_kernel(RaceParams p) {
                        (race_oob(p, c.x, c.y) ? DEAD : ALIVE);
             p.reward[e] = rr;
             p.done[e] = (uint8_t)code;
+            if (p.packed) p.packed[e] = make_float2(rr, (float)code);
             touched = true;
             if (p.auto_reset && code != ALIVE) do_reset = true;
         }

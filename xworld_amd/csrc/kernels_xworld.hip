@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
             p.success[e] = success ? 1 : 0;
             p.reward[e] = r;
             p.done[e] = (uint8_t)code;
+            if (p.packed) p.packed[e] = make_float2(r, (float)code);
             is_done = code != ALIVE;
         }
     }

@@ -65,6 +65,7 @@ struct xwb_sim {
     float *d_reward = nullptr;
     uint8_t *d_done = nullptr, *d_success = nullptr;
     void *d_obs = nullptr, *d_obs_owned = nullptr;
+    float2 *d_packed = nullptr;            // caller-owned (xwb_bind_results)
     // simple_game
     int32_t *d_pos = nullptr;
     uint8_t *d_flags = nullptr;
@@ -346,6 +347,7 @@ int xw_setup(xwb_sim *s) {
     p.grid = s->d_grid; p.agent_xy = s->d_agent; p.task_steps = s->d_task_steps; p.task_state = s->d_task_state;
     p.num_steps = s->d_num_steps; p.episode = s->d_episode; p.success = s->d_success; p.fresh = s->d_fresh;
     p.reward = s->d_reward; p.done = s->d_done; p.obs = static_cast<uint8_t *>(s->d_obs);
+    p.packed = s->d_packed;
     p.done_list = s->d_done_list; p.done_count = s->d_done_count; p.done_count_next = s->d_done_count + 1;
     p.err_count = s->d_err;
     return XWB_OK;
@@ -376,6 +378,7 @@ SgParams sg_params(xwb_sim *s) {
     p.actions = nullptr; p.mask = nullptr; p.actions_out = s->d_actions;
     p.pos = s->d_pos; p.flags = s->d_flags; p.num_steps = s->d_num_steps; p.episode = s->d_episode;
     p.reward = s->d_reward; p.done = s->d_done; p.obs = static_cast<uint8_t *>(s->d_obs);
+    p.packed = s->d_packed;
     p.err_count = s->d_err; p.reset_count = s->d_reset_count;
     return p;
 }
@@ -389,6 +392,7 @@ RaceParams race_params(xwb_sim *s) {
     p.actions = nullptr; p.mask = nullptr; p.actions_out = s->d_actions;
     p.x = s->d_x; p.y = s->d_y; p.angle = s->d_angle; p.num_steps = s->d_num_steps; p.episode = s->d_episode;
     p.reward = s->d_reward; p.done = s->d_done; p.obs = static_cast<float *>(s->d_obs);
+    p.packed = s->d_packed;
     p.err_count = s->d_err; p.reset_count = s->d_reset_count;
     return p;
 }
@@ -413,6 +417,7 @@ int simple_reset(xwb_sim *s, int mode, const uint8_t *mask, hipStream_t st) {
 XwParams xw_params(xwb_sim *s) {
     XwParams p = s->xw;
     p.obs = static_cast<uint8_t *>(s->d_obs);
+    p.packed = s->d_packed;
     p.policy_step = s->policy_step;
     p.list_flag = 2;
     p.done_count = s->d_done_count + s->count_sel;
@@ -717,6 +722,13 @@ int xwb_obs_dev(xwb_sim *s, void **ptr, size_t *bytes_per_env) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
     if (ptr) *ptr = s->d_obs;
     if (bytes_per_env) *bytes_per_env = s->obs_bytes_per_env;
+    return XWB_OK;
+}
+
+int xwb_bind_results(xwb_sim *s, float *packed_dev) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    if (packed_dev && (reinterpret_cast<uintptr_t>(packed_dev) & 7u)) return fail(XWB_ERR_ARG, "results buffer must be 8-byte aligned");
+    s->d_packed = reinterpret_cast<float2 *>(packed_dev);
     return XWB_OK;
 }
 

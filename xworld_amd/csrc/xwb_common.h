@@ -86,6 +86,7 @@ struct SgParams {
     int32_t *num_steps;
     uint32_t *episode;
     float   *reward;
+    float2 *packed;             // nullable: (reward, game_over code as float) of every stepped env, for a one-buffer exchange
     uint8_t *done;
     uint8_t *obs;               // [n][context][array_size]
     int32_t *err_count;
@@ -112,6 +113,7 @@ struct RaceParams {
     int32_t *num_steps;
     uint32_t *episode;
     float *reward;
+    float2 *packed;             // nullable: (reward, game_over code as float) of every stepped env, for a one-buffer exchange
     uint8_t *done;
     float *obs;                 // [n][context][4]
     int32_t *err_count;
@@ -173,6 +175,7 @@ struct XwParams {
     uint8_t *success;            // last_action_success
     uint8_t *fresh;              // set by reset, consumed by render (context ring init)
     float *reward;
+    float2 *packed;             // nullable: (reward, game_over code as float) of every stepped env, for a one-buffer exchange
     uint8_t *done;
     uint8_t *obs;                // [n][context][channels][12*max_dim][12*max_dim]
     int32_t *done_list;          // compacted env ids

@@ -48,14 +48,20 @@ class ResultGather:
         self.slot = 0
         self.pending = None          # (work handle or None, slot)
 
-    def start(self, reward, game_over):
+    def next_buffer(self):
+        """The packed [n, 2] buffer the NEXT start() ships: bind it as the simulator's results output
+        (BatchedSimulator.bind_results) and call start() without arguments -- no packing kernels at all."""
+        return self.packed[self.slot]
+
+    def start(self, reward=None, game_over=None):
         if self.pending is not None:
             raise RuntimeError("ResultGather.start() called twice without finish()")
         k = self.slot
         self.slot ^= 1
         packed, out = self.packed[k], self.out[k]
-        packed[:, 0] = reward
-        packed[:, 1] = game_over.to(torch.float32)
+        if reward is not None:
+            packed[:, 0] = reward
+            packed[:, 1] = game_over.to(torch.float32)
         work = None
         if self.world == 1:
             out.copy_(packed)
