@@ -53,11 +53,11 @@ __device__ __forceinline__ int vresize(int b0, int h0, int b1, int h1) {
 // All pixels of one frame.  DIR = the agent's heading: cv::warpAffine(view, rot(centre S/2, 90 + yaw deg)) is undone
 // per tap row / column -- quarter turns are exact integer maps, separable in x and y; the source index S falls outside
 // and leaves one black row / column (borderValue 0).
-template <int CH, int DIR>
+template <int CH, int DIR, int BS>
 __device__ __forceinline__ void ego_pixels(const EgoCtx &c, const EgoTap (*s_row)[3], const EgoTap (*s_col)[3],
                                            uint8_t *s_frame, int O, int tid) {
     const int S = c.S;
-    for (int o = tid; o < O * O; o += 256) {
+    for (int o = tid; o < O * O; o += BS) {
         const int oy = o / O, ox = o - oy * O;
         // the 2 x 2 intermediate pixels this output pixel blends, and the 4 x 4 view pixels behind them
         const EgoTap ty = s_row[oy][2], tx = s_col[ox][2];
@@ -125,8 +125,9 @@ __device__ __forceinline__ void ego_pixels(const EgoCtx &c, const EgoTap (*s_row
 }  // namespace
 
 // MODE 0: every env; 1: the compacted done list; 2: every env whose done code is 0 (step_autoreset)
-template <int CH, int MODE>
-__global__ __launch_bounds__(256) void xw_render_ego_kernel(XwParams p, const uint32_t *atlas4, const EgoTap *tap_h1,
+// BS threads per workgroup: 256 for the whole batch; 1024 for the short done list, where the latency of one env counts
+template <int CH, int MODE, int BS>
+__global__ __launch_bounds__(BS) void xw_render_ego_kernel(XwParams p, const uint32_t *atlas4, const EgoTap *tap_h1,
                                                             const EgoTap *tap_v1, const EgoTap *tap_h2, const EgoTap *tap_v2,
                                                             const int32_t *count_now) {
     extern __shared__ uint4 smem4[];
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void xw_render_ego_kernel(XwParams p, const ui
     uint8_t *s_gc = s_ray + ((r + 3) & ~3);
     // composed taps of one output row / column: the two intermediate indices' taps and the output tap (static: O <= 84)
     __shared__ EgoTap s_row[84][3], s_col[84][3];
-    for (int i = threadIdx.x; i < O; i += 256) {
+    for (int i = threadIdx.x; i < O; i += BS) {
         const EgoTap ty = tap_v2[i], tx = tap_h2[i];
         s_row[i][0] = tap_v1[ty.s0]; s_row[i][1] = tap_v1[ty.s1]; s_row[i][2] = ty;
         s_col[i][0] = tap_h1[tx.s0]; s_col[i][1] = tap_h1[tx.s1]; s_col[i][2] = tx;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void xw_render_ego_kernel(XwParams p, const ui
         __syncthreads();
         const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
         const uint32_t *gimg = p.goal_img + (size_t)e * p.num_goals * 4096;
-        for (int k = tid; k < r * r; k += 256) {                // what each view cell shows
+        for (int k = tid; k < r * r; k += BS) {                 // what each view cell shows
             const int gx = x_st - r + k % r, gy = y_st - r + k / r;
             EgoCell c{black, 0, 0};                             // outside the map, or in a wall's shadow
             if ((unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && !s_shadow[k]) {
@@ -217,15 +218,15 @@ __global__ __launch_bounds__(256) void xw_render_ego_kernel(XwParams p, const ui
         __syncthreads();
         EgoCtx ctx{s_cells, white, black, r, S};
         switch (dir) {
-            case 0: ego_pixels<CH, 0>(ctx, s_row, s_col, s_frame, O, tid); break;
-            case 1: ego_pixels<CH, 1>(ctx, s_row, s_col, s_frame, O, tid); break;
-            case 2: ego_pixels<CH, 2>(ctx, s_row, s_col, s_frame, O, tid); break;
-            default: ego_pixels<CH, 3>(ctx, s_row, s_col, s_frame, O, tid); break;
+            case 0: ego_pixels<CH, 0, BS>(ctx, s_row, s_col, s_frame, O, tid); break;
+            case 1: ego_pixels<CH, 1, BS>(ctx, s_row, s_col, s_frame, O, tid); break;
+            case 2: ego_pixels<CH, 2, BS>(ctx, s_row, s_col, s_frame, O, tid); break;
+            default: ego_pixels<CH, 3, BS>(ctx, s_row, s_col, s_frame, O, tid); break;
         }
         __syncthreads();
         const int flag = MODE == 1 ? p.list_flag : p.fresh[e];
         uint4 *frame0 = reinterpret_cast<uint4 *>(p.obs) + (size_t)e * p.context * cpf;
-        for (int cc = tid; cc < cpf; cc += 256) xw_store_chunk(frame0, cc, cpf, p.context, p.context > 1 ? flag : 1, smem4[cc]);
+        for (int cc = tid; cc < cpf; cc += BS) xw_store_chunk(frame0, cc, cpf, p.context, p.context > 1 ? flag : 1, smem4[cc]);
         if (MODE == 1 && tid == 0 && p.list_flag == 2) { p.fresh[e] = 0; if (p.auto_reset == 2) p.done[e] = 0; }
     }
 }
@@ -335,7 +336,8 @@ hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s) {
                        (size_t)((r + 3) & ~3) + XW_MAX_GOALS + 16;
     const unsigned blocks = indexed == 1 ? 2048u : (unsigned)(p.n < 16384 ? p.n : 16384);
     const int32_t *cnt = (const int32_t *)p.done_count;
-#define EGO_LAUNCH(CHV, MODEV) hipLaunchKernelGGL((xw_render_ego_kernel<CHV, MODEV>), dim3(blocks), dim3(256), lds, s, p, reinterpret_cast<const uint32_t *>(p.atlas64), h1, v1, h2, v2, cnt)
+#define EGO_LAUNCH(CHV, MODEV) do { if (MODEV == 1) hipLaunchKernelGGL((xw_render_ego_kernel<CHV, MODEV, 1024>), dim3(blocks), dim3(1024), lds, s, p, reinterpret_cast<const uint32_t *>(p.atlas64), h1, v1, h2, v2, cnt); \
+    else hipLaunchKernelGGL((xw_render_ego_kernel<CHV, MODEV, 256>), dim3(blocks), dim3(256), lds, s, p, reinterpret_cast<const uint32_t *>(p.atlas64), h1, v1, h2, v2, cnt); } while (0)
     if (CH == 3) { if (indexed == 1) EGO_LAUNCH(3, 1); else if (indexed == 2) EGO_LAUNCH(3, 2); else EGO_LAUNCH(3, 0); }
     else { if (indexed == 1) EGO_LAUNCH(1, 1); else if (indexed == 2) EGO_LAUNCH(1, 2); else EGO_LAUNCH(1, 0); }
 #undef EGO_LAUNCH
