@@ -14,7 +14,7 @@ generation, re-render).  Default workload = BASELINE.json config C4 (the configu
 target is quoted on): XWorld2D 7x7, 84x84x3 uint8 planar BGR, 32 768 envs per GPU.
 
 Multi-GPU: the env batch is sharded by global env id (weak scaling: 32 768 envs per GPU); every step
-rank 0 receives each shard's (reward, game_over) through one RCCL gather.  `--gather-screens` also
+every rank's (reward, game_over) is exchanged through one RCCL all-gather (rank 0 consumes it).  `--gather-screens` also
 gathers every shard's screens into one contiguous tensor on rank 0 (xGMI-link bound).
 
 Prints ONE JSON line (rank 0).
@@ -246,7 +246,7 @@ def main():
             "config": {"workload": args.workload, "envs_per_gpu": n_local, "total_envs": total_envs,
                        "obs": list(sim.obs.shape[1:]), "seed": args.seed, "policy": "uniform random, drawn on device",
                        "loop": "step_autoreset" if args.autoreset else "step + reset_done",
-                       "exchange": ("gather(reward,done)" + ("+gather(screens)" if args.gather_screens else ""))
+                       "exchange": ("all_gather(reward,done)" + ("+gather(screens)" if args.gather_screens else ""))
                        if world > 1 else "none", "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

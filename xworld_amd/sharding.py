@@ -28,7 +28,7 @@ def shard_counts(total_envs, world_size):
 
 
 class ResultGather:
-    """Per-step gather of (reward, game_over) to `dst`.  Equal shard sizes -> one dist.gather of a packed
+    """Per-step gather of (reward, game_over) to `dst`.  Equal shard sizes -> one all_gather_into_tensor of a packed
     [n, 2] float tensor; ragged shards -> point-to-point into slices.
 
     `start()` enqueues the exchange of the step that just finished and returns at once; `finish()` waits for
@@ -43,7 +43,9 @@ class ResultGather:
         n = counts[rank]
         self.total = sum(counts)
         self.packed = [torch.empty((n, 2), dtype=torch.float32, device=device) for _ in range(2)]
-        self.out = [torch.empty((self.total, 2), dtype=torch.float32, device=device) if rank == dst else None
+        # equal shards use all_gather_into_tensor (the plainest RCCL collective; 8 B/env, so the extra copies on the
+        # other ranks are noise): every rank owns an output buffer; ragged shards gather point-to-point into `dst` only
+        self.out = [torch.empty((self.total, 2), dtype=torch.float32, device=device) if (rank == dst or self.equal) else None
                     for _ in range(2)]
         self.slot = 0
         self.pending = None          # (work handle or None, slot)
@@ -66,9 +68,7 @@ class ResultGather:
         if self.world == 1:
             out.copy_(packed)
         elif self.equal:
-            n = self.counts[0]
-            lst = [out[r * n:(r + 1) * n] for r in range(self.world)] if self.rank == self.dst else None
-            work = dist.gather(packed, lst, dst=self.dst, group=self.group, async_op=True)
+            work = dist.all_gather_into_tensor(out, packed, group=self.group, async_op=True)
         else:
             gather_slabs(packed, out, self.counts, self.rank, self.dst, self.group)
         self.pending = (work, k)
