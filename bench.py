@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--gather-screens", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--autoreset", action="store_true", help="use the fused step+reset+single-render call")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo with every rank "
+                    "on the visible GPUs modulo their count only exercises the N > 1 code path on a smaller box)")
     args = ap.parse_args()
 
     import torch
@@ -143,8 +145,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % torch.cuda.device_count()
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
     n_gpus = world
