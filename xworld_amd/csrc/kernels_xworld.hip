@@ -176,6 +176,23 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
         }
     }
     wave_append(is_done, e, p.done_list, count_now);
+    if (!p.visible_radius) {
+        // terminal snapshot: the frame of a finished env is rendered from this copy, which lets xwb_reset_done rebuild
+        // the live grid on the side stream while the big render is still running.  The wavefront copies the grids of
+        // its finished envs together (consecutive lanes = consecutive cells).
+        if (e < p.n) p.term_flag[e] = is_done ? 1 : 0;
+        unsigned long long m = __ballot(is_done);
+        const int cells = p.max_dim * p.max_dim, lane = threadIdx.x & 63;
+        if (m) __threadfence();                            // the agent's move was stored by one lane, the copy reads it from all
+        while (m) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int ej = __shfl(e, j);
+            const uint16_t *g = p.grid + (size_t)ej * cells;
+            uint16_t *t = p.term_grid + (size_t)ej * cells;
+            for (int c = lane; c < cells; c += 64) t[c] = g[c];
+        }
+    }
 }
 
 hipError_t launch_xw_step(const XwParams &p, hipStream_t s) {
@@ -232,8 +249,9 @@ __device__ __forceinline__ uint4 xw_expand_chunk(const uint32_t *atlas, const ui
 // the side stream, so that render runs beside this kernel instead of after it.
 // ES = bytes per pixel: 1 = uint8 frames; 4 = float32 frames (pixel * 1/255, py_simulator.cpp:262-272) expanded from
 // a float copy of the tile table (628 KB, still L2-resident): the same kernel with 48-byte tile rows.
-template <int DIM_T, int CH, bool CTX1, int BS, int PER, bool SKIP_DONE, int ES>
+template <int DIM_T, int CH, bool CTX1, int BS, int PER, int RMODE, int ES>
 __global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
+    constexpr bool SKIP_DONE = RMODE == 2, TERM = RMODE == 3;
     constexpr int SPAN = BS * PER;
     constexpr int TB = 12 * ES, TD = 3 * ES;                               // bytes / dwords per tile row
     constexpr int PAD = (TD + 3) / 4 * 4;                                   // dword index of the span's first chunk
@@ -254,7 +272,11 @@ __global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
     const unsigned long long b_lo = c_lo * 16, b_hi = c_hi * 16;
     const int e0 = (int)(b_lo / FB), e1 = (int)((b_hi - 1) / FB);
     const int ncode = (e1 - e0 + 1) * cells;
-    for (int i = tid; i < ncode; i += BS) s_code[i] = p.grid[(size_t)e0 * cells + i] & CELL_ICON_MASK;
+    for (int i = tid; i < ncode; i += BS) {
+        const size_t gi = (size_t)e0 * cells + i;
+        const uint16_t *src = TERM && p.term_flag[e0 + i / cells] ? p.term_grid : p.grid;
+        s_code[i] = src[gi] & CELL_ICON_MASK;
+    }
     if (SKIP_DONE) for (int i = tid; i <= e1 - e0; i += BS) s_done[i] = p.done[e0 + i];
     __syncthreads();
     // TB-byte units [u0, u1) cover the span; env and plane boundaries are multiples of TB, so flooring b_lo to a unit
@@ -313,7 +335,8 @@ __global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
         } else {
             const unsigned long long gc = c_lo + c;
             const int e = (int)(gc / cpf), cc = (int)(gc - (unsigned long long)e * cpf);
-            xw_store_chunk(obs4 + (size_t)e * p.context * cpf, cc, cpf, p.context, p.fresh[e], val);
+            // (a finished env was stepped by this call: ring shift, whatever the reset beside us already wrote to fresh[])
+            xw_store_chunk(obs4 + (size_t)e * p.context * cpf, cc, cpf, p.context, TERM && p.term_flag[e] ? 1 : p.fresh[e], val);
         }
     }
 }
@@ -342,7 +365,7 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
 }
 
 // render_all launch shape: XWB_RENDER_SHAPE = "<threads>x<chunks per lane>" overrides the default (A/B hook)
-template <int DIM_T, int CH, int BS, int PER, bool SKIP, int ES>
+template <int DIM_T, int CH, int BS, int PER, int SKIP, int ES>
 static hipError_t render_all_shape(const XwParams &p, hipStream_t s) {
     const unsigned long long n_chunks = (unsigned long long)p.n * (CH * 9 * ES * p.max_dim * p.max_dim);
     const unsigned blocks = (unsigned)((n_chunks + BS * PER - 1) / (BS * PER));
@@ -351,7 +374,7 @@ static hipError_t render_all_shape(const XwParams &p, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int DIM_T, int CH, bool SKIP, int ES>
+template <int DIM_T, int CH, int SKIP, int ES>
 static hipError_t render_all(const XwParams &p, hipStream_t s) {
     // measured on C4 / 8x8 / 11x11 (profiles/r1/render_shapes.txt): 128 x 2 is best everywhere (8 KiB spans, up to
     // 16 two-wave groups per CU); one chunk per lane leaves too few bytes per barrier, four too few groups in flight
@@ -376,16 +399,16 @@ static hipError_t render_list(const XwParams &p, hipStream_t s) {
 
 template <int CH, int ES>
 static hipError_t render_dispatch(const XwParams &p, int indexed, hipStream_t s) {
-#define XW_CASE(DIMV) case DIMV: return indexed == 1 ? render_list<DIMV, CH, ES>(p, s) : (indexed == 2 ? render_all<DIMV, CH, true, ES>(p, s) : render_all<DIMV, CH, false, ES>(p, s));
+#define XW_CASE(DIMV) case DIMV: return indexed == 1 ? render_list<DIMV, CH, ES>(p, s) : (indexed == 2 ? render_all<DIMV, CH, 2, ES>(p, s) : (indexed == 3 ? render_all<DIMV, CH, 3, ES>(p, s) : render_all<DIMV, CH, 0, ES>(p, s)));
     switch (p.max_dim) {
         XW_CASE(7) XW_CASE(8) XW_CASE(11)
-        default: return indexed == 1 ? render_list<0, CH, ES>(p, s) : (indexed == 2 ? render_all<0, CH, true, ES>(p, s) : render_all<0, CH, false, ES>(p, s));
+        default: return indexed == 1 ? render_list<0, CH, ES>(p, s) : (indexed == 2 ? render_all<0, CH, 2, ES>(p, s) : (indexed == 3 ? render_all<0, CH, 3, ES>(p, s) : render_all<0, CH, 0, ES>(p, s)));
     }
 #undef XW_CASE
 }
 
 hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s) {
-    if (p.visible_radius) return launch_xw_render_ego(p, indexed, s);
+    if (p.visible_radius) return launch_xw_render_ego(p, indexed == 3 ? 0 : indexed, s);
     if (p.obs_f32) return p.channels == 3 ? render_dispatch<3, 4>(p, indexed, s) : render_dispatch<1, 4>(p, indexed, s);
     return p.channels == 3 ? render_dispatch<3, 1>(p, indexed, s) : render_dispatch<1, 1>(p, indexed, s);
 }

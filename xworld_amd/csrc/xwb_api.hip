@@ -78,6 +78,8 @@ struct xwb_sim {
             *d_done_count = nullptr;
     uint8_t *d_fresh = nullptr, *d_icon_type = nullptr, *d_icon_colored = nullptr, *d_goal_cells = nullptr;
     uint32_t *d_cand2d = nullptr, *d_sent_names = nullptr;
+    uint16_t *d_term_grid = nullptr;
+    uint8_t *d_term_flag = nullptr;
     uint8_t *d_agent_dir = nullptr, *d_atlas64 = nullptr;
     uint32_t *d_goal_img = nullptr, *d_agent_rot = nullptr;
     EgoTap *d_ego_taps = nullptr;
@@ -267,6 +269,8 @@ int xw_setup(xwb_sim *s) {
     if ((rc = dev_alloc(s, &s->d_goal_cells, (size_t)n * XW_MAX_GOALS, 0xff))) return rc;
     if ((rc = dev_alloc(s, &s->d_cand2d, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_sent_names, n, 0xff))) return rc;
+    if ((rc = dev_alloc(s, &s->d_term_grid, (size_t)n * cells))) return rc;
+    if ((rc = dev_alloc(s, &s->d_term_flag, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_agent_dir, n, 1))) return rc;                 // heading "down": yaw 1.5707963
     if (c.visible_radius > 0) {
         if ((rc = dev_alloc(s, &s->d_goal_warp, (size_t)n * XW_MAX_GOALS * 6))) return rc;
@@ -332,7 +336,7 @@ int xw_setup(xwb_sim *s) {
     p.obs_f32 = f32 ? 1 : 0;
     p.n_tasks = c.n_tasks;
     p.group2d = c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET;
-    p.sent_names = s->d_sent_names;
+    p.sent_names = s->d_sent_names; p.term_grid = s->d_term_grid; p.term_flag = s->d_term_flag;
     p.goal_cells = s->d_goal_cells; p.cand2d = s->d_cand2d; p.icon_colored = s->d_icon_colored;
     p.visible_radius = c.visible_radius; p.out_dim = s->out_h;
     p.agent_dir = s->d_agent_dir; p.goal_warp = s->d_goal_warp; p.atlas64 = s->d_atlas64; p.ego_taps = s->d_ego_taps; p.goal_img = s->d_goal_img; p.ego_agent_rot = s->d_agent_rot;
@@ -495,14 +499,18 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
             HIP_TRY(hipEventRecord(s->ev_reset, s->side));
             s->list_valid = false;
         } else {
-            // finished envs: their terminal frames are rendered from the (short) list first; everything a following
-            // xwb_reset_done regenerates beside the big render has then been read (ev_step marks that point)
-            pr.list_flag = 1;
-            HIP_TRY(launch_xw_render(pr, 1, st));
+            // Finished envs keep a terminal snapshot of their grid (step kernel) from which the big render draws their
+            // last frame, so a following xwb_reset_done can regenerate the live state beside that render right away.
+            // The egocentric render reads more than the grid (heading, goal images): there the terminal frames are
+            // rendered from the (short) list first and the big render skips them.
+            if (p.visible_radius) {
+                pr.list_flag = 1;
+                HIP_TRY(launch_xw_render(pr, 1, st));
+            }
             HIP_TRY(hipEventRecord(s->ev_step, st));
         }
         timer_begin(s, s->t_render, st);
-        HIP_TRY(launch_xw_render(p, 2, st));                // every env that is still alive
+        HIP_TRY(launch_xw_render(p, autoreset || p.visible_radius ? 2 : 3, st));
         timer_end(s, s->t_render, st);
         if (autoreset) HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
     }

@@ -157,6 +157,9 @@ struct XwParams {
     int32_t *agent_xy;           // x | y << 16
     int32_t *task_steps;         // steps_in_cur_task
     uint8_t *goal_cells;         // [n][XW_MAX_GOALS] cell of goal slot i (entity order), 0xff = none
+    uint16_t *term_grid;         // [n][max_dim*max_dim] the grid of an env at the step that finished it (see term_flag)
+    uint8_t *term_flag;          // [n] 1: this step finished the env; its terminal frame is rendered from term_grid, so a
+                                 //     reset_done running beside the render may already regenerate the live grid
     uint32_t *sent_names;        // [n] goal-name ids the idle stage binds into the teacher's sentence: a | b << 16 (0xffff none)
     uint8_t *agent_dir;          // [n] egocentric heading: 0 right, 1 down, 2 left, 3 up (XItem::get_item_facing_dir)
     double *goal_warp;           // [n][XW_MAX_GOALS][6] egocentric: inverse affine map of the goal's icon warp
@@ -190,7 +193,8 @@ hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s);
 hipError_t launch_xw_compact(const XwParams &p, int mode, hipStream_t s);
 // render: indexed == 0 -> all envs (LDS-resident atlas, persistent workgroups);
 //         indexed == 1 -> envs in done_list (atlas through L2)
-// indexed: 0 = every env, 1 = the compacted done list, 2 = every env whose done code is 0 (the rest follows as a list)
+// indexed: 0 = every env, 1 = the compacted done list, 2 = every env whose done code is 0 (the rest follows as a list),
+// 3 = every env, those the step just finished from their terminal snapshot (term_grid)
 hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s);
 hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s);
 hipError_t launch_xw_warp_goals(const XwParams &p, bool list, hipStream_t s);
