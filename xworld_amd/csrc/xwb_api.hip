@@ -325,8 +325,8 @@ int xw_setup(xwb_sim *s) {
         HIP_TRY(hipMemcpy(s->d_atlas, atlas.data(), atlas.size(), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&s->ev_step, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&s->ev_reset, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_step, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_reset, hipEventDisableTiming | hipEventDisableSystemFence));
 
     XwParams &p = s->xw;
     p.n = n; p.context = c.context; p.max_steps = c.max_steps; p.act_rep = 1; p.auto_reset = 0;
