@@ -239,7 +239,7 @@ static void idle_rearranging(orc_xworld *w, penv *p, int kind) {
     pcell o1 = {px(p, g1), py_(p, g1)}, o2 = {px(p, g2), py_(p, g2)};
     p->avail[o1.y * p->X + o1.x] = 1;                                    /* delete g1, g2 "to make space" */
     p->avail[o2.y * p->X + o2.x] = 1;
-    static ptile tiles[MAXCELLS * 6];
+    ptile tiles[MAXCELLS * 6];                                           /* on the stack: rollouts run in parallel threads */
     int nt = kind == ORC_TASK_NEAR ? p_tiles(p, tiles) : (kind == ORC_TASK_BETWEEN ? t_tiles(p, tiles) : l_tiles(p, tiles));
     if (nt == 0) goto crowded;
     {
