@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--gather-screens", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--autoreset", action="store_true", help="use the fused step+reset+single-render call")
+    ap.add_argument("--fused", type=int, default=1, help="simple games only: steps per launch (xwb_step_n); --steps must be "
+                    "a multiple; every step still writes its reward / code / observation")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo with every rank "
                     "on the visible GPUs modulo their count only exercises the N > 1 code path on a smaller box)")
     args = ap.parse_args()
@@ -205,7 +207,13 @@ def main():
         if world > 1 and args.gather_screens:
             sharding.gather_slabs(sim.obs, screens_all, counts, rank)
 
+    fused = args.fused if WORKLOADS[args.workload][0] != "xworld" else 1
+    assert args.steps % fused == 0 and args.warmup % fused == 0 or fused == 1, "--steps / --warmup must be multiples of --fused"
+
     def one_step():
+        if fused > 1:                                    # `fused` steps in one launch (built-in policy, auto-reset)
+            sim.step_n(fused)
+            return
         if results is not None:
             sim.bind_results(results.next_buffer())
         if args.autoreset:
@@ -225,12 +233,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(args.warmup // fused):
         one_step()
     # ---- the timed region: exactly K steps between two barrier + synchronize fences ----
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps // fused):
         one_step()
     fence()
     dt_clean = time.perf_counter() - t0
@@ -244,7 +252,7 @@ def main():
     # launch stream, recorded inside libxwb) to get that kernel's average duration for the roofline ----
     sim.profile_begin()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps // fused):
         one_step()
     fence()
     dt = time.perf_counter() - t0
@@ -257,7 +265,8 @@ def main():
     if rank == 0:
         total_envs = n_local * world
         value = total_envs * args.steps / dt_max
-        achieved = n_local * per_launch / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
+        # algorithmic bytes of one launch = per-step bytes x the steps that launch runs
+        achieved = n_local * per_launch * fused / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
         traffic, traffic_src = measured_traffic(args.workload) if n_local == WORKLOADS[args.workload][2] else (None, None)
         line = {
             "metric": "env-steps/sec (batched random policy)",
@@ -275,14 +284,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "envs_per_gpu": n_local, "total_envs": total_envs,
                        "obs": list(sim.obs.shape[1:]), "seed": args.seed, "policy": "uniform random, drawn on device",
-                       "loop": "step_autoreset" if args.autoreset else "step + reset_done",
+                       "loop": ("step_n(%d): %d steps per launch, auto-reset" % (fused, fused)) if fused > 1 else
+                               ("step_autoreset" if args.autoreset else "step + reset_done"),
                        "exchange": ("all_gather(reward,done)" + ("+gather(screens)" if args.gather_screens else ""))
                        if world > 1 else "none", "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name,
                          "kernel_avg_us": kern_us, "kernel_launches": kern_n,
-                         "algorithmic_bytes_per_launch": n_local * per_launch,
+                         "algorithmic_bytes_per_launch": n_local * per_launch * fused,
                          "algorithmic_bytes_per_env_step": per_step,
                          "step_loop_GBps": total_envs * per_step * args.steps / dt_max / 1e9},
             "timed_with_events_ms_per_step": dt / args.steps * 1e3,

@@ -161,6 +161,10 @@ int xwb_step_host(xwb_sim *sim, const int32_t *actions_host, int32_t act_rep, vo
  * (the observation of a finished env is the first frame of its next episode; reward / game_over
  * keep the values of the terminal transition). */
 int xwb_step_autoreset(xwb_sim *sim, const int32_t *actions_dev, int32_t act_rep, void *stream);
+/* n_steps consecutive xwb_step_autoreset calls under the built-in random policy (actions drawn on the device).  For
+ * SimpleGame / SimpleRace they run inside ONE launch -- a step there moves a few MB and is launch-bound -- with every
+ * step's reward, code and observation written exactly as separate launches would; XWorld2D loops on the host. */
+int xwb_step_n(xwb_sim *sim, int32_t n_steps, int32_t act_rep, void *stream);
 
 /* returns the number of envs that flagged an out-of-range action since the last call (synchronises stream) */
 int xwb_check_errors(xwb_sim *sim, void *stream, int32_t *n_bad);

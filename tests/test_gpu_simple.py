@@ -247,3 +247,25 @@ def test_action_skip_leaves_env_untouched(oracle):
     keep[7] = False
     assert torch.equal(sim.obs[keep], before[keep]) and int(sim.num_steps[keep].sum()) == 0
     sim.close()
+
+
+@pytest.mark.parametrize("game,opts", [("simple_game", {"array_size": 16, "context": 2}), ("simple_game", {"array_size": 64}),
+                                        ("simple_race", {"track_width": 20.0, "track_length": 100.0, "track_radius": 30.0, "random": True})])
+def test_step_n_equals_n_autoreset_steps(oracle, game, opts):
+    """xwb_step_n: n steps inside one launch leave exactly the state n separate step_autoreset calls leave."""
+    torch = _torch()
+    from xworld_amd.batched import BatchedSimulator
+    n = 5000
+    a = BatchedSimulator(game, opts, num_envs=n, policy_seed=21, seed=9)
+    b = BatchedSimulator(game, opts, num_envs=n, policy_seed=21, seed=9)
+    for k in (1, 7, 40):
+        a.step_n(k)
+        for _ in range(k):
+            b.step_autoreset()
+        assert torch.equal(a.reward, b.reward) and torch.equal(a.game_over_codes, b.game_over_codes)
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.num_steps, b.num_steps) and torch.equal(a.actions, b.actions)
+    a.step()                                                  # and the policy step counter moved with it
+    b.step()
+    assert torch.equal(a.actions, b.actions) and torch.equal(a.obs, b.obs)
+    a.close()
+    b.close()

@@ -150,6 +150,10 @@ class BatchedSimulator:
         ptr = None if actions is None else C.c_void_p(actions.data_ptr())
         lib.check(self.L.xwb_step(self.h, ptr, int(act_rep), self._stream(stream)))
 
+    def step_n(self, n_steps, act_rep=1, stream=None):
+        """n_steps x step_autoreset under the built-in random policy; one launch for the simple games."""
+        lib.check(self.L.xwb_step_n(self.h, int(n_steps), int(act_rep), self._stream(stream)))
+
     def step_autoreset(self, actions=None, act_rep=1, stream=None):
         ptr = None if actions is None else C.c_void_p(actions.data_ptr())
         lib.check(self.L.xwb_step_autoreset(self.h, ptr, int(act_rep), self._stream(stream)))

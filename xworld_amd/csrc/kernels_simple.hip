@@ -62,9 +62,9 @@ template <> __device__ __forceinline__ uint4 zero_chunk<16>() { return make_uint
 template <> __device__ __forceinline__ uint32_t zero_chunk<4>() { return 0u; }
 template <> __device__ __forceinline__ uint8_t zero_chunk<1>() { return 0; }
 
-// One launch = one SimulatorInterface::take_actions (or reset_game) for every env.
+// One call = one SimulatorInterface::take_actions (or reset_game) for every env.
 template <int G>
-__global__ __launch_bounds__(256) void sg_kernel(SgParams p) {
+__device__ __forceinline__ void sg_body(const SgParams &p, uint32_t policy_step) {
     using chunk_t = typename ChunkT<G>::type;
     __shared__ int s_pos[256];      // -1: leave this env's observation untouched
     __shared__ uint8_t s_fresh[256];
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void sg_kernel(SgParams p) {
         int steps = p.num_steps[e];
         bool do_reset = false;
         if (p.mode == MODE_STEP) {
-            int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step, 2);
+            int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, policy_step, 2);
             p.actions_out[e] = a;
             if (a == ACTION_SKIP) {
                 // this env does not take part in the call
@@ -142,6 +142,16 @@ __global__ __launch_bounds__(256) void sg_kernel(SgParams p) {
             for (int f = 0; f + 1 < ctx; ++f) frame0[(size_t)f * cpf] = frame0[(size_t)(f + 1) * cpf];
         }
         frame0[(size_t)(ctx - 1) * cpf] = sg_onehot_chunk<G>(pos - j * G);
+    }
+}
+
+// n_steps > 1 (xwb_step_n): consecutive steps under the built-in policy with in-kernel auto-reset, each one writing its
+// reward / code / observation like a separate launch would -- one launch instead of n (a 6 MB step is launch-bound)
+template <int G>
+__global__ __launch_bounds__(256) void sg_kernel(SgParams p) {
+    for (int it = 0; it < p.n_steps; ++it) {
+        sg_body<G>(p, p.policy_step + (uint32_t)it);      // (p stays in kernel-argument memory: never written)
+        __syncthreads();                                   // the shared staging of this step is dead
     }
 }
 
@@ -244,14 +254,14 @@ __device__ __forceinline__ void race_reset(const RaceParams &p, RaceCar &c, uint
     c.angle = (float)((double)(u_ang * 2) * RACE_PI);   // BaseCar::set_angle(true) cpp:237-243
 }
 
-__global__ __launch_bounds__(256) void race_kernel(RaceParams p) {
+__device__ __forceinline__ void race_body(const RaceParams &p, uint32_t policy_step) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= p.n) return;
     RaceCar c = {p.x[e], p.y[e], p.angle[e]};
     int steps = p.num_steps[e];
     bool do_reset = false, touched = false;
     if (p.mode == MODE_STEP) {
-        int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step, p.n_legal);
+        int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, policy_step, p.n_legal);
         p.actions_out[e] = a;
         if (a == ACTION_SKIP) {
             // this env does not take part in the call
@@ -322,6 +332,12 @@ __global__ __launch_bounds__(256) void race_kernel(RaceParams p) {
         for (int f = 0; f + 1 < p.context; ++f) frames[f] = frames[f + 1];
     }
     frames[p.context - 1] = race_screen(p, c);
+}
+
+__global__ __launch_bounds__(256) void race_kernel(RaceParams p) {
+    for (int it = 0; it < p.n_steps; ++it) {               // n_steps > 1: xwb_step_n, see sg_kernel
+        race_body(p, p.policy_step + (uint32_t)it);
+    }
 }
 
 hipError_t launch_simple_race(const RaceParams &p, hipStream_t s) {

@@ -383,6 +383,7 @@ SgParams sg_params(xwb_sim *s) {
     p.pos = s->d_pos; p.flags = s->d_flags; p.num_steps = s->d_num_steps; p.episode = s->d_episode;
     p.reward = s->d_reward; p.done = s->d_done; p.obs = static_cast<uint8_t *>(s->d_obs);
     p.packed = s->d_packed;
+    p.n_steps = 1;
     p.err_count = s->d_err; p.reset_count = s->d_reset_count;
     return p;
 }
@@ -397,6 +398,7 @@ RaceParams race_params(xwb_sim *s) {
     p.x = s->d_x; p.y = s->d_y; p.angle = s->d_angle; p.num_steps = s->d_num_steps; p.episode = s->d_episode;
     p.reward = s->d_reward; p.done = s->d_done; p.obs = static_cast<float *>(s->d_obs);
     p.packed = s->d_packed;
+    p.n_steps = 1;
     p.err_count = s->d_err; p.reset_count = s->d_reset_count;
     return p;
 }
@@ -710,6 +712,30 @@ int xwb_step_host(xwb_sim *s, const int32_t *actions_host, int32_t act_rep, void
     hipStream_t st = as_stream(stream);
     HIP_TRY(hipMemcpyAsync(s->d_actions_in, actions_host, sizeof(int32_t) * (size_t)s->n, hipMemcpyHostToDevice, st));
     return do_step(s, s->d_actions_in, act_rep, false, st);
+}
+
+int xwb_step_n(xwb_sim *s, int32_t n_steps, int32_t act_rep, void *stream) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    if (n_steps < 1 || act_rep < 1) return fail(XWB_ERR_ARG, "n_steps and act_rep must be >= 1");
+    hipStream_t st = as_stream(stream);
+    if (s->cfg.game == XWB_XWORLD2D) {                      // one render per step is the work: nothing to fuse
+        for (int i = 0; i < n_steps; ++i) { int rc = do_step(s, nullptr, act_rep, true, st); if (rc) return rc; }
+        return XWB_OK;
+    }
+    HIP_TRY(hipMemsetAsync(s->d_reset_count, 0, sizeof(int32_t), st));
+    timer_begin(s, s->t_step, st);
+    if (s->cfg.game == XWB_SIMPLE_GAME) {
+        SgParams p = sg_params(s);
+        p.actions = nullptr; p.act_rep = act_rep; p.auto_reset = 1; p.n_steps = n_steps;
+        HIP_TRY(launch_simple_game(p, st));
+    } else {
+        RaceParams p = race_params(s);
+        p.actions = nullptr; p.act_rep = act_rep; p.auto_reset = 1; p.n_steps = n_steps;
+        HIP_TRY(launch_simple_race(p, st));
+    }
+    timer_end(s, s->t_step, st);
+    s->policy_step += (uint32_t)n_steps;
+    return XWB_OK;
 }
 
 int xwb_step_autoreset(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, void *stream) {

@@ -76,7 +76,7 @@ enum : int { MODE_STEP = 0, MODE_RESET_ALL = 1, MODE_RESET_DONE = 2, MODE_RESET_
 
 // ------------------------------------------------------------ SimpleGame ---
 struct SgParams {
-    int n, array_size, context, max_steps, act_rep, mode, auto_reset;
+    int n, array_size, context, max_steps, act_rep, mode, auto_reset, n_steps;
     uint32_t policy_seed, env_gid0, policy_step;
     const int32_t *actions;     // nullable
     const uint8_t *mask;        // MODE_RESET_MASK
@@ -96,7 +96,7 @@ hipError_t launch_simple_game(const SgParams &p, hipStream_t s);
 
 // ------------------------------------------------------------ SimpleRace ---
 struct RaceParams {
-    int n, context, max_steps, act_rep, mode, auto_reset;
+    int n, context, max_steps, act_rep, mode, auto_reset, n_steps;
     uint32_t policy_seed, env_gid0, policy_step, seed;
     int track_type, random, difficulty_hard, n_legal;
     int legal[9];

@@ -59,6 +59,7 @@ _SIGS = [
     ("xwb_reset_env", C.c_int, [_vp, C.c_int32, _vp]),
     ("xwb_step", C.c_int, [_vp, _vp, C.c_int32, _vp]),
     ("xwb_step_host", C.c_int, [_vp, _vp, C.c_int32, _vp]),
+    ("xwb_step_n", C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
     ("xwb_step_autoreset", C.c_int, [_vp, _vp, C.c_int32, _vp]),
     ("xwb_check_errors", C.c_int, [_vp, _vp, C.POINTER(C.c_int32)]),
     ("xwb_obs_dev", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
