@@ -64,7 +64,7 @@ template <> __device__ __forceinline__ uint8_t zero_chunk<1>() { return 0; }
 
 // One call = one SimulatorInterface::take_actions (or reset_game) for every env.
 template <int G>
-__device__ __forceinline__ void sg_body(const SgParams &p, uint32_t policy_step) {
+__device__ __forceinline__ void sg_body(const SgParams &p, uint32_t policy_step, int &pos, uint32_t &flags, int &steps) {
     using chunk_t = typename ChunkT<G>::type;
     __shared__ int s_pos[256];      // -1: leave this env's observation untouched
     __shared__ uint8_t s_fresh[256];
@@ -74,9 +74,6 @@ __device__ __forceinline__ void sg_body(const SgParams &p, uint32_t policy_step)
     int obs_pos = -1;
     bool fresh = false;
     if (e < p.n) {
-        int pos = p.pos[e];
-        uint32_t flags = p.flags[e];
-        int steps = p.num_steps[e];
         bool do_reset = false;
         if (p.mode == MODE_STEP) {
             int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, policy_step, 2);
@@ -149,8 +146,13 @@ __device__ __forceinline__ void sg_body(const SgParams &p, uint32_t policy_step)
 // reward / code / observation like a separate launch would -- one launch instead of n (a 6 MB step is launch-bound)
 template <int G>
 __global__ __launch_bounds__(256) void sg_kernel(SgParams p) {
+    // the env's state stays in registers across the steps of one launch (it is still written back every step)
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    int pos = 0, steps = 0;
+    uint32_t flags = 0;
+    if (e < p.n) { pos = p.pos[e]; flags = p.flags[e]; steps = p.num_steps[e]; }
     for (int it = 0; it < p.n_steps; ++it) {
-        sg_body<G>(p, p.policy_step + (uint32_t)it);      // (p stays in kernel-argument memory: never written)
+        sg_body<G>(p, p.policy_step + (uint32_t)it, pos, flags, steps);      // (p stays in kernel-argument memory: never written)
         __syncthreads();                                   // the shared staging of this step is dead
     }
 }
