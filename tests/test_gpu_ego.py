@@ -227,3 +227,23 @@ def test_ego_config_errors():
     sim = BatchedSimulator("xworld", {"xwd_conf_path": nav, "visible_radius": 99, "max_dim": 7}, num_envs=4)
     assert sim.cfg.visible_radius == 99 and sim.screen_dims[:2] == (84, 84) and sim.num_actions == 6   # clamped to 7 inside
     sim.close()
+
+
+def test_ego_float32_frames(oracle):
+    """obs_format="float32" in egocentric mode: every frame = the uint8 frame * float32(1/255), through resets and the ring."""
+    torch = _torch()
+    n = 300
+    a, _, _ = _make(oracle, "nav7", n, 3, seed=6, policy_seed=5, color=True, context=2)
+    b, _, _ = _make(oracle, "nav7", n, 3, seed=6, policy_seed=5, color=True, context=2, obs_format="float32")
+    assert b.obs.dtype == torch.float32 and b.obs_bytes_per_env == 4 * a.obs_bytes_per_env
+    scale = torch.tensor(1 / 255.0, dtype=torch.float32, device="cuda")
+    for t in range(40):
+        assert torch.equal(b.obs, a.obs.to(torch.float32) * scale), t
+        if t % 2:
+            a.step_autoreset(); b.step_autoreset()
+        else:
+            a.step(); b.step()
+            assert torch.equal(b.obs, a.obs.to(torch.float32) * scale), t
+            a.reset_done(); b.reset_done()
+    a.close()
+    b.close()

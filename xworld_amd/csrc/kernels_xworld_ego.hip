@@ -146,7 +146,7 @@ __global__ __launch_bounds__(BS) void xw_render_ego_kernel(XwParams p, const uin
     }
     const int tid = threadIdx.x;
     const int cells = D * D;
-    const int cpf = CH * O * O / 16;
+    const int cpf = CH * O * O / (p.obs_f32 ? 4 : 16);    // 16-byte chunks per frame: 16 uint8 pixels, or 4 float32 ones
     const int n_items = MODE == 1 ? *count_now : p.n;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int e = MODE == 1 ? p.done_list[item] : item;
@@ -226,7 +226,18 @@ __global__ __launch_bounds__(BS) void xw_render_ego_kernel(XwParams p, const uin
         __syncthreads();
         const int flag = MODE == 1 ? p.list_flag : p.fresh[e];
         uint4 *frame0 = reinterpret_cast<uint4 *>(p.obs) + (size_t)e * p.context * cpf;
-        for (int cc = tid; cc < cpf; cc += BS) xw_store_chunk(frame0, cc, cpf, p.context, p.context > 1 ? flag : 1, smem4[cc]);
+        if (p.obs_f32) {
+            // float32 frames: pixel * (1 / 255.0f), the product py_simulator.cpp:262-272 computes in get_state()
+            const float scale = (float)(1 / 255.0);
+            for (int cc = tid; cc < cpf; cc += BS) {
+                const uchar4 b = reinterpret_cast<const uchar4 *>(s_frame)[cc];
+                const float f0 = (float)b.x * scale, f1 = (float)b.y * scale, f2 = (float)b.z * scale, f3 = (float)b.w * scale;
+                xw_store_chunk(frame0, cc, cpf, p.context, p.context > 1 ? flag : 1,
+                               make_uint4(__float_as_uint(f0), __float_as_uint(f1), __float_as_uint(f2), __float_as_uint(f3)));
+            }
+        } else {
+            for (int cc = tid; cc < cpf; cc += BS) xw_store_chunk(frame0, cc, cpf, p.context, p.context > 1 ? flag : 1, smem4[cc]);
+        }
         if (MODE == 1 && tid == 0 && p.list_flag == 2) { p.fresh[e] = 0; if (p.auto_reset == 2) p.done[e] = 0; }
     }
 }

@@ -602,7 +602,6 @@ int xwb_create(const xwb_config *cfg, xwb_sim **out) {
                     return bail(fail(XWB_ERR_ARG, "xworld: visible_radius > 0 needs a maze map (XWorldNav): without maze "
                                                   "generation the reference's set_property rejects the agent's default yaw "
                                                   "(xworld_env.py:208-210, py_util.py:27-29)"));
-                if (cfg->obs_format != XWB_OBS_U8) return bail(fail(XWB_ERR_ARG, "xworld: egocentric frames are uint8 only"));
                 s->out_h = s->out_w = r * (84 / r);
                 s->num_actions = 6;                                       // xitem.cpp:84-86
             }
