@@ -373,3 +373,32 @@ def test_float32_observations(oracle, key, color, context):
     assert np.array_equal(b.env_obs(e), a.env_obs(e).astype(np.float32) * np.float32(1 / 255.0))
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("md,blocks", [(15, 60), (16, 70), (13, 40)])
+def test_largest_maps(oracle, md, blocks):
+    """max_dim up to 16 (four 64-bit mask words per board, the generic-dimension render): reset, rollout, frames."""
+    torch = _torch()
+    from xworld_amd.batched import BatchedSimulator
+    n, steps = 256, 120
+    opts = {"xwd_conf_path": os.path.join(CONF, "navigation2d.json"), "task_mode": "lang_acquisition", "max_dim": md,
+            "num_blocks": blocks, "color": True}
+    sim = BatchedSimulator("xworld", opts, num_envs=n, seed=3, policy_seed=4)
+    pal = oracle.Palette(oracle.NAV_SUBTREES)
+    cfg = dict(map_kind=0, max_dim=md, dim=md, num_goals=4, num_blocks=blocks, color=1, seed=3, tasks=[0, 1, 2, 3, 4])
+    ow = oracle.XWorld(pal, render=True, **cfg)
+    obs = sim.obs.cpu().numpy()
+    for e in range(0, n, 5):
+        ow.reset_game(e, 0)
+        st = sim.env_state(e)
+        assert np.array_equal(sim.env_grid(e).astype(np.int32), ow.grid()) and (st.xw_agent_x, st.xw_agent_y) == ow.agent_xy()
+        assert st.xw_task == ow.task_kind()
+        if e % 25 == 0:
+            assert np.array_equal(obs[e], ow.state_screen()), e
+    ref = oracle.xw_rollout(n, oracle.xw_cfg(**cfg), pal, steps, policy_seed=4)
+    for t in range(steps):
+        sim.reset_done()
+        sim.step()
+        assert np.array_equal(sim.reward.cpu().numpy().view(np.uint32), ref.rewards[t].view(np.uint32)), t
+        assert np.array_equal(sim.game_over_codes.cpu().numpy(), ref.codes[t]), t
+    sim.close()
