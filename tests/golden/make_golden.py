@@ -32,6 +32,7 @@ Fixtures written:
   maps_nav.json  XWorldNav.reset() maps (python random seeded), entity lists as palette indices,
                  + reference _reachable() per goal
   maps_walls.json  same for XWorldWalls
+  maps_levels.json XWorldNav at curriculum levels 0..4 (3x3 .. 7x7 inside the 8x8 world): placed entities and the padded C++ view
   teacher.json   XWorld3DNavTarget idle/navigation_reward run over random action strings on those maps:
                  per step action, reward, event, stage, agent cell, action success
   tasks_ego.json the five tasks with FLAGS_visible_radius = 3: entity poses (yaw, scale, offset) as the reference's
@@ -204,6 +205,35 @@ def gen_maps(cls, pal, n_maps, seed0):
         maps.append({"py_seed": seed0 + k, "dim": h, "max_dim": env.get_max_dims()[0], "entities": ents,
                      "goal_reachable": reach})
     return maps
+
+
+def gen_maps_levels(pal, per_level, seed0):
+    """XWorldNav at the curriculum levels 0..4 (XWorldNav.py:27-39: dims 3..7 inside the 8x8 world, goals / blocks per level):
+    the entities in env coordinates (what the generator placed) and the C++ view cpp_get_entities() returns -- shifted
+    by the padding offset and followed by the padding wall (xworld_env.py:354-365, 454-493)."""
+    out = []
+    FLAGS["curriculum"] = 1e9                      # level logic on, never advancing
+    try:
+        for level in range(5):
+            env = XWorldNav(ITEM_PATH, start_level=level)
+            for k in range(per_level):
+                random.seed(seed0 + 100 * level + k)
+                env.reset()
+                h, w = env.get_dims()
+                task = XWorld3DNavTarget(env)
+                agent = [e for e in env.get_entities() if e.type == "agent"][0]
+                reach = [bool(task._reachable(agent.loc, g.loc)) for g in env.get_goals()]
+                # cpp_get_entities() shifts the entities' own locs by the offset (update_entities_from_cpp undoes it in
+                # the real flow), so it comes last here
+                cpp = entity_records(env, pal)
+                n_actual = len(env.get_entities())
+                actual = [[t, x - env.offset_w, y - env.offset_h, icon, name, serial] for t, x, y, icon, name, serial in cpp[:n_actual]]
+                out.append({"py_seed": seed0 + 100 * level + k, "level": level, "dim": h, "max_dim": env.get_max_dims()[0],
+                            "num_goals": len(env.get_goals()), "num_blocks": len(env.get_blocks()),
+                            "entities": actual, "cpp_entities": cpp, "goal_reachable": reach})
+    finally:
+        FLAGS["curriculum"] = 0.0
+    return out
 
 
 # --------------------------------------------------------------- teacher ----
@@ -608,6 +638,7 @@ def main():
         "bfs.json": lambda: gen_bfs(),
         "maps_nav.json": lambda: gen_maps(XWorldNav, nav_pal, 60, 100),
         "maps_walls.json": lambda: gen_maps(XWorldWalls, walls_pal, 30, 500),
+        "maps_levels.json": lambda: gen_maps_levels(nav_pal, 8, 700),
         "teacher.json": lambda: {"nav": gen_teacher(XWorldNav, nav_pal, 40, 2000, 700),
                                  "walls": gen_teacher(XWorldWalls, walls_pal, 24, 3000, 500)},
         "tasks.json": lambda: gen_tasks(nav_pal, 24, 9000, 660),

@@ -103,3 +103,22 @@ def test_reward_values_are_the_double_sums(oracle):
     runs = load("teacher.json")["nav"]
     vals = {np.float32(s[1]).item() for r in runs for s in r["trace"]}
     assert vals <= {np.float32(-0.01).item(), np.float32(0.99).item(), np.float32(-1.01).item(), 0.0}
+
+
+def test_curriculum_levels_padding_matches_reference(oracle):
+    """XWorldNav at curriculum levels 0..4 (3x3 .. 7x7 inside the 8x8 world): the entities the reference placed are
+    loaded in env coordinates; the oracle must produce the reference's C++ view -- everything shifted by the padding
+    offset, the padding bricks appended in the reference's order with its ids -- and the same reachability."""
+    pal = oracle.Palette(oracle.NAV_SUBTREES)
+    levels = set()
+    for m in load("maps_levels.json"):
+        w = oracle.XWorld(pal, render=False, map_kind=0, max_dim=m["max_dim"], dim=m["dim"], num_goals=m["num_goals"],
+                          num_blocks=m["num_blocks"])
+        cand = [i for i, r in enumerate(m["goal_reachable"]) if r]
+        w.load_map([tuple(e) for e in m["entities"]], m["dim"], target_pick=0 if cand else -1)
+        assert [list(e) for e in w.entities()] == m["cpp_entities"], (m["py_seed"], m["level"])
+        goals = [e for e in m["entities"] if e[0] == 0]
+        assert w.target_name() == (goals[cand[0]][4] if cand else -1)     # no candidate: the reference asserts
+        assert (w.grid() != 0).sum() == len(m["cpp_entities"])
+        levels.add(m["level"])
+    assert levels == {0, 1, 2, 3, 4}
