@@ -599,8 +599,11 @@ def gen_sentences(n_per_task, seed0):
     names = sorted(_orig_names(env, "goal"))
     rnd = random.Random(seed0)
     out = {"goal_names": names, "tasks": {}}
+    sys.path.insert(0, os.path.join(REF, "games", "xworld", "tasks"))
+    colors = sorted(set(env.get_all_colors()))
+    out["colors"] = colors
     for name in ["XWorld3DNavTarget", "XWorld3DNavTargetNear", "XWorld3DNavTargetBetween", "XWorld3DNavTargetDirection",
-                 "XWorld3DNavTargetAvoid"]:
+                 "XWorld3DNavTargetAvoid", "XWorldNavTarget", "XWorldNavColorTarget"]:
         mod = importlib.import_module(name)
         task = getattr(mod, name)(env)
         grammar, start = task._define_grammar()
@@ -608,9 +611,14 @@ def gen_sentences(n_per_task, seed0):
         recs = []
         for k in range(n_per_task):
             what = ["start", "correct", "wrong", "timeup"][0 if k % 4 else rnd.randrange(1, 4)] if k % 7 == 0 else "start"
+            if not name.startswith("XWorld3D") and what in ("correct", "wrong"):
+                what = "finish"
             binds = {"S": what}
             if what == "start":
-                if name == "XWorld3DNavTargetBetween":
+                if name == "XWorldNavColorTarget":
+                    binds["O"] = "'%s'" % rnd.choice(names)
+                    binds["C"] = "'%s'" % rnd.choice(colors)
+                elif name == "XWorld3DNavTargetBetween":
                     binds["G1"] = "'%s'" % rnd.choice(names)
                     binds["G2"] = "'%s'" % rnd.choice(names)
                 else:

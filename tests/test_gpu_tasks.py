@@ -313,3 +313,29 @@ def test_sentences_follow_the_episode(oracle):
     g.reset_game()
     assert g.get_state()["sentence"] == g.batch.sentence(0) != ""
     sim.close()
+
+
+def test_sentences_of_the_2d_native_group(oracle):
+    """XWorldNavTarget / ColorTarget speak on the teach() call that picks the target only; the sentence names the goal
+    (and its colour) at the target cell."""
+    _torch()
+    n = 256
+    sim, pal, cfg = _make(oracle, "nav8", n, [KINDS2D[0], KINDS2D[2]], seed=5, task_mode="lang_acquisition", max_steps=30)
+    md = cfg["max_dim"]
+    spoke = 0
+    for e in range(n):
+        st = sim.env_state(e)
+        s = sim.sentence(e)
+        if st.xw_stage == 1:
+            icon = int(sim.env_grid(e)[st.xw_target // md, st.xw_target % md]) - 1
+            m = sim.palette.meta[icon]
+            assert m["name"] in s.split(), (e, s)
+            if st.xw_task == 7:
+                assert m["color"] in s.split() and m["color"] != "na"
+            spoke += 1
+        else:
+            assert s == ""
+    assert spoke > n // 2
+    sim.step()
+    assert all(sim.sentence(e) == "" for e in range(0, n, 5))      # the navigation stage says nothing
+    sim.close()

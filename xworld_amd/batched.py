@@ -295,6 +295,15 @@ class BatchedSimulator:
         """The teacher's sentence of one env after the last call (language.py); "" where the reference shows "-"."""
         from . import language
         st = self.env_state(env, stream)
+        if st.xw_task in (5, 7):
+            # 2-D-native Target / ColorTarget: they speak only on the teach() call that picked the target
+            if st.xw_stage != 1 or st.xw_steps_in_task != 0 or st.xw_target < 0:
+                return ""
+            d = self.cfg.max_dim
+            icon = int(self.env_grid(env, stream)[st.xw_target // d, st.xw_target % d]) - 1
+            m = self.palette.meta[icon]
+            return language.sentence_2d(st.xw_task, m["name"], m.get("color", "na"), self.cfg.seed,
+                                        self.cfg.env_gid0 + int(env), st.episode, int(st.num_steps))
         sn = st.xw_sentence_names
         return language.sentence(st.xw_task, st.xw_stage, st.xw_event, self.palette.names["goal"], sn & 0xffff, sn >> 16,
                                  (st.xw_target >> 8) & 7 if st.xw_task == 3 and st.xw_target >= 0 else 0,

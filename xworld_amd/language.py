@@ -7,7 +7,10 @@ every step of the episode, replaced by the "correct" / "wrong" / "timeup" messag
 ("-" in get_state) afterwards.  Here the sentence of an env is a pure function of the batch state (task, bound goal
 names, direction word, stage, event, episode) and of the xwb-rng-v1 stream 3 ("language": key = (seed, global env id),
 counter = (block, episode, 3, 0); one `below(n)` per expanded non-terminal, also when it is bound), so nothing has to
-be stored per env and the device never sees strings.  Sentences of the 2-D-native group (rule D14b) are not built.
+be stored per env and the device never sees strings.  The 2-D-native group (rule D14b; games/xworld/tasks/XWorldNav*.py)
+speaks only on the teach() call that picks a target (its navigation stage returns ""): XWorldNavTarget /
+XWorldNavColorTarget instructions are expanded from stream 3 starting at block 4 * num_steps; its "Time up ." message of
+the one_channel mode is not built.
 
 Pinned by tests/golden/sentences.json: the reference's CFG run on each task's own grammar, replayed decision by
 decision (tests/test_language.py).
@@ -137,6 +140,35 @@ E -> 'anything' 'except' | 'anything' 'but'
 """),
 }
 
+_COMMON_2D = """
+S -> start | finish | timeup
+finish -> 'Well' 'done' '!'
+timeup -> 'Time' 'up' '.'
+A -> 'go' 'to' | 'navigate' 'to' | 'reach' | 'move' 'to'
+Y -> 'Could' 'you' 'please' | 'Can' 'you' | 'Will' 'you'
+D -> 'destination' | 'target' | 'goal'
+"""
+GRAMMARS[5] = Grammar(_COMMON_2D + """
+start -> I1 | I2 | I3 | I4 | I5 | I6
+I1 -> A G 'please' '.'
+I2 -> 'Please' A G '.'
+I3 -> A G '.'
+I4 -> G 'is' 'your' D '.'
+I5 -> G 'is' 'the' D '.'
+I6 -> Y A G '?'
+""")
+GRAMMARS[7] = Grammar(_COMMON_2D + """
+start -> I1 | I2 | I3 | I4 | I5 | I6 | I7
+I1 -> A G 'please' '.'
+I2 -> 'Please' A G '.'
+I3 -> A G '.'
+I4 -> G 'is' 'your' D '.'
+I5 -> G 'is' 'the' D '.'
+I6 -> Y A G '?'
+I7 -> G '.'
+G -> C O
+""")
+
 DIRECTION_WORDS = {1: "FRONT", 2: "BEHIND", 3: "LEFT", 4: "RIGHT"}      # xw_device.h DIR_*
 EVENT_RULE = {1: "correct", 2: "wrong", 3: "timeup"}                    # xw_device.h EV_*
 
@@ -150,6 +182,19 @@ def instruction_bindings(task, name_a, name_b=None, direction=0):
     if task == 3:
         b["P"] = DIRECTION_WORDS[direction]
     return b
+
+
+def sentence_2d(task, goal_name, color, seed, gid, episode, num_steps):
+    """The instruction of a 2-D-native task on the teach() call that picked its target (XWorldNavTarget.py:22-33,
+    XWorldNavColorTarget.py:8-20): G (or O and C) bound, the rest drawn from stream 3, blocks 4 * num_steps onwards."""
+    st = Stream(seed, gid, episode, 3)
+    st.blk = 4 * num_steps
+    b = {"S": "start"}
+    if task == 7:
+        b["O"], b["C"] = "'%s'" % goal_name, "'%s'" % color
+    else:
+        b["G"] = "'%s'" % goal_name
+    return GRAMMARS[task].expand(st.below, b)
 
 
 def sentence(task, stage, event, goal_names, name_a, name_b, direction, seed, gid, episode):
