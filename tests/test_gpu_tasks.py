@@ -247,18 +247,28 @@ def test_reference_2d_task_traces_through_product(oracle, key):
     sim.close()
 
 
-def test_conf_walls_json_navigation_group():
+def test_conf_walls_json_navigation_group(tmp_path):
     _torch()
+    import json
     from xworld_amd.batched import BatchedSimulator
-    with pytest.raises(RuntimeError):
-        BatchedSimulator("xworld", {"xwd_conf_path": os.path.join(CONF, "walls.json")}, num_envs=4)
-    sim = BatchedSimulator("xworld", {"xwd_conf_path": os.path.join(CONF, "walls.json"), "task_group": "XWorldNav"},
-                           num_envs=64, seed=2)
+    sim = BatchedSimulator("xworld", {"xwd_conf_path": os.path.join(CONF, "walls.json")}, num_envs=64, seed=2)
     assert sim.tasks == [5, 6, 7, 8]
+    sim.close()
+    # a conf with several groups (the reference's walls.json also lists the language group): one must be picked
+    with open(os.path.join(CONF, "walls.json")) as f:
+        conf = json.load(f)
+    conf["task_groups"]["XWorldRec"] = {"schedule": "weighted", "weight": 1, "tasks": {"XWorldRecColorToObject": 1}}
+    two = tmp_path / "two_groups.json"
+    two.write_text(json.dumps(conf))
+    with pytest.raises(RuntimeError):
+        BatchedSimulator("xworld", {"xwd_conf_path": str(two)}, num_envs=4)
+    sim = BatchedSimulator("xworld", {"xwd_conf_path": str(two), "task_group": "XWorldNav"}, num_envs=4)
+    assert sim.tasks == [5, 6, 7, 8]
+    sim.close()
     with pytest.raises(RuntimeError):
         BatchedSimulator("xworld", {"xwd_conf_path": os.path.join(CONF, "nav_target.json"),
                                     "tasks": ["XWorldNavTarget", "XWorld3DNavTarget"]}, num_envs=4)
-    sim.close()
+
 
 
 # ------------------------------------------------------------------------------------------ the teacher's sentences
