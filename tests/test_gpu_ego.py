@@ -127,7 +127,9 @@ def test_reference_ego_traces_through_product(oracle, kind):
 
 
 @pytest.mark.parametrize("key,r,color,context", [("nav7", 3, True, 1), ("nav8", 5, False, 1), ("nav7", 7, True, 2),
-                                                 ("nav11", 3, True, 1), ("nav8_dim5", 1, True, 1)])
+                                                 ("nav11", 3, True, 1), ("nav8_dim5", 1, True, 1),
+                                                 # 81 and 77 pixel edges: frames that are not whole 16-byte chunks
+                                                 ("nav11", 9, True, 2), ("nav11", 11, False, 1)])
 def test_ego_frames_with_host_poses(oracle, key, r, color, context):
     """Frames bit for bit: maps from the oracle's generator are loaded into the product with the goal poses set through
     the host (same libm as the oracle), then both run the same action strings."""
@@ -229,12 +231,13 @@ def test_ego_config_errors():
     sim.close()
 
 
-def test_ego_float32_frames(oracle):
+@pytest.mark.parametrize("key,r", [("nav7", 3), ("nav11", 9)])
+def test_ego_float32_frames(oracle, key, r):
     """obs_format="float32" in egocentric mode: every frame = the uint8 frame * float32(1/255), through resets and the ring."""
     torch = _torch()
     n = 300
-    a, _, _ = _make(oracle, "nav7", n, 3, seed=6, policy_seed=5, color=True, context=2)
-    b, _, _ = _make(oracle, "nav7", n, 3, seed=6, policy_seed=5, color=True, context=2, obs_format="float32")
+    a, _, _ = _make(oracle, key, n, r, seed=6, policy_seed=5, color=True, context=2)
+    b, _, _ = _make(oracle, key, n, r, seed=6, policy_seed=5, color=True, context=2, obs_format="float32")
     assert b.obs.dtype == torch.float32 and b.obs_bytes_per_env == 4 * a.obs_bytes_per_env
     scale = torch.tensor(1 / 255.0, dtype=torch.float32, device="cuda")
     for t in range(40):

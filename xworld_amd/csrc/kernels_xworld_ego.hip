@@ -12,8 +12,13 @@
 // the intermediate image, each of which blends 2 x 2 view pixels; a view pixel is found by undoing the quarter-turn view
 // rotation (exact integer map, one border row / column), the cell lookup, and for goals the inverse affine warp with
 // cv::remap's 5-bit sub-pixel bilinear weights.  One workgroup renders one env; the frame is assembled in LDS and
-// leaves as aligned 16-byte stores.  Work per env: (84^2) x 16 view-pixel evaluations -- compute-bound, not HBM-bound
-// (21 KB written per env); icons (64x64x3, 4.2 MB for the XWorldNav palette) are read through L2.
+// leaves as aligned 16-byte stores.  Evaluating all 84^2 pixels that way is instruction-bound (16 view pixels and ~400
+// VALU operations each), so only the pixels that need it are: an output pixel whose 4 x 4 view pixels all lie inside
+// ONE view cell depends on nothing but that cell's image, its position in the frame and the heading, and for blocks,
+// the agent, empty cells and black cells that image is one of a few constants.  xw_ego_build_tab_kernel renders, once
+// per batch, the frame "every cell shows icon i" for each icon and heading with the very same pixel code; the render
+// copies interior pixels from those frames (4 pixels per load, through L2) and evaluates only the pixels on a cell
+// border and the pixels of goal cells (whose images are per env: pose-warped).
 //
 // OpenCV 3.2 arithmetic restated (third party, cmake/opencv.cmake:5-6; DESIGN.md lists the pieces): the tests compare
 // this kernel bit for bit with a CPU restatement of the same pipeline; pixel parity with the real library is unpinned.
@@ -35,7 +40,7 @@ namespace {
 struct EgoCell {
     const uint32_t *img;
     int mask;                    // -1: index the image; 0: a constant pixel
-    int pad;
+    int tab;                     // frame of the interior-pixel table that shows this cell's image, -1: none (a goal)
 };
 
 struct EgoCtx {
@@ -53,11 +58,13 @@ __device__ __forceinline__ int vresize(int b0, int h0, int b1, int h1) {
 // All pixels of one frame.  DIR = the agent's heading: cv::warpAffine(view, rot(centre S/2, 90 + yaw deg)) is undone
 // per tap row / column -- quarter turns are exact integer maps, separable in x and y; the source index S falls outside
 // and leaves one black row / column (borderValue 0).
-template <int CH, int DIR, int BS>
+// LIST: the `count` pixels named in s_list; otherwise every pixel of the frame.
+template <int CH, int DIR, int BS, bool LIST>
 __device__ __forceinline__ void ego_pixels(const EgoCtx &c, const EgoTap (*s_row)[3], const EgoTap (*s_col)[3],
-                                           uint8_t *s_frame, int O, int tid) {
+                                           uint8_t *s_frame, int O, int tid, const uint16_t *s_list, int count) {
     const int S = c.S;
-    for (int o = tid; o < O * O; o += BS) {
+    for (int i = tid; i < (LIST ? count : O * O); i += BS) {
+        const int o = LIST ? (int)s_list[i] : i;
         const int oy = o / O, ox = o - oy * O;
         // the 2 x 2 intermediate pixels this output pixel blends, and the 4 x 4 view pixels behind them
         const EgoTap ty = s_row[oy][2], tx = s_col[ox][2];
@@ -122,31 +129,142 @@ __device__ __forceinline__ void ego_pixels(const EgoCtx &c, const EgoTap (*s_row
     }
 }
 
-}  // namespace
+// Interior pixels: copy 4 pixels of one frame row at a time from the table frame of the cell they fall into (rt / ct:
+// per output row / column, the view-cell index term of its interior pixels, bit 15 = the row / column touches a cell
+// border or the black border the quarter turn leaves).  Whatever cannot be copied -- border rows and columns, goal
+// cells -- is appended to s_list for the per-pixel code; its bytes in s_frame are overwritten there.
+template <int CH, int BS>
+__device__ __forceinline__ void ego_copy_interior(const EgoCell *s_cells, const uint16_t *s_rt, const uint16_t *s_ct,
+                                                  const uint8_t *tab, size_t frame_bytes, uint8_t *s_frame,
+                                                  uint16_t *s_list, int *s_nslow, int O, int tid) {
+    const int rowd = O >> 2, nd = O * rowd;
+    uint32_t *f32 = reinterpret_cast<uint32_t *>(s_frame);
+    const int lane = tid & 63;
+    for (int d0 = 0; d0 < nd; d0 += BS) {                       // uniform trip count: the ballots below are convergent
+        const int d = d0 + tid;
+        const bool act = d < nd;
+        int slow = 0, o0 = 0;
+        if (act) {
+            const int oy = d / rowd, x4 = d - oy * rowd;
+            o0 = oy * O + 4 * x4;
+            const uint32_t rt = s_rt[oy];
+            const uint2 c2 = *reinterpret_cast<const uint2 *>(&s_ct[4 * x4]);
+            const uint32_t ct[4] = {c2.x & 0xffffu, c2.x >> 16, c2.y & 0xffffu, c2.y >> 16};
+            int cell[4], tb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cell[j] = (int)((rt & 0x7fffu) + (ct[j] & 0x7fffu)); tb[j] = s_cells[cell[j]].tab; }
+            uint32_t m = 0;                                     // bytes that come from the last pixel's cell
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool other = cell[j] != cell[0];
+                if (other) m |= 0xffu << (8 * j);
+                const bool s = ((rt | ct[j]) & 0x8000u) || tb[j] < 0 || (other && cell[j] != cell[3]);
+                slow |= (s ? 1 : 0) << j;
+            }
+            const uint8_t *a = tab + (size_t)(tb[0] < 0 ? 0 : tb[0]) * frame_bytes + 4 * (size_t)d;
+            const uint8_t *b = tab + (size_t)(tb[3] < 0 ? 0 : tb[3]) * frame_bytes + 4 * (size_t)d;
+            uint32_t va[CH], vb[CH];
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+                va[ch] = *reinterpret_cast<const uint32_t *>(a + (size_t)ch * O * O);
+                vb[ch] = *reinterpret_cast<const uint32_t *>(b + (size_t)ch * O * O);
+            }
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) f32[ch * nd + d] = (va[ch] & ~m) | (vb[ch] & m);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool s = (slow >> j) & 1;
+            const unsigned long long bal = __ballot(s);
+            int base = 0;
+            if (lane == 0 && bal) base = atomicAdd(s_nslow, __popcll(bal));
+            base = __shfl(base, 0);
+            if (s) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(o0 + j);
+        }
+    }
+}
 
-// MODE 0: every env; 1: the compacted done list; 2: every env whose done code is 0 (step_autoreset)
-// BS threads per workgroup: 256 for the whole batch; 1024 for the short done list, where the latency of one env counts
-template <int CH, int MODE, int BS>
-__global__ __launch_bounds__(BS) void xw_render_ego_kernel(XwParams p, const uint32_t *atlas4, const EgoTap *tap_h1,
-                                                            const EgoTap *tap_v1, const EgoTap *tap_h2, const EgoTap *tap_v2,
-                                                            const int32_t *count_now) {
-    extern __shared__ uint4 smem4[];
-    const int r = p.visible_radius, S = 64 * r, D = p.max_dim, O = p.out_dim;
-    uint8_t *s_frame = reinterpret_cast<uint8_t *>(smem4);                       // CH * O * O, planar
-    EgoCell *s_cells = reinterpret_cast<EgoCell *>(s_frame + ((CH * O * O + 15) & ~15));
-    uint8_t *s_shadow = reinterpret_cast<uint8_t *>(s_cells + r * r);
-    uint8_t *s_ray = s_shadow + r * r;
-    uint8_t *s_gc = s_ray + ((r + 3) & ~3);
-    // composed taps of one output row / column: the two intermediate indices' taps and the output tap (static: O <= 84)
-    __shared__ EgoTap s_row[84][3], s_col[84][3];
-    for (int i = threadIdx.x; i < O; i += BS) {
+// What one view cell shows.  dir: heading; tab: -1 for goals (their images are per env)
+__device__ __forceinline__ EgoCell ego_icon_cell(const XwParams &p, const uint32_t *atlas4, int icon, int dir) {
+    EgoCell c{atlas4 + (size_t)icon * 4096, -1, icon * 4 + dir};
+    // the agent: XItem::get_item_image turns its icon by 90 - yaw deg
+    if (p.icon_type[icon] == 2 && dir != 1) c.img = atlas4 + p.ego_agent_rot[icon] + (size_t)(dir == 0 ? 0 : (dir == 2 ? 1 : 2)) * 4096;
+    return c;
+}
+
+template <int CH, int BS, bool LIST>
+__device__ __forceinline__ void ego_pixels_dir(int dir, const EgoCtx &ctx, const EgoTap (*s_row)[3], const EgoTap (*s_col)[3],
+                                               uint8_t *s_frame, int O, int tid, const uint16_t *s_list, int count) {
+    switch (dir) {
+        case 0: ego_pixels<CH, 0, BS, LIST>(ctx, s_row, s_col, s_frame, O, tid, s_list, count); break;
+        case 1: ego_pixels<CH, 1, BS, LIST>(ctx, s_row, s_col, s_frame, O, tid, s_list, count); break;
+        case 2: ego_pixels<CH, 2, BS, LIST>(ctx, s_row, s_col, s_frame, O, tid, s_list, count); break;
+        default: ego_pixels<CH, 3, BS, LIST>(ctx, s_row, s_col, s_frame, O, tid, s_list, count); break;
+    }
+}
+
+__device__ __forceinline__ void ego_compose_taps(EgoTap (*s_row)[3], EgoTap (*s_col)[3], const EgoTap *tap_h1, const EgoTap *tap_v1,
+                                                 const EgoTap *tap_h2, const EgoTap *tap_v2, int O, int tid, int bs) {
+    for (int i = tid; i < O; i += bs) {
         const EgoTap ty = tap_v2[i], tx = tap_h2[i];
         s_row[i][0] = tap_v1[ty.s0]; s_row[i][1] = tap_v1[ty.s1]; s_row[i][2] = ty;
         s_col[i][0] = tap_h1[tx.s0]; s_col[i][1] = tap_h1[tx.s1]; s_col[i][2] = tx;
     }
+}
+
+}  // namespace
+
+// The interior-pixel table: frame (slot, heading) = the frame of a view whose every cell shows slot's image; slots
+// 0 .. n_icons - 1 = the icons, n_icons = an empty (white) cell, n_icons + 1 = a black cell.  One workgroup per frame.
+template <int CH>
+__global__ __launch_bounds__(256) void xw_ego_build_tab_kernel(XwParams p, const uint32_t *atlas4, const EgoTap *tap_h1,
+                                                               const EgoTap *tap_v1, const EgoTap *tap_h2, const EgoTap *tap_v2,
+                                                               uint8_t *tab, size_t frame_bytes) {
+    extern __shared__ uint4 smem4[];
+    const int r = p.visible_radius, O = p.out_dim;
+    uint8_t *s_frame = reinterpret_cast<uint8_t *>(smem4);
+    EgoCell *s_cells = reinterpret_cast<EgoCell *>(s_frame + ((CH * O * O + 15) & ~15));
+    __shared__ EgoTap s_row[84][3], s_col[84][3];
+    const int tid = threadIdx.x, slot = blockIdx.x >> 2, dir = blockIdx.x & 3;
+    ego_compose_taps(s_row, s_col, tap_h1, tap_v1, tap_h2, tap_v2, O, tid, 256);
+    const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
+    EgoCell c{slot == p.n_icons ? white : black, 0, -1};
+    if (slot < p.n_icons) c = ego_icon_cell(p, atlas4, slot, dir);
+    for (int k = tid; k < r * r; k += 256) s_cells[k] = c;
+    __syncthreads();
+    EgoCtx ctx{s_cells, white, black, r, 64 * r};
+    ego_pixels_dir<CH, 256, false>(dir, ctx, s_row, s_col, s_frame, O, tid, nullptr, 0);
+    __syncthreads();
+    uint8_t *out = tab + (size_t)blockIdx.x * frame_bytes;
+    for (int i = tid; i < CH * O * O; i += 256) out[i] = s_frame[i];
+}
+
+// MODE 0: every env; 1: the compacted done list; 2: every env whose done code is 0 (step_autoreset)
+// BS threads per workgroup: 256 for the whole batch; 1024 for the short done list, where the latency of one env counts
+// FAST: frame rows are whole dwords (O % 4 == 0; r <= 7): interior pixels are copied from the table and frames leave as
+// 16-byte chunks.  Otherwise (r >= 9: 81, 77, 78, 75 pixel edges) every pixel is evaluated and frames leave element by
+// element -- their byte size is not a multiple of 16.
+template <int CH, int MODE, int BS, bool FAST>
+__global__ __launch_bounds__(BS) void xw_render_ego_kernel(XwParams p, const uint32_t *atlas4, const EgoTap *tap_h1,
+                                                            const EgoTap *tap_v1, const EgoTap *tap_h2, const EgoTap *tap_v2,
+                                                            const uint16_t *cell_lut, const uint8_t *tab,
+                                                            const int32_t *count_now) {
+    extern __shared__ uint4 smem4[];
+    const int r = p.visible_radius, S = 64 * r, D = p.max_dim, O = p.out_dim, O4 = (O + 3) & ~3;
+    const size_t frame_bytes = (size_t)((CH * O * O + 15) & ~15);
+    uint8_t *s_frame = reinterpret_cast<uint8_t *>(smem4);                       // CH * O * O, planar
+    EgoCell *s_cells = reinterpret_cast<EgoCell *>(s_frame + frame_bytes);
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_cells + r * r);            // FAST: O * O pixel indices
+    uint16_t *s_rt = s_list + (FAST ? ((O * O + 3) & ~3) : 0), *s_ct = s_rt + O4;
+    uint8_t *s_shadow = reinterpret_cast<uint8_t *>(s_ct + O4);
+    uint8_t *s_ray = s_shadow + r * r;
+    uint8_t *s_gc = s_ray + ((r + 3) & ~3);
+    // composed taps of one output row / column: the two intermediate indices' taps and the output tap (static: O <= 84)
+    __shared__ EgoTap s_row[84][3], s_col[84][3];
+    __shared__ int s_nslow;
     const int tid = threadIdx.x;
+    ego_compose_taps(s_row, s_col, tap_h1, tap_v1, tap_h2, tap_v2, O, tid, BS);
     const int cells = D * D;
-    const int cpf = CH * O * O / (p.obs_f32 ? 4 : 16);    // 16-byte chunks per frame: 16 uint8 pixels, or 4 float32 ones
     const int n_items = MODE == 1 ? *count_now : p.n;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int e = MODE == 1 ? p.done_list[item] : item;
@@ -156,6 +274,11 @@ __global__ __launch_bounds__(BS) void xw_render_ego_kernel(XwParams p, const uin
         const int dir = p.agent_dir[e];
         __syncthreads();
         if (tid < XW_MAX_GOALS) s_gc[tid] = p.goal_cells[(size_t)e * XW_MAX_GOALS + tid];
+        if (FAST) {
+            if (tid == 0) s_nslow = 0;
+            const uint16_t *lut = cell_lut + (size_t)dir * 2 * O4;
+            for (int i = tid; i < 2 * O4; i += BS) s_rt[i] = lut[i];             // s_ct follows s_rt
+        }
         auto is_block = [&](int x, int y) {
             if ((unsigned)x >= (unsigned)D || (unsigned)y >= (unsigned)D) return false;
             const int code = grid[y * D + x] & CELL_ICON_MASK;
@@ -196,20 +319,17 @@ __global__ __launch_bounds__(BS) void xw_render_ego_kernel(XwParams p, const uin
         const uint32_t *gimg = p.goal_img + (size_t)e * p.num_goals * 4096;
         for (int k = tid; k < r * r; k += BS) {                 // what each view cell shows
             const int gx = x_st - r + k % r, gy = y_st - r + k / r;
-            EgoCell c{black, 0, 0};                             // outside the map, or in a wall's shadow
+            EgoCell c{black, 0, (p.n_icons + 1) * 4 + dir};     // outside the map, or in a wall's shadow
             if ((unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && !s_shadow[k]) {
                 const int code = grid[gy * D + gx] & CELL_ICON_MASK;
-                if (code == 0) c.img = white;
+                if (code == 0) { c.img = white; c.tab = p.n_icons * 4 + dir; }
                 else {
-                    const int t = p.icon_type[code - 1];
-                    c.img = atlas4 + (size_t)(code - 1) * 4096;
-                    c.mask = -1;
-                    if (t == 2) {                               // the agent: XItem::get_item_image turns its icon by 90 - yaw deg
-                        if (dir != 1) c.img = atlas4 + p.ego_agent_rot[code - 1] + (size_t)(dir == 0 ? 0 : (dir == 2 ? 1 : 2)) * 4096;
-                    } else if (t == 0) {
+                    c = ego_icon_cell(p, atlas4, code - 1, dir);
+                    if (p.icon_type[code - 1] == 0) {           // a goal: this env's warped copy
                         int slot = 0;
                         for (int i = 0; i < XW_MAX_GOALS; ++i) if (s_gc[i] == gy * D + gx) slot = i;
                         c.img = gimg + slot * 4096;
+                        c.tab = -1;
                     }
                 }
             }
@@ -217,26 +337,45 @@ __global__ __launch_bounds__(BS) void xw_render_ego_kernel(XwParams p, const uin
         }
         __syncthreads();
         EgoCtx ctx{s_cells, white, black, r, S};
-        switch (dir) {
-            case 0: ego_pixels<CH, 0, BS>(ctx, s_row, s_col, s_frame, O, tid); break;
-            case 1: ego_pixels<CH, 1, BS>(ctx, s_row, s_col, s_frame, O, tid); break;
-            case 2: ego_pixels<CH, 2, BS>(ctx, s_row, s_col, s_frame, O, tid); break;
-            default: ego_pixels<CH, 3, BS>(ctx, s_row, s_col, s_frame, O, tid); break;
+        if (FAST) {
+            ego_copy_interior<CH, BS>(s_cells, s_rt, s_ct, tab, frame_bytes, s_frame, s_list, &s_nslow, O, tid);
+            __syncthreads();
+            ego_pixels_dir<CH, BS, true>(dir, ctx, s_row, s_col, s_frame, O, tid, s_list, s_nslow);
+        } else {
+            ego_pixels_dir<CH, BS, false>(dir, ctx, s_row, s_col, s_frame, O, tid, nullptr, 0);
         }
         __syncthreads();
-        const int flag = MODE == 1 ? p.list_flag : p.fresh[e];
-        uint4 *frame0 = reinterpret_cast<uint4 *>(p.obs) + (size_t)e * p.context * cpf;
-        if (p.obs_f32) {
-            // float32 frames: pixel * (1 / 255.0f), the product py_simulator.cpp:262-272 computes in get_state()
-            const float scale = (float)(1 / 255.0);
-            for (int cc = tid; cc < cpf; cc += BS) {
-                const uchar4 b = reinterpret_cast<const uchar4 *>(s_frame)[cc];
-                const float f0 = (float)b.x * scale, f1 = (float)b.y * scale, f2 = (float)b.z * scale, f3 = (float)b.w * scale;
-                xw_store_chunk(frame0, cc, cpf, p.context, p.context > 1 ? flag : 1,
-                               make_uint4(__float_as_uint(f0), __float_as_uint(f1), __float_as_uint(f2), __float_as_uint(f3)));
+        const int flag = p.context > 1 ? (MODE == 1 ? p.list_flag : (int)p.fresh[e]) : 1;
+        const float scale = (float)(1 / 255.0);   // float32 frames: pixel * (1 / 255.0f), the product py_simulator.cpp:262-272 computes
+        if (FAST) {
+            const int cpf = CH * O * O / (p.obs_f32 ? 4 : 16);  // 16-byte chunks per frame: 16 uint8 pixels, or 4 float32 ones
+            uint4 *frame0 = reinterpret_cast<uint4 *>(p.obs) + (size_t)e * p.context * cpf;
+            if (p.obs_f32) {
+                for (int cc = tid; cc < cpf; cc += BS) {
+                    const uchar4 b = reinterpret_cast<const uchar4 *>(s_frame)[cc];
+                    const float f0 = (float)b.x * scale, f1 = (float)b.y * scale, f2 = (float)b.z * scale, f3 = (float)b.w * scale;
+                    xw_store_chunk(frame0, cc, cpf, p.context, flag,
+                                   make_uint4(__float_as_uint(f0), __float_as_uint(f1), __float_as_uint(f2), __float_as_uint(f3)));
+                }
+            } else {
+                for (int cc = tid; cc < cpf; cc += BS) xw_store_chunk(frame0, cc, cpf, p.context, flag, smem4[cc]);
             }
-        } else {
-            for (int cc = tid; cc < cpf; cc += BS) xw_store_chunk(frame0, cc, cpf, p.context, p.context > 1 ? flag : 1, smem4[cc]);
+        } else if (flag != 0) {
+            // shift_context / init_screen element by element (simulator.cpp:36-85)
+            const int F = CH * O * O, ctxn = p.context;
+            if (p.obs_f32) {
+                float *q = reinterpret_cast<float *>(p.obs) + (size_t)e * ctxn * F;
+                for (int i = tid; i < F; i += BS) {
+                    for (int f = 0; f + 1 < ctxn; ++f) q[(size_t)f * F + i] = flag == 2 ? 0.f : q[(size_t)(f + 1) * F + i];
+                    q[(size_t)(ctxn - 1) * F + i] = (float)s_frame[i] * scale;
+                }
+            } else {
+                uint8_t *q = p.obs + (size_t)e * ctxn * F;
+                for (int i = tid; i < F; i += BS) {
+                    for (int f = 0; f + 1 < ctxn; ++f) q[(size_t)f * F + i] = flag == 2 ? (uint8_t)0 : q[(size_t)(f + 1) * F + i];
+                    q[(size_t)(ctxn - 1) * F + i] = s_frame[i];
+                }
+            }
         }
         if (MODE == 1 && tid == 0 && p.list_flag == 2) { p.fresh[e] = 0; if (p.auto_reset == 2) p.done[e] = 0; }
     }
@@ -324,34 +463,92 @@ static void resize_taps(int src, int dst, std::vector<EgoTap> &h, std::vector<Eg
     }
 }
 
-hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out /* h1, v1, h2, v2 contiguous */) {
+// The taps of both resizes (h1, v1: view -> canvas size; h2, v2: canvas size -> frame), then per heading the view-cell
+// term of every output row and column (uint16 [4][2][O4]; see ego_copy_interior): an output row is interior when the four
+// view rows behind it exist and lie in one cell row (or column, for the sideways headings).
+hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out) {
     std::vector<EgoTap> h1, v1, h2, v2;
     resize_taps(64 * r, 64 * max_dim, h1, v1);
     resize_taps(64 * max_dim, out_dim, h2, v2);
     std::vector<EgoTap> all;
     all.insert(all.end(), h1.begin(), h1.end()); all.insert(all.end(), v1.begin(), v1.end());
     all.insert(all.end(), h2.begin(), h2.end()); all.insert(all.end(), v2.begin(), v2.end());
-    EgoTap *d = nullptr;
-    hipError_t err = hipMalloc(&d, all.size() * sizeof(EgoTap));
+    const int O = out_dim, O4 = (O + 3) & ~3, S = 64 * r;
+    std::vector<uint16_t> lut((size_t)4 * 2 * O4, 0x8000);
+    for (int dir = 0; dir < 4; ++dir) {
+        const bool row_is_y = dir == 3 || dir == 1;
+        for (int axis = 0; axis < 2; ++axis) {                 // 0: output rows, 1: output columns
+            const std::vector<EgoTap> &t1 = axis ? h1 : v1, &t2 = axis ? h2 : v2;
+            const bool flip = axis ? !(dir == 3 || dir == 0) : !(dir == 3 || dir == 2);
+            for (int o = 0; o < O; ++o) {
+                const int idx[4] = {t1[t2[o].s0].s0, t1[t2[o].s0].s1, t1[t2[o].s1].s0, t1[t2[o].s1].s1};
+                int cell = -1;
+                bool ok = true;
+                for (int i = 0; i < 4; ++i) {
+                    const int f = flip ? S - idx[i] : idx[i];
+                    if (f < 0 || f >= S) { ok = false; break; }
+                    if (cell < 0) cell = f >> 6;
+                    else if (cell != (f >> 6)) ok = false;
+                }
+                const bool times_r = axis ? !row_is_y : row_is_y;
+                lut[((size_t)dir * 2 + axis) * O4 + o] = ok ? (uint16_t)(times_r ? cell * r : cell) : (uint16_t)0x8000;
+            }
+        }
+    }
+    const size_t tap_bytes = all.size() * sizeof(EgoTap), lut_bytes = lut.size() * sizeof(uint16_t);
+    uint8_t *d = nullptr;
+    hipError_t err = hipMalloc(&d, tap_bytes + lut_bytes);
     if (err != hipSuccess) return err;
-    err = hipMemcpy(d, all.data(), all.size() * sizeof(EgoTap), hipMemcpyHostToDevice);
-    *dev_out = d;
+    err = hipMemcpy(d, all.data(), tap_bytes, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d + tap_bytes, lut.data(), lut_bytes, hipMemcpyHostToDevice);
+    *dev_out = reinterpret_cast<EgoTap *>(d);
     return err;
 }
 
+namespace {
+struct EgoTables { const EgoTap *h1, *v1, *h2, *v2; const uint16_t *lut; };
+EgoTables ego_tables_of(const XwParams &p) {
+    const int P = 64 * p.max_dim, O = p.out_dim;
+    EgoTables t;
+    t.h1 = reinterpret_cast<const EgoTap *>(p.ego_taps); t.v1 = t.h1 + P; t.h2 = t.v1 + P; t.v2 = t.h2 + O;
+    t.lut = reinterpret_cast<const uint16_t *>(t.v2 + O);
+    return t;
+}
+size_t ego_frame_bytes(const XwParams &p) { return (size_t)((p.channels * p.out_dim * p.out_dim + 15) & ~15); }
+}  // namespace
+
+size_t xw_ego_tab_bytes(const XwParams &p) { return (size_t)(p.n_icons + 2) * 4 * ego_frame_bytes(p); }
+
+// fills p.ego_tab (xw_ego_tab_bytes) -- once per batch, after the atlas and the taps are on the device
+hipError_t launch_xw_ego_build_tab(const XwParams &p, hipStream_t s) {
+    const EgoTables t = ego_tables_of(p);
+    const int r = p.visible_radius;
+    const size_t fb = ego_frame_bytes(p), lds = fb + (size_t)r * r * sizeof(EgoCell);
+    const unsigned blocks = (unsigned)(p.n_icons + 2) * 4;
+    const uint32_t *a4 = reinterpret_cast<const uint32_t *>(p.atlas64);
+    uint8_t *tab = const_cast<uint8_t *>(p.ego_tab);
+    if (p.channels == 3) hipLaunchKernelGGL((xw_ego_build_tab_kernel<3>), dim3(blocks), dim3(256), lds, s, p, a4, t.h1, t.v1, t.h2, t.v2, tab, fb);
+    else hipLaunchKernelGGL((xw_ego_build_tab_kernel<1>), dim3(blocks), dim3(256), lds, s, p, a4, t.h1, t.v1, t.h2, t.v2, tab, fb);
+    return hipGetLastError();
+}
+
 hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s) {
-    const int r = p.visible_radius, O = p.out_dim, P = 64 * p.max_dim;
-    const EgoTap *h1 = reinterpret_cast<const EgoTap *>(p.ego_taps), *v1 = h1 + P, *h2 = v1 + P, *v2 = h2 + O;
+    const EgoTables t = ego_tables_of(p);
+    const int r = p.visible_radius, O = p.out_dim, O4 = (O + 3) & ~3;
     const int CH = p.channels;
-    const size_t lds = (size_t)((CH * O * O + 15) & ~15) + (size_t)r * r * (sizeof(EgoCell) + 1) +
-                       (size_t)((r + 3) & ~3) + XW_MAX_GOALS + 16;
+    const bool fast = (O & 3) == 0;
+    const size_t lds = ego_frame_bytes(p) + (size_t)r * r * (sizeof(EgoCell) + 1) + (fast ? (size_t)((O * O + 3) & ~3) * 2 : 0) +
+                       (size_t)O4 * 4 + (size_t)((r + 3) & ~3) + XW_MAX_GOALS + 16;
     const unsigned blocks = indexed == 1 ? 2048u : (unsigned)(p.n < 16384 ? p.n : 16384);
     const int32_t *cnt = (const int32_t *)p.done_count;
-#define EGO_LAUNCH(CHV, MODEV) do { if (MODEV == 1) hipLaunchKernelGGL((xw_render_ego_kernel<CHV, MODEV, 1024>), dim3(blocks), dim3(1024), lds, s, p, reinterpret_cast<const uint32_t *>(p.atlas64), h1, v1, h2, v2, cnt); \
-    else hipLaunchKernelGGL((xw_render_ego_kernel<CHV, MODEV, 256>), dim3(blocks), dim3(256), lds, s, p, reinterpret_cast<const uint32_t *>(p.atlas64), h1, v1, h2, v2, cnt); } while (0)
-    if (CH == 3) { if (indexed == 1) EGO_LAUNCH(3, 1); else if (indexed == 2) EGO_LAUNCH(3, 2); else EGO_LAUNCH(3, 0); }
-    else { if (indexed == 1) EGO_LAUNCH(1, 1); else if (indexed == 2) EGO_LAUNCH(1, 2); else EGO_LAUNCH(1, 0); }
+    const uint32_t *a4 = reinterpret_cast<const uint32_t *>(p.atlas64);
+#define EGO_LAUNCH2(CHV, MODEV, BSV, FASTV) hipLaunchKernelGGL((xw_render_ego_kernel<CHV, MODEV, BSV, FASTV>), dim3(blocks), dim3(BSV), lds, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, p.ego_tab, cnt)
+#define EGO_LAUNCH1(CHV, MODEV, BSV) do { if (fast) EGO_LAUNCH2(CHV, MODEV, BSV, true); else EGO_LAUNCH2(CHV, MODEV, BSV, false); } while (0)
+#define EGO_LAUNCH(CHV) do { if (indexed == 1) EGO_LAUNCH1(CHV, 1, 1024); else if (indexed == 2) EGO_LAUNCH1(CHV, 2, 256); else EGO_LAUNCH1(CHV, 0, 256); } while (0)
+    if (CH == 3) EGO_LAUNCH(3); else EGO_LAUNCH(1);
 #undef EGO_LAUNCH
+#undef EGO_LAUNCH1
+#undef EGO_LAUNCH2
     return hipGetLastError();
 }
 

@@ -83,6 +83,7 @@ struct xwb_sim {
     uint8_t *d_agent_dir = nullptr, *d_atlas64 = nullptr;
     uint32_t *d_goal_img = nullptr, *d_agent_rot = nullptr;
     EgoTap *d_ego_taps = nullptr;
+    uint8_t *d_ego_tab = nullptr;
     double *d_goal_warp = nullptr;
     int16_t *d_icon_name = nullptr, *d_name_first = nullptr, *d_name_variants = nullptr;
     uint32_t *d_atlas = nullptr;
@@ -354,6 +355,12 @@ int xw_setup(xwb_sim *s) {
     p.packed = s->d_packed;
     p.done_list = s->d_done_list; p.done_count = s->d_done_count; p.done_count_next = s->d_done_count + 1;
     p.err_count = s->d_err;
+    if (c.visible_radius > 0) {
+        if ((rc = dev_alloc(s, &s->d_ego_tab, xw_ego_tab_bytes(p)))) return rc;
+        p.ego_tab = s->d_ego_tab;
+        HIP_TRY(launch_xw_ego_build_tab(p, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+    }
     return XWB_OK;
 }
 

@@ -168,7 +168,8 @@ struct XwParams {
     const uint32_t *ego_agent_rot;   // egocentric: [n_icons] pixel offset in atlas64 of an agent icon's three turned copies
                                  // (heading right, left, up; heading down is the icon itself)
     uint32_t *goal_img;          // egocentric: [n][num_goals][64 * 64] warped goal images (B | G << 8 | R << 16)
-    const void *ego_taps;        // egocentric: cv::resize taps of the two resizes (kernels_xworld_ego.hip)
+    const void *ego_taps;        // egocentric: cv::resize taps of the two resizes, then the row / column cell terms per heading
+    const uint8_t *ego_tab;      // egocentric: [(n_icons + 2) * 4] frames "every cell shows icon i", per heading (interior pixels)
     uint32_t *cand2d;            // [n] goal slots the agent can reach, blocks as the only obstacles: bits 0..15
                                  //     any goal (XWorldNavTarget), bits 16..31 coloured goals (XWorldNavColorTarget)
     const uint8_t *icon_colored; // [n_icons] properties.txt colour != "na"
@@ -200,6 +201,8 @@ hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s);
 hipError_t launch_xw_warp_goals(const XwParams &p, bool list, hipStream_t s);
 struct EgoTap;
 hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out);
+size_t xw_ego_tab_bytes(const XwParams &p);
+hipError_t launch_xw_ego_build_tab(const XwParams &p, hipStream_t s);
 
 // host: builds the 12x12 tile table (OpenCV 3.2 fixed-point bilinear + BGR2GRAY) from 64x64 icons
 void build_tile_table(const uint8_t *icons64, int n_icons, int channels, uint8_t *out /* n*c*12*12 */);
