@@ -40,7 +40,7 @@ def build(force=False, verbose=False):
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            cmd = [cc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [cc] + FLAGS + os.environ.get("XWB_EXTRA_FLAGS", "").split() + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -30,6 +30,15 @@
 
 namespace xwb {
 
+#ifdef XWB_EGO_PROF
+__device__ unsigned long long g_ego_prof[8];
+#define EGO_T0() unsigned long long t_last = wall_clock64()
+#define EGO_T(i) do { if (tid == 0) { const unsigned long long now = wall_clock64(); atomicAdd(&g_ego_prof[i], now - t_last); t_last = now; } } while (0)
+#else
+#define EGO_T0()
+#define EGO_T(i)
+#endif
+
 struct EgoTap { int16_t s0, s1, w0, w1; };        // cv::resize: source indices and 11-bit weights of one output index
 
 namespace {
@@ -55,17 +64,14 @@ __device__ __forceinline__ int vresize(int b0, int h0, int b1, int h1) {
     return (int)((((__umul24((unsigned)b0, (unsigned)(h0 >> 4))) >> 16) + ((__umul24((unsigned)b1, (unsigned)(h1 >> 4))) >> 16) + 2u) >> 2);
 }
 
-// All pixels of one frame.  DIR = the agent's heading: cv::warpAffine(view, rot(centre S/2, 90 + yaw deg)) is undone
-// per tap row / column -- quarter turns are exact integer maps, separable in x and y; the source index S falls outside
-// and leaves one black row / column (borderValue 0).
-// LIST: the `count` pixels named in s_list; otherwise every pixel of the frame.
-template <int CH, int DIR, int BS, bool LIST>
-__device__ __forceinline__ void ego_pixels(const EgoCtx &c, const EgoTap (*s_row)[3], const EgoTap (*s_col)[3],
-                                           uint8_t *s_frame, int O, int tid, const uint16_t *s_list, int count) {
-    const int S = c.S;
-    for (int i = tid; i < (LIST ? count : O * O); i += BS) {
-        const int o = LIST ? (int)s_list[i] : i;
-        const int oy = o / O, ox = o - oy * O;
+// One output pixel.  DIR = the agent's heading: cv::warpAffine(view, rot(centre S/2, 90 + yaw deg)) is undone per tap
+// row / column -- quarter turns are exact integer maps, separable in x and y; the source index S falls outside and
+// leaves one black row / column (borderValue 0).
+template <int CH, int DIR>
+__device__ __forceinline__ void ego_pixel(const EgoCtx &c, const EgoTap (*s_row)[3], const EgoTap (*s_col)[3],
+                                          uint8_t *s_frame, int O, int ox, int oy) {
+    const int S = c.S, o = oy * O + ox;
+    {
         // the 2 x 2 intermediate pixels this output pixel blends, and the 4 x 4 view pixels behind them
         const EgoTap ty = s_row[oy][2], tx = s_col[ox][2];
         const EgoTap my[2] = {s_row[oy][0], s_row[oy][1]}, mx[2] = {s_col[ox][0], s_col[ox][1]};
@@ -129,78 +135,122 @@ __device__ __forceinline__ void ego_pixels(const EgoCtx &c, const EgoTap (*s_row
     }
 }
 
-// Interior pixels: copy 4 pixels of one frame row at a time from the table frame of the cell they fall into (rt / ct:
-// per output row / column, the view-cell index term of its interior pixels, bit 15 = the row / column touches a cell
-// border or the black border the quarter turn leaves).  Whatever cannot be copied -- border rows and columns, goal
-// cells -- is appended to s_list for the per-pixel code; its bytes in s_frame are overwritten there.
+// The per-heading layout tables (xw_ego_tables builds them; uint16 words):
+//   [0, O4)            row term: the view-cell index part every interior pixel of this output row adds (cell row * r, or
+//                      the cell column for the sideways headings); bit 15: the row touches a cell border or the black
+//                      border the quarter turn leaves -- all of its pixels are evaluated one by one
+//   [O4, 2 O4)         column term, same
+//   [2 O4, 2 O4 + Q)   column term per group of four columns (cell boundaries fall on multiples of four here, else the
+//                      table is not used at all), Q = O4 / 4 rounded up to a multiple of 4
+//   then 4 words       number of border rows, of border columns, largest edge of a cell's pixel rectangle, 0
+//   then O4, O4        the border rows, the border columns
+//   then r * r * 4     per view cell: x0, y0, width, height of its interior pixels in the frame
+struct EgoLayout {
+    const uint16_t *rt, *ct, *ct4, *br, *bc, *rect;
+    int nbr, nbc, cw;
+};
+__host__ __device__ inline int ego_layout_words(int O4, int r) { return 2 * O4 + ((O4 / 4 + 3) & ~3) + 4 + 2 * O4 + 4 * r * r; }
+__device__ __forceinline__ EgoLayout ego_layout(const uint16_t *base, int O4, int r) {
+    EgoLayout l;
+    l.rt = base; l.ct = base + O4; l.ct4 = base + 2 * O4;
+    const uint16_t *h = l.ct4 + ((O4 / 4 + 3) & ~3);
+    l.nbr = h[0]; l.nbc = h[1]; l.cw = h[2];
+    l.br = h + 4; l.bc = l.br + O4; l.rect = l.bc + O4;
+    return l;
+}
+
+__device__ __forceinline__ int ego_div(int i, float inv_n) { return (int)(((float)i + 0.5f) * inv_n); }   // i / n, exact: i < 2^16, n <= 84 * 84
+
+// The pixels that are evaluated one by one: FAST: every pixel of the border rows, of the border columns, and of the
+// cells that show a goal (goal_k: their view-cell ids); otherwise every pixel of the frame.
+template <int CH, int DIR, int BS, bool FAST>
+__device__ __forceinline__ void ego_pixels(const EgoCtx &c, const EgoTap (*s_row)[3], const EgoTap (*s_col)[3],
+                                           uint8_t *s_frame, int O, int tid, const EgoLayout &l, const uint8_t *goal_k, int n_goal) {
+    const float inv_O = 1.0f / (float)O;
+    if (!FAST) {
+        for (int i = tid; i < O * O; i += BS) {
+            const int oy = ego_div(i, inv_O);
+            ego_pixel<CH, DIR>(c, s_row, s_col, s_frame, O, i - oy * O, oy);
+        }
+        return;
+    }
+    const int cw2 = l.cw * l.cw, n_row_px = l.nbr * O, n_border_px = n_row_px + l.nbc * O, total = n_border_px + n_goal * cw2;
+    const float inv_cw = 1.0f / (float)l.cw, inv_cw2 = 1.0f / (float)cw2;
+    for (int i = tid; i < total; i += BS) {
+        int ox, oy;
+        bool ok = true;
+        if (i < n_row_px) {
+            const int q = ego_div(i, inv_O);
+            oy = l.br[q]; ox = i - q * O;
+        } else if (i < n_border_px) {
+            const int j = i - n_row_px, q = ego_div(j, inv_O);
+            ox = l.bc[q]; oy = j - q * O;
+            ok = !(l.rt[oy] & 0x8000u);                         // already done with its row
+        } else {
+            const int j = i - n_border_px, g = ego_div(j, inv_cw2), jj = j - g * cw2;
+            const uint16_t *rc = l.rect + 4 * (int)goal_k[g];
+            const int py = ego_div(jj, inv_cw), px = jj - py * l.cw;
+            ok = px < (int)rc[2] && py < (int)rc[3];
+            ox = ok ? (int)rc[0] + px : 0; oy = ok ? (int)rc[1] + py : 0;
+            ok = ok && !((l.rt[oy] | l.ct[ox]) & 0x8000u);
+        }
+        if (ok) ego_pixel<CH, DIR>(c, s_row, s_col, s_frame, O, ox, oy);
+    }
+}
+
+template <int CH, int BS, bool FAST>
+__device__ __forceinline__ void ego_pixels_dir(int dir, const EgoCtx &ctx, const EgoTap (*s_row)[3], const EgoTap (*s_col)[3],
+                                               uint8_t *s_frame, int O, int tid, const EgoLayout &l, const uint8_t *goal_k, int n_goal) {
+    switch (dir) {
+        case 0: ego_pixels<CH, 0, BS, FAST>(ctx, s_row, s_col, s_frame, O, tid, l, goal_k, n_goal); break;
+        case 1: ego_pixels<CH, 1, BS, FAST>(ctx, s_row, s_col, s_frame, O, tid, l, goal_k, n_goal); break;
+        case 2: ego_pixels<CH, 2, BS, FAST>(ctx, s_row, s_col, s_frame, O, tid, l, goal_k, n_goal); break;
+        default: ego_pixels<CH, 3, BS, FAST>(ctx, s_row, s_col, s_frame, O, tid, l, goal_k, n_goal); break;
+    }
+}
+
+// Interior pixels: every dword of the frame (4 pixels of one row and plane) is copied from the table frame of the view
+// cell it falls into.  All loads of a thread are issued before its first LDS write; pixels of border rows / columns and
+// of goal cells get whatever the table holds there and are overwritten by ego_pixels.
+// (oy0, x40): row and dword-in-row of this thread's first dword; (sy, sx): the same for a stride of BS dwords.
 template <int CH, int BS>
-__device__ __forceinline__ void ego_copy_interior(const EgoCell *s_cells, const uint16_t *s_rt, const uint16_t *s_ct,
-                                                  const uint8_t *tab, size_t frame_bytes, uint8_t *s_frame,
-                                                  uint16_t *s_list, int *s_nslow, int O, int tid) {
+__device__ __forceinline__ void ego_copy_interior(const EgoCell *s_cells, const EgoLayout &l, const uint8_t *tab, uint32_t frame_bytes,
+                                                  uint8_t *s_frame, int O, int tid, int oy0, int x40, int sy, int sx) {
+    constexpr int IT = (84 * 21 + BS - 1) / BS;
     const int rowd = O >> 2, nd = O * rowd;
     uint32_t *f32 = reinterpret_cast<uint32_t *>(s_frame);
-    const int lane = tid & 63;
-    for (int d0 = 0; d0 < nd; d0 += BS) {                       // uniform trip count: the ballots below are convergent
-        const int d = d0 + tid;
-        const bool act = d < nd;
-        int slow = 0, o0 = 0;
-        if (act) {
-            const int oy = d / rowd, x4 = d - oy * rowd;
-            o0 = oy * O + 4 * x4;
-            const uint32_t rt = s_rt[oy];
-            const uint2 c2 = *reinterpret_cast<const uint2 *>(&s_ct[4 * x4]);
-            const uint32_t ct[4] = {c2.x & 0xffffu, c2.x >> 16, c2.y & 0xffffu, c2.y >> 16};
-            int cell[4], tb[4];
+    uint32_t v[IT][CH];
+    int oy = oy0, x4 = x40;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { cell[j] = (int)((rt & 0x7fffu) + (ct[j] & 0x7fffu)); tb[j] = s_cells[cell[j]].tab; }
-            uint32_t m = 0;                                     // bytes that come from the last pixel's cell
+    for (int it = 0; it < IT; ++it) {
+        const int d = it * BS + tid;
+        if (d < nd) {
+            const int cell = (int)(l.rt[oy] & 0x7fffu) + (int)l.ct4[x4];
+            const int t = s_cells[cell].tab;
+            const uint8_t *src = tab + (uint32_t)(t < 0 ? 0 : t) * frame_bytes + 4u * (uint32_t)d;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool other = cell[j] != cell[0];
-                if (other) m |= 0xffu << (8 * j);
-                const bool s = ((rt | ct[j]) & 0x8000u) || tb[j] < 0 || (other && cell[j] != cell[3]);
-                slow |= (s ? 1 : 0) << j;
-            }
-            const uint8_t *a = tab + (size_t)(tb[0] < 0 ? 0 : tb[0]) * frame_bytes + 4 * (size_t)d;
-            const uint8_t *b = tab + (size_t)(tb[3] < 0 ? 0 : tb[3]) * frame_bytes + 4 * (size_t)d;
-            uint32_t va[CH], vb[CH];
-#pragma unroll
-            for (int ch = 0; ch < CH; ++ch) {
-                va[ch] = *reinterpret_cast<const uint32_t *>(a + (size_t)ch * O * O);
-                vb[ch] = *reinterpret_cast<const uint32_t *>(b + (size_t)ch * O * O);
-            }
-#pragma unroll
-            for (int ch = 0; ch < CH; ++ch) f32[ch * nd + d] = (va[ch] & ~m) | (vb[ch] & m);
+            for (int ch = 0; ch < CH; ++ch) v[it][ch] = *reinterpret_cast<const uint32_t *>(src + (uint32_t)(ch * O * O));
         }
+        x4 += sx; oy += sy;
+        if (x4 >= rowd) { x4 -= rowd; ++oy; }
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool s = (slow >> j) & 1;
-            const unsigned long long bal = __ballot(s);
-            int base = 0;
-            if (lane == 0 && bal) base = atomicAdd(s_nslow, __popcll(bal));
-            base = __shfl(base, 0);
-            if (s) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(o0 + j);
+    for (int it = 0; it < IT; ++it) {
+        const int d = it * BS + tid;
+        if (d < nd) {
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) f32[ch * nd + d] = v[it][ch];
         }
     }
 }
 
 // What one view cell shows.  dir: heading; tab: -1 for goals (their images are per env)
-__device__ __forceinline__ EgoCell ego_icon_cell(const XwParams &p, const uint32_t *atlas4, int icon, int dir) {
+__device__ __forceinline__ EgoCell ego_icon_cell(const uint8_t *icon_type, const uint32_t *agent_rot, const uint32_t *atlas4,
+                                                 int icon, int dir) {
     EgoCell c{atlas4 + (size_t)icon * 4096, -1, icon * 4 + dir};
     // the agent: XItem::get_item_image turns its icon by 90 - yaw deg
-    if (p.icon_type[icon] == 2 && dir != 1) c.img = atlas4 + p.ego_agent_rot[icon] + (size_t)(dir == 0 ? 0 : (dir == 2 ? 1 : 2)) * 4096;
+    if (icon_type[icon] == 2 && dir != 1) c.img = atlas4 + agent_rot[icon] + (size_t)(dir == 0 ? 0 : (dir == 2 ? 1 : 2)) * 4096;
     return c;
-}
-
-template <int CH, int BS, bool LIST>
-__device__ __forceinline__ void ego_pixels_dir(int dir, const EgoCtx &ctx, const EgoTap (*s_row)[3], const EgoTap (*s_col)[3],
-                                               uint8_t *s_frame, int O, int tid, const uint16_t *s_list, int count) {
-    switch (dir) {
-        case 0: ego_pixels<CH, 0, BS, LIST>(ctx, s_row, s_col, s_frame, O, tid, s_list, count); break;
-        case 1: ego_pixels<CH, 1, BS, LIST>(ctx, s_row, s_col, s_frame, O, tid, s_list, count); break;
-        case 2: ego_pixels<CH, 2, BS, LIST>(ctx, s_row, s_col, s_frame, O, tid, s_list, count); break;
-        default: ego_pixels<CH, 3, BS, LIST>(ctx, s_row, s_col, s_frame, O, tid, s_list, count); break;
-    }
 }
 
 __device__ __forceinline__ void ego_compose_taps(EgoTap (*s_row)[3], EgoTap (*s_col)[3], const EgoTap *tap_h1, const EgoTap *tap_v1,
@@ -229,11 +279,11 @@ __global__ __launch_bounds__(256) void xw_ego_build_tab_kernel(XwParams p, const
     ego_compose_taps(s_row, s_col, tap_h1, tap_v1, tap_h2, tap_v2, O, tid, 256);
     const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
     EgoCell c{slot == p.n_icons ? white : black, 0, -1};
-    if (slot < p.n_icons) c = ego_icon_cell(p, atlas4, slot, dir);
+    if (slot < p.n_icons) c = ego_icon_cell(p.icon_type, p.ego_agent_rot, atlas4, slot, dir);
     for (int k = tid; k < r * r; k += 256) s_cells[k] = c;
     __syncthreads();
     EgoCtx ctx{s_cells, white, black, r, 64 * r};
-    ego_pixels_dir<CH, 256, false>(dir, ctx, s_row, s_col, s_frame, O, tid, nullptr, 0);
+    ego_pixels_dir<CH, 256, false>(dir, ctx, s_row, s_col, s_frame, O, tid, EgoLayout{}, nullptr, 0);
     __syncthreads();
     uint8_t *out = tab + (size_t)blockIdx.x * frame_bytes;
     for (int i = tid; i < CH * O * O; i += 256) out[i] = s_frame[i];
@@ -241,48 +291,72 @@ __global__ __launch_bounds__(256) void xw_ego_build_tab_kernel(XwParams p, const
 
 // MODE 0: every env; 1: the compacted done list; 2: every env whose done code is 0 (step_autoreset)
 // BS threads per workgroup: 256 for the whole batch; 1024 for the short done list, where the latency of one env counts
-// FAST: frame rows are whole dwords (O % 4 == 0; r <= 7): interior pixels are copied from the table and frames leave as
-// 16-byte chunks.  Otherwise (r >= 9: 81, 77, 78, 75 pixel edges) every pixel is evaluated and frames leave element by
-// element -- their byte size is not a multiple of 16.
+// FAST: frame rows are whole dwords and cell boundaries fall on dwords (r <= 7): interior pixels are copied from the
+// table and frames leave as 16-byte chunks.  Otherwise (r >= 9: 81, 77, 78, 75 pixel edges) every pixel is evaluated
+// and frames leave element by element -- their byte size is not a multiple of 16.
 template <int CH, int MODE, int BS, bool FAST>
 __global__ __launch_bounds__(BS) void xw_render_ego_kernel(XwParams p, const uint32_t *atlas4, const EgoTap *tap_h1,
                                                             const EgoTap *tap_v1, const EgoTap *tap_h2, const EgoTap *tap_v2,
-                                                            const uint16_t *cell_lut, const uint8_t *tab,
+                                                            const uint16_t *layout, const uint8_t *tab,
                                                             const int32_t *count_now) {
     extern __shared__ uint4 smem4[];
     const int r = p.visible_radius, S = 64 * r, D = p.max_dim, O = p.out_dim, O4 = (O + 3) & ~3;
-    const size_t frame_bytes = (size_t)((CH * O * O + 15) & ~15);
+    const uint32_t frame_bytes = (uint32_t)((CH * O * O + 15) & ~15);
+    const int lw = ego_layout_words(O4, r);
     uint8_t *s_frame = reinterpret_cast<uint8_t *>(smem4);                       // CH * O * O, planar
     EgoCell *s_cells = reinterpret_cast<EgoCell *>(s_frame + frame_bytes);
-    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_cells + r * r);            // FAST: O * O pixel indices
-    uint16_t *s_rt = s_list + (FAST ? ((O * O + 3) & ~3) : 0), *s_ct = s_rt + O4;
-    uint8_t *s_shadow = reinterpret_cast<uint8_t *>(s_ct + O4);
-    uint8_t *s_ray = s_shadow + r * r;
+    uint16_t *s_layout = reinterpret_cast<uint16_t *>(s_cells + r * r);          // FAST: the four headings' layout tables
+    uint32_t *s_rot = reinterpret_cast<uint32_t *>(s_layout + (FAST ? 4 * lw : 0));   // [n_icons] ego_agent_rot
+    uint8_t *s_itype = reinterpret_cast<uint8_t *>(s_rot + p.n_icons);           // [n_icons] icon_type
+    uint8_t *s_type = s_itype + ((p.n_icons + 3) & ~3);                          // [D * D] type of the entity in a cell, 3 = none
+    uint8_t *s_shadow = s_type + ((D * D + 3) & ~3);
+    uint8_t *s_ray = s_shadow + ((r * r + 3) & ~3);
     uint8_t *s_gc = s_ray + ((r + 3) & ~3);
+    uint8_t *s_goal_k = s_gc + XW_MAX_GOALS;                                     // [XW_MAX_GOALS] view cells that show a goal
     // composed taps of one output row / column: the two intermediate indices' taps and the output tap (static: O <= 84)
     __shared__ EgoTap s_row[84][3], s_col[84][3];
-    __shared__ int s_nslow;
+    __shared__ uint16_t s_code[XW_MAX_DIM * XW_MAX_DIM];                         // the env's grid, target bit stripped
+    __shared__ int s_ngoal;
     const int tid = threadIdx.x;
     ego_compose_taps(s_row, s_col, tap_h1, tap_v1, tap_h2, tap_v2, O, tid, BS);
+    for (int i = tid; i < p.n_icons; i += BS) { s_itype[i] = p.icon_type[i]; s_rot[i] = p.ego_agent_rot[i]; }
+    if (FAST) for (int i = tid; i < 4 * lw; i += BS) s_layout[i] = layout[i];
     const int cells = D * D;
+    const int rowd = O >> 2, copy_oy0 = tid / rowd, copy_x40 = tid - copy_oy0 * rowd, copy_sy = BS / rowd, copy_sx = BS - copy_sy * rowd;
     const int n_items = MODE == 1 ? *count_now : p.n;
+    // Everything the env's setup reads from global memory is fetched one env ahead (one value per thread: cells <= 256
+    // <= BS) and staged in LDS, so the serial part -- shadow rays, scan lines, cell table -- never waits for HBM / L2.
+    struct Fetch { int e, axy, dir, skip; uint32_t code, gc; };
+    auto fetch = [&](int item) {
+        Fetch f;
+        f.e = MODE == 1 ? p.done_list[item] : item;
+        f.skip = MODE == 2 ? (int)p.done[f.e] : 0;
+        f.axy = p.agent_xy[f.e]; f.dir = p.agent_dir[f.e];
+        f.code = tid < cells ? (uint32_t)p.grid[(size_t)f.e * cells + tid] : 0u;
+        f.gc = tid < XW_MAX_GOALS ? (uint32_t)p.goal_cells[(size_t)f.e * XW_MAX_GOALS + tid] : 0xffu;
+        return f;
+    };
+    Fetch nxt{};
+    if ((int)blockIdx.x < n_items) nxt = fetch(blockIdx.x);
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int e = MODE == 1 ? p.done_list[item] : item;
-        if (MODE == 2 && p.done[e] != 0) continue;
-        const uint16_t *grid = p.grid + (size_t)e * cells;
-        const int axy = p.agent_xy[e], ax = axy & 0xffff, ay = axy >> 16;
-        const int dir = p.agent_dir[e];
-        __syncthreads();
-        if (tid < XW_MAX_GOALS) s_gc[tid] = p.goal_cells[(size_t)e * XW_MAX_GOALS + tid];
-        if (FAST) {
-            if (tid == 0) s_nslow = 0;
-            const uint16_t *lut = cell_lut + (size_t)dir * 2 * O4;
-            for (int i = tid; i < 2 * O4; i += BS) s_rt[i] = lut[i];             // s_ct follows s_rt
+        const Fetch f = nxt;
+        const int e = f.e, ax = f.axy & 0xffff, ay = f.axy >> 16, dir = f.dir;
+        __syncthreads();                                        // the previous env's frame has left LDS
+        EGO_T0();
+        if (tid < cells) {
+            const int code = (int)(f.code & CELL_ICON_MASK);
+            s_code[tid] = (uint16_t)code;
+            s_type[tid] = code ? s_itype[code - 1] : (uint8_t)3;
         }
+        if (tid < XW_MAX_GOALS) s_gc[tid] = (uint8_t)f.gc;
+        if (tid < r) s_ray[tid] = 1;
+        if (tid == 0) s_ngoal = 0;
+        if (item + (int)gridDim.x < n_items) nxt = fetch(item + gridDim.x);
+        if (f.skip) continue;
+        EgoLayout lay{};
+        if (FAST) lay = ego_layout(s_layout + dir * lw, O4, r);
         auto is_block = [&](int x, int y) {
-            if ((unsigned)x >= (unsigned)D || (unsigned)y >= (unsigned)D) return false;
-            const int code = grid[y * D + x] & CELL_ICON_MASK;
-            return code != 0 && p.icon_type[code - 1] == 1;
+            return (unsigned)x < (unsigned)D && (unsigned)y < (unsigned)D && s_type[y * D + x] == 1;
         };
         // XMap::image_masking (xmap.cpp:273-362)
         int major_x = 0, major_y = 0, minor_x = 0, minor_y = 0, scan_x0 = 0, scan_y0 = 0, xa = ax + r, ya = ay + r;
@@ -291,8 +365,8 @@ __global__ __launch_bounds__(BS) void xw_render_ego_kernel(XwParams p, const uin
         else if (dir == 2) { xa -= r / 2; major_y = 1; minor_x = -1; scan_x0 = r - 1; }
         else { ya += r / 2; major_x = 1; minor_y = 1; }
         const int x_st = xa - r / 2, y_st = ya - r / 2;
-        if (tid < r) s_ray[tid] = 1;
         __syncthreads();
+        EGO_T(0);
         if (tid < 2) {                                          // rays to either side of the agent
             const int o = tid ? 1 : -1;
             bool block = false;
@@ -304,6 +378,7 @@ __global__ __launch_bounds__(BS) void xw_render_ego_kernel(XwParams p, const uin
             }
         }
         __syncthreads();
+        EGO_T(1);
         if (tid < r) {                                          // one scan line per lane
             bool block = !s_ray[tid];
             int cx = scan_x0 + tid * major_x, cy = scan_y0 + tid * major_y;
@@ -315,36 +390,39 @@ __global__ __launch_bounds__(BS) void xw_render_ego_kernel(XwParams p, const uin
             }
         }
         __syncthreads();
+        EGO_T(2);
         const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
         const uint32_t *gimg = p.goal_img + (size_t)e * p.num_goals * 4096;
         for (int k = tid; k < r * r; k += BS) {                 // what each view cell shows
             const int gx = x_st - r + k % r, gy = y_st - r + k / r;
             EgoCell c{black, 0, (p.n_icons + 1) * 4 + dir};     // outside the map, or in a wall's shadow
             if ((unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && !s_shadow[k]) {
-                const int code = grid[gy * D + gx] & CELL_ICON_MASK;
+                const int code = s_code[gy * D + gx];
                 if (code == 0) { c.img = white; c.tab = p.n_icons * 4 + dir; }
                 else {
-                    c = ego_icon_cell(p, atlas4, code - 1, dir);
-                    if (p.icon_type[code - 1] == 0) {           // a goal: this env's warped copy
+                    c = ego_icon_cell(s_itype, s_rot, atlas4, code - 1, dir);
+                    if (s_type[gy * D + gx] == 0) {             // a goal: this env's warped copy
                         int slot = 0;
                         for (int i = 0; i < XW_MAX_GOALS; ++i) if (s_gc[i] == gy * D + gx) slot = i;
                         c.img = gimg + slot * 4096;
                         c.tab = -1;
+                        if (FAST) s_goal_k[atomicAdd(&s_ngoal, 1)] = (uint8_t)k;
                     }
                 }
             }
             s_cells[k] = c;
         }
         __syncthreads();
+        EGO_T(3);
         EgoCtx ctx{s_cells, white, black, r, S};
         if (FAST) {
-            ego_copy_interior<CH, BS>(s_cells, s_rt, s_ct, tab, frame_bytes, s_frame, s_list, &s_nslow, O, tid);
+            ego_copy_interior<CH, BS>(s_cells, lay, tab, frame_bytes, s_frame, O, tid, copy_oy0, copy_x40, copy_sy, copy_sx);
             __syncthreads();
-            ego_pixels_dir<CH, BS, true>(dir, ctx, s_row, s_col, s_frame, O, tid, s_list, s_nslow);
-        } else {
-            ego_pixels_dir<CH, BS, false>(dir, ctx, s_row, s_col, s_frame, O, tid, nullptr, 0);
+            EGO_T(4);
         }
+        ego_pixels_dir<CH, BS, FAST>(dir, ctx, s_row, s_col, s_frame, O, tid, lay, s_goal_k, s_ngoal);
         __syncthreads();
+        EGO_T(5);
         const int flag = p.context > 1 ? (MODE == 1 ? p.list_flag : (int)p.fresh[e]) : 1;
         const float scale = (float)(1 / 255.0);   // float32 frames: pixel * (1 / 255.0f), the product py_simulator.cpp:262-272 computes
         if (FAST) {
@@ -377,9 +455,11 @@ __global__ __launch_bounds__(BS) void xw_render_ego_kernel(XwParams p, const uin
                 }
             }
         }
+        EGO_T(6);
         if (MODE == 1 && tid == 0 && p.list_flag == 2) { p.fresh[e] = 0; if (p.auto_reset == 2) p.done[e] = 0; }
     }
 }
+
 
 // The warped 64x64 image of every goal of the listed envs (XItem::get_item_image, xitem.cpp:46-60): cv::warpAffine with
 // the goal's inverse matrix, INTER_LINEAR, BORDER_CONSTANT white.  A goal keeps its pose for the whole episode, so this
@@ -463,23 +543,32 @@ static void resize_taps(int src, int dst, std::vector<EgoTap> &h, std::vector<Eg
     }
 }
 
-// The taps of both resizes (h1, v1: view -> canvas size; h2, v2: canvas size -> frame), then per heading the view-cell
-// term of every output row and column (uint16 [4][2][O4]; see ego_copy_interior): an output row is interior when the four
-// view rows behind it exist and lie in one cell row (or column, for the sideways headings).
-hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out) {
+// The taps of both resizes (h1, v1: view -> canvas size; h2, v2: canvas size -> frame), then the four headings' layout
+// tables (EgoLayout).  An output row is interior when the four view rows behind it exist and lie in one cell row (or
+// column, for the sideways headings).  *fast_out: frame rows are whole dwords and no dword holds interior pixels of two
+// cells -- the condition for copying interior pixels from the table.
+hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int *fast_out) {
     std::vector<EgoTap> h1, v1, h2, v2;
     resize_taps(64 * r, 64 * max_dim, h1, v1);
     resize_taps(64 * max_dim, out_dim, h2, v2);
     std::vector<EgoTap> all;
     all.insert(all.end(), h1.begin(), h1.end()); all.insert(all.end(), v1.begin(), v1.end());
     all.insert(all.end(), h2.begin(), h2.end()); all.insert(all.end(), v2.begin(), v2.end());
-    const int O = out_dim, O4 = (O + 3) & ~3, S = 64 * r;
-    std::vector<uint16_t> lut((size_t)4 * 2 * O4, 0x8000);
+    const int O = out_dim, O4 = (O + 3) & ~3, S = 64 * r, lw = ego_layout_words(O4, r), q4 = (O4 / 4 + 3) & ~3;
+    std::vector<uint16_t> lay((size_t)4 * lw, 0);
+    bool fast = (O & 3) == 0 && r * r <= 64;
     for (int dir = 0; dir < 4; ++dir) {
+        uint16_t *L = lay.data() + (size_t)dir * lw;
+        uint16_t *rt = L, *ct = L + O4, *ct4 = L + 2 * O4, *hd = ct4 + q4, *br = hd + 4, *bc = br + O4, *rect = bc + O4;
         const bool row_is_y = dir == 3 || dir == 1;
+        std::vector<int> cell_of[2];                           // per axis: the cell coordinate of an interior row / column, -1 border
         for (int axis = 0; axis < 2; ++axis) {                 // 0: output rows, 1: output columns
             const std::vector<EgoTap> &t1 = axis ? h1 : v1, &t2 = axis ? h2 : v2;
             const bool flip = axis ? !(dir == 3 || dir == 0) : !(dir == 3 || dir == 2);
+            const bool times_r = axis ? !row_is_y : row_is_y;
+            cell_of[axis].assign(O, -1);
+            uint16_t *term = axis ? ct : rt, *border = axis ? bc : br;
+            int nb = 0;
             for (int o = 0; o < O; ++o) {
                 const int idx[4] = {t1[t2[o].s0].s0, t1[t2[o].s0].s1, t1[t2[o].s1].s0, t1[t2[o].s1].s1};
                 int cell = -1;
@@ -490,18 +579,45 @@ hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out) {
                     if (cell < 0) cell = f >> 6;
                     else if (cell != (f >> 6)) ok = false;
                 }
-                const bool times_r = axis ? !row_is_y : row_is_y;
-                lut[((size_t)dir * 2 + axis) * O4 + o] = ok ? (uint16_t)(times_r ? cell * r : cell) : (uint16_t)0x8000;
+                if (ok) { term[o] = (uint16_t)(times_r ? cell * r : cell); cell_of[axis][o] = cell; }
+                else { term[o] = 0x8000; border[nb++] = (uint16_t)o; }
             }
+            hd[axis] = (uint16_t)nb;
         }
+        for (int x4 = 0; x4 < O4 / 4; ++x4) {                  // the column term of a dword
+            int term = -1;
+            for (int j = 0; j < 4 && 4 * x4 + j < O; ++j) {
+                if (ct[4 * x4 + j] & 0x8000) continue;
+                if (term < 0) term = ct[4 * x4 + j];
+                else if (term != ct[4 * x4 + j]) fast = false;
+            }
+            ct4[x4] = (uint16_t)(term < 0 ? 0 : term);
+        }
+        int cw = 1;
+        for (int k = 0; k < r * r; ++k) {                       // view cell k = vy * r + vx: where its interior pixels are
+            const int vx = k % r, vy = k / r;
+            const int row_cell = row_is_y ? vy : vx, col_cell = row_is_y ? vx : vy;
+            int y0 = O, y1 = -1, x0 = O, x1 = -1;
+            for (int o = 0; o < O; ++o) {
+                if (cell_of[0][o] == row_cell) { if (o < y0) y0 = o; if (o > y1) y1 = o; }
+                if (cell_of[1][o] == col_cell) { if (o < x0) x0 = o; if (o > x1) x1 = o; }
+            }
+            const int w = x1 >= x0 ? x1 - x0 + 1 : 0, h = y1 >= y0 ? y1 - y0 + 1 : 0;
+            rect[4 * k] = (uint16_t)(w ? x0 : 0); rect[4 * k + 1] = (uint16_t)(h ? y0 : 0);
+            rect[4 * k + 2] = (uint16_t)w; rect[4 * k + 3] = (uint16_t)h;
+            if (w > cw) cw = w;
+            if (h > cw) cw = h;
+        }
+        hd[2] = (uint16_t)cw; hd[3] = 0;
     }
-    const size_t tap_bytes = all.size() * sizeof(EgoTap), lut_bytes = lut.size() * sizeof(uint16_t);
+    const size_t tap_bytes = all.size() * sizeof(EgoTap), lay_bytes = lay.size() * sizeof(uint16_t);
     uint8_t *d = nullptr;
-    hipError_t err = hipMalloc(&d, tap_bytes + lut_bytes);
+    hipError_t err = hipMalloc(&d, tap_bytes + lay_bytes);
     if (err != hipSuccess) return err;
     err = hipMemcpy(d, all.data(), tap_bytes, hipMemcpyHostToDevice);
-    if (err == hipSuccess) err = hipMemcpy(d + tap_bytes, lut.data(), lut_bytes, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d + tap_bytes, lay.data(), lay_bytes, hipMemcpyHostToDevice);
     *dev_out = reinterpret_cast<EgoTap *>(d);
+    *fast_out = fast ? 1 : 0;
     return err;
 }
 
@@ -534,11 +650,12 @@ hipError_t launch_xw_ego_build_tab(const XwParams &p, hipStream_t s) {
 
 hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s) {
     const EgoTables t = ego_tables_of(p);
-    const int r = p.visible_radius, O = p.out_dim, O4 = (O + 3) & ~3;
+    const int r = p.visible_radius, O = p.out_dim, O4 = (O + 3) & ~3, D = p.max_dim;
     const int CH = p.channels;
-    const bool fast = (O & 3) == 0;
-    const size_t lds = ego_frame_bytes(p) + (size_t)r * r * (sizeof(EgoCell) + 1) + (fast ? (size_t)((O * O + 3) & ~3) * 2 : 0) +
-                       (size_t)O4 * 4 + (size_t)((r + 3) & ~3) + XW_MAX_GOALS + 16;
+    const bool fast = p.ego_fast != 0;
+    const size_t lds = ego_frame_bytes(p) + (size_t)r * r * sizeof(EgoCell) + (fast ? (size_t)ego_layout_words(O4, r) * 8 : 0) +
+                       (size_t)p.n_icons * 4 + (size_t)((p.n_icons + 3) & ~3) + (size_t)((D * D + 3) & ~3) +
+                       (size_t)((r * r + 3) & ~3) + (size_t)((r + 3) & ~3) + 2 * XW_MAX_GOALS + 16;
     const unsigned blocks = indexed == 1 ? 2048u : (unsigned)(p.n < 16384 ? p.n : 16384);
     const int32_t *cnt = (const int32_t *)p.done_count;
     const uint32_t *a4 = reinterpret_cast<const uint32_t *>(p.atlas64);
@@ -553,3 +670,11 @@ hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s) {
 }
 
 }  // namespace xwb
+
+#ifdef XWB_EGO_PROF
+extern "C" int xwb_debug_ego_prof(unsigned long long *out) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(xwb::g_ego_prof), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(xwb::g_ego_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -299,7 +299,7 @@ int xw_setup(xwb_sim *s) {
         HIP_TRY(hipMemcpy(s->d_atlas64, a4.data(), a4.size(), hipMemcpyHostToDevice));
         if ((rc = dev_alloc(s, &s->d_agent_rot, (size_t)c.n_icons))) return rc;
         HIP_TRY(hipMemcpy(s->d_agent_rot, rot_off.data(), rot_off.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(xw_ego_tables(c.visible_radius, c.max_dim, s->out_h, &s->d_ego_taps));
+        HIP_TRY(xw_ego_tables(c.visible_radius, c.max_dim, s->out_h, &s->d_ego_taps, &s->xw.ego_fast));
         s->allocs.push_back(s->d_ego_taps);
     }
     if ((rc = dev_alloc(s, &s->d_icon_name, c.n_icons))) return rc;

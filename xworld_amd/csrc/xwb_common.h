@@ -168,7 +168,8 @@ struct XwParams {
     const uint32_t *ego_agent_rot;   // egocentric: [n_icons] pixel offset in atlas64 of an agent icon's three turned copies
                                  // (heading right, left, up; heading down is the icon itself)
     uint32_t *goal_img;          // egocentric: [n][num_goals][64 * 64] warped goal images (B | G << 8 | R << 16)
-    const void *ego_taps;        // egocentric: cv::resize taps of the two resizes, then the row / column cell terms per heading
+    const void *ego_taps;        // egocentric: cv::resize taps of the two resizes, then the four headings' layout tables
+    int ego_fast;                // egocentric: interior pixels can be copied from ego_tab (kernels_xworld_ego.hip)
     const uint8_t *ego_tab;      // egocentric: [(n_icons + 2) * 4] frames "every cell shows icon i", per heading (interior pixels)
     uint32_t *cand2d;            // [n] goal slots the agent can reach, blocks as the only obstacles: bits 0..15
                                  //     any goal (XWorldNavTarget), bits 16..31 coloured goals (XWorldNavColorTarget)
@@ -200,7 +201,7 @@ hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s);
 hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s);
 hipError_t launch_xw_warp_goals(const XwParams &p, bool list, hipStream_t s);
 struct EgoTap;
-hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out);
+hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int *fast_out);
 size_t xw_ego_tab_bytes(const XwParams &p);
 hipError_t launch_xw_ego_build_tab(const XwParams &p, hipStream_t s);
 
