@@ -105,9 +105,12 @@ __device__ __forceinline__ void ego_pixel(const EgoCtx &c, const EgoTap (*s_row)
             const uint32_t *q = cell.img + ((py * 64 + px) & cell.mask);
             src[k] = inview ? q : c.black;
         }
+        // the descriptors come from LDS, so the compiler cannot tell these pointers are global: say so (global_load instead
+        // of flat_load, which would also wait on the LDS counter)
+        typedef const uint32_t __attribute__((address_space(1))) *global_u32;
         uint32_t v[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = *src[k];
+        for (int k = 0; k < 16; ++k) v[k] = *(global_u32)src[k];
         int out[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
@@ -166,7 +169,7 @@ __device__ __forceinline__ int ego_div(int i, float inv_n) { return (int)(((floa
 template <int CH, int DIR, int BS, bool FAST>
 __device__ __forceinline__ void ego_pixels(const EgoCtx &c, const EgoTap (*s_row)[3], const EgoTap (*s_col)[3],
                                            uint8_t *s_frame, int O, int tid, const EgoLayout &l, const uint8_t *goal_k, int n_goal) {
-    const float inv_O = 1.0f / (float)O;
+    const float inv_O = __builtin_amdgcn_rcpf((float)O);         // 1 ulp: far inside ego_div's margin
     if (!FAST) {
         for (int i = tid; i < O * O; i += BS) {
             const int oy = ego_div(i, inv_O);
@@ -175,7 +178,7 @@ __device__ __forceinline__ void ego_pixels(const EgoCtx &c, const EgoTap (*s_row
         return;
     }
     const int cw2 = l.cw * l.cw, n_row_px = l.nbr * O, n_border_px = n_row_px + l.nbc * O, total = n_border_px + n_goal * cw2;
-    const float inv_cw = 1.0f / (float)l.cw, inv_cw2 = 1.0f / (float)cw2;
+    const float inv_cw = __builtin_amdgcn_rcpf((float)l.cw), inv_cw2 = __builtin_amdgcn_rcpf((float)cw2);
     for (int i = tid; i < total; i += BS) {
         int ox, oy;
         bool ok = true;
@@ -216,30 +219,33 @@ __device__ __forceinline__ void ego_pixels_dir(int dir, const EgoCtx &ctx, const
 template <int CH, int BS>
 __device__ __forceinline__ void ego_copy_interior(const EgoCell *s_cells, const EgoLayout &l, const uint8_t *tab, uint32_t frame_bytes,
                                                   uint8_t *s_frame, int O, int tid, int oy0, int x40, int sy, int sx) {
-    constexpr int IT = (84 * 21 + BS - 1) / BS;
+    constexpr int IT = (84 * 21 + BS - 1) / BS, HALF = (IT + 1) / 2;    // two batches: 12 live registers instead of 21
     const int rowd = O >> 2, nd = O * rowd;
     uint32_t *f32 = reinterpret_cast<uint32_t *>(s_frame);
-    uint32_t v[IT][CH];
     int oy = oy0, x4 = x40;
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int d = it * BS + tid;
-        if (d < nd) {
-            const int cell = (int)(l.rt[oy] & 0x7fffu) + (int)l.ct4[x4];
-            const int t = s_cells[cell].tab;
-            const uint8_t *src = tab + (uint32_t)(t < 0 ? 0 : t) * frame_bytes + 4u * (uint32_t)d;
+    for (int b = 0; b < IT; b += HALF) {
+        uint32_t v[HALF][CH];
 #pragma unroll
-            for (int ch = 0; ch < CH; ++ch) v[it][ch] = *reinterpret_cast<const uint32_t *>(src + (uint32_t)(ch * O * O));
+        for (int it = b; it < b + HALF && it < IT; ++it) {
+            const int d = it * BS + tid;
+            if (d < nd) {
+                const int cell = (int)(l.rt[oy] & 0x7fffu) + (int)l.ct4[x4];
+                const int t = s_cells[cell].tab;
+                const uint8_t *src = tab + (uint32_t)(t < 0 ? 0 : t) * frame_bytes + 4u * (uint32_t)d;
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) v[it - b][ch] = *reinterpret_cast<const uint32_t *>(src + (uint32_t)(ch * O * O));
+            }
+            x4 += sx; oy += sy;
+            if (x4 >= rowd) { x4 -= rowd; ++oy; }
         }
-        x4 += sx; oy += sy;
-        if (x4 >= rowd) { x4 -= rowd; ++oy; }
-    }
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int d = it * BS + tid;
-        if (d < nd) {
+        for (int it = b; it < b + HALF && it < IT; ++it) {
+            const int d = it * BS + tid;
+            if (d < nd) {
 #pragma unroll
-            for (int ch = 0; ch < CH; ++ch) f32[ch * nd + d] = v[it][ch];
+                for (int ch = 0; ch < CH; ++ch) f32[ch * nd + d] = v[it - b][ch];
+            }
         }
     }
 }
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(256) void xw_ego_build_tab_kernel(XwParams p, const
 // table and frames leave as 16-byte chunks.  Otherwise (r >= 9: 81, 77, 78, 75 pixel edges) every pixel is evaluated
 // and frames leave element by element -- their byte size is not a multiple of 16.
 template <int CH, int MODE, int BS, bool FAST>
-__global__ __launch_bounds__(BS) void xw_render_ego_kernel(XwParams p, const uint32_t *atlas4, const EgoTap *tap_h1,
+__global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const uint32_t *atlas4, const EgoTap *tap_h1,
                                                             const EgoTap *tap_v1, const EgoTap *tap_h2, const EgoTap *tap_v2,
                                                             const uint16_t *layout, const uint8_t *tab,
                                                             const int32_t *count_now) {
@@ -656,7 +662,9 @@ hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s) {
     const size_t lds = ego_frame_bytes(p) + (size_t)r * r * sizeof(EgoCell) + (fast ? (size_t)ego_layout_words(O4, r) * 8 : 0) +
                        (size_t)p.n_icons * 4 + (size_t)((p.n_icons + 3) & ~3) + (size_t)((D * D + 3) & ~3) +
                        (size_t)((r * r + 3) & ~3) + (size_t)((r + 3) & ~3) + 2 * XW_MAX_GOALS + 16;
-    const unsigned blocks = indexed == 1 ? 2048u : (unsigned)(p.n < 16384 ? p.n : 16384);
+    // whole batch: as many workgroups as are resident at once (256 CUs x 4), each looping over its envs with the next
+    // env's state in flight, so the per-workgroup prologue (taps, layout tables -> LDS) is paid 1024 times, not 16384
+    const unsigned blocks = indexed == 1 ? 2048u : (unsigned)(p.n < 1024 ? p.n : 1024);
     const int32_t *cnt = (const int32_t *)p.done_count;
     const uint32_t *a4 = reinterpret_cast<const uint32_t *>(p.atlas64);
 #define EGO_LAUNCH2(CHV, MODEV, BSV, FASTV) hipLaunchKernelGGL((xw_render_ego_kernel<CHV, MODEV, BSV, FASTV>), dim3(blocks), dim3(BSV), lds, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, p.ego_tab, cnt)
