@@ -67,9 +67,10 @@ __device__ __forceinline__ int vresize(int b0, int h0, int b1, int h1) {
 // One output pixel.  DIR = the agent's heading: cv::warpAffine(view, rot(centre S/2, 90 + yaw deg)) is undone per tap
 // row / column -- quarter turns are exact integer maps, separable in x and y; the source index S falls outside and
 // leaves one black row / column (borderValue 0).
-template <int CH, int DIR>
+// ONE: all sixteen view pixels lie in the view cell `one` (an interior pixel of that cell, whose image is indexed: a goal)
+template <int CH, int DIR, bool ONE>
 __device__ __forceinline__ void ego_pixel(const EgoCtx &c, const EgoTap (*s_row)[3], const EgoTap (*s_col)[3],
-                                          uint8_t *s_frame, int O, int ox, int oy) {
+                                          uint8_t *s_frame, int O, int ox, int oy, int one) {
     const int S = c.S, o = oy * O + ox;
     {
         // the 2 x 2 intermediate pixels this output pixel blends, and the 4 x 4 view pixels behind them
@@ -86,24 +87,34 @@ __device__ __forceinline__ void ego_pixel(const EgoCtx &c, const EgoTap (*s_row)
         }
         // fr is sy for headings up / down and sx for right / left (and fc the other one)
         constexpr bool ROW_IS_Y = DIR == 3 || DIR == 1;
-        int cr[4], cc[4], pr[4], pc[4];
-        bool okr[4], okc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            okr[i] = (unsigned)fr[i] < (unsigned)S; okc[i] = (unsigned)fc[i] < (unsigned)S;
-            cr[i] = ROW_IS_Y ? __mul24(fr[i] >> 6, c.r) : (fr[i] >> 6);
-            cc[i] = ROW_IS_Y ? (fc[i] >> 6) : __mul24(fc[i] >> 6, c.r);
-            pr[i] = fr[i] & 63; pc[i] = fc[i] & 63;
-        }
         const uint32_t *src[16];
+        if (ONE) {
+            const uint32_t *img = c.cells[one].img;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int i = k >> 2, j = k & 3;
-            const bool inview = okr[i] && okc[j];
-            const EgoCell cell = c.cells[inview ? cr[i] + cc[j] : 0];
-            const int px = ROW_IS_Y ? pc[j] : pr[i], py = ROW_IS_Y ? pr[i] : pc[j];
-            const uint32_t *q = cell.img + ((py * 64 + px) & cell.mask);
-            src[k] = inview ? q : c.black;
+            for (int k = 0; k < 16; ++k) {
+                const int i = k >> 2, j = k & 3;
+                const int px = (ROW_IS_Y ? fc[j] : fr[i]) & 63, py = (ROW_IS_Y ? fr[i] : fc[j]) & 63;
+                src[k] = img + (py * 64 + px);
+            }
+        } else {
+            int cr[4], cc[4], pr[4], pc[4];
+            bool okr[4], okc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                okr[i] = (unsigned)fr[i] < (unsigned)S; okc[i] = (unsigned)fc[i] < (unsigned)S;
+                cr[i] = ROW_IS_Y ? __mul24(fr[i] >> 6, c.r) : (fr[i] >> 6);
+                cc[i] = ROW_IS_Y ? (fc[i] >> 6) : __mul24(fc[i] >> 6, c.r);
+                pr[i] = fr[i] & 63; pc[i] = fc[i] & 63;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = k >> 2, j = k & 3;
+                const bool inview = okr[i] && okc[j];
+                const EgoCell cell = c.cells[inview ? cr[i] + cc[j] : 0];
+                const int px = ROW_IS_Y ? pc[j] : pr[i], py = ROW_IS_Y ? pr[i] : pc[j];
+                const uint32_t *q = cell.img + ((py * 64 + px) & cell.mask);
+                src[k] = inview ? q : c.black;
+            }
         }
         // the descriptors come from LDS, so the compiler cannot tell these pointers are global: say so (global_load instead
         // of flat_load, which would also wait on the LDS counter)
@@ -173,31 +184,35 @@ __device__ __forceinline__ void ego_pixels(const EgoCtx &c, const EgoTap (*s_row
     if (!FAST) {
         for (int i = tid; i < O * O; i += BS) {
             const int oy = ego_div(i, inv_O);
-            ego_pixel<CH, DIR>(c, s_row, s_col, s_frame, O, i - oy * O, oy);
+            ego_pixel<CH, DIR, false>(c, s_row, s_col, s_frame, O, i - oy * O, oy, 0);
         }
         return;
     }
-    const int cw2 = l.cw * l.cw, n_row_px = l.nbr * O, n_border_px = n_row_px + l.nbc * O, total = n_border_px + n_goal * cw2;
+    const int cw2 = l.cw * l.cw, n_row_px = l.nbr * O, n_border_px = n_row_px + l.nbc * O;
     const float inv_cw = __builtin_amdgcn_rcpf((float)l.cw), inv_cw2 = __builtin_amdgcn_rcpf((float)cw2);
-    for (int i = tid; i < total; i += BS) {
+    // border rows and columns: any of the sixteen view pixels may belong to another cell, or to none
+    for (int i = tid; i < n_border_px; i += BS) {
         int ox, oy;
         bool ok = true;
         if (i < n_row_px) {
             const int q = ego_div(i, inv_O);
             oy = l.br[q]; ox = i - q * O;
-        } else if (i < n_border_px) {
+        } else {
             const int j = i - n_row_px, q = ego_div(j, inv_O);
             ox = l.bc[q]; oy = j - q * O;
             ok = !(l.rt[oy] & 0x8000u);                         // already done with its row
-        } else {
-            const int j = i - n_border_px, g = ego_div(j, inv_cw2), jj = j - g * cw2;
-            const uint16_t *rc = l.rect + 4 * (int)goal_k[g];
-            const int py = ego_div(jj, inv_cw), px = jj - py * l.cw;
-            ok = px < (int)rc[2] && py < (int)rc[3];
-            ox = ok ? (int)rc[0] + px : 0; oy = ok ? (int)rc[1] + py : 0;
-            ok = ok && !((l.rt[oy] | l.ct[ox]) & 0x8000u);
         }
-        if (ok) ego_pixel<CH, DIR>(c, s_row, s_col, s_frame, O, ox, oy);
+        if (ok) ego_pixel<CH, DIR, false>(c, s_row, s_col, s_frame, O, ox, oy, 0);
+    }
+    // goal cells: interior pixels only
+    for (int j = tid; j < n_goal * cw2; j += BS) {
+        const int g = ego_div(j, inv_cw2), jj = j - g * cw2, k = goal_k[g];
+        const uint16_t *rc = l.rect + 4 * k;
+        const int py = ego_div(jj, inv_cw), px = jj - py * l.cw;
+        bool ok = px < (int)rc[2] && py < (int)rc[3];
+        const int ox = ok ? (int)rc[0] + px : 0, oy = ok ? (int)rc[1] + py : 0;
+        ok = ok && !((l.rt[oy] | l.ct[ox]) & 0x8000u);
+        if (ok) ego_pixel<CH, DIR, true>(c, s_row, s_col, s_frame, O, ox, oy, k);
     }
 }
 
