@@ -35,12 +35,14 @@ def main(out, bench_args):
             print("%-70s %8s %14s %12s %8s" % (r.get("Name", "")[:70], r.get("Calls"), r.get("TotalDurationNs"),
                                                r.get("AverageNs"), r.get("Percentage")))
     per_kernel = {}
+    agg_count = {}
     for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         agg = counter_by_kernel(out, tag, counter)
         print("== rocprofv3 --pmc %s (raw counter, KiB per dispatch) ==" % counter)
         for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]:
             print("%-70s dispatches %5d  %.1f" % (k[:70], n, v / n))
             per_kernel.setdefault(k, {})[counter] = v / n * 1024.0
+            agg_count[k] = n
     # calibration: bytes the counters report for a fill / copy of exactly FILL_BYTES
     cal = {}
     for tag, counter in (("cal_write", "WRITE_SIZE"), ("cal_fetch", "FETCH_SIZE")):
@@ -50,9 +52,9 @@ def main(out, bench_args):
             b = v / n * 1024.0
             print("%-70s dispatches %5d  %.0f B per dispatch = %.3f x buffer" % (k[:70], n, b, b / FILL_BYTES))
             cal.setdefault(counter, {})[k[:60]] = b / FILL_BYTES
-    dom = [k for k in per_kernel if "render_all" in k or "sg_kernel" in k or "race_kernel" in k]
+    dom = [k for k in per_kernel if "render_all" in k or "sg_kernel" in k or "race_kernel" in k or "render_ego" in k]
     if dom:
-        k = dom[0]
+        k = max(dom, key=lambda name: per_kernel[name].get("WRITE_SIZE", 0.0) * agg_count.get(name, 1))   # the step loop's kernel
         # write side: the fill kernels of the calibration report ~1.0 x -> WRITE_SIZE taken at face value;
         # read side: FETCH_SIZE x 2 (gfx950 correction for 16 B/lane streaming reads, MI355X_MICROARCH.md "HBM")
         w = per_kernel[k].get("WRITE_SIZE", 0.0)
