@@ -345,18 +345,24 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
     const int cells = D * D;
     const int rowd = O >> 2, copy_oy0 = tid / rowd, copy_x40 = tid - copy_oy0 * rowd, copy_sy = BS / rowd, copy_sx = BS - copy_sy * rowd;
     const int n_items = MODE == 1 ? *count_now : p.n;
-    // Everything the env's setup reads from global memory is fetched one env ahead (one value per thread: cells <= 256
-    // <= BS) and staged in LDS, so the serial part -- shadow rays, scan lines, cell table -- never waits for HBM / L2.
-    struct Fetch { int e, axy, dir, skip; uint32_t code, gc; };
+    // Everything the env's setup reads from global memory is fetched one env ahead and staged in LDS, so the serial part
+    // -- shadow rays, scan lines, cell table -- never waits for HBM / L2.  The setup is the first wavefront's job alone
+    // (its lanes hold the grid: cells <= 256 = 4 per lane): it is scalar-heavy code that every wavefront would otherwise
+    // repeat, and inside one wavefront its phases need no workgroup barrier (LDS operations of a wave complete in order).
+    constexpr int CPL = XW_MAX_DIM * XW_MAX_DIM / 64;           // grid cells per lane of the first wavefront
+    const bool wave0 = tid < 64;
+    struct Fetch { int e, axy, dir, skip; uint32_t code[CPL], gc; };
     auto fetch = [&](int item) {
         Fetch f;
         f.e = MODE == 1 ? p.done_list[item] : item;
         f.skip = MODE == 2 ? (int)p.done[f.e] : 0;
         f.axy = p.agent_xy[f.e]; f.dir = p.agent_dir[f.e];
-        f.code = tid < cells ? (uint32_t)p.grid[(size_t)f.e * cells + tid] : 0u;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) f.code[k] = wave0 && tid + 64 * k < cells ? (uint32_t)p.grid[(size_t)f.e * cells + tid + 64 * k] : 0u;
         f.gc = tid < XW_MAX_GOALS ? (uint32_t)p.goal_cells[(size_t)f.e * XW_MAX_GOALS + tid] : 0xffu;
         return f;
     };
+    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); };
     Fetch nxt{};
     if ((int)blockIdx.x < n_items) nxt = fetch(blockIdx.x);
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -364,74 +370,79 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
         const int e = f.e, ax = f.axy & 0xffff, ay = f.axy >> 16, dir = f.dir;
         __syncthreads();                                        // the previous env's frame has left LDS
         EGO_T0();
-        if (tid < cells) {
-            const int code = (int)(f.code & CELL_ICON_MASK);
-            s_code[tid] = (uint16_t)code;
-            s_type[tid] = code ? s_itype[code - 1] : (uint8_t)3;
+        if (wave0) {
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int c = tid + 64 * k;
+                if (c < cells) {
+                    const int code = (int)(f.code[k] & CELL_ICON_MASK);
+                    s_code[c] = (uint16_t)code;
+                    s_type[c] = code ? s_itype[code - 1] : (uint8_t)3;
+                }
+            }
+            if (tid < XW_MAX_GOALS) s_gc[tid] = (uint8_t)f.gc;
+            if (tid < r) s_ray[tid] = 1;
+            if (tid == 0) s_ngoal = 0;
         }
-        if (tid < XW_MAX_GOALS) s_gc[tid] = (uint8_t)f.gc;
-        if (tid < r) s_ray[tid] = 1;
-        if (tid == 0) s_ngoal = 0;
         if (item + (int)gridDim.x < n_items) nxt = fetch(item + gridDim.x);
         if (f.skip) continue;
         EgoLayout lay{};
         if (FAST) lay = ego_layout(s_layout + dir * lw, O4, r);
-        auto is_block = [&](int x, int y) {
-            return (unsigned)x < (unsigned)D && (unsigned)y < (unsigned)D && s_type[y * D + x] == 1;
-        };
-        // XMap::image_masking (xmap.cpp:273-362)
-        int major_x = 0, major_y = 0, minor_x = 0, minor_y = 0, scan_x0 = 0, scan_y0 = 0, xa = ax + r, ya = ay + r;
-        if (dir == 0) { xa += r / 2; major_y = 1; minor_x = 1; }
-        else if (dir == 3) { ya -= r / 2; major_x = 1; minor_y = -1; scan_y0 = r - 1; }
-        else if (dir == 2) { xa -= r / 2; major_y = 1; minor_x = -1; scan_x0 = r - 1; }
-        else { ya += r / 2; major_x = 1; minor_y = 1; }
-        const int x_st = xa - r / 2, y_st = ya - r / 2;
-        __syncthreads();
-        EGO_T(0);
-        if (tid < 2) {                                          // rays to either side of the agent
-            const int o = tid ? 1 : -1;
-            bool block = false;
-            int rx = ax, ry = ay;
-            for (int k = 1; k <= r / 2; ++k) {
-                rx += o * major_x; ry += o * major_y;
-                if (block) s_ray[r / 2 + o * k] = 0;
-                if (is_block(rx, ry)) block = true;
-            }
-        }
-        __syncthreads();
-        EGO_T(1);
-        if (tid < r) {                                          // one scan line per lane
-            bool block = !s_ray[tid];
-            int cx = scan_x0 + tid * major_x, cy = scan_y0 + tid * major_y;
-            for (int j = 0; j < r; ++j) {
-                s_shadow[cy * r + cx] = block ? 1 : 0;
-                if (is_block(x_st - r + cx, y_st - r + cy)) block = true;
-                cx = (cx + minor_x + r) % r;
-                cy = (cy + minor_y + r) % r;
-            }
-        }
-        __syncthreads();
-        EGO_T(2);
         const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
-        const uint32_t *gimg = p.goal_img + (size_t)e * p.num_goals * 4096;
-        for (int k = tid; k < r * r; k += BS) {                 // what each view cell shows
-            const int gx = x_st - r + k % r, gy = y_st - r + k / r;
-            EgoCell c{black, 0, (p.n_icons + 1) * 4 + dir};     // outside the map, or in a wall's shadow
-            if ((unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && !s_shadow[k]) {
-                const int code = s_code[gy * D + gx];
-                if (code == 0) { c.img = white; c.tab = p.n_icons * 4 + dir; }
-                else {
-                    c = ego_icon_cell(s_itype, s_rot, atlas4, code - 1, dir);
-                    if (s_type[gy * D + gx] == 0) {             // a goal: this env's warped copy
-                        int slot = 0;
-                        for (int i = 0; i < XW_MAX_GOALS; ++i) if (s_gc[i] == gy * D + gx) slot = i;
-                        c.img = gimg + slot * 4096;
-                        c.tab = -1;
-                        if (FAST) s_goal_k[atomicAdd(&s_ngoal, 1)] = (uint8_t)k;
-                    }
+        if (wave0) {
+            auto is_block = [&](int x, int y) {
+                return (unsigned)x < (unsigned)D && (unsigned)y < (unsigned)D && s_type[y * D + x] == 1;
+            };
+            // XMap::image_masking (xmap.cpp:273-362)
+            int major_x = 0, major_y = 0, minor_x = 0, minor_y = 0, scan_x0 = 0, scan_y0 = 0, xa = ax + r, ya = ay + r;
+            if (dir == 0) { xa += r / 2; major_y = 1; minor_x = 1; }
+            else if (dir == 3) { ya -= r / 2; major_x = 1; minor_y = -1; scan_y0 = r - 1; }
+            else if (dir == 2) { xa -= r / 2; major_y = 1; minor_x = -1; scan_x0 = r - 1; }
+            else { ya += r / 2; major_x = 1; minor_y = 1; }
+            const int x_st = xa - r / 2, y_st = ya - r / 2;
+            wave_sync();
+            if (tid < 2) {                                      // rays to either side of the agent
+                const int o = tid ? 1 : -1;
+                bool block = false;
+                int rx = ax, ry = ay;
+                for (int k = 1; k <= r / 2; ++k) {
+                    rx += o * major_x; ry += o * major_y;
+                    if (block) s_ray[r / 2 + o * k] = 0;
+                    if (is_block(rx, ry)) block = true;
                 }
             }
-            s_cells[k] = c;
+            wave_sync();
+            if (tid < r) {                                      // one scan line per lane
+                bool block = !s_ray[tid];
+                int cx = scan_x0 + tid * major_x, cy = scan_y0 + tid * major_y;
+                for (int j = 0; j < r; ++j) {
+                    s_shadow[cy * r + cx] = block ? 1 : 0;
+                    if (is_block(x_st - r + cx, y_st - r + cy)) block = true;
+                    cx = (cx + minor_x + r) % r;
+                    cy = (cy + minor_y + r) % r;
+                }
+            }
+            wave_sync();
+            const uint32_t *gimg = p.goal_img + (size_t)e * p.num_goals * 4096;
+            for (int k = tid; k < r * r; k += 64) {             // what each view cell shows
+                const int gx = x_st - r + k % r, gy = y_st - r + k / r;
+                EgoCell c{black, 0, (p.n_icons + 1) * 4 + dir}; // outside the map, or in a wall's shadow
+                if ((unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && !s_shadow[k]) {
+                    const int code = s_code[gy * D + gx];
+                    if (code == 0) { c.img = white; c.tab = p.n_icons * 4 + dir; }
+                    else {
+                        c = ego_icon_cell(s_itype, s_rot, atlas4, code - 1, dir);
+                        if (s_type[gy * D + gx] == 0) {         // a goal: this env's warped copy
+                            int slot = 0;
+                            for (int i = 0; i < XW_MAX_GOALS; ++i) if (s_gc[i] == gy * D + gx) slot = i;
+                            c.img = gimg + slot * 4096;
+                            c.tab = -1;
+                            if (FAST) s_goal_k[atomicAdd(&s_ngoal, 1)] = (uint8_t)k;
+                        }
+                    }
+                }
+                s_cells[k] = c;
+            }
         }
         __syncthreads();
         EGO_T(3);
