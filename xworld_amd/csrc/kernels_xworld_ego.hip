@@ -339,12 +339,13 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
     __shared__ uint16_t s_code[XW_MAX_DIM * XW_MAX_DIM];                         // the env's grid, target bit stripped
     __shared__ int s_ngoal;
     const int tid = threadIdx.x;
+    const int n_items = MODE == 1 ? *count_now : p.n;
+    if ((int)blockIdx.x >= n_items) return;                    // the done list is short: most of its workgroups leave here
     ego_compose_taps(s_row, s_col, tap_h1, tap_v1, tap_h2, tap_v2, O, tid, BS);
     for (int i = tid; i < p.n_icons; i += BS) { s_itype[i] = p.icon_type[i]; s_rot[i] = p.ego_agent_rot[i]; }
     if (FAST) for (int i = tid; i < 4 * lw; i += BS) s_layout[i] = layout[i];
     const int cells = D * D;
     const int rowd = O >> 2, copy_oy0 = tid / rowd, copy_x40 = tid - copy_oy0 * rowd, copy_sy = BS / rowd, copy_sx = BS - copy_sy * rowd;
-    const int n_items = MODE == 1 ? *count_now : p.n;
     // Everything the env's setup reads from global memory is fetched one env ahead and staged in LDS, so the serial part
     // -- shadow rays, scan lines, cell table -- never waits for HBM / L2.  The setup is the first wavefront's job alone
     // (its lanes hold the grid: cells <= 256 = 4 per lane): it is scalar-heavy code that every wavefront would otherwise
