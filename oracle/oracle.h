@@ -139,6 +139,8 @@ typedef struct {
     int visible_radius;      /* FLAGS_visible_radius: 0 = full observation; odd r > 0 = egocentric r x r view, 6 actions */
     int n_tasks;             /* tasks of the group, sampled uniformly per episode (teaching_task.cpp:204-213); 0 = {TARGET} */
     int tasks[8];            /* ORC_TASK_* in conf order */
+    double curriculum;       /* FLAGS_curriculum: != 0 -> XWorldNav grows with the agent's success rate (XWorldNav.py:36-53) */
+    int start_level;         /* XWorldNav(item_path, start_level): the level a --curriculum_stamp file holds (xworld.cpp:93-100) */
 } orc_xw_cfg;
 
 typedef struct {
@@ -206,6 +208,13 @@ void    orc_xw_screen_dims(const orc_xworld *w, int *h, int *wd, int *c);
 /* XWorldSimulator::get_screen: canvas -> get_screen_rgb -> down_sample_image */
 void    orc_xw_get_screen(const orc_xworld *w, uint8_t *out);
 void    orc_xw_get_state_screen(const orc_xworld *w, uint8_t *out /* context * c*h*w */);
+
+/* curriculum (FLAGS_curriculum != 0, XWorldNav only): level and check counter of the env; the pieces, for golden replays:
+ * orc_xw_curriculum_configure = the level logic XWorldNav._configure runs at every reset (returns the level; dim, goals,
+ * blocks of that level); orc_xw_record_result = XWorld(3D)Task.__record_result of the task class `kind` */
+void    orc_xw_curriculum_state(const orc_xworld *w, int *level, int *counter);
+int     orc_xw_curriculum_configure(orc_xworld *w, int *dim, int *num_goals, int *num_blocks);
+void    orc_xw_record_result(orc_xworld *w, int kind, int result);
 
 /* reference helper restatements exposed for golden-vector tests */
 /* maze2d.spanning_tree_maze_generator with the shuffle decisions drawn from `s`;

@@ -270,17 +270,59 @@ static void set_dims(orc_xworld *w, int h, int wd) {
  *        block: loc = blocks.pop(); name below(#block names); variant below(nv)
  *        agent: loc = avail[below(n_avail)]; name below(#agent names); variant below(nv)
  *      (below(n) always consumes one draw, also for n <= 1)                           */
+/* XWorld(3D)Task.__record_result: success_seq.append(res), at most performance_window_size = 200 kept
+ * (xworld3d_task.py:129-133, xworld_task.py:87-91); _record_env_usage hands the list to the env */
+void orc_xw_record_result(orc_xworld *w, int kind, int result) {
+    if (kind < 0 || kind >= 9) abort();
+    if (w->use_len[kind] < 200) {
+        w->use_bits[kind][(w->use_head[kind] + w->use_len[kind]) % 200] = (uint8_t)result;
+        w->use_len[kind]++;
+        w->use_sum[kind] += result;
+    } else {
+        w->use_sum[kind] += result - w->use_bits[kind][w->use_head[kind]];
+        w->use_bits[kind][w->use_head[kind]] = (uint8_t)result;
+        w->use_head[kind] = (w->use_head[kind] + 1) % 200;
+    }
+}
+
+/* XWorldNav._configure, the curriculum != 0 branch (XWorldNav.py:27-55) with XWorldEnv.get_current_usage
+ * (xworld_env.py:103-110): every 100th call that finds a recorded task compares the worst task's success rate
+ * over its window with FLAGS_curriculum and moves to the next of the six levels */
+int orc_xw_curriculum_configure(orc_xworld *w, int *dim, int *num_goals, int *num_blocks) {
+    static const int goals_seq[6] = {2, 2, 2, 4, 4, 4}, blocks_seq[6] = {0, 3, 6, 9, 12, 16};
+    if (w->cfg.max_dim != 8) abort();                 /* assert len(num_goals_seq) == n_levels */
+    w->cur_counter += 1;
+    int any = 0;
+    for (int k = 0; k < 9; ++k) if (w->use_len[k] > 0) any = 1;
+    double usage = 0;
+    if (w->cur_counter >= 100 && any) {
+        usage = 2;
+        for (int k = 0; k < 9; ++k)
+            if (w->use_len[k] > 0) {
+                double u = (double)w->use_sum[k] / (double)w->use_len[k];
+                if (u < usage) usage = u;
+            }
+        w->cur_counter = 0;
+    }
+    if (usage >= w->cfg.curriculum && w->cur_level < 5) w->cur_level += 1;
+    *dim = 3 + w->cur_level; *num_goals = goals_seq[w->cur_level]; *num_blocks = blocks_seq[w->cur_level];
+    return w->cur_level;
+}
+
+void orc_xw_curriculum_state(const orc_xworld *w, int *level, int *counter) { *level = w->cur_level; *counter = w->cur_counter; }
+
 static void gen_map_nav(orc_xworld *w) {
-    int D = w->cfg.dim;
+    int D = w->cfg.dim, num_goals = w->cfg.num_goals, num_blocks = w->cfg.num_blocks;
+    if (w->cfg.curriculum != 0) orc_xw_curriculum_configure(w, &D, &num_goals, &num_blocks);
     set_dims(w, D, D);
     w->n_ents = 0;
     w->running_id = 0;
     int M = w->n_names[0];
     int names[1024];
-    if (M > 1024 || w->cfg.num_goals > M) abort();
+    if (M > 1024 || num_goals > M) abort();
     for (int i = 0; i < M; ++i) names[i] = i;
     int goal_name[64];
-    for (int i = 0; i < w->cfg.num_goals; ++i) {
+    for (int i = 0; i < num_goals; ++i) {
         int j = (int)orc_stream_below(&w->rs, (uint32_t)(M - i));
         goal_name[i] = names[j];
         names[j] = names[M - 1 - i];
@@ -298,8 +340,8 @@ static void gen_map_nav(orc_xworld *w) {
         int j = (int)orc_stream_below(&w->rs, (uint32_t)(i + 1));
         cell t = blocks[i]; blocks[i] = blocks[j]; blocks[j] = t;
     }
-    if (w->cfg.num_blocks > nb) abort();    /* assert blocks, "too many blocks for a valid maze" */
-    for (int i = 0; i < w->cfg.num_goals; ++i) {
+    if (num_blocks > nb) abort();    /* assert blocks, "too many blocks for a valid maze" */
+    for (int i = 0; i < num_goals; ++i) {
         int k = (int)orc_stream_below(&w->rs, (uint32_t)na);
         cell c = avail[k]; na = cell_list_remove_at(avail, na, k);
         int v = (int)orc_stream_below(&w->rs, (uint32_t)n_variants(w, 0, goal_name[i]));
@@ -314,7 +356,7 @@ static void gen_map_nav(orc_xworld *w) {
             w->e_offset[k] = 0 + ((1 - w->e_scale[k]) - 0) * u2;
         }
     }
-    for (int i = 0; i < w->cfg.num_blocks; ++i) {
+    for (int i = 0; i < num_blocks; ++i) {
         cell c = blocks[--nb];
         int nm = (int)orc_stream_below(&w->rs, (uint32_t)w->n_names[1]);
         int v = (int)orc_stream_below(&w->rs, (uint32_t)n_variants(w, 1, nm));
@@ -440,6 +482,7 @@ static void task_navigation_reward(orc_xworld *w) {
     w->steps_in_cur_task += 1;
     if (w->steps_in_cur_task >= w->actual_h * w->actual_w * w->cfg.max_steps_factor) {
         w->event = ORC_EV_TIMEUP;
+        orc_xw_record_result(w, w->task_kind, 0);   /* _time_reward: _record_failure */
         time_out = 1;
     }
     int next_stage = ORC_STAGE_NAV;
@@ -461,10 +504,12 @@ static void task_navigation_reward(orc_xworld *w) {
         }
         if (target_reach) {
             w->event = ORC_EV_CORRECT;
+            orc_xw_record_result(w, w->task_kind, 1);                /* _successful_goal: _record_success */
             reward += 1.0;                        /* correct_reward */
             next_stage = ORC_STAGE_TERMINAL;
         } else if (any_reach) {
             w->event = ORC_EV_WRONG;
+            orc_xw_record_result(w, w->task_kind, 0);                /* _failed_goal: _record_failure */
             reward += -1.0;                       /* wrong_reward */
             next_stage = ORC_STAGE_TERMINAL;
         }
@@ -668,6 +713,11 @@ orc_xworld *orc_xw_create(const orc_xw_cfg *cfg, int n_icons, const orc_icon_inf
     w->channels = w->cfg.color ? 3 : 1;
     w->screens = (uint8_t *)calloc(screen_size(w) * (size_t)w->cfg.context, 1);
     w->last_action_success = 1;       /* GameSimulator ctor default, simulator.cpp:33-34 */
+    w->cur_level = w->cfg.start_level;
+    if (w->cfg.curriculum != 0) {
+        if (w->cfg.map_kind != ORC_MAP_NAV) w->cfg.curriculum = 0;            /* XWorldWalls never reads the flag */
+        else if (w->cur_level < 0 || w->cur_level > 5 || w->cfg.max_dim != 8) abort();
+    }
     return w;
 }
 

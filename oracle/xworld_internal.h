@@ -48,6 +48,11 @@ struct orc_xworld {
     int forced_sticky;
     const double *staged_poses; int n_staged_poses;
     const int *forced; int n_forced, forced_at;   /* golden replay: decisions instead of stream draws */
+    /* curriculum: XWorldEnv.current_level / curriculum_check_counter (xworld_env.py:73-77); per task class the
+     * success_seq window of the last 200 results (xworld3d_task.py:129-146) -- current_usage holds a class once it recorded */
+    int cur_level, cur_counter;
+    int use_len[9], use_sum[9], use_head[9];
+    uint8_t use_bits[9][200];
     /* GameSimulator */
     int64_t num_steps;
     uint8_t *screens;
@@ -64,6 +69,7 @@ void orc_xw_ego_view(const orc_xworld *w, int r, uint8_t *view);
 void orc_xw_rebuild_map(orc_xworld *w);                 /* XWorld::reset(false): rebuild the cube from the entity list */
 int  orc_xw_draw_below(orc_xworld *w, int n);           /* next decision: forced (golden replay) or stream draw */
 /* xworld_tasks.c */
+void orc_xw_record_result(orc_xworld *w, int kind, int result);
 void orc_task_idle(orc_xworld *w);                      /* TaskGroup::run_stage: sample a task, run its idle stage */
 int  orc_task_is_target(const orc_xworld *w, int ent);
 void orc_task2d_navigation_reward(orc_xworld *w);       /* XWorldTask.simple_navigation_reward */

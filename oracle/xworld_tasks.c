@@ -352,9 +352,11 @@ void orc_task2d_navigation_reward(orc_xworld *w) {
     if (w->cfg.task_mode == ORC_TASKMODE_ONE_CHANNEL &&
         w->steps_in_cur_task >= w->height * w->width / 2) {             /* get_max_dims(); Python-2 int division */
         w->steps_in_cur_task = 0;
-        next_stage = ORC_STAGE_IDLE;                                     /* _record_failure; "S -> timeup" */
+        orc_xw_record_result(w, w->task_kind, 0);                        /* _record_failure */
+        next_stage = ORC_STAGE_IDLE;                                     /* "S -> timeup" */
     } else if (a->x == w->target2d_x && a->y == w->target2d_y) {
         w->steps_in_cur_task = 0;
+        orc_xw_record_result(w, w->task_kind, 1);                        /* _record_success */
         w->event = ORC_EV_CORRECT;
         reward += 1.0;
         next_stage = ORC_STAGE_IDLE;

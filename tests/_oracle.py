@@ -42,7 +42,8 @@ class XwCfg(C.Structure):
     _fields_ = [("map_kind", C.c_int), ("max_dim", C.c_int), ("dim", C.c_int), ("num_goals", C.c_int),
                 ("num_blocks", C.c_int), ("max_steps", C.c_int), ("max_steps_factor", C.c_int),
                 ("task_mode", C.c_int), ("color", C.c_int), ("context", C.c_int), ("seed", C.c_uint32),
-                ("visible_radius", C.c_int), ("n_tasks", C.c_int), ("tasks", C.c_int * 8)]
+                ("visible_radius", C.c_int), ("n_tasks", C.c_int), ("tasks", C.c_int * 8),
+                ("curriculum", C.c_double), ("start_level", C.c_int)]
 
 
 class Entity(C.Structure):
@@ -140,6 +141,9 @@ def lib():
     sig("orc_xw_get_pose", None, vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
     sig("orc_xw_agent_yaw", C.c_double, vp)
     sig("orc_xw_sentence_names", None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
+    sig("orc_xw_curriculum_state", None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
+    sig("orc_xw_curriculum_configure", C.c_int, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
+    sig("orc_xw_record_result", None, vp, C.c_int, C.c_int)
     sig("orc_xw_direction_target", None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
     sig("orc_xw_num_actions", C.c_int, vp)
     sig("orc_xw_stage_poses", None, vp, C.POINTER(C.c_double), C.c_int)
@@ -413,6 +417,21 @@ class XWorld:
 
     def num_actions(self):
         return self.L.orc_xw_num_actions(self.h)
+
+    def curriculum_state(self):
+        """(level, check counter) -- XWorldEnv.current_level, curriculum_check_counter"""
+        a, b = C.c_int(), C.c_int()
+        self.L.orc_xw_curriculum_state(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def curriculum_configure(self):
+        """the level logic of XWorldNav._configure alone: (level, dim, num_goals, num_blocks)"""
+        d, g, b = C.c_int(), C.c_int(), C.c_int()
+        lv = self.L.orc_xw_curriculum_configure(self.h, C.byref(d), C.byref(g), C.byref(b))
+        return lv, d.value, g.value, b.value
+
+    def record_result(self, kind, result):
+        self.L.orc_xw_record_result(self.h, TASK_ID.get(kind, kind), int(result))
 
     def sentence_names(self):
         a, b = C.c_int(), C.c_int()

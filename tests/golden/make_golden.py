@@ -638,6 +638,110 @@ def gen_sentences(n_per_task, seed0):
     return out
 
 
+# ------------------------------------------------------------ curriculum ----
+def gen_curriculum(pal, n_episodes, seed0, threshold):
+    """FLAGS_curriculum != 0 (XWorldNav.py:36-53, xworld_env.py:103-110, xworld3d_task.py:129-146): ONE XWorldNav env and
+    one object per task class live through `n_episodes` resets, as inside a reference process.  A scripted agent (walk
+    to the cell above a target goal and bump into it, or wander) makes the success rate swing; per episode: the level,
+    dims and entity counts the reset chose, and every result the busy task recorded, next to the event of that step."""
+    import importlib
+    from collections import deque
+    names = ["XWorld3DNavTarget", "XWorld3DNavTargetBetween", "XWorld3DNavTargetAvoid"]   # the ones this script can solve
+    FLAGS["curriculum"] = threshold
+    try:
+        env = XWorldNav(ITEM_PATH)
+        tasks, episodes = {}, []
+        rnd = random.Random(777)
+        for k in range(n_episodes):
+            random.seed(seed0 + k)
+            env.reset()
+            env.env_changed()
+            rec = {"level": int(env.dump_curriculum_progress()), "dim": int(env.get_dims()[0]),
+                   "num_goals": len(env.get_goals()), "num_blocks": len(env.get_blocks()),
+                   "counter": int(env.curriculum_check_counter), "records": [], "events": []}
+            episodes.append(rec)
+            name = names[rnd.randrange(len(names))]
+            rec["task"] = name
+            mod = importlib.import_module(name)
+            if name not in tasks:
+                tasks[name] = getattr(mod, name)(env)
+            task = tasks[name]
+            task.reset()
+            h = Harness(env)
+            fake = DecisionRandom(seed0 * 11 + k)
+            real = mod.random
+            mod.random = fake
+            try:
+                h.env.update_entities_from_cpp([dict(e) for e in h.ents])
+                h.env.update_agent_sentence_from_cpp("")
+                h.env.update_agent_action_success_from_cpp(False)
+                h.env.update_game_event_from_cpp("")
+                try:
+                    ret = task.idle()
+                except AssertionError:                       # "map too crowded?": no task this episode
+                    continue
+            finally:
+                mod.random = real
+            task.get_event()
+            if env.env_changed():
+                h.ents = [dict(e) for e in env.cpp_get_entities()]
+                for e in h.ents:
+                    e["loc"] = tuple(int(v) for v in e["loc"])
+                h.agent = [e for e in h.ents if e["type"] == "agent"][0]
+            # where the scripted agent wants to stand, and the move that ends the task from there
+            if name == "XWorld3DNavTargetBetween":
+                l1, l2 = task.target
+                want, last = [(int((l1[0] + l2[0]) // 2) + env.offset_w, int((l1[1] + l2[1]) // 2) + env.offset_h)], None
+            elif name == "XWorld3DNavTargetDirection":
+                referent, direction = task.target
+                agent = [e for e in env.get_entities() if e.type == "agent"][0]
+                fn = getattr(task, "_XWorld3DNavTargetDirection__compute_triple_direction")
+                want = [(int(g.loc[0]) + env.offset_w, int(g.loc[1]) + env.offset_h - 1) for g in env.get_goals()
+                        if task._get_distance(g.loc, referent.loc) < 1.0 + 1e-3 and fn(g, referent, agent.loc, agent.yaw) == direction]
+                last = 1
+            else:
+                want, last = [(int(t.loc[0]) + env.offset_w, int(t.loc[1]) + env.offset_h - 1) for t in task.target], 1
+            skilled = rnd.random() < (0.05 if 20 <= k < 200 else 0.97)
+            stage = "navigation_reward"
+            total = task.num_successes + task.num_failures
+            for t in range(h.H * h.W * 10 + 5):
+                a = rnd.randrange(4)
+                if skilled:
+                    start = (h.agent["loc"][0], h.agent["loc"][1])
+                    prev, todo = {start: None}, deque([start])
+                    while todo:                                  # BFS over empty cells
+                        c = todo.popleft()
+                        for act, (dx, dy) in enumerate([(0, -1), (0, 1), (-1, 0), (1, 0)]):
+                            n = (c[0] + dx, c[1] + dy)
+                            if n in prev or not (0 <= n[0] < h.W and 0 <= n[1] < h.H) or h.cell(n[0], n[1]):
+                                continue
+                            prev[n] = (c, act)
+                            todo.append(n)
+                    goal = [w for w in want if w in prev]
+                    if goal:
+                        c = goal[0]
+                        if c == start:
+                            a = last if last is not None else a
+                        else:
+                            while prev[c][0] != start:
+                                c = prev[c][0]
+                            a = prev[c][1]
+                h.act(a)
+                stage, reward, event = h.py_stage(task, stage)
+                now = task.num_successes + task.num_failures
+                if now != total or event:
+                    rec["events"].append([event, int(task.success_seq[-1]) if now != total else -1])
+                if now != total:
+                    assert now == total + 1
+                    rec["records"].append(int(task.success_seq[-1]))
+                    total = now
+                if stage == "terminal":
+                    break
+        return {"threshold": threshold, "tasks": names, "episodes": episodes}
+    finally:
+        FLAGS["curriculum"] = 0.0
+
+
 def main():
     nav_pal = O.Palette(O.NAV_SUBTREES)
     walls_pal = O.Palette(O.WALLS_SUBTREES)
@@ -653,6 +757,7 @@ def main():
         "tasks_ego.json": lambda: gen_tasks(nav_pal, 16, 15000, 900, ego=3),
         "sentences.json": lambda: gen_sentences(60, 31000),
         "tasks2d.json": lambda: gen_tasks2d({"nav": nav_pal, "walls": walls_pal}, 6, 12000, 70),
+        "curriculum.json": lambda: gen_curriculum(nav_pal, 920, 41000, 0.33),
     }
     only = sys.argv[1:]                      # optional: the fixtures to (re)generate
     out = {name: make() for name, make in makers.items() if not only or name in only}
