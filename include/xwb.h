@@ -114,6 +114,12 @@ typedef struct xwb_config {
     const int32_t *icon_name;    /* host, n_icons, index into the sorted names of that type */
     const int32_t *icon_colored; /* host, n_icons or NULL: properties.txt colour != "na" (xworld_env.py:201-205);
                                   * only XWB_TASK2D_COLOR reads it */
+    double   curriculum;         /* FLAGS_curriculum (py_simulator.cpp:127): != 0 -> every XWorldNav env grows through the six
+                                  * levels of XWorldNav.py:27-55 (dims 3..8, goals 2/2/2/4/4/4, blocks 0/3/6/9/12/16) as its own
+                                  * success rate passes the value -- checked every 100th reset over the last 200 results of
+                                  * each task class (xworld_env.py:103-110, xworld3d_task.py:129-146); dim / num_goals /
+                                  * num_blocks are then ignored and max_dim must be 8.  XWorldWalls never reads it. */
+    int32_t  start_level;        /* XWorldNav(item_path, start_level): the level a --curriculum_stamp file holds (xworld.cpp:93-100) */
 } xwb_config;
 
 typedef struct xwb_sim xwb_sim;
@@ -211,6 +217,8 @@ typedef struct xwb_env_state {
     int32_t  xw_target;          /* TARGET: goal name id; BETWEEN and the 2-D-native tasks: cell y * max_dim + x;
                                   * DIRECTION: referent cell | direction word << 8 (1 front 2 behind 3 left 4 right); else -1 */
     int32_t  xw_agent_dir;       /* egocentric heading: 0 right, 1 down, 2 left, 3 up; 1 under full observation */
+    int32_t  xw_level;           /* curriculum: XWorldEnv.current_level (0 when FLAGS_curriculum == 0) */
+    int32_t  xw_check_counter;   /* curriculum: XWorldEnv.curriculum_check_counter */
     uint32_t xw_sentence_names;  /* goal-name ids the idle stage binds into the teacher's sentence: a | b << 16 (0xffff none):
                                   * TARGET G = the picked goal; NEAR G = g1; BETWEEN G1, G2; DIRECTION, AVOID G = the referent */
 } xwb_env_state;

@@ -920,6 +920,9 @@ uint64_t orc_xw_rollout(int n_envs, const orc_xw_cfg *cfg, int n_icons, const or
     uint8_t *obs = (uint8_t *)malloc(sz ? sz : 1);
     for (int e = 0; e < n_envs; ++e) {
         uint32_t episode = 0;
+        /* one object stands in for every env in turn: each env has a curriculum history of its own */
+        w->cur_level = w->cfg.start_level; w->cur_counter = 0;
+        memset(w->use_len, 0, sizeof w->use_len); memset(w->use_sum, 0, sizeof w->use_sum); memset(w->use_head, 0, sizeof w->use_head);
         orc_xw_reset_game(w, env_gid0 + (uint32_t)e, episode);
         for (int t = 0; t < steps; ++t) {
             if (orc_xw_game_over(w) != ORC_ALIVE) {

@@ -93,10 +93,10 @@ class BatchedSimulator:
                 cfg.tasks[i] = int(t)
             self.tasks = list(tasks)
             cfg.visible_radius = int(opts.get("visible_radius", 0))         # py_simulator.cpp:133
-            if float(opts.get("curriculum", 0)) != 0:
-                # XWorldNav.py:27-55: the map grows with the agent's success rate; here `dim`, `num_goals`, `num_blocks`
-                # select a level for the whole batch (level k of XWorldNav = dim 3 + k, goals 2/2/2/4/4/4, blocks 0/3/6/9/12/16)
-                raise RuntimeError("curriculum != 0 (success-driven level changes) is not built; pick a level with dim / num_goals / num_blocks")
+            # py_simulator.cpp:127: FLAGS_curriculum.  XWorldNav.py:27-55: != 0 -> every env walks through the six levels
+            # (dims 3..8) as its success rate passes the value; XWorldWalls never reads the flag
+            cfg.curriculum = float(opts.get("curriculum", 0.0))
+            cfg.start_level = int(opts.get("start_level", 0))
             self.palette = assets.Palette(mc["subtrees"], opts.get("assets_dir", assets.ASSETS))
             cfg.n_icons = len(self.palette)
             cfg.icons64 = self.palette.icons64.ctypes.data

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
             int stage = task_stage(ts);
             int tsteps = p.task_steps[e];
             int event = EV_NONE;
+            int record = -1;                                // curriculum: the result this step adds to the task's window
             double rew = 0.0;
             if (p.group2d) {
                 // rule D14b (games/xworld/tasks/xworld_task.py:184-223): the group draws a task whenever its busy
@@ -123,9 +124,11 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
                     tsteps += 1;
                     if (p.task_mode == 1 && tsteps >= D * D / 2) {           // one_channel: h*w / 2 (max dims)
                         tsteps = 0;
-                        stage = STAGE_IDLE;                 // _record_failure, "S -> timeup"
+                        record = 0;                         // _record_failure
+                        stage = STAGE_IDLE;                 // "S -> timeup"
                     } else if (ay * D + ax == target) {     // agent.loc == self.target
                         tsteps = 0;
+                        record = 1;                         // _record_success
                         event = EV_CORRECT; rew += 1.0;
                         stage = STAGE_IDLE;
                     }
@@ -134,8 +137,10 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
             } else if (stage == STAGE_NAV) {
                 rew = -0.01;                                // time_penalty
                 tsteps += 1;
-                if (tsteps >= p.dim * p.dim * p.max_steps_factor) {
+                const int dim = p.curriculum != 0 ? 3 + p.cur_level[e] : p.dim;       // env.get_dims()
+                if (tsteps >= dim * dim * p.max_steps_factor) {
                     event = EV_TIMEUP;
+                    record = 0;
                     stage = STAGE_TERMINAL;
                 } else if (hit != 0 && ddx == vx && ddy == vy && p.icon_type[(hit & CELL_ICON_MASK) - 1] == 0) {
                     // _reach_object: id in collisions and |theta| < pi/4, i.e. the goal was bumped into along the
@@ -153,13 +158,16 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
                     }
                     if (good) { event = EV_CORRECT; rew += 1.0; }
                     else { event = EV_WRONG; rew += -1.0; }
+                    record = good ? 1 : 0;                  // _successful_goal / _failed_goal
                     stage = STAGE_TERMINAL;
                 } else if (kind == TASK_BETWEEN && ay * D + ax == target) {
                     // XWorld3DNavTargetBetween.navigation_reward: dist(agent, middle) < threshold / 2
                     event = EV_CORRECT; rew += 1.0;
+                    record = 1;
                     stage = STAGE_TERMINAL;
                 }
             }
+            if (record >= 0 && p.curriculum != 0) usage_push(p.cur_usage + ((size_t)e * 9 + kind) * XW_USAGE_BYTES, record);
             float r = 0.0f;                                 // SimulatorInterface::take_actions
             r += 0.0f;                                      // XWorldSimulator::take_action returns 0
             r = (float)((double)r + rew);                   // r += teacher_->give_reward() (double)

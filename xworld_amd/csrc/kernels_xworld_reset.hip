@@ -213,7 +213,15 @@ __device__ __forceinline__ Mask<NW> xw_maze(Stream &s, int D, const LaneLds &L) 
 
 template <int NW, int KIND>
 __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneLds &L, int e, bool keep_done) {
-    const int MD = p.max_dim, D = p.dim, off = (MD - D) / 2;
+    int level_dim = p.dim, level_goals = p.num_goals, level_blocks = p.num_blocks;
+    if (KIND == 0 && p.curriculum != 0) {
+        // XWorldNav._configure: level -> dims, goals, blocks (XWorldNav.py:27-34)
+        const int level = curriculum_configure(p, e);
+        level_dim = 3 + level;
+        level_goals = level < 3 ? 2 : 4;
+        level_blocks = level == 5 ? 16 : 3 * level;
+    }
+    const int MD = p.max_dim, D = level_dim, off = (MD - D) / 2;
     const uint32_t ep = p.episode[e] + 1;
     p.episode[e] = ep;
     Stream s;
@@ -237,7 +245,7 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
     auto put_code = [&](int c, uint16_t code) { g[(c / D + off) * MD + (c % D + off)] = code; };
     auto put = [&](int c, int icon) { put_code(c, (uint16_t)(icon + 1)); };
 
-    const int ng = p.num_goals;
+    const int ng = level_goals;
     Mask<NW> avail, occupied;
     occupied.clear();
     int na, agent_cell, agent_icon;
@@ -311,7 +319,7 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
                 for (int k = 0; k < 6; ++k) gw[k] = M[k];
             }
         }
-        for (int i = 0; i < p.num_blocks; ++i) {
+        for (int i = 0; i < level_blocks; ++i) {
             const int c = L.blk[L.at(--nb)];                   // blocks.pop()
             const int nm = (int)s.below((uint32_t)p.n_names[1]);
             const int v = (int)s.below((uint32_t)T.nv(1, nm));
@@ -333,7 +341,7 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
         // ---- XWorldWalls: one full brick row, a partial brick column, then agent, goals, blocks ----
         avail = valid;
         int nb = 0;
-        int n_blocks = p.num_blocks;
+        int n_blocks = level_blocks;
         const int row = (int)s.below((uint32_t)D);
         const int first = n_blocks < D ? n_blocks : D;
         for (int i = 0; i < first; ++i) L.blk[L.at(nb++)] = (uint8_t)(row * D + i);
@@ -682,7 +690,8 @@ __global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int 
     L.blk = L.gcell + XW_MAX_GOALS * 64;                               // D*D x 64 B
     // name -> icon-variant tables staged in LDS once per wavefront: every lookup afterwards is an LDS read
     // instead of a dependent chain of global loads queued behind render_all's write stream
-    int16_t *t_first = reinterpret_cast<int16_t *>(L.blk + p.dim * p.dim * 64);
+    const int lds_dim = p.curriculum != 0 ? p.max_dim : p.dim;          // a curriculum env may be at any level
+    int16_t *t_first = reinterpret_cast<int16_t *>(L.blk + lds_dim * lds_dim * 64);
     int16_t *t_var = t_first + ((p.name_first_len + 1) & ~1);
     for (int k = threadIdx.x; k < p.name_first_len; k += 64) t_first[k] = p.name_first[k];
     for (int k = threadIdx.x; k < p.name_variants_len; k += 64) t_var[k] = p.name_variants[k];
@@ -706,7 +715,8 @@ static void launch_reset_nw(const XwParams &p, int mode, dim3 grid, size_t lds, 
 
 hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s) {
     dim3 grid((p.n + 63) / 64);
-    const int cells = p.dim * p.dim;
+    const int lds_dim = p.curriculum != 0 ? p.max_dim : p.dim;
+    const int cells = lds_dim * lds_dim;
     const size_t lds = 64 * 64 * 4 + 3 * XW_MAX_GOALS * 64 * 2 + XW_MAX_GOALS * 64 + (size_t)cells * 64 +
                        2 * (size_t)(p.name_first_len + 2 + p.name_variants_len);
     if (lds > 65536) return hipErrorInvalidValue;

@@ -58,6 +58,49 @@ __device__ __forceinline__ int done_code(const XwParams &p, int num_steps, int e
 }
 
 
+// ---- curriculum (FLAGS_curriculum != 0) ----
+// XWorld(3D)Task.__record_result (xworld3d_task.py:129-133, xworld_task.py:87-91): success_seq.append(res), the oldest of
+// more than performance_window_size = 200 dropped.  One window: len, sum, head, pad, 200 bits.
+__device__ inline void usage_push(uint8_t *u, int res) {
+    int len = u[0], sum = u[1], head = u[2];
+    uint8_t *bits = u + 4;
+    auto get = [&](int i) { return (bits[i >> 3] >> (i & 7)) & 1; };
+    auto put = [&](int i, int v) { bits[i >> 3] = (uint8_t)((bits[i >> 3] & ~(1 << (i & 7))) | (v << (i & 7))); };
+    if (len < 200) {
+        put((head + len) % 200, res);
+        len++; sum += res;
+    } else {
+        sum += res - get(head);
+        put(head, res);
+        head = (head + 1) % 200;
+    }
+    u[0] = (uint8_t)len; u[1] = (uint8_t)sum; u[2] = (uint8_t)head;
+}
+
+// XWorldNav._configure with curriculum != 0 (XWorldNav.py:27-55) + XWorldEnv.get_current_usage (xworld_env.py:103-110):
+// every 100th reset that finds a task with results compares the worst task's success rate over its window with the
+// flag and moves to the next of the six levels.  Returns the level of the episode that is being set up.
+__device__ inline int curriculum_configure(const XwParams &p, int e) {
+    int counter = p.cur_counter[e] + 1;
+    const uint8_t *u = p.cur_usage + (size_t)e * 9 * XW_USAGE_BYTES;
+    double usage = 0;
+    bool any = false;
+    for (int k = 0; k < 9; ++k) any = any || u[k * XW_USAGE_BYTES] > 0;
+    if (counter >= 100 && any) {
+        usage = 2;
+        for (int k = 0; k < 9; ++k) {
+            const int len = u[k * XW_USAGE_BYTES], sum = u[k * XW_USAGE_BYTES + 1];
+            if (len > 0) { const double r = (double)sum / (double)len; if (r < usage) usage = r; }
+        }
+        counter = 0;
+    }
+    p.cur_counter[e] = counter;
+    int level = p.cur_level[e];
+    if (usage >= p.curriculum && level < 5) level++;
+    p.cur_level[e] = (uint8_t)level;
+    return level;
+}
+
 // ---- shared by the render kernels ----
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 

@@ -78,6 +78,8 @@ struct xwb_sim {
             *d_done_count = nullptr;
     uint8_t *d_fresh = nullptr, *d_icon_type = nullptr, *d_icon_colored = nullptr, *d_goal_cells = nullptr;
     uint32_t *d_cand2d = nullptr, *d_sent_names = nullptr;
+    uint8_t *d_cur_level = nullptr, *d_cur_usage = nullptr;
+    int32_t *d_cur_counter = nullptr;
     uint16_t *d_term_grid = nullptr;
     uint8_t *d_term_flag = nullptr;
     uint8_t *d_agent_dir = nullptr, *d_atlas64 = nullptr;
@@ -197,6 +199,11 @@ int xw_setup(xwb_sim *s) {
     if (c.max_dim < 1 || c.max_dim > XW_MAX_DIM || c.dim < 1 || c.dim > c.max_dim)
         return fail(XWB_ERR_ARG, "xworld: need 1 <= dim <= max_dim <= 16");
     if (c.num_goals < 1 || c.num_goals > XW_MAX_GOALS) return fail(XWB_ERR_ARG, "xworld: need 1 <= num_goals <= 16");
+    if (c.curriculum != 0 && c.map_kind == XWB_MAP_NAV) {
+        // XWorldNav.py:27-30: six levels, dims 3 .. max_h -- the class asserts n_levels == 6, i.e. its 8x8 world
+        if (c.max_dim != 8) return fail(XWB_ERR_ARG, "xworld: curriculum != 0 needs XWorldNav's 8x8 world (max_dim 8)");
+        if (c.start_level < 0 || c.start_level > 5) return fail(XWB_ERR_ARG, "xworld: start_level must be in 0..5");
+    }
     if (c.n_icons < 1 || !c.icons64 || !c.icon_type || !c.icon_name)
         return fail(XWB_ERR_ARG, "xworld: icons64 / icon_type / icon_name are required (the reference loads item_path images)");
     if (c.n_icons > 4000) return fail(XWB_ERR_ARG, "xworld: too many icons");
@@ -270,6 +277,12 @@ int xw_setup(xwb_sim *s) {
     if ((rc = dev_alloc(s, &s->d_goal_cells, (size_t)n * XW_MAX_GOALS, 0xff))) return rc;
     if ((rc = dev_alloc(s, &s->d_cand2d, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_sent_names, n, 0xff))) return rc;
+    const bool curriculum = c.curriculum != 0 && c.map_kind == XWB_MAP_NAV;       // XWorldWalls never reads the flag
+    if (curriculum) {
+        if ((rc = dev_alloc(s, &s->d_cur_level, n, c.start_level))) return rc;
+        if ((rc = dev_alloc(s, &s->d_cur_counter, n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_cur_usage, (size_t)n * 9 * XW_USAGE_BYTES))) return rc;
+    }
     if ((rc = dev_alloc(s, &s->d_term_grid, (size_t)n * cells))) return rc;
     if ((rc = dev_alloc(s, &s->d_term_flag, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_agent_dir, n, 1))) return rc;                 // heading "down": yaw 1.5707963
@@ -337,6 +350,7 @@ int xw_setup(xwb_sim *s) {
     p.obs_f32 = f32 ? 1 : 0;
     p.n_tasks = c.n_tasks;
     p.group2d = c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET;
+    p.curriculum = curriculum ? c.curriculum : 0.0; p.cur_level = s->d_cur_level; p.cur_counter = s->d_cur_counter; p.cur_usage = s->d_cur_usage;
     p.sent_names = s->d_sent_names; p.term_grid = s->d_term_grid; p.term_flag = s->d_term_flag;
     p.goal_cells = s->d_goal_cells; p.cand2d = s->d_cand2d; p.icon_colored = s->d_icon_colored;
     p.visible_radius = c.visible_radius; p.out_dim = s->out_h;
@@ -881,6 +895,13 @@ int xwb_get_env_state(xwb_sim *s, int32_t env, void *stream, xwb_env_state *o) {
         uint8_t dir = 1;
         HIP_TRY(hipMemcpy(&dir, s->d_agent_dir + env, 1, hipMemcpyDeviceToHost));
         o->xw_agent_dir = dir;
+        o->xw_level = 0; o->xw_check_counter = 0;
+        if (s->d_cur_level) {
+            uint8_t lv = 0;
+            HIP_TRY(hipMemcpy(&lv, s->d_cur_level + env, 1, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&o->xw_check_counter, s->d_cur_counter + env, 4, hipMemcpyDeviceToHost));
+            o->xw_level = lv;
+        }
         uint32_t sn = 0xffffffffu;
         HIP_TRY(hipMemcpy(&sn, s->d_sent_names + env, 4, hipMemcpyDeviceToHost));
         o->xw_sentence_names = sn;
@@ -915,7 +936,9 @@ int xwb_xw_load_map_task(xwb_sim *s, int32_t env, const uint16_t *grid_host, int
     if (task < XWB_TASK_TARGET || task > XWB_TASK2D_BETWEEN) return fail(XWB_ERR_ARG, "unknown task id");
     if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
-    if (dim != s->cfg.dim) return fail(XWB_ERR_ARG, "dim differs from the batch's dim");
+    if (s->d_cur_level) {
+        if (dim < 3 || dim > 8) return fail(XWB_ERR_ARG, "dim is not one of the curriculum's levels (3..8)");
+    } else if (dim != s->cfg.dim) return fail(XWB_ERR_ARG, "dim differs from the batch's dim");
     const int D = s->cfg.max_dim;
     if (agent_x < 0 || agent_y < 0 || agent_x >= D || agent_y >= D) return fail(XWB_ERR_ARG, "agent outside the map");
     HIP_TRY(hipDeviceSynchronize());
@@ -923,6 +946,10 @@ int xwb_xw_load_map_task(xwb_sim *s, int32_t env, const uint16_t *grid_host, int
     int32_t axy = agent_x | (agent_y << 16);
     const bool is2d = task >= XWB_TASK2D_TARGET;
     if (is2d != (s->xw.group2d != 0)) return fail(XWB_ERR_ARG, "task is not of this batch's task family");
+    if (s->d_cur_level) {                                                // the level whose dims the map has
+        const uint8_t lv = (uint8_t)(dim - 3);
+        HIP_TRY(hipMemcpy(s->d_cur_level + env, &lv, 1, hipMemcpyHostToDevice));
+    }
     // stage NAV, no event (xw_device.h); a 2-D-native task without a target stays in its idle stage
     const int stage = is2d && target < 0 ? 0 : 1;
     int32_t ts = (target & 0xffff) | (stage << 16) | (task << 24);
@@ -1112,6 +1139,7 @@ std::vector<StateArray> state_arrays(xwb_sim *s, bool include_obs) {
         add(s->d_done_list, n * 4); add(s->d_done_count, 8); add(s->d_fresh, n);
         add(s->d_goal_cells, n * XW_MAX_GOALS); add(s->d_cand2d, n * 4); add(s->d_agent_dir, n); add(s->d_sent_names, n * 4);
         add(s->d_goal_warp, n * XW_MAX_GOALS * 6 * sizeof(double));     // goal images are re-warped from these on load
+        add(s->d_cur_level, n); add(s->d_cur_counter, n * 4); add(s->d_cur_usage, n * 9 * XW_USAGE_BYTES);
     }
     if (include_obs) add(s->d_obs, n * s->obs_bytes_per_env);
     return a;
@@ -1131,6 +1159,7 @@ uint64_t config_hash(const xwb_config &c) {            // everything that shapes
                          c.n_tasks, c.color, c.visible_radius, c.obs_format, c.n_icons};
     mix(v, sizeof v); mix(c.tasks, sizeof c.tasks);
     mix(&c.seed, 4); mix(&c.policy_seed, 4); mix(&c.env_gid0, 4);
+    mix(&c.curriculum, 8); mix(&c.start_level, 4);
     return h;
 }
 }  // namespace

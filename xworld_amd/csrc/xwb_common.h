@@ -124,6 +124,7 @@ hipError_t launch_simple_race(const RaceParams &p, hipStream_t s);
 // -------------------------------------------------------------- XWorld2D ---
 constexpr int XW_MAX_DIM = 16;
 constexpr int XW_MAX_GOALS = 16;
+constexpr int XW_USAGE_BYTES = 32;  // one task class's success window
 constexpr int XW_TILE = 12;           // block_size, xworld_simulator.cpp:57
 constexpr int XW_TILE_DW = 3;         // dwords per tile row (12 bytes)
 
@@ -160,6 +161,11 @@ struct XwParams {
     uint16_t *term_grid;         // [n][max_dim*max_dim] the grid of an env at the step that finished it (see term_flag)
     uint8_t *term_flag;          // [n] 1: this step finished the env; its terminal frame is rendered from term_grid, so a
                                  //     reset_done running beside the render may already regenerate the live grid
+    double curriculum;           // FLAGS_curriculum (0 = off; XWorldNav only)
+    uint8_t *cur_level;          // [n] curriculum: XWorldEnv.current_level
+    int32_t *cur_counter;        // [n] curriculum: XWorldEnv.curriculum_check_counter
+    uint8_t *cur_usage;          // [n][9][XW_USAGE_BYTES] curriculum: per task class the window of its last 200 results
+                                 //     (len, sum, head, -, 25 bytes of bits; xw_device.h usage_push)
     uint32_t *sent_names;        // [n] goal-name ids the idle stage binds into the teacher's sentence: a | b << 16 (0xffff none)
     uint8_t *agent_dir;          // [n] egocentric heading: 0 right, 1 down, 2 left, 3 up (XItem::get_item_facing_dir)
     double *goal_warp;           // [n][XW_MAX_GOALS][6] egocentric: inverse affine map of the goal's icon warp

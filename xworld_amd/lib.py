@@ -32,6 +32,7 @@ class XwbConfig(C.Structure):
         ("n_tasks", C.c_int32), ("tasks", C.c_int32 * 8),
         ("color", C.c_int32), ("visible_radius", C.c_int32), ("obs_format", C.c_int32), ("n_icons", C.c_int32),
         ("icons64", C.c_void_p), ("icon_type", C.c_void_p), ("icon_name", C.c_void_p), ("icon_colored", C.c_void_p),
+        ("curriculum", C.c_double), ("start_level", C.c_int32),
     ]
 
 
@@ -43,7 +44,7 @@ class XwbEnvState(C.Structure):
         ("race_x", C.c_float), ("race_y", C.c_float), ("race_angle", C.c_float),
         ("xw_agent_x", C.c_int32), ("xw_agent_y", C.c_int32), ("xw_event", C.c_int32), ("xw_stage", C.c_int32),
         ("xw_target_name", C.c_int32), ("xw_steps_in_task", C.c_int32),
-        ("episode", C.c_uint32), ("xw_task", C.c_int32), ("xw_target", C.c_int32), ("xw_agent_dir", C.c_int32), ("xw_sentence_names", C.c_uint32),
+        ("episode", C.c_uint32), ("xw_task", C.c_int32), ("xw_target", C.c_int32), ("xw_agent_dir", C.c_int32), ("xw_level", C.c_int32), ("xw_check_counter", C.c_int32), ("xw_sentence_names", C.c_uint32),
     ]
 
 
