@@ -63,6 +63,7 @@ enum { XWB_TASK_TARGET = 0, XWB_TASK_NEAR = 1, XWB_TASK_BETWEEN = 2, XWB_TASK_DI
 enum { XWB_TASKMODE_LANG_ACQ = 0, XWB_TASKMODE_ONE_CHANNEL = 1 };   /* FLAGS_task_mode, xworld_simulator.cpp:33-37 */
 enum { XWB_EV_NONE = 0, XWB_EV_CORRECT_GOAL = 1, XWB_EV_WRONG_GOAL = 2, XWB_EV_TIME_UP = 3 };
 enum { XWB_OBS_U8 = 0, XWB_OBS_F32 = 1 };
+enum { XWB_SCHEDULE_RANDOM = 0, XWB_SCHEDULE_WEIGHTED = 1 };
 enum { XWB_ICON_GOAL = 0, XWB_ICON_BLOCK = 1, XWB_ICON_AGENT = 2 };  /* xworld_env.py:66 grid_types */
 
 /*
@@ -120,6 +121,9 @@ typedef struct xwb_config {
                                   * each task class (xworld_env.py:103-110, xworld3d_task.py:129-146); dim / num_goals /
                                   * num_blocks are then ignored and max_dim must be 8.  XWorldWalls never reads it. */
     int32_t  start_level;        /* XWorldNav(item_path, start_level): the level a --curriculum_stamp file holds (xworld.cpp:93-100) */
+    int32_t  task_schedule;      /* the group's "schedule" (teaching_task.cpp:204-213): XWB_SCHEDULE_RANDOM = uniform over its
+                                  * tasks, XWB_SCHEDULE_WEIGHTED = util::simple_importance_sampling over task_weights */
+    double   task_weights[8];    /* the per-task numbers of the conf JSON (TaskGroup::add_task: > 0); read when weighted */
 } xwb_config;
 
 typedef struct xwb_sim xwb_sim;

@@ -141,6 +141,8 @@ typedef struct {
     int tasks[8];            /* ORC_TASK_* in conf order */
     double curriculum;       /* FLAGS_curriculum: != 0 -> XWorldNav grows with the agent's success rate (XWorldNav.py:36-53) */
     int start_level;         /* XWorldNav(item_path, start_level): the level a --curriculum_stamp file holds (xworld.cpp:93-100) */
+    int task_schedule;       /* 0 "random": util::get_rand_ind; 1 "weighted": util::simple_importance_sampling (teaching_task.cpp:204-213) */
+    double task_weights[8];  /* TaskGroup::add_task weights, conf order */
 } orc_xw_cfg;
 
 typedef struct {

@@ -377,7 +377,18 @@ void orc_task_idle(orc_xworld *w) {
     w->sent_a = w->sent_b = -1;
     /* TaskGroup::run_stage: idx = get_rand_ind(task_list_.size()) */
     int n_tasks = w->cfg.n_tasks > 0 ? w->cfg.n_tasks : 1;
-    int t = orc_xw_draw_below(w, n_tasks);
+    int t;
+    if (w->cfg.task_schedule == 1 && w->cfg.n_tasks > 0) {
+        /* util::simple_importance_sampling (simulator_util.cpp:57-86): float uniform in [0, float(acc.back())), the first
+         * task whose accumulated weight is >= it; the draw is the 24-bit integer behind orc_stream_unit */
+        double acc[8], total = 0;
+        for (int i = 0; i < n_tasks; ++i) { total += w->cfg.task_weights[i]; acc[i] = total; }
+        float val = ((float)orc_xw_draw_below(w, 1 << 24) * (1.0f / 16777216.0f)) * (float)total;
+        t = n_tasks - 1;
+        for (int i = 0; i < n_tasks; ++i) if ((double)val <= acc[i]) { t = i; break; }
+    } else {
+        t = orc_xw_draw_below(w, n_tasks);
+    }
     w->task_kind = w->cfg.n_tasks > 0 ? w->cfg.tasks[t] : ORC_TASK_TARGET;
     if (w->task_kind >= ORC_TASK2D_TARGET) { idle_2d(w, &p); return; }
     if (w->task_kind == ORC_TASK_TARGET || w->task_kind == ORC_TASK_AVOID) {

@@ -43,7 +43,8 @@ class XwCfg(C.Structure):
                 ("num_blocks", C.c_int), ("max_steps", C.c_int), ("max_steps_factor", C.c_int),
                 ("task_mode", C.c_int), ("color", C.c_int), ("context", C.c_int), ("seed", C.c_uint32),
                 ("visible_radius", C.c_int), ("n_tasks", C.c_int), ("tasks", C.c_int * 8),
-                ("curriculum", C.c_double), ("start_level", C.c_int)]
+                ("curriculum", C.c_double), ("start_level", C.c_int),
+                ("task_schedule", C.c_int), ("task_weights", C.c_double * 8)]
 
 
 class Entity(C.Structure):
@@ -343,6 +344,11 @@ def xw_cfg(**kw):
     c = XwCfg(map_kind=0, max_dim=8, dim=8, num_goals=4, num_blocks=16, max_steps=0,
               max_steps_factor=10, task_mode=0, color=0, context=1, seed=0xC0FFEE, visible_radius=0)
     tasks = kw.pop("tasks", None)
+    weights = kw.pop("task_weights", None)
+    if weights is not None:
+        c.task_schedule = 1
+        for i, x in enumerate(weights):
+            c.task_weights[i] = float(x)
     for k, v in kw.items():
         setattr(c, k, v)
     if tasks is not None:

@@ -349,3 +349,41 @@ def test_sentences_of_the_2d_native_group(oracle):
     sim.step()
     assert all(sim.sentence(e) == "" for e in range(0, n, 5))      # the navigation stage says nothing
     sim.close()
+
+
+def test_weighted_schedule(oracle):
+    """Schedule "weighted" (teaching_task.cpp:204-213, util::simple_importance_sampling): tasks are drawn by the conf's
+    per-task weights -- same draws as the oracle, frequencies as the weights say, rollout parity through resets."""
+    _torch()
+    n = 4096
+    weights = [4.0, 1.0, 0.5, 0.5, 2.0]
+    sim, pal, cfg = _make(oracle, "nav8", n, KINDS, seed=77, policy_seed=3, gid0=5, task_weights=weights)
+    cfg["task_weights"] = weights
+    ow = oracle.XWorld(pal, render=False, **cfg)
+    counts = np.zeros(5)
+    for e in range(n):
+        ow.reset_game(5 + e, 0)
+        st = sim.env_state(e)
+        assert st.xw_task == ow.task_kind(), e
+        counts[st.xw_task] += 1
+    assert np.abs(counts / n - np.array(weights) / sum(weights)).max() < 0.03, counts
+    steps = 200
+    ref = oracle.xw_rollout(n, oracle.xw_cfg(**cfg), pal, steps, policy_seed=3, env_gid0=5)
+    for t in range(steps):
+        sim.reset_done()
+        sim.step()
+        assert np.array_equal(sim.reward.cpu().numpy().view(np.uint32), ref.rewards[t].view(np.uint32)), t
+        assert np.array_equal(sim.game_over_codes.cpu().numpy(), ref.codes[t]), t
+    sim.close()
+    # the 2-D-native group draws a task at step time too
+    w2 = [1.0, 3.0, 1.0, 2.0]
+    kinds2 = ["XWorldNavTarget", "XWorldNavNear", "XWorldNavColorTarget", "XWorldNavBetween"]
+    sim, pal, cfg = _make(oracle, "walls7", 2048, kinds2, seed=8, policy_seed=1, task_weights=w2, task_mode="one_channel", max_steps=60)
+    cfg.update(task_weights=w2, task_mode=1, max_steps=60)
+    ref = oracle.xw_rollout(2048, oracle.xw_cfg(**cfg), pal, 150, policy_seed=1)
+    for t in range(150):
+        sim.reset_done()
+        sim.step()
+        assert np.array_equal(sim.reward.cpu().numpy().view(np.uint32), ref.rewards[t].view(np.uint32)), t
+        assert np.array_equal(sim.game_over_codes.cpu().numpy(), ref.codes[t]), t
+    sim.close()

@@ -81,8 +81,8 @@ def conf_tasks(conf, group=None):
     if len(groups) != 1:
         raise RuntimeError("one task group runs per batch; pick one with the 'task_group' option: " + ", ".join(groups))
     (gname, g), = groups.items()
-    if g.get("schedule", "random") != "random":
-        raise RuntimeError("task group schedule '%s' is not built (only 'random')" % g.get("schedule"))
+    if g.get("schedule", "random") not in ("random", "weighted"):
+        raise RuntimeError("unknown task group schedule '%s'" % g.get("schedule"))
     out = []
     for t in g.get("tasks", {}):
         if t not in TASK_IDS:
@@ -91,3 +91,16 @@ def conf_tasks(conf, group=None):
     if not 1 <= len(out) <= 8:
         raise RuntimeError("a task group needs 1..8 tasks")
     return out
+
+
+def conf_task_weights(conf, group=None):
+    """(weights in task order, or None for the "random" schedule) of the group conf_tasks picks."""
+    groups = conf.get("task_groups") or {}
+    if group is not None:
+        groups = {group: groups[group]} if group in groups else {}
+    if len(groups) != 1:
+        return None
+    (_, g), = groups.items()
+    if g.get("schedule", "random") != "weighted":
+        return None
+    return [float(w) for w in g.get("tasks", {}).values()]

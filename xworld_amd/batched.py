@@ -91,6 +91,14 @@ class BatchedSimulator:
             cfg.n_tasks = len(tasks)
             for i, t in enumerate(tasks):
                 cfg.tasks[i] = int(t)
+            # teaching_task.cpp:204-213: schedule "weighted" samples by the per-task numbers of the conf; "task_weights" overrides
+            weights = opts.get("task_weights", assets.conf_task_weights(conf, opts.get("task_group")) if opts.get("tasks") is None else None)
+            if weights is not None:
+                if len(weights) != len(tasks):
+                    raise RuntimeError("task_weights needs one weight per task")
+                cfg.task_schedule = 1
+                for i, x in enumerate(weights):
+                    cfg.task_weights[i] = float(x)
             self.tasks = list(tasks)
             cfg.visible_radius = int(opts.get("visible_radius", 0))         # py_simulator.cpp:133
             # py_simulator.cpp:127: FLAGS_curriculum.  XWorldNav.py:27-55: != 0 -> every env walks through the six levels

@@ -58,6 +58,18 @@ __device__ __forceinline__ int done_code(const XwParams &p, int num_steps, int e
 }
 
 
+// TaskGroup::run_stage's sample_task (teaching_task.cpp:204-213): util::get_rand_ind, or for the "weighted" schedule
+// util::simple_importance_sampling (simulator_util.cpp:57-86): a float uniform in [0, float(total)), first task whose
+// accumulated weight is >= it.  One draw either way.
+template <typename S>
+__device__ inline int sample_task(const XwParams &p, S &s) {
+    const int n = p.n_tasks > 0 ? p.n_tasks : 1;
+    if (!p.task_weighted) return (int)s.below((uint32_t)n);
+    const double w = (double)(s.unit() * (float)p.task_acc[n - 1]);
+    for (int i = 0; i < n; ++i) if (w <= p.task_acc[i]) return i;
+    return n - 1;
+}
+
 // ---- curriculum (FLAGS_curriculum != 0) ----
 // XWorld(3D)Task.__record_result (xworld3d_task.py:129-133, xworld_task.py:87-91): success_seq.append(res), the oldest of
 // more than performance_window_size = 200 dropped.  One window: len, sum, head, pad, 200 bits.

@@ -199,6 +199,12 @@ int xw_setup(xwb_sim *s) {
     if (c.max_dim < 1 || c.max_dim > XW_MAX_DIM || c.dim < 1 || c.dim > c.max_dim)
         return fail(XWB_ERR_ARG, "xworld: need 1 <= dim <= max_dim <= 16");
     if (c.num_goals < 1 || c.num_goals > XW_MAX_GOALS) return fail(XWB_ERR_ARG, "xworld: need 1 <= num_goals <= 16");
+    if (c.task_schedule != XWB_SCHEDULE_RANDOM && c.task_schedule != XWB_SCHEDULE_WEIGHTED) return fail(XWB_ERR_ARG, "xworld: unknown task_schedule");
+    if (c.task_schedule == XWB_SCHEDULE_WEIGHTED) {
+        if (c.n_tasks < 1) return fail(XWB_ERR_ARG, "xworld: the weighted schedule needs the task list");
+        for (int i = 0; i < c.n_tasks; ++i)
+            if (!(c.task_weights[i] > 0)) return fail(XWB_ERR_ARG, "A task must have a positive weight");   // teaching_task.cpp:148
+    }
     if (c.curriculum != 0 && c.map_kind == XWB_MAP_NAV) {
         // XWorldNav.py:27-30: six levels, dims 3 .. max_h -- the class asserts n_levels == 6, i.e. its 8x8 world
         if (c.max_dim != 8) return fail(XWB_ERR_ARG, "xworld: curriculum != 0 needs XWorldNav's 8x8 world (max_dim 8)");
@@ -356,6 +362,8 @@ int xw_setup(xwb_sim *s) {
     p.visible_radius = c.visible_radius; p.out_dim = s->out_h;
     p.agent_dir = s->d_agent_dir; p.goal_warp = s->d_goal_warp; p.atlas64 = s->d_atlas64; p.ego_taps = s->d_ego_taps; p.goal_img = s->d_goal_img; p.ego_agent_rot = s->d_agent_rot;
     for (int i = 0; i < 8; ++i) p.tasks[i] = i < c.n_tasks ? c.tasks[i] : 0;
+    p.task_weighted = c.task_schedule == XWB_SCHEDULE_WEIGHTED;
+    for (int i = 0; i < 8; ++i) p.task_acc[i] = (i ? p.task_acc[i - 1] : 0.0) + (i < c.n_tasks && p.task_weighted ? c.task_weights[i] : 0.0);
     p.policy_seed = c.policy_seed; p.env_gid0 = c.env_gid0; p.policy_step = 0; p.seed = c.seed;
     p.icon_type = s->d_icon_type; p.icon_name = s->d_icon_name;
     p.name_first = s->d_name_first; p.name_variants = s->d_name_variants;
@@ -1159,7 +1167,7 @@ uint64_t config_hash(const xwb_config &c) {            // everything that shapes
                          c.n_tasks, c.color, c.visible_radius, c.obs_format, c.n_icons};
     mix(v, sizeof v); mix(c.tasks, sizeof c.tasks);
     mix(&c.seed, 4); mix(&c.policy_seed, 4); mix(&c.env_gid0, 4);
-    mix(&c.curriculum, 8); mix(&c.start_level, 4);
+    mix(&c.curriculum, 8); mix(&c.start_level, 4); mix(&c.task_schedule, 4); mix(c.task_weights, sizeof c.task_weights);
     return h;
 }
 }  // namespace

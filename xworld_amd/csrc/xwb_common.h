@@ -135,7 +135,9 @@ struct XwParams {
     int out_dim;                 // egocentric frame edge: r * (84 / r)
     int obs_f32;                 // frames are float32 (pixel * 1/255), the tile table too
     int n_icons;
-    int n_tasks, tasks[8];       // tasks of the teacher's group, sampled uniformly whenever the group is idle
+    int n_tasks, tasks[8];       // tasks of the teacher's group, sampled whenever the group is idle: uniformly, or
+    int task_weighted;           // schedule "weighted": util::simple_importance_sampling over the accumulated weights
+    double task_acc[8];
     int list_flag;               // list render: 2 = first frame of a new episode (init_screen: older context frames zeroed,
                                  // fresh / done flags cleared); 1 = the terminal frame of a finished env (ring shift only)
     int group2d;                 // the group holds the 2-D-native tasks (rule D14b): idle stages also run at step time
