@@ -349,6 +349,19 @@ def test_sentences_of_the_2d_native_group(oracle):
     sim.step()
     assert all(sim.sentence(e) == "" for e in range(0, n, 5))      # the navigation stage says nothing
     sim.close()
+    # one_channel: the task runs out of time after h * w / 2 = 32 steps and says so on that step (xworld_task.py:205-211)
+    sim, pal, cfg = _make(oracle, "nav8", 64, [KINDS2D[0]], seed=5, task_mode="one_channel")
+    busy = [e for e in range(64) if sim.env_state(e).xw_stage == 1]
+    assert len(busy) > 32
+    for t in range(32):
+        assert all(sim.sentence(e) == "" for e in busy[:4]) or t == 0
+        sim.step()
+    for e in busy:
+        st = sim.env_state(e)
+        assert st.xw_stage == 0 and st.xw_steps_in_task == 0 and sim.sentence(e) == "Time up ."
+    sim.step()                                                      # the next teach() call picks a new target and speaks
+    assert all(sim.sentence(e) not in ("", "Time up .") for e in busy)
+    sim.close()
 
 
 def test_weighted_schedule(oracle):

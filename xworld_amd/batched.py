@@ -304,7 +304,10 @@ class BatchedSimulator:
         from . import language
         st = self.env_state(env, stream)
         if st.xw_task in (5, 7):
-            # 2-D-native Target / ColorTarget: they speak only on the teach() call that picked the target
+            # 2-D-native Target / ColorTarget: they speak on the teach() call that picked the target, and "Time up ." on
+            # the one_channel step that runs out of time (xworld_task.py:205-211): back to idle with the target still recorded
+            if st.xw_stage == 0 and st.xw_event == 0 and st.xw_target >= 0 and st.num_steps > 0 and self.cfg.task_mode == 1:
+                return language.sentence_2d_timeup(st.xw_task)
             if st.xw_stage != 1 or st.xw_steps_in_task != 0 or st.xw_target < 0:
                 return ""
             d = self.cfg.max_dim

@@ -9,8 +9,9 @@ names, direction word, stage, event, episode) and of the xwb-rng-v1 stream 3 ("l
 counter = (block, episode, 3, 0); one `below(n)` per expanded non-terminal, also when it is bound), so nothing has to
 be stored per env and the device never sees strings.  The 2-D-native group (rule D14b; games/xworld/tasks/XWorldNav*.py)
 speaks only on the teach() call that picks a target (its navigation stage returns ""): XWorldNavTarget /
-XWorldNavColorTarget instructions are expanded from stream 3 starting at block 4 * num_steps; its "Time up ." message of
-the one_channel mode is not built.
+XWorldNavColorTarget instructions are expanded from stream 3 starting at block 4 * num_steps; the one_channel mode's
+time-up step says "Time up ." (S -> timeup).  XWorldNavNear / XWorldNavBetween never find a target in this snapshot of
+the reference and so never speak.
 
 Pinned by tests/golden/sentences.json: the reference's CFG run on each task's own grammar, replayed decision by
 decision (tests/test_language.py).
@@ -195,6 +196,11 @@ def sentence_2d(task, goal_name, color, seed, gid, episode, num_steps):
     else:
         b["G"] = "'%s'" % goal_name
     return GRAMMARS[task].expand(st.below, b)
+
+
+def sentence_2d_timeup(task):
+    """xworld_task.py:205-211: `self._bind("S -> timeup")`, then generate() -- no free choice left."""
+    return GRAMMARS[task].expand(lambda n: 0, {"S": "timeup"})
 
 
 def sentence(task, stage, event, goal_names, name_a, name_b, direction, seed, gid, episode):
