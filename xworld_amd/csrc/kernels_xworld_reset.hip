@@ -671,13 +671,16 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
 }
 
 template <int NW, int KIND>
-__global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int keep_done, const int32_t *count_now) {
+__global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int keep_done, const int32_t *count_now, int epw) {
     extern __shared__ uint32_t lds32[];
     // a handful of latency-bound wavefronts that run beside render_all's 16 waves per CU
     __builtin_amdgcn_s_setprio(3);
-    const int i = blockIdx.x * 64 + threadIdx.x;
+    // epw envs per wavefront, on lanes 0, 64 / epw, ...: map generation is data-dependent serial code, and a wavefront
+    // runs the union of its lanes' paths -- the short done list is spread over many wavefronts instead
+    const int stride = 64 / epw;
+    const int i = blockIdx.x * epw + (int)threadIdx.x / stride;
     const int total = mode == MODE_RESET_ALL ? p.n : *count_now;
-    if (blockIdx.x * 64 >= total) return;                              // whole wavefront idle
+    if ((int)blockIdx.x * epw >= total) return;                        // whole wavefront idle
     LaneLds L;
     L.lane = threadIdx.x;
     L.stack = lds32;                                                   // 64 x 64 x 4 B
@@ -695,7 +698,7 @@ __global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int 
     for (int k = threadIdx.x; k < p.name_first_len; k += 64) t_first[k] = p.name_first[k];
     for (int k = threadIdx.x; k < p.name_variants_len; k += 64) t_var[k] = p.name_variants[k];
     __syncthreads();
-    if (i >= total) return;
+    if (i >= total || (int)threadIdx.x % stride != 0) return;
     const int e = mode == MODE_RESET_ALL ? i : p.done_list[i];
     IconTables T;
     T.first[0] = t_first + p.name_first_off[0];
@@ -706,22 +709,26 @@ __global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int 
 }
 
 template <int NW>
-static void launch_reset_nw(const XwParams &p, int mode, dim3 grid, size_t lds, hipStream_t s) {
+static void launch_reset_nw(const XwParams &p, int mode, dim3 grid, size_t lds, hipStream_t s, int epw) {
     const int32_t *cnt = p.done_count;
-    if (p.map_kind == 0) hipLaunchKernelGGL((xw_reset_kernel<NW, 0>), grid, dim3(64), lds, s, p, mode, p.auto_reset, cnt);
-    else hipLaunchKernelGGL((xw_reset_kernel<NW, 1>), grid, dim3(64), lds, s, p, mode, p.auto_reset, cnt);
+    if (p.map_kind == 0) hipLaunchKernelGGL((xw_reset_kernel<NW, 0>), grid, dim3(64), lds, s, p, mode, p.auto_reset, cnt, epw);
+    else hipLaunchKernelGGL((xw_reset_kernel<NW, 1>), grid, dim3(64), lds, s, p, mode, p.auto_reset, cnt, epw);
 }
 
 hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s) {
-    dim3 grid((p.n + 63) / 64);
+    // every env of the batch: one per lane; the done list / mask (a fraction of a percent of the batch per step): one env
+    // per wavefront -- no divergence between envs: 64 -> 16 -> 4 -> 1 envs per wavefront = 0.1346, 0.1296, 0.1264, 0.1243 ms
+    // per step of the C4 loop (8x8 and 11x11: no difference); idle wavefronts leave at once
+    const int epw = mode == MODE_RESET_ALL ? 64 : 1;
+    dim3 grid((p.n + epw - 1) / epw);
     const int lds_dim = p.curriculum != 0 ? p.max_dim : p.dim;
     const int cells = lds_dim * lds_dim;
     const size_t lds = 64 * 64 * 4 + 3 * XW_MAX_GOALS * 64 * 2 + XW_MAX_GOALS * 64 + (size_t)cells * 64 +
                        2 * (size_t)(p.name_first_len + 2 + p.name_variants_len);
     if (lds > 65536) return hipErrorInvalidValue;
-    if (cells <= 64) launch_reset_nw<1>(p, mode, grid, lds, s);
-    else if (cells <= 128) launch_reset_nw<2>(p, mode, grid, lds, s);
-    else launch_reset_nw<4>(p, mode, grid, lds, s);
+    if (cells <= 64) launch_reset_nw<1>(p, mode, grid, lds, s, epw);
+    else if (cells <= 128) launch_reset_nw<2>(p, mode, grid, lds, s, epw);
+    else launch_reset_nw<4>(p, mode, grid, lds, s, epw);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
     // egocentric: the goals of the reset envs got new poses; render their warped images once
