@@ -678,7 +678,6 @@ __global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int 
     // epw envs per wavefront, on lanes 0, 64 / epw, ...: map generation is data-dependent serial code, and a wavefront
     // runs the union of its lanes' paths -- the short done list is spread over many wavefronts instead
     const int stride = 64 / epw;
-    const int i = blockIdx.x * epw + (int)threadIdx.x / stride;
     const int total = mode == MODE_RESET_ALL ? p.n : *count_now;
     if ((int)blockIdx.x * epw >= total) return;                        // whole wavefront idle
     LaneLds L;
@@ -698,14 +697,17 @@ __global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int 
     for (int k = threadIdx.x; k < p.name_first_len; k += 64) t_first[k] = p.name_first[k];
     for (int k = threadIdx.x; k < p.name_variants_len; k += 64) t_var[k] = p.name_variants[k];
     __syncthreads();
-    if (i >= total || (int)threadIdx.x % stride != 0) return;
-    const int e = mode == MODE_RESET_ALL ? i : p.done_list[i];
+    if ((int)threadIdx.x % stride != 0) return;
     IconTables T;
     T.first[0] = t_first + p.name_first_off[0];
     T.first[1] = t_first + p.name_first_off[1];
     T.first[2] = t_first + p.name_first_off[2];
     T.variants = t_var;
-    xw_reset_env<NW, KIND>(p, T, L, e, keep_done != 0);
+    // the grid is capped (a short list should not cost the dispatch of one workgroup per env of the batch): loop
+    for (int i = blockIdx.x * epw + (int)threadIdx.x / stride; i < total; i += gridDim.x * epw) {
+        const int e = mode == MODE_RESET_ALL ? i : p.done_list[i];
+        xw_reset_env<NW, KIND>(p, T, L, e, keep_done != 0);
+    }
 }
 
 template <int NW>
@@ -720,7 +722,8 @@ hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s) {
     // per wavefront -- no divergence between envs: 64 -> 16 -> 4 -> 1 envs per wavefront = 0.1346, 0.1296, 0.1264, 0.1243 ms
     // per step of the C4 loop (8x8 and 11x11: no difference); idle wavefronts leave at once
     const int epw = mode == MODE_RESET_ALL ? 64 : 1;
-    dim3 grid((p.n + epw - 1) / epw);
+    const int want = (p.n + epw - 1) / epw;
+    dim3 grid(mode == MODE_RESET_ALL || want < 2048 ? want : 2048);
     const int lds_dim = p.curriculum != 0 ? p.max_dim : p.dim;
     const int cells = lds_dim * lds_dim;
     const size_t lds = 64 * 64 * 4 + 3 * XW_MAX_GOALS * 64 * 2 + XW_MAX_GOALS * 64 + (size_t)cells * 64 +
