@@ -184,11 +184,12 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
         }
     }
     wave_append(is_done, e, p.done_list, count_now);
+    // "this step finished the env": stays put until the next step, whatever a reset_done does to the done codes meanwhile
+    if (e < p.n) p.term_flag[e] = is_done ? 1 : 0;
     if (!p.visible_radius) {
         // terminal snapshot: the frame of a finished env is rendered from this copy, which lets xwb_reset_done rebuild
         // the live grid on the side stream while the big render is still running.  The wavefront copies the grids of
         // its finished envs together (consecutive lanes = consecutive cells).
-        if (e < p.n) p.term_flag[e] = is_done ? 1 : 0;
         unsigned long long m = __ballot(is_done);
         const int cells = p.max_dim * p.max_dim, lane = threadIdx.x & 63;
         if (m) __threadfence();                            // the agent's move was stored by one lane, the copy reads it from all
@@ -206,6 +207,17 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
 hipError_t launch_xw_step(const XwParams &p, hipStream_t s) {
     dim3 grid((p.n + 255) / 256), block(256);
     hipLaunchKernelGGL(xw_step_kernel, grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
+// the done codes of the listed envs, cleared on the caller's stream (after whatever it still has queued that reads them)
+__global__ __launch_bounds__(256) void xw_clear_done_kernel(XwParams p, const int32_t *count_now) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < *count_now) p.done[p.done_list[i]] = 0;
+}
+
+hipError_t launch_xw_clear_done(const XwParams &p, hipStream_t s) {
+    hipLaunchKernelGGL(xw_clear_done_kernel, dim3((p.n + 255) / 256), dim3(256), 0, s, p, (const int32_t *)p.done_count);
     return hipGetLastError();
 }
 

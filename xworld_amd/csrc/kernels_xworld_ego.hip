@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void xw_ego_build_tab_kernel(XwParams p, const
     for (int i = tid; i < CH * O * O; i += 256) out[i] = s_frame[i];
 }
 
-// MODE 0: every env; 1: the compacted done list; 2: every env whose done code is 0 (step_autoreset)
+// MODE 0: every env; 1: the compacted done list; 2: every env the last step did not finish (the rest is drawn from the list)
 // BS threads per workgroup: 256 for the whole batch; 1024 for the short done list, where the latency of one env counts
 // FAST: frame rows are whole dwords and cell boundaries fall on dwords (r <= 7): interior pixels are copied from the
 // table and frames leave as 16-byte chunks.  Otherwise (r >= 9: 81, 77, 78, 75 pixel edges) every pixel is evaluated
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
     auto fetch = [&](int item) {
         Fetch f;
         f.e = MODE == 1 ? p.done_list[item] : item;
-        f.skip = MODE == 2 ? (int)p.done[f.e] : 0;
+        f.skip = MODE == 2 ? (int)p.term_flag[f.e] : 0;      // finished by this step: drawn from the list instead
         f.axy = p.agent_xy[f.e]; f.dir = p.agent_dir[f.e];
 #pragma unroll
         for (int k = 0; k < CPL; ++k) f.code[k] = wave0 && tid + 64 * k < cells ? (uint32_t)p.grid[(size_t)f.e * cells + tid + 64 * k] : 0u;
@@ -697,7 +697,7 @@ hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s) {
     const uint32_t *a4 = reinterpret_cast<const uint32_t *>(p.atlas64);
 #define EGO_LAUNCH2(CHV, MODEV, BSV, FASTV) hipLaunchKernelGGL((xw_render_ego_kernel<CHV, MODEV, BSV, FASTV>), dim3(blocks), dim3(BSV), lds, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, p.ego_tab, cnt)
 #define EGO_LAUNCH1(CHV, MODEV, BSV) do { if (fast) EGO_LAUNCH2(CHV, MODEV, BSV, true); else EGO_LAUNCH2(CHV, MODEV, BSV, false); } while (0)
-#define EGO_LAUNCH(CHV) do { if (indexed == 1) EGO_LAUNCH1(CHV, 1, 1024); else if (indexed == 2) EGO_LAUNCH1(CHV, 2, 256); else EGO_LAUNCH1(CHV, 0, 256); } while (0)
+#define EGO_LAUNCH(CHV) do { if (indexed == 1) { if (p.ego_list_beside) EGO_LAUNCH1(CHV, 1, 256); else EGO_LAUNCH1(CHV, 1, 1024); } else if (indexed == 2) EGO_LAUNCH1(CHV, 2, 256); else EGO_LAUNCH1(CHV, 0, 256); } while (0)
     if (CH == 3) EGO_LAUNCH(3); else EGO_LAUNCH(1);
 #undef EGO_LAUNCH
 #undef EGO_LAUNCH1

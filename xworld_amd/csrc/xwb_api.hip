@@ -56,7 +56,7 @@ struct xwb_sim {
     bool profiling = false;
     KernelTimer t_render, t_step, t_reset;
     hipStream_t side = nullptr;            // reset of finished envs runs here, beside render_all
-    hipEvent_t ev_step = nullptr, ev_reset = nullptr;
+    hipEvent_t ev_step = nullptr, ev_reset = nullptr, ev_term = nullptr;
     // common device buffers
     int32_t *d_actions_in = nullptr;       // staging for xwb_step_host
     uint8_t *d_mask = nullptr;             // staging for xwb_reset_env
@@ -347,6 +347,7 @@ int xw_setup(xwb_sim *s) {
     HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_step, hipEventDisableTiming | hipEventDisableSystemFence));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_reset, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_term, hipEventDisableTiming | hipEventDisableSystemFence));
 
     XwParams &p = s->xw;
     p.n = n; p.context = c.context; p.max_steps = c.max_steps; p.act_rep = 1; p.auto_reset = 0;
@@ -476,6 +477,17 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
     timer_begin(s, s->t_reset, rs);
     HIP_TRY(launch_xw_reset(p, mode, rs));
     timer_end(s, s->t_reset, rs);
+    if (beside_render && render && p.visible_radius && mode != MODE_RESET_ALL) {
+        // egocentric: the first frames of the new episodes are drawn on the side stream too, beside the big render (which
+        // skips these envs); only the done codes are cleared on the caller's stream, behind whatever still reads them
+        p.auto_reset = 3;
+        p.ego_list_beside = 1;
+        HIP_TRY(launch_xw_render(p, 1, rs));
+        HIP_TRY(hipEventRecord(s->ev_reset, s->side));
+        HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
+        HIP_TRY(launch_xw_clear_done(p, st));
+        return XWB_OK;
+    }
     if (beside_render) {
         HIP_TRY(hipEventRecord(s->ev_reset, s->side));
         HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
@@ -533,16 +545,21 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
             // Finished envs keep a terminal snapshot of their grid (step kernel) from which the big render draws their
             // last frame, so a following xwb_reset_done can regenerate the live state beside that render right away.
             // The egocentric render reads more than the grid (heading, goal images): there the terminal frames are
-            // rendered from the (short) list first and the big render skips them.
+            // rendered from the (short) list on the side stream, beside the big render, which skips those envs; a
+            // following xwb_reset_done queues behind that list render.
+            HIP_TRY(hipEventRecord(s->ev_step, st));
             if (p.visible_radius) {
                 pr.list_flag = 1;
-                HIP_TRY(launch_xw_render(pr, 1, st));
+                pr.ego_list_beside = 1;
+                HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
+                HIP_TRY(launch_xw_render(pr, 1, s->side));
+                HIP_TRY(hipEventRecord(s->ev_term, s->side));
             }
-            HIP_TRY(hipEventRecord(s->ev_step, st));
         }
         timer_begin(s, s->t_render, st);
         HIP_TRY(launch_xw_render(p, autoreset || p.visible_radius ? 2 : 3, st));
         timer_end(s, s->t_render, st);
+        if (!autoreset && p.visible_radius) HIP_TRY(hipStreamWaitEvent(st, s->ev_term, 0));
         if (autoreset) HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
     }
     s->policy_step += 1;
@@ -681,6 +698,7 @@ int xwb_destroy(xwb_sim *s) {
     if (s->side) (void)hipStreamDestroy(s->side);
     if (s->ev_step) (void)hipEventDestroy(s->ev_step);
     if (s->ev_reset) (void)hipEventDestroy(s->ev_reset);
+    if (s->ev_term) (void)hipEventDestroy(s->ev_term);
     for (KernelTimer *t : {&s->t_render, &s->t_step, &s->t_reset})
         for (auto &ep : t->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     delete s;

@@ -177,6 +177,8 @@ struct XwParams {
                                  // (heading right, left, up; heading down is the icon itself)
     uint32_t *goal_img;          // egocentric: [n][num_goals][64 * 64] warped goal images (B | G << 8 | R << 16)
     const void *ego_taps;        // egocentric: cv::resize taps of the two resizes, then the four headings' layout tables
+    int ego_list_beside;         // egocentric list render: launched beside the big render -> small workgroups that fit into
+                                 // the slots it frees (a 1024-thread group needs a whole idle CU and would wait for the end)
     int ego_fast;                // egocentric: interior pixels can be copied from ego_tab (kernels_xworld_ego.hip)
     const uint8_t *ego_tab;      // egocentric: [(n_icons + 2) * 4] frames "every cell shows icon i", per heading (interior pixels)
     uint32_t *cand2d;            // [n] goal slots the agent can reach, blocks as the only obstacles: bits 0..15
@@ -207,6 +209,7 @@ hipError_t launch_xw_compact(const XwParams &p, int mode, hipStream_t s);
 // 3 = every env, those the step just finished from their terminal snapshot (term_grid)
 hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s);
 hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s);
+hipError_t launch_xw_clear_done(const XwParams &p, hipStream_t s);
 hipError_t launch_xw_warp_goals(const XwParams &p, bool list, hipStream_t s);
 struct EgoTap;
 hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int *fast_out);
