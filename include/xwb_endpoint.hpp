@@ -55,6 +55,24 @@ class Message {
         b_.insert(b_.end(), s.c_str(), s.c_str() + s.length() + 1);
     }
     void append(const char *s) { append(std::string(s)); }
+    template <typename T>
+    void append(const std::vector<T> &v) {                   // memory_util.h:297-304: element count, then the elements
+        append((size_t)v.size());
+        append(v.data(), v.size());
+    }
+    template <typename T>
+    void append(const T *a, size_t n) {                      // memory_util.h:285-291: raw elements, no count
+        const uint8_t *p = reinterpret_cast<const uint8_t *>(a);
+        b_.insert(b_.end(), p, p + n * sizeof(T));
+    }
+    void append(const Message &m) { b_.insert(b_.end(), m.b_.begin(), m.b_.end()); }   // memory_util.h:316-319
+    template <typename T>
+    void insert(size_t offset, const T *a, size_t n) {       // memory_util.h:321-333
+        if (offset > b_.size()) throw Error("wire::Message: insert beyond the end");
+        const uint8_t *p = reinterpret_cast<const uint8_t *>(a);
+        b_.insert(b_.begin() + (std::ptrdiff_t)offset, p, p + n * sizeof(T));
+    }
+    bool eof() const { return at_ >= b_.size(); }
     void append(const StatePacket &p) { const std::vector<uint8_t> e = p.encode(); b_.insert(b_.end(), e.begin(), e.end()); }
 
     template <typename T>
@@ -65,6 +83,15 @@ class Message {
         s.assign(reinterpret_cast<const char *>(b_.data() + at_), n);
         at_ += n + 1;
     }
+    template <typename T>
+    void read(std::vector<T> &v) {                           // memory_util.h:362-369
+        size_t n; read(n);
+        need(n * sizeof(T));
+        v.resize(n);
+        read(v.data(), n);
+    }
+    template <typename T>
+    void read(T *a, size_t n) { need(n * sizeof(T)); if (n) memcpy(a, b_.data() + at_, n * sizeof(T)); at_ += n * sizeof(T); }
     void read(StatePacket &p) { p.decode(b_.data() + at_, b_.size() - at_); at_ = b_.size(); }   // always last
 
   private:

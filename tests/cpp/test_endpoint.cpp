@@ -131,10 +131,81 @@ static int game_tests() {
     return 0;
 }
 
+// The reference's own gtest for the wire container, tests/test_binary_buffer.cpp:151-246 (TEST(BinaryBuffer, read_write)),
+// run on xwb::wire::Message: vectors carry their element count, arrays do not, strings carry length and a NUL,
+// buffers concatenate, insert() splices raw elements.
+static int buffer_tests() {
+    using xwb::wire::Message;
+    Message b1, b2, b3, b5;
+    std::vector<int> v({1, 2, 3, 4});
+    float f[3] = {4, 5, 6};
+    float ff[6];
+    {
+        b1.append(v);
+        b1.append(std::vector<float>(0));
+        b1.rewind();
+        std::vector<int> v1, v2;
+        b1.read(v1);
+        b1.read(v2);
+        EXPECT(v1.size() == v.size() && v1[0] == 1 && v1[1] == 2 && v1[2] == 3 && v1[3] == 4 && v2.size() == 0);
+    }
+    {
+        b2.append(f, 3);
+        b2.append(f, 3);
+        b2.rewind();
+        b2.read(ff, 6);
+        EXPECT(b2.size() == 6 * sizeof(float));
+        for (int i = 0; i < 6; ++i) EXPECT(ff[i] == f[i % 3]);
+    }
+    {
+        std::string str("789");
+        b3.append(str);
+        b3.append(std::string(""));
+        std::string tmp;
+        b3.rewind();
+        b3.read(tmp);
+        EXPECT(tmp.length() == 3 && tmp == str);
+        b3.read(tmp);
+        EXPECT(tmp.length() == 0 && tmp == "");
+        EXPECT(b3.size() == 2 * sizeof(size_t) + 3 + 1 + 1);
+    }
+    {
+        b1.append(b2);
+        b1.rewind();
+        size_t sz;
+        b1.read(sz);
+        EXPECT(sz == v.size());
+        int x;
+        for (size_t i = 0; i < sz; ++i) { b1.read(x); EXPECT(x == v[i]); }
+        b1.read(sz);
+        EXPECT(sz == 0);
+        float g;
+        for (int i = 0; i < 3; ++i) { b1.read(g); EXPECT(g == ff[i]); }
+        b1.read(g);
+        EXPECT(!b1.eof());
+    }
+    {
+        std::string s("a");
+        b5.append(int(1));
+        b5.append(s);
+        std::vector<int> a({2, 3});
+        b5.insert(sizeof(int), a.data(), a.size());
+        b5.rewind();
+        for (int i = 1; i <= 3; ++i) { int w; b5.read(w); EXPECT(w == i); }
+        b5.read(s);
+        EXPECT(s == "a" && b5.eof());
+    }
+    bool threw = false;
+    try { int w; b5.read(w); } catch (const std::exception &) { threw = true; }   // BinaryBuffer::read CHECK_LE
+    EXPECT(threw);
+    printf("buffer ok\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
     const std::string mode = argc > 1 ? argv[1] : "wire";
     try {
-        return mode == "game" ? game_tests() : wire_tests();
+        return mode == "game" ? game_tests() : (mode == "buffer" ? buffer_tests() : wire_tests());
     } catch (const std::exception &e) {
         printf("FAILED: exception %s\n", e.what());
         return 1;

@@ -26,6 +26,13 @@ def test_rpc_wire_layout_against_scripted_peer():
     assert out.returncode == 0 and "wire ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_wire_container_against_reference_gtest():
+    """tests/test_binary_buffer.cpp TEST(BinaryBuffer, read_write) restated on xwb::wire::Message (host only)."""
+    _build()
+    out = subprocess.run([EXE, "buffer"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "buffer ok" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.gpu
 def test_slot_served_over_tcp():
     """A trainer-side SimulatorServer drives one slot of a batch through xwb::SlotClient: the reference's SimpleGame
