@@ -108,3 +108,37 @@ def test_extra_info_string():
     sim = BatchedSimulator("simple_game", {"array_size": 8}, num_envs=2)
     assert sim.L.xwb_get_extra_info(sim.h, 0, None, buf, 256) == 0 and buf.value == b""
     sim.close()
+
+
+def test_reference_example_1_options():
+    """python/examples/test_xworld.py:31-60, "Navigation with language instruction (with curriculum)": the option dict as
+    the reference passes it, and its loop."""
+    from xworld_amd.py_simulator import Simulator
+    options = {
+        "xwd_conf_path": os.path.join(ROOT, "xworld_amd", "confs", "walls.json"),
+        "curriculum": 0.1,
+        "task_mode": "lang_acquisition",
+        "context": 1,
+        "pause_screen": True,
+        "task_groups_exclusive": False,
+        "visible_radius": 0,
+    }
+    xworld = Simulator.create("xworld", options)
+    xworld.reset_game()
+    num_actions = xworld.get_num_actions()
+    assert num_actions == 4
+    h, w, c, _ = xworld.get_screen_out_dimensions()
+    rng = np.random.default_rng(0)
+    reward = 0.0
+    for i in range(100):
+        game_over_str = xworld.game_over()
+        if game_over_str != "alive":
+            xworld.reset_game()
+            continue
+        states = xworld.get_state()
+        assert len(states["screen"]) == h * w * c and isinstance(states["sentence"], str)
+        r = xworld.take_actions({"action": int(rng.integers(0, num_actions))}, 1, False)
+        # rule D14b: -0.1 (-0.3 on a blocked move) while a Target / ColorTarget task runs, 0 while Near / Between idle
+        assert min(abs(r), abs(r + 0.1), abs(r + 0.3)) < 1e-6, r
+        reward += r
+    assert reward < 0
