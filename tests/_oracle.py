@@ -72,7 +72,11 @@ _lib = None
 
 
 def build():
-    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+    # one builder at a time: several test processes starting together must not load a half-linked library
+    import fcntl
+    with open(os.path.join(ORACLE_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
 
 
 def lib():
