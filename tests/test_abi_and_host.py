@@ -106,3 +106,31 @@ def test_product_never_touches_the_oracle():
                 assert "liboracle" not in src and "_oracle" not in src and "oracle/" not in src.replace("the test oracle", ""), f
     out = subprocess.check_output(["ldd", os.path.join(pkg, "libxwb.so")]).decode()
     assert "oracle" not in out
+
+
+def test_ctypes_offsets_match_the_c_header(tmp_path):
+    """Every field of xwb_config / xwb_env_state sits where the C compiler puts it (offsetof from include/xwb.h)."""
+    import subprocess
+    from xworld_amd import lib
+    structs = {"xwb_config": lib.XwbConfig, "xwb_env_state": lib.XwbEnvState}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "xwb.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        src.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            src.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    src += ['return 0;', '}']
+    c_file = tmp_path / "offsets.c"
+    c_file.write_text("\n".join(src))
+    exe = tmp_path / "offsets"
+    subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(c_file), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True)
+    seen = 0
+    for line in out.splitlines():
+        cname, fname, off = line.split()
+        cls = structs[cname]
+        if fname == "sizeof":
+            assert C.sizeof(cls) == int(off), (cname, C.sizeof(cls), off)
+        else:
+            assert getattr(cls, fname).offset == int(off), (cname, fname)
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in structs.values())

@@ -146,3 +146,24 @@ def test_decode_game_over_code(oracle):
     assert oracle.decode_game_over_code(1) == "max_step"
     assert oracle.decode_game_over_code(2 | 4) == "dead|success"
     assert oracle.decode_game_over_code(15) == "max_step|dead|success|lost_life"
+
+
+def test_oracle_ctypes_structs_match_the_header(oracle, tmp_path):
+    """tests/_oracle.py mirrors oracle/oracle.h by hand: offsets and sizes against the C compiler's."""
+    import ctypes as C
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {"orc_xw_cfg": oracle.XwCfg, "orc_entity": oracle.Entity, "orc_icon_info": oracle.IconInfo}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "oracle.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        src.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            src.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    src += ['return 0;', '}']
+    (tmp_path / "o.c").write_text("\n".join(src))
+    subprocess.check_call(["gcc", "-I" + os.path.join(root, "oracle"), str(tmp_path / "o.c"), "-o", str(tmp_path / "o")])
+    for line in subprocess.check_output([str(tmp_path / "o")], text=True).splitlines():
+        cname, fname, off = line.split()
+        cls = structs[cname]
+        assert (C.sizeof(cls) if fname == "sizeof" else getattr(cls, fname).offset) == int(off), (cname, fname)
