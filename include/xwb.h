@@ -198,6 +198,13 @@ int xwb_episode_dev(xwb_sim *sim, uint32_t **ptr);      /* uint32[num_envs]: res
 int xwb_xw_grid_dev(xwb_sim *sim, uint16_t **ptr);      /* xworld: uint16[num_envs][max_dim*max_dim] cell codes */
 int xwb_done_count(xwb_sim *sim, void *stream, int32_t *n_done);   /* envs reset by the last reset_done (sync) */
 
+/* The whole batch's outputs copied into caller-owned memory, host or device (hipMemcpyDefault), ordered on `stream`;
+ * host destinations are complete when the call returns.  obs: num_envs * bytes_per_env (see xwb_obs_dev);
+ * reward: float[num_envs]; done: uint8[num_envs] game_over codes. */
+int xwb_get_obs(xwb_sim *sim, void *dst, size_t bytes, void *stream);
+int xwb_get_reward(xwb_sim *sim, float *dst, void *stream);
+int xwb_get_done(xwb_sim *sim, uint8_t *dst, void *stream);
+
 /* ---- static queries (SimulatorInterface getters) ---- */
 int xwb_get_num_actions(const xwb_sim *sim, int32_t *n);                         /* get_num_actions() */
 int xwb_get_screen_out_dimensions(const xwb_sim *sim, size_t *h, size_t *w, size_t *c);

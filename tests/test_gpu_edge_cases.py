@@ -180,3 +180,27 @@ def test_bind_results_packed_output(game, opts):
     sim.step()
     assert torch.equal(bufs[1], keep)
     sim.close()
+
+
+def test_batch_copy_out_functions():
+    """xwb_get_obs / xwb_get_reward / xwb_get_done: the whole batch's outputs into caller-owned host or device memory."""
+    import ctypes as C
+    import torch
+    from xworld_amd.batched import BatchedSimulator
+    sim = BatchedSimulator("simple_game", {"array_size": 16, "context": 2}, num_envs=512)
+    for _ in range(5):
+        sim.step()
+    n, b = sim.num_envs, sim.obs_bytes_per_env
+    host = np.empty(n * b, np.uint8)
+    assert sim.L.xwb_get_obs(sim.h, host.ctypes.data, host.size, None) == 0
+    assert np.array_equal(host, sim.obs.cpu().numpy().reshape(-1))
+    dev = torch.empty(n * b, dtype=torch.uint8, device="cuda")
+    assert sim.L.xwb_get_obs(sim.h, C.c_void_p(dev.data_ptr()), n * b, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dev, sim.obs.reshape(-1))
+    r = np.empty(n, np.float32)
+    d = np.empty(n, np.uint8)
+    assert sim.L.xwb_get_reward(sim.h, r.ctypes.data, None) == 0 and sim.L.xwb_get_done(sim.h, d.ctypes.data, None) == 0
+    assert np.array_equal(r, sim.reward.cpu().numpy()) and np.array_equal(d, sim.game_over_codes.cpu().numpy())
+    assert sim.L.xwb_get_obs(sim.h, host.ctypes.data, host.size - 1, None) != 0
+    sim.close()

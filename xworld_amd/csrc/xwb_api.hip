@@ -935,6 +935,26 @@ int xwb_get_env_state(xwb_sim *s, int32_t env, void *stream, xwb_env_state *o) {
     return XWB_OK;
 }
 
+namespace {
+int copy_out(xwb_sim *s, void *dst, const void *src, size_t bytes, void *stream) {
+    if (!s || !dst) return fail(XWB_ERR_ARG, "NULL argument");
+    hipStream_t st = as_stream(stream);
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st));
+    hipPointerAttribute_t attr;
+    const bool device = hipPointerGetAttributes(&attr, dst) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    if (!device) { (void)hipGetLastError(); HIP_TRY(hipStreamSynchronize(st)); }
+    return XWB_OK;
+}
+}  // namespace
+
+int xwb_get_obs(xwb_sim *s, void *dst, size_t bytes, void *stream) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    if (bytes != (size_t)s->n * s->obs_bytes_per_env) return fail(XWB_ERR_ARG, "bytes must be num_envs * bytes_per_env");
+    return copy_out(s, dst, s->d_obs, bytes, stream);
+}
+int xwb_get_reward(xwb_sim *s, float *dst, void *stream) { return s ? copy_out(s, dst, s->d_reward, (size_t)s->n * 4, stream) : fail(XWB_ERR_ARG, "sim is NULL"); }
+int xwb_get_done(xwb_sim *s, uint8_t *dst, void *stream) { return s ? copy_out(s, dst, s->d_done, (size_t)s->n, stream) : fail(XWB_ERR_ARG, "sim is NULL"); }
+
 int xwb_get_env_obs(xwb_sim *s, int32_t env, void *stream, void *out_host, size_t bytes) {
     if (!s || !out_host) return fail(XWB_ERR_ARG, "NULL argument");
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");

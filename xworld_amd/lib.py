@@ -69,6 +69,9 @@ _SIGS = [
     ("xwb_bind_obs", C.c_int, [_vp, _vp]),
     ("xwb_reward_dev", C.c_int, [_vp, C.POINTER(_vp)]),
     ("xwb_game_over_dev", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("xwb_get_obs", C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    ("xwb_get_reward", C.c_int, [_vp, _vp, _vp]),
+    ("xwb_get_done", C.c_int, [_vp, _vp, _vp]),
     ("xwb_actions_dev", C.c_int, [_vp, C.POINTER(_vp)]),
     ("xwb_num_steps_dev", C.c_int, [_vp, C.POINTER(_vp)]),
     ("xwb_success_dev", C.c_int, [_vp, C.POINTER(_vp)]),
