@@ -158,6 +158,10 @@ class BatchedSimulator:
     def reset_masked(self, mask, stream=None):
         lib.check(self.L.xwb_reset_masked(self.h, C.c_void_p(mask.data_ptr()), self._stream(stream)))
 
+    def reset_env(self, env, stream=None):
+        """SimulatorInterface::reset_game of one env slot."""
+        lib.check(self.L.xwb_reset_env(self.h, int(env), self._stream(stream)))
+
     def step(self, actions=None, act_rep=1, stream=None):
         ptr = None if actions is None else C.c_void_p(actions.data_ptr())
         lib.check(self.L.xwb_step(self.h, ptr, int(act_rep), self._stream(stream)))
@@ -193,6 +197,11 @@ class BatchedSimulator:
     @property
     def reward(self):
         return self._view("reward", self.L.xwb_reward_dev, (self.num_envs,), "<f4")
+
+    @property
+    def episode(self):
+        """resets so far per env (the RNG's episode index), as int32"""
+        return self._view("episode", self.L.xwb_episode_dev, (self.num_envs,), "<i4")
 
     @property
     def game_over_codes(self):
