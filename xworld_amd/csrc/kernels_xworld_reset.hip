@@ -671,15 +671,18 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
 }
 
 template <int NW, int KIND>
-__global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int keep_done, const int32_t *count_now, int epw) {
+__global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int keep_done, const int32_t *count_now) {
     extern __shared__ uint32_t lds32[];
     // a handful of latency-bound wavefronts that run beside render_all's 16 waves per CU
     __builtin_amdgcn_s_setprio(3);
-    // epw envs per wavefront, on lanes 0, 64 / epw, ...: map generation is data-dependent serial code, and a wavefront
-    // runs the union of its lanes' paths -- the short done list is spread over many wavefronts instead
-    const int stride = 64 / epw;
+    // Envs per wavefront: map generation is data-dependent serial code and a wavefront runs the union of its lanes' paths,
+    // so the list is spread as thinly as the grid allows -- one env per wavefront for the usual fraction of a percent of
+    // the batch (C4 loop: 64 / 16 / 4 / 1 envs per wavefront = 0.1346 / 0.1296 / 0.1264 / 0.1243 ms per step), more lanes
+    // per wavefront when many envs finish together (fixed-length episodes), 64 when the whole batch is reset.
     const int total = mode == MODE_RESET_ALL ? p.n : *count_now;
-    if ((int)blockIdx.x * epw >= total) return;                        // whole wavefront idle
+    int per_wave = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    per_wave = per_wave < 1 ? 1 : (per_wave > 64 ? 64 : per_wave);
+    if ((int)blockIdx.x * per_wave >= total) return;                   // whole wavefront idle
     LaneLds L;
     L.lane = threadIdx.x;
     L.stack = lds32;                                                   // 64 x 64 x 4 B
@@ -697,41 +700,39 @@ __global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int 
     for (int k = threadIdx.x; k < p.name_first_len; k += 64) t_first[k] = p.name_first[k];
     for (int k = threadIdx.x; k < p.name_variants_len; k += 64) t_var[k] = p.name_variants[k];
     __syncthreads();
-    if ((int)threadIdx.x % stride != 0) return;
+    if ((int)threadIdx.x >= per_wave) return;
     IconTables T;
     T.first[0] = t_first + p.name_first_off[0];
     T.first[1] = t_first + p.name_first_off[1];
     T.first[2] = t_first + p.name_first_off[2];
     T.variants = t_var;
     // the grid is capped (a short list should not cost the dispatch of one workgroup per env of the batch): loop
-    for (int i = blockIdx.x * epw + (int)threadIdx.x / stride; i < total; i += gridDim.x * epw) {
+    for (int i = blockIdx.x * per_wave + (int)threadIdx.x; i < total; i += gridDim.x * per_wave) {
         const int e = mode == MODE_RESET_ALL ? i : p.done_list[i];
         xw_reset_env<NW, KIND>(p, T, L, e, keep_done != 0);
     }
 }
 
 template <int NW>
-static void launch_reset_nw(const XwParams &p, int mode, dim3 grid, size_t lds, hipStream_t s, int epw) {
+static void launch_reset_nw(const XwParams &p, int mode, dim3 grid, size_t lds, hipStream_t s) {
     const int32_t *cnt = p.done_count;
-    if (p.map_kind == 0) hipLaunchKernelGGL((xw_reset_kernel<NW, 0>), grid, dim3(64), lds, s, p, mode, p.auto_reset, cnt, epw);
-    else hipLaunchKernelGGL((xw_reset_kernel<NW, 1>), grid, dim3(64), lds, s, p, mode, p.auto_reset, cnt, epw);
+    if (p.map_kind == 0) hipLaunchKernelGGL((xw_reset_kernel<NW, 0>), grid, dim3(64), lds, s, p, mode, p.auto_reset, cnt);
+    else hipLaunchKernelGGL((xw_reset_kernel<NW, 1>), grid, dim3(64), lds, s, p, mode, p.auto_reset, cnt);
 }
 
 hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s) {
-    // every env of the batch: one per lane; the done list / mask (a fraction of a percent of the batch per step): one env
-    // per wavefront -- no divergence between envs: 64 -> 16 -> 4 -> 1 envs per wavefront = 0.1346, 0.1296, 0.1264, 0.1243 ms
-    // per step of the C4 loop (8x8 and 11x11: no difference); idle wavefronts leave at once
-    const int epw = mode == MODE_RESET_ALL ? 64 : 1;
-    const int want = (p.n + epw - 1) / epw;
-    dim3 grid(mode == MODE_RESET_ALL || want < 2048 ? want : 2048);
+    // every env of the batch: one per lane; the done list / mask: a fixed grid of 2048 wavefronts that share the list
+    // among themselves (xw_reset_kernel)
+    const int all = (p.n + 63) / 64;
+    dim3 grid(mode == MODE_RESET_ALL || p.n < 2048 ? (mode == MODE_RESET_ALL ? all : p.n) : 2048);
     const int lds_dim = p.curriculum != 0 ? p.max_dim : p.dim;
     const int cells = lds_dim * lds_dim;
     const size_t lds = 64 * 64 * 4 + 3 * XW_MAX_GOALS * 64 * 2 + XW_MAX_GOALS * 64 + (size_t)cells * 64 +
                        2 * (size_t)(p.name_first_len + 2 + p.name_variants_len);
     if (lds > 65536) return hipErrorInvalidValue;
-    if (cells <= 64) launch_reset_nw<1>(p, mode, grid, lds, s, epw);
-    else if (cells <= 128) launch_reset_nw<2>(p, mode, grid, lds, s, epw);
-    else launch_reset_nw<4>(p, mode, grid, lds, s, epw);
+    if (cells <= 64) launch_reset_nw<1>(p, mode, grid, lds, s);
+    else if (cells <= 128) launch_reset_nw<2>(p, mode, grid, lds, s);
+    else launch_reset_nw<4>(p, mode, grid, lds, s);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
     // egocentric: the goals of the reset envs got new poses; render their warped images once
