@@ -412,7 +412,7 @@ static hipError_t render_all(const XwParams &p, hipStream_t s) {
 
 template <int DIM_T, int CH, int ES>
 static hipError_t render_list(const XwParams &p, hipStream_t s) {
-    dim3 grid(512), block(256);
+    dim3 grid(2048), block(256);       // looping workgroups; a long list (a whole batch finishing together) keeps 8 per CU busy
     hipLaunchKernelGGL((xw_render_list_kernel<DIM_T, CH, ES>), grid, block, 0, s, p, (const int32_t *)p.done_count);
     return hipGetLastError();
 }
