@@ -124,6 +124,8 @@ typedef struct xwb_config {
     int32_t  task_schedule;      /* the group's "schedule" (teaching_task.cpp:204-213): XWB_SCHEDULE_RANDOM = uniform over its
                                   * tasks, XWB_SCHEDULE_WEIGHTED = util::simple_importance_sampling over task_weights */
     double   task_weights[8];    /* the per-task numbers of the conf JSON (TaskGroup::add_task: > 0); read when weighted */
+    int32_t  no_wall_shadow;     /* != 0: FLAGS_wall_shadow = false (xmap.cpp:19,170): the egocentric view keeps the cells
+                                  * behind walls visible (a gflag of the C++ binaries; not settable from py_simulator) */
 } xwb_config;
 
 typedef struct xwb_sim xwb_sim;

@@ -143,6 +143,7 @@ typedef struct {
     int start_level;         /* XWorldNav(item_path, start_level): the level a --curriculum_stamp file holds (xworld.cpp:93-100) */
     int task_schedule;       /* 0 "random": util::get_rand_ind; 1 "weighted": util::simple_importance_sampling (teaching_task.cpp:204-213) */
     double task_weights[8];  /* TaskGroup::add_task weights, conf order */
+    int no_wall_shadow;      /* FLAGS_wall_shadow = false (xmap.cpp:19,170) */
 } orc_xw_cfg;
 
 typedef struct {

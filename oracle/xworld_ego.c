@@ -162,6 +162,7 @@ void orc_xw_ego_view(const orc_xworld *w, int r, uint8_t *view /* (r*64)^2 * 3, 
     uint8_t *shadow = (uint8_t *)malloc((size_t)r * r);
     int x_st, y_st;
     orc_xw_image_masking(w, a->x, a->y, yaw, r, &x_st, &y_st, shadow);
+    if (w->cfg.no_wall_shadow) memset(shadow, 0, (size_t)r * r);      /* xmap.cpp:170: if (FLAGS_wall_shadow) ... */
     /* world canvas (white) with the item images, padded by r cells of black, cropped to the ROI = cells
      * (x_st - r + i, y_st - r + j) of the unpadded map */
     uint8_t item[ITEM_SIZE * ITEM_SIZE * 3];

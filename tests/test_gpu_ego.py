@@ -250,3 +250,43 @@ def test_ego_float32_frames(oracle, key, r):
             a.reset_done(); b.reset_done()
     a.close()
     b.close()
+
+
+def test_ego_without_wall_shadow(oracle):
+    """FLAGS_wall_shadow = false (xmap.cpp:19,170): cells behind walls stay visible; frames against the oracle, and they
+    differ from the shadowed ones where a wall hides something."""
+    torch = _torch()
+    n = 64
+    a, pal, cfg = _make(oracle, "nav7", n, 3, tasks=[KINDS[0]], seed=5, color=True, wall_shadow=False)
+    b, _, _ = _make(oracle, "nav7", n, 3, tasks=[KINDS[0]], seed=5, color=True)
+    cfg["no_wall_shadow"] = 1
+    envs = []
+    for e in range(n):
+        w = oracle.XWorld(pal, render=True, **cfg)
+        w.reset_game(e, 0)
+        envs.append(w)
+        g = w.grid().astype(np.uint16)
+        ax, ay = w.agent_xy()
+        g[w.target_cells() != 0] |= 0x8000
+        for sim in (a, b):
+            sim.load_map(e, g, ax, ay, dim=cfg["dim"], task=KINDS[0], target=w.target_name())
+            sim.set_agent_dir(e, _facing(w.agent_yaw()))
+            for i, ent in enumerate(w.entities()):
+                if ent[0] == 0:
+                    sim.set_goal_pose(e, ent[1], ent[2], *w.get_pose(i))
+            sim.refresh_obs(e)
+    rng = np.random.default_rng(2)
+    differ = 0
+    for t in range(10):
+        oa, ob = a.obs.cpu().numpy(), b.obs.cpu().numpy()
+        for e, w in enumerate(envs):
+            assert np.array_equal(oa[e], w.state_screen()), (t, e)
+        differ += int((oa != ob).any(axis=(1, 2, 3)).sum())
+        acts = rng.integers(0, 6, n).astype(np.int32)
+        for sim in (a, b):
+            sim.step(torch.from_numpy(acts).cuda())
+        for e, w in enumerate(envs):
+            w.take_actions(int(acts[e]))
+    assert differ > 0
+    a.close()
+    b.close()

@@ -101,6 +101,7 @@ class BatchedSimulator:
                     cfg.task_weights[i] = float(x)
             self.tasks = list(tasks)
             cfg.visible_radius = int(opts.get("visible_radius", 0))         # py_simulator.cpp:133
+            cfg.no_wall_shadow = 0 if opts.get("wall_shadow", True) else 1   # FLAGS_wall_shadow (xmap.cpp:19), C++ gflag only
             # py_simulator.cpp:127: FLAGS_curriculum.  XWorldNav.py:27-55: != 0 -> every env walks through the six levels
             # (dims 3..8) as its success rate passes the value; XWorldWalls never reads the flag
             cfg.curriculum = float(opts.get("curriculum", 0.0))

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
             for (int k = tid; k < r * r; k += 64) {             // what each view cell shows
                 const int gx = x_st - r + k % r, gy = y_st - r + k / r;
                 EgoCell c{black, 0, (p.n_icons + 1) * 4 + dir}; // outside the map, or in a wall's shadow
-                if ((unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && !s_shadow[k]) {
+                if ((unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && !(s_shadow[k] && !p.no_wall_shadow)) {
                     const int code = s_code[gy * D + gx];
                     if (code == 0) { c.img = white; c.tab = p.n_icons * 4 + dir; }
                     else {

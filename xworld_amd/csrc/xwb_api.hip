@@ -360,7 +360,7 @@ int xw_setup(xwb_sim *s) {
     p.curriculum = curriculum ? c.curriculum : 0.0; p.cur_level = s->d_cur_level; p.cur_counter = s->d_cur_counter; p.cur_usage = s->d_cur_usage;
     p.sent_names = s->d_sent_names; p.term_grid = s->d_term_grid; p.term_flag = s->d_term_flag;
     p.goal_cells = s->d_goal_cells; p.cand2d = s->d_cand2d; p.icon_colored = s->d_icon_colored;
-    p.visible_radius = c.visible_radius; p.out_dim = s->out_h;
+    p.visible_radius = c.visible_radius; p.out_dim = s->out_h; p.no_wall_shadow = c.no_wall_shadow;
     p.agent_dir = s->d_agent_dir; p.goal_warp = s->d_goal_warp; p.atlas64 = s->d_atlas64; p.ego_taps = s->d_ego_taps; p.goal_img = s->d_goal_img; p.ego_agent_rot = s->d_agent_rot;
     for (int i = 0; i < 8; ++i) p.tasks[i] = i < c.n_tasks ? c.tasks[i] : 0;
     p.task_weighted = c.task_schedule == XWB_SCHEDULE_WEIGHTED;
@@ -1205,7 +1205,7 @@ uint64_t config_hash(const xwb_config &c) {            // everything that shapes
                          c.n_tasks, c.color, c.visible_radius, c.obs_format, c.n_icons};
     mix(v, sizeof v); mix(c.tasks, sizeof c.tasks);
     mix(&c.seed, 4); mix(&c.policy_seed, 4); mix(&c.env_gid0, 4);
-    mix(&c.curriculum, 8); mix(&c.start_level, 4); mix(&c.task_schedule, 4); mix(c.task_weights, sizeof c.task_weights);
+    mix(&c.curriculum, 8); mix(&c.start_level, 4); mix(&c.task_schedule, 4); mix(c.task_weights, sizeof c.task_weights); mix(&c.no_wall_shadow, 4);
     return h;
 }
 }  // namespace

@@ -177,6 +177,7 @@ struct XwParams {
                                  // (heading right, left, up; heading down is the icon itself)
     uint32_t *goal_img;          // egocentric: [n][num_goals][64 * 64] warped goal images (B | G << 8 | R << 16)
     const void *ego_taps;        // egocentric: cv::resize taps of the two resizes, then the four headings' layout tables
+    int no_wall_shadow;          // FLAGS_wall_shadow = false: nothing is blacked out behind walls
     int ego_list_beside;         // egocentric list render: launched beside the big render -> small workgroups that fit into
                                  // the slots it frees (a 1024-thread group needs a whole idle CU and would wait for the end)
     int ego_fast;                // egocentric: interior pixels can be copied from ego_tab (kernels_xworld_ego.hip)

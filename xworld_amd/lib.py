@@ -33,7 +33,7 @@ class XwbConfig(C.Structure):
         ("color", C.c_int32), ("visible_radius", C.c_int32), ("obs_format", C.c_int32), ("n_icons", C.c_int32),
         ("icons64", C.c_void_p), ("icon_type", C.c_void_p), ("icon_name", C.c_void_p), ("icon_colored", C.c_void_p),
         ("curriculum", C.c_double), ("start_level", C.c_int32),
-        ("task_schedule", C.c_int32), ("task_weights", C.c_double * 8),
+        ("task_schedule", C.c_int32), ("task_weights", C.c_double * 8), ("no_wall_shadow", C.c_int32),
     ]
 
 
