@@ -36,6 +36,7 @@ def test_reset_verbs_agree(mode):
     sims = [BatchedSimulator("xworld", MODES[mode], num_envs=n, seed=9, policy_seed=4) for _ in range(4)]
     done_list, masked, single, fused = sims
     side = torch.cuda.Stream()
+    own = torch.cuda.Stream()                                # the reference verbs of this test run on a caller stream too
     rng = np.random.default_rng(1)
     n_act = done_list.num_actions
     for t in range(steps):
@@ -44,9 +45,13 @@ def test_reset_verbs_agree(mode):
             a = rng.integers(0, n_act, n).astype(np.int32)
             a[rng.integers(0, n, 7)] = -1
             acts = torch.from_numpy(a).cuda()
-        done_list.step(acts)
-        done_list.reset_done()
+        with torch.cuda.stream(own):
+            done_list.step(acts, stream=own)
+            codes_after_step = done_list.game_over_codes.clone()     # queued behind the render, read before reset_done clears
+            done_list.reset_done(stream=own)
+        own.synchronize()
         masked.step(acts)
+        assert torch.equal(codes_after_step, masked.game_over_codes), (mode, t, "codes survive until reset_done")
         masked.reset_masked(masked.game_over_codes != 0)
         if t % 4 == 0:                                   # the slow verb, now and then on every finished env
             single.step(acts)
