@@ -13,15 +13,30 @@ loop's `if game_over: reset_game()` for the envs that finished (wavefront-ballot
 generation, re-render).  Default workload = BASELINE.json config C4 (the configuration the north-star
 target is quoted on): XWorld2D 7x7, 84x84x3 uint8 planar BGR, 32 768 envs per GPU.
 
-Multi-GPU: the env batch is sharded by global env id (weak scaling: 32 768 envs per GPU); every step
-every rank's (reward, game_over) is exchanged through one RCCL all-gather (rank 0 consumes it).  `--gather-screens` also
-gathers every shard's screens into one contiguous tensor on rank 0 (xGMI-link bound).
+Timing: W untimed warm-up steps, then the same loop is spun (untimed) until the clocks are warm
+(--spin-seconds, default 0.3 s), then EXACTLY K steps are timed between two barrier + synchronize fences,
+max over ranks -- R times over (--repeats); `ms_per_step` / `value` are the MEDIAN region, the spread is
+reported (`regions`).  A 20-step region of the default workload is 2.5 ms of GPU work: one region alone
+measures the box's clock ramp, not the code.
+
+Parity gate ("parity gates reported with every perf number"): every step of the whole run writes
+(reward, game_over) of every env into a device-side record (xwb_bind_results_ring, no extra launches); after
+the timed regions the record of a slab of envs is compared, bit for bit, with the CPU oracle's rollout of the
+same envs from reset (the oracle is test infrastructure: it is only used here, outside every timed region, and
+by the cpu_baseline leg).
+
+Multi-GPU: the env batch is sharded by global env id (weak scaling: 32 768 envs per GPU).  `value` = screens
+left device-resident, one RCCL all-gather of (reward, game_over) per step; `screens_gather` = the same loop
+with every shard's screens gathered into one contiguous tensor on rank 0 (double-buffered: the transfer of step
+t runs beside step t + 1; xGMI-link bound), with the link-bound ceiling beside it.
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
+import math
 import os
+import statistics
 import sys
 import time
 
@@ -29,9 +44,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+XGMI_LINK_GBS = 153.6       # one xGMI link, per direction (MI355X_MICROARCH.md); every remote shard has ONE link to the root
 
 WORKLOADS = {
-    # name: (game, opts, envs per GPU, algorithmic bytes per env-step, bytes per env per render launch)
+    # name: (game, opts, envs per GPU)
     "xworld7": ("xworld", {"max_dim": 7, "num_blocks": 16, "color": True}, 32768),
     "xworld7_f32": ("xworld", {"max_dim": 7, "num_blocks": 16, "color": True, "obs_format": "float32"}, 32768),
     "xworld7_ego3": ("xworld", {"max_dim": 7, "num_blocks": 16, "color": True, "visible_radius": 3}, 32768),
@@ -40,6 +56,8 @@ WORKLOADS = {
     "simple_game": ("simple_game", {"array_size": 64}, 65536),
     "simple_race": ("simple_race", {"track_width": 20.0, "track_length": 100.0, "track_radius": 30.0}, 65536),
 }
+POLICY_SEED = 0x5EED
+REC_BYTES_CAP = 6 << 30      # the per-step (reward, game_over) record: a ring of at most this many bytes
 
 
 def make_sim(workload, n_envs, device, gid0, seed=0xC0FFEE):
@@ -50,7 +68,7 @@ def make_sim(workload, n_envs, device, gid0, seed=0xC0FFEE):
         opts["xwd_conf_path"] = os.path.join(ROOT, "xworld_amd", "confs", "navigation2d.json")       # the five XWorld3DNav tasks
         opts["task_mode"] = "lang_acquisition"
     return BatchedSimulator(game, opts, num_envs=n_envs, device=device, env_gid0=gid0,
-                            seed=seed, policy_seed=0x5EED)
+                            seed=seed, policy_seed=POLICY_SEED)
 
 
 def algorithmic_bytes(workload, sim):
@@ -87,28 +105,55 @@ def measured_traffic(workload):
     return t["traffic_bytes_per_launch"], os.path.relpath(best, ROOT)
 
 
-def cpu_baseline(workload, seconds_target=8.0):
+def _oracle():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    return O
+
+
+def oracle_rollout(workload, n, steps, gid0, seed, render):
+    """The CPU restatement's rollout of envs gid0 .. gid0 + n - 1 from reset (same RNG keys, same policy)."""
+    O = _oracle()
+    game, sim_opts, _ = WORKLOADS[workload]
+    if game == "simple_game":
+        return O.sg_rollout(n, sim_opts["array_size"], steps, POLICY_SEED, env_gid0=gid0)
+    if game == "simple_race":
+        return O.race_rollout(n, O.race_cfg(), seed, steps, POLICY_SEED, env_gid0=gid0)
+    pal = O.Palette(O.NAV_SUBTREES)
+    d = sim_opts.get("max_dim", 8)
+    cfg = O.xw_cfg(map_kind=0, max_dim=d, dim=d, num_goals=4, num_blocks=sim_opts.get("num_blocks", 16),
+                   color=1, seed=seed, tasks=[0, 1, 2, 3, 4], visible_radius=sim_opts.get("visible_radius", 0))
+    return O.xw_rollout(n, cfg, pal, steps, POLICY_SEED, env_gid0=gid0, render=render)
+
+
+def parity_gate(workload, rec, calls, slots, fused, gid0, seed, slab, calls_before):
+    """Compare the device's per-step record of envs [0, slab) with the oracle's rollout of the same envs.
+    rec: [slots, n, 2] ring written by the step kernels; `calls` step calls were recorded, each `fused` steps long,
+    after `calls_before` unrecorded ones (the probe)."""
+    import numpy as np
+    steps = (calls_before + calls) * fused
+    ref = oracle_rollout(workload, slab, steps, gid0, seed, render=False)
+    first = max(0, calls - slots)                     # oldest call still in the ring
+    got = rec[:, :slab, :].cpu().numpy()              # [slots, slab, 2]
+    mism = 0
+    for k in range(first, calls):
+        t = (calls_before + k + 1) * fused - 1        # a fused call keeps its last step
+        row = got[k % slots]
+        mism += int(np.count_nonzero(row[:, 0].view(np.uint32) != ref.rewards[t].view(np.uint32)))
+        mism += int(np.count_nonzero(row[:, 1].astype(np.uint8) != ref.codes[t]))
+    return {"checked_env_steps": (calls - first) * slab, "mismatches": mism, "envs": slab,
+            "step_calls": [calls_before + first, calls_before + calls], "against": "oracle/liboracle.so rollout from reset, reward bits + game_over code"}
+
+
+def cpu_baseline(workload, seed, seconds_target=8.0):
     """The oracle (CPU restatement of the reference path, kind = "port") timed on this box's host cores on a bounded
     sample of the same workload (same loop: game_over? -> reset; get_state; random action; take_actions incl. screen):
     first one thread (calibration, also reported), then one independent env batch per thread on every core (ctypes
     releases the GIL; the oracle keeps no global state) -- `value` / `cores` are the all-core figures."""
     import threading
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import _oracle as O
-    game = WORKLOADS[workload][0]
-    sim_opts = WORKLOADS[workload][1]
-    pal = O.Palette(O.NAV_SUBTREES) if game == "xworld" else None
 
     def rollout(n, steps, gid0):
-        if game == "simple_game":
-            O.sg_rollout(n, 64, steps, 0x5EED, env_gid0=gid0)
-        elif game == "simple_race":
-            O.race_rollout(n, O.race_cfg(), 0xC0FFEE, steps, 0x5EED, env_gid0=gid0)
-        else:
-            d = sim_opts.get("max_dim", 8)
-            cfg = O.xw_cfg(map_kind=0, max_dim=d, dim=d, num_goals=4, num_blocks=sim_opts.get("num_blocks", 16),
-                           color=1, seed=0xC0FFEE, tasks=[0, 1, 2, 3, 4], visible_radius=sim_opts.get("visible_radius", 0))
-            O.xw_rollout(n, cfg, pal, steps, 0x5EED, env_gid0=gid0, render=True)
+        oracle_rollout(workload, n, steps, gid0, seed, render=True)
 
     # one thread: grow the sample until a call takes about two seconds
     n, steps = 8, 50
@@ -150,11 +195,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--repeats", type=int, default=9, help="timed K-step regions; the median one is reported")
+    ap.add_argument("--spin-seconds", type=float, default=0.3, help="untimed run of the same loop before the timed regions (clock ramp)")
     ap.add_argument("--seed", type=lambda v: int(v, 0), default=0xC0FFEE, help="env RNG seed (xwb-rng-v1 key word 0)")
     ap.add_argument("--workload", default="xworld7", choices=list(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=0)
-    ap.add_argument("--gather-screens", action="store_true")
+    ap.add_argument("--no-screens-gather", action="store_true", help="N > 1: skip the screens-gather-inclusive regions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--parity-envs", type=int, default=256)
     ap.add_argument("--autoreset", action="store_true", help="use the fused step+reset+single-render call")
     ap.add_argument("--fused", type=int, default=1, help="simple games only: steps per launch (xwb_step_n); --steps must be "
                     "a multiple; every step still writes its reward / code / observation")
@@ -179,43 +228,39 @@ def main():
             dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
-    n_gpus = world
     dev = torch.device("cuda", local_rank)
     n_local = args.envs_per_gpu or WORKLOADS[args.workload][2]
     sim = make_sim(args.workload, n_local, local_rank, rank * n_local, args.seed)
     per_step, per_launch, kernel_name = algorithmic_bytes(args.workload, sim)
+    is_xworld = WORKLOADS[args.workload][0] == "xworld"
+    fused = args.fused if not is_xworld else 1
+    assert fused == 1 or (args.steps % fused == 0 and args.warmup % fused == 0), "--steps / --warmup must be multiples of --fused"
+    K, W, R = args.steps // fused, args.warmup // fused, max(1, args.repeats)       # in step CALLS
 
-    # per-step exchange (xworld_amd/sharding.py): (reward, game_over) of every shard to rank 0 through one
-    # RCCL gather; with --gather-screens also every shard's screens into one contiguous tensor on rank 0
     from xworld_amd import sharding
     counts = [n_local] * world
     results = sharding.ResultGather(counts, rank, dev) if world > 1 else None
-    screens_all = None
-    if world > 1 and args.gather_screens and rank == 0:
-        screens_all = torch.empty((world * n_local,) + tuple(sim.obs.shape[1:]), dtype=sim.obs.dtype, device=dev)
-        sim.bind_obs(screens_all[:n_local])              # rank 0 renders straight into its slice
+    with_screens = world > 1 and not args.no_screens_gather
+    screens = None                                   # ScreensGather while the screens regions run
+
+    calls = [0]                                      # step calls so far == the record slot counter
+    rec = [None]
 
     def exchange_results():
-        if world == 1:
+        if results is None:
             return
         # finish the gather of the previous step (it ran beside this step's kernels), start this step's: the step
-        # kernel wrote (reward, code) straight into the buffer, no packing kernels
+        # kernel wrote (reward, code) straight into the record's slot, no packing kernels
         results.finish()
-        results.start()
-
-    def exchange_screens():
-        if world > 1 and args.gather_screens:
-            sharding.gather_slabs(sim.obs, screens_all, counts, rank)
-
-    fused = args.fused if WORKLOADS[args.workload][0] != "xworld" else 1
-    assert args.steps % fused == 0 and args.warmup % fused == 0 or fused == 1, "--steps / --warmup must be multiples of --fused"
+        results.start(packed=rec[0][(calls[0] - 1) % rec[0].shape[0]])
 
     def one_step():
+        if screens is not None:
+            screens.bind_next()
+        calls[0] += 1
         if fused > 1:                                    # `fused` steps in one launch (built-in policy, auto-reset)
             sim.step_n(fused)
             return
-        if results is not None:
-            sim.bind_results(results.next_buffer())
         if args.autoreset:
             sim.step_autoreset()
             exchange_results()
@@ -223,48 +268,103 @@ def main():
             sim.step()
             exchange_results()                           # this step's results, before reset_done clears the codes
             sim.reset_done()
-        exchange_screens()                               # the frames the next policy step would see
+        if screens is not None:
+            screens.start()                              # the frames the next policy step would see
 
     def fence():
         if results is not None:
             results.finish()
+        if screens is not None:
+            screens.drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup // fused):
-        one_step()
-    # ---- the timed region: exactly K steps between two barrier + synchronize fences ----
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps // fused):
-        one_step()
-    fence()
-    dt_clean = time.perf_counter() - t0
-    dt_max = dt_clean
-    if world > 1:
-        tt = torch.tensor([dt_clean], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt_max = float(tt.item())
+    def bcast_int(v):
+        if world == 1:
+            return int(v)
+        t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+        dist.broadcast(t, 0)
+        return int(t.item())
 
-    # ---- same K steps again with hipEvents around every launch of the dominant kernel (on its
-    # launch stream, recorded inside libxwb) to get that kernel's average duration for the roofline ----
-    sim.profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps // fused):
+    # ---- plan the run: the record ring must exist before the first step; its length needs the step count, which needs
+    # the spin length, which needs a step time: a short untimed probe on a throw-away ring gives it ----
+    probe = torch.zeros((2, n_local, 2), dtype=torch.float32, device=dev)
+    sim.bind_results_ring(probe)
+    rec[0] = probe
+    for _ in range(3):
         one_step()
     fence()
-    dt = time.perf_counter() - t0
-    kern = "render" if WORKLOADS[args.workload][0] == "xworld" else "step"
+    t0 = time.perf_counter()
+    for _ in range(10):
+        one_step()
+    fence()
+    est = (time.perf_counter() - t0) / 10
+    spin_calls = bcast_int(min(200000, math.ceil(max(0.0, args.spin_seconds) / max(est, 1e-7))))
+    screens_regions = R if with_screens else 0
+    total_calls = 13 + W + spin_calls + 2 * R * K + screens_regions * K + (2 * K if with_screens else 0)
+    slots = int(max(2, min(total_calls, REC_BYTES_CAP // (n_local * 8))))
+    rec[0] = torch.zeros((slots, n_local, 2), dtype=torch.float32, device=dev)
+    # the probe's 13 calls happened with another ring: restart the slot counter with the library's (bind resets it)
+    sim.bind_results_ring(rec[0])
+    probe_calls = calls[0]
+    calls[0] = 0
+
+    for _ in range(W):
+        one_step()
+    for _ in range(spin_calls):                          # clocks warm, caches and allocator settled
+        one_step()
+
+    def timed_region():
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            one_step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    # ---- the timed regions: exactly K steps each between two barrier + synchronize fences, max over ranks ----
+    regions = [timed_region() for _ in range(R)]
+    dt_med = statistics.median(regions)
+
+    # ---- R more regions with hipEvents around every launch of the dominant kernel (on its launch stream, recorded
+    # inside libxwb) to get that kernel's average duration for the roofline ----
+    sim.profile_begin()
+    ev_regions = [timed_region() for _ in range(R)]
+    kern = "render" if is_xworld else "step"
     kern_us, kern_n = sim.profile_end(kern)
     sim.profile_stop()
+
+    # ---- N > 1: the same loop with the screens of every shard gathered into one tensor on rank 0 ----
+    sg_line = None
+    if with_screens:
+        screens = sharding.ScreensGather(sim, counts, rank)
+        for _ in range(2 * K):
+            one_step()
+        sg_regions = [timed_region() for _ in range(R)]
+        fence()
+        sg_med = statistics.median(sg_regions)
+        shard_bytes = n_local * sim.obs_bytes_per_env
+        link_s = shard_bytes / (XGMI_LINK_GBS * 1e9)
+        sg_line = {"ms_per_step": sg_med / args.steps * 1e3, "value": n_local * world * args.steps / sg_med,
+                   "unit": "env-steps/s", "bytes_into_root_per_step": shard_bytes * (world - 1),
+                   "link_bound_ms_per_step": link_s * 1e3, "link_bound_ceiling": n_local * world / link_s,
+                   "link_GBps_assumed": XGMI_LINK_GBS, "achieved_GBps_per_link": shard_bytes / (sg_med / args.steps) / 1e9,
+                   "overlap": "double-buffered: transfer of step t beside the kernels of step t+1" if screens.depth == 2 else "none (context ring)",
+                   "regions_ms_per_step": {"min": min(sg_regions) / args.steps * 1e3, "max": max(sg_regions) / args.steps * 1e3}}
+        screens = None                                   # (the batch keeps the buffer it is bound to alive)
     errs = sim.check_errors()
     assert errs == 0
 
     if rank == 0:
         total_envs = n_local * world
-        value = total_envs * args.steps / dt_max
+        value = total_envs * args.steps / dt_med
         # algorithmic bytes of one launch = per-step bytes x the steps that launch runs
         achieved = n_local * per_launch * fused / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
         traffic, traffic_src = measured_traffic(args.workload) if n_local == WORKLOADS[args.workload][2] else (None, None)
@@ -272,10 +372,10 @@ def main():
             "metric": "env-steps/sec (batched random policy)",
             "value": value,
             "unit": "env-steps/s",
-            "n_gpus": n_gpus,
+            "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3,
+            "ms_per_step": dt_med / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -286,19 +386,32 @@ def main():
                        "obs": list(sim.obs.shape[1:]), "seed": args.seed, "policy": "uniform random, drawn on device",
                        "loop": ("step_n(%d): %d steps per launch, auto-reset" % (fused, fused)) if fused > 1 else
                                ("step_autoreset" if args.autoreset else "step + reset_done"),
-                       "exchange": ("all_gather(reward,done)" + ("+gather(screens)" if args.gather_screens else ""))
-                       if world > 1 else "none", "parallelism": "env-sharded x%d" % world},
+                       "exchange": "all_gather(reward,done) per step, screens device-resident" if world > 1 else "none",
+                       "parallelism": "env-sharded x%d" % world},
+            "regions": {"repetitions": R, "statistic": "median", "steps_per_region": args.steps,
+                        "ms_per_step_min": min(regions) / args.steps * 1e3, "ms_per_step_max": max(regions) / args.steps * 1e3,
+                        "ms_per_step_all": [r / args.steps * 1e3 for r in regions],
+                        "untimed_before": {"warmup_steps": args.warmup, "spin_steps": spin_calls * fused,
+                                           "spin_seconds_target": args.spin_seconds, "probe_steps": probe_calls * fused}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name,
                          "kernel_avg_us": kern_us, "kernel_launches": kern_n,
                          "algorithmic_bytes_per_launch": n_local * per_launch * fused,
                          "algorithmic_bytes_per_env_step": per_step,
-                         "step_loop_GBps": total_envs * per_step * args.steps / dt_max / 1e9},
-            "timed_with_events_ms_per_step": dt / args.steps * 1e3,
+                         "step_loop_GBps": total_envs * per_step * args.steps / dt_med / 1e9,
+                         "step_loop_frac": total_envs * per_step * args.steps / dt_med / 1e9 / HBM_PEAK_GBS / world},
+            "timed_with_events_ms_per_step": statistics.median(ev_regions) / args.steps * 1e3,
+            "rccl": sharding.backend_info(),
         }
+        if sg_line is not None:
+            line["screens_gather"] = sg_line
+        if not args.no_parity:
+            # the checker leg: nothing above this line touched the oracle
+            line["parity"] = parity_gate(args.workload, rec[0], calls[0], slots, fused, 0, args.seed,
+                                         min(args.parity_envs, n_local), probe_calls)
         if not args.no_cpu_baseline and world == 1:          # rank 0, N = 1 only
-            line["cpu_baseline"] = cpu_baseline(args.workload)
+            line["cpu_baseline"] = cpu_baseline(args.workload, args.seed)
         print(json.dumps(line))
     sim.close()
     if world > 1:

@@ -188,6 +188,11 @@ int xwb_obs_dev(xwb_sim *sim, void **ptr, size_t *bytes_per_env);
 /* Optional second output of every step: packed_dev[e] = (reward, game_over code as float) for every env the call steps,
  * float[num_envs][2] in caller-owned device memory (NULL = off) -- one buffer to ship per step (sharding.ResultGather). */
 int xwb_bind_results(xwb_sim *sim, float *packed_dev);
+/* The same with a ring of `slots` such buffers, float[slots][num_envs][2]: the k-th step call after the bind writes slot
+ * k % slots (one xwb_step_n launch = one call: the slot keeps its last step).  A per-step record of a rollout without a
+ * host call or a copy kernel per step -- bench.py's parity gate and the pipelined result exchange read it (SURVEY 8(d):
+ * "parity gates reported with every perf number"). */
+int xwb_bind_results_ring(xwb_sim *sim, float *packed_dev, int64_t slots);
 
 /* redirect the observation output to caller-owned device memory (e.g. a shard of a gathered tensor) */
 int xwb_bind_obs(xwb_sim *sim, void *obs_dev);

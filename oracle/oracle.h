@@ -45,6 +45,13 @@ enum { ORC_ALIVE = 0, ORC_MAX_STEP = 1, ORC_DEAD = 2, ORC_SUCCESS = 4, ORC_LOST_
 
 /* ---------------------------------------------------------------- RNG ---- */
 /* libstdc++ minstd_rand0 + distributions as used by simulator_util.cpp:38-73 */
+/* ---- trig.c: cos / sin of the SimpleRace and goal-warp call sites: include/xwb_trig.h (default) or the host's libm ---- */
+void   orc_set_trig_libm(int on);
+int    orc_get_trig_libm(void);
+double orc_trig_cos(double x);
+double orc_trig_sin(double x);
+void   orc_xwb_sincos(double x, double *s, double *c);
+
 typedef struct { uint32_t x; } orc_minstd;
 void     orc_minstd_seed(orc_minstd *g, uint64_t s);            /* engine.seed(s) */
 uint32_t orc_minstd_next(orc_minstd *g);                        /* engine()      */

@@ -138,7 +138,7 @@ static pt2f track_start_pos(const orc_simple_race *g, int random, float u_first,
         } else {
             float theta = (float)((double)(u_first * 2) * PI);
             float r = g->inner_radius + u_second * g->width;
-            pt2f q = {(float)((double)r * cos((double)theta)), (float)((double)r * sin((double)theta))};
+            pt2f q = {(float)((double)r * orc_trig_cos((double)theta)), (float)((double)r * orc_trig_sin((double)theta))};
             p.x = q.x + g->center.x;
             p.y = q.y + g->center.y;
         }
@@ -160,7 +160,7 @@ static void car_move(orc_simple_race *g, float d, float da) {
         g->angle = (float)((double)g->angle - 2 * PI);
     else if (g->angle < 0)
         g->angle = (float)((double)g->angle + 2 * PI);
-    pt2f dir = {(float)cos((double)g->angle), (float)sin((double)g->angle)};
+    pt2f dir = {(float)orc_trig_cos((double)g->angle), (float)orc_trig_sin((double)g->angle)};
     pt2f step = {d * dir.x, d * dir.y};   /* float * Point2f */
     g->pos.x += step.x;
     g->pos.y += step.y;
@@ -177,7 +177,7 @@ static void car_set_angle(orc_simple_race *g, int random, float u) {
 static float engine_get_reward(const orc_simple_race *g, float forward, float angle) {
     pt2f p = g->pos;
     pt2f t = track_tangent(g, p);
-    float vx = (float)cos((double)angle), vy = (float)sin((double)angle);
+    float vx = (float)orc_trig_cos((double)angle), vy = (float)orc_trig_sin((double)angle);
     float reward_speed = (vx * t.x + vy * t.y) * forward;
     float reward_finish = track_race_finish(g, p) ? 2.0f : 0.0f;
     float reward_boundary = 0;
@@ -216,10 +216,10 @@ static float engine_act(orc_simple_race *g, int a) {
 static void engine_get_screen(const orc_simple_race *g, float *state) {
     pt2f t = track_tangent(g, g->pos);
     float a = g->angle;
-    double c = (double)t.x * cos((double)a) + (double)t.y * sin((double)a);
+    double c = (double)t.x * orc_trig_cos((double)a) + (double)t.y * orc_trig_sin((double)a);
     float cos_theta = (float)fmax(-1.0, fmin(1.0, c));
     float sin_theta = (float)sqrt((double)(1 - cos_theta * cos_theta));
-    if (cos((double)a) * (double)t.y + sin((double)a) * (double)t.x < 0) sin_theta = -sin_theta;
+    if (orc_trig_cos((double)a) * (double)t.y + orc_trig_sin((double)a) * (double)t.x < 0) sin_theta = -sin_theta;
     state[0] = cos_theta;
     state[1] = sin_theta;
     state[2] = track_h_disp(g, g->pos);

@@ -26,7 +26,7 @@ static int cv_round(double v) { return (int)lrint(v); }            /* cvRound: r
 
 void orc_cv_get_rotation_matrix_2d(double cx, double cy, double angle_deg, double scale, double M[6]) {
     double angle = angle_deg * 3.1415926535897932384626433832795 / 180;   /* CV_PI */
-    double alpha = cos(angle) * scale, beta = sin(angle) * scale;
+    double alpha = orc_trig_cos(angle) * scale, beta = orc_trig_sin(angle) * scale;   /* trig.c */
     M[0] = alpha; M[1] = beta;  M[2] = (1 - alpha) * cx - beta * cy;
     M[3] = -beta; M[4] = alpha; M[5] = beta * cx + (1 - alpha) * cy;
 }

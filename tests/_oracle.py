@@ -96,6 +96,11 @@ def lib():
         f.restype = res
         f.argtypes = list(args)
 
+    sig("orc_set_trig_libm", None, C.c_int)
+    sig("orc_get_trig_libm", C.c_int)
+    sig("orc_trig_cos", C.c_double, C.c_double)
+    sig("orc_trig_sin", C.c_double, C.c_double)
+    sig("orc_xwb_sincos", None, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double))
     sig("orc_minstd_seed", None, C.POINTER(MinStd), C.c_uint64)
     sig("orc_minstd_next", C.c_uint32, C.POINTER(MinStd))
     sig("orc_minstd_rand_ind", C.c_int, C.POINTER(MinStd), C.c_int)

@@ -201,6 +201,65 @@ def test_full_size_c4(oracle):
     sim.close()
 
 
+def test_full_size_c5_shard(oracle):
+    """BASELINE config C5's per-GPU shard at the size it names: 32 768 envs x 11x11 x 132x132x3 (1.7 GB of frames), the five
+    navigation2d.json tasks, env ids of shard 5 of 8 (global ids 163 840 ...).  Rewards / codes vs the oracle batch driver;
+    screens through obs == tile_table[grid] over every env (the table itself is checked icon by icon above)."""
+    torch = _torch()
+    from xworld_amd.batched import BatchedSimulator
+    n, steps, D, gid0 = 32768, 16, 11, 5 * 32768
+    opts = {"xwd_conf_path": os.path.join(CONF, "navigation2d.json"), "task_mode": "lang_acquisition", "max_dim": D,
+            "num_blocks": 30, "color": True}
+    sim = BatchedSimulator("xworld", opts, num_envs=n, seed=0xC0FFEE, policy_seed=0x5EED, env_gid0=gid0)
+    assert sim.obs.shape == (n, 3, 132, 132) and sim.obs.numel() == n * 52272
+    pal = oracle.Palette(oracle.NAV_SUBTREES)
+    cfg = dict(map_kind=0, max_dim=D, dim=D, num_goals=4, num_blocks=30, color=1, seed=0xC0FFEE, tasks=[0, 1, 2, 3, 4])
+    ref = oracle.xw_rollout(n, oracle.xw_cfg(**cfg), pal, steps, policy_seed=0x5EED, env_gid0=gid0)
+    table = torch.from_numpy(sim.tile_table()).cuda()
+    full = torch.cat([torch.full_like(table[:1], 255), table])          # index 0 = empty cell
+    for t in range(steps):
+        sim.reset_done()
+        sim.step()
+        assert np.array_equal(sim.reward.cpu().numpy().view(np.uint32), ref.rewards[t].view(np.uint32)), t
+        assert np.array_equal(sim.game_over_codes.cpu().numpy(), ref.codes[t]), t
+        if t % 5 == 0 or t == steps - 1:
+            for lo in range(0, n, 4096):                                # every env, in slabs
+                G = sim.grid[lo:lo + 4096].to(torch.int64) & 0x7fff            # bit 15 = target-set flag
+                exp = full[G].permute(0, 3, 1, 4, 2, 5).reshape(G.shape[0], 3, 12 * D, 12 * D)
+                assert torch.equal(sim.obs[lo:lo + 4096], exp), (t, lo)
+    sim.close()
+
+
+def test_autoreset_then_reset_done_resets_once(oracle):
+    """xwb_step_autoreset keeps the codes of the envs it already reset; a following xwb_reset_done only clears them."""
+    torch = _torch()
+    sim, pal, cfg = _make(oracle, "nav7", 2048, seed=2, policy_seed=8)
+    seen = 0
+    for t in range(60):
+        sim.step_autoreset()
+        codes = sim.game_over_codes.clone()
+        ep = sim.episode.clone()
+        grid = sim.grid.clone()
+        sim.reset_done()
+        seen += int((codes != 0).sum())
+        assert int(sim.game_over_codes.sum()) == 0
+        assert torch.equal(sim.episode, ep) and torch.equal(sim.grid, grid), t
+    assert seen > 0
+    sim.close()
+    for name, opts in (("simple_game", {"array_size": 8}), ("simple_race", {"track_width": 20.0, "track_length": 100.0, "track_radius": 30.0})):
+        from xworld_amd.batched import BatchedSimulator
+        g = BatchedSimulator(name, opts, num_envs=512, policy_seed=3)
+        seen = 0
+        for t in range(80):
+            g.step_autoreset()
+            ep = g.episode.clone()
+            seen += int((g.game_over_codes != 0).sum())
+            g.reset_done()
+            assert int(g.game_over_codes.sum()) == 0 and torch.equal(g.episode, ep), (name, t)
+        assert seen > 0
+        g.close()
+
+
 def test_autoreset_equals_step_then_reset(oracle):
     torch = _torch()
     n = 4096

@@ -71,6 +71,51 @@ def _worker(rank, world, port, total, q):
                 assert torch.equal(got_prev[1], (g % 5 == 0).to(torch.uint8) * 4)
             prev = step
         rg.finish()
+        # the pipelined form shipping caller-owned rows of a per-step record (bench.py: xwb_bind_results_ring)
+        ring = torch.zeros((3, n, 2))
+        for step in range(5):
+            ring[step % 3, :, 0] = reward + 100 * step
+            ring[step % 3, :, 1] = done.to(torch.float32)
+            got_prev = rg.finish()
+            rg.start(packed=ring[step % 3])
+            if rank == 0 and step > 0:
+                g = torch.arange(total)
+                assert torch.equal(got_prev[0], g.to(torch.float32) * 0.5 - 3.0 + 100 * (step - 1))
+        rg.finish()
+        # double-buffered screens gather: the simulator renders step t into the free buffer pair, the transfer of step t
+        # is waited for when its buffers come up again (context 1) or at once (context ring: one buffer)
+        for context in (1, 2):
+            class FakeSim:
+                class cfg:
+                    pass
+                def __init__(self):
+                    self.cfg.context = context
+                    self.obs = torch.zeros((n, context, 3, 4), dtype=torch.uint8)
+                def bind_obs(self, t):
+                    self.obs = t
+            fs = FakeSim()
+            sg = sharding.ScreensGather(fs, counts, rank)
+            assert sg.depth == (2 if context == 1 else 1)
+            g = torch.arange(total)
+            for step in range(5):
+                sg.bind_next()
+                fs.obs.copy_(((gid[:, None] * 3 + step + torch.arange(12 * context)[None, :]) % 251).to(torch.uint8).reshape(n, context, 3, 4))
+                sg.start()
+                got = sg.latest()
+                if rank == 0:
+                    want_step = step - 1 if context == 1 else step
+                    if want_step >= 0:
+                        exp = ((g[:, None] * 3 + want_step + torch.arange(12 * context)[None, :]) % 251).to(torch.uint8).reshape(total, context, 3, 4)
+                        assert got is not None and got.is_contiguous() and torch.equal(got, exp), (context, step)
+                    else:
+                        assert got is None
+                else:
+                    assert got is None
+            final = sg.drain()
+            if rank == 0:
+                exp = ((g[:, None] * 3 + 4 + torch.arange(12 * context)[None, :]) % 251).to(torch.uint8).reshape(total, context, 3, 4)
+                assert torch.equal(final, exp)
+        assert sharding.backend_info() == {"world_size": world, "backend": "gloo", "version": None}
         dist.barrier()
         q.put((rank, "ok"))
     except Exception as e:                               # pragma: no cover

@@ -252,6 +252,14 @@ class BatchedSimulator:
             lib.check(self.L.xwb_bind_results(self.h, C.c_void_p(tensor.data_ptr())))
         self._results = tensor
 
+    def bind_results_ring(self, tensor):
+        """float32 [slots, num_envs, 2] device tensor: the k-th step call after the bind writes (reward, game_over code)
+        of every env into slot k % slots -- a per-step record of a rollout without any per-step host call."""
+        assert tensor.is_contiguous() and tensor.dtype.itemsize == 4 and tensor.dim() == 3
+        assert tensor.shape[1] == self.num_envs and tensor.shape[2] == 2
+        lib.check(self.L.xwb_bind_results_ring(self.h, C.c_void_p(tensor.data_ptr()), int(tensor.shape[0])))
+        self._results = tensor
+
     def bind_obs(self, tensor):
         """Redirect the observation output into caller-owned device memory (e.g. a shard of a gathered tensor)."""
         assert tensor.is_contiguous() and tensor.numel() * tensor.element_size() == self.num_envs * self.obs_bytes_per_env

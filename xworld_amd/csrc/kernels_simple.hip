@@ -14,6 +14,7 @@
 // Build with -ffp-contract=off: SimpleRace's float state must see the same
 // float/double rounding points as the reference (no FMA contraction).
 #include "xwb_common.h"
+#include "../../include/xwb_trig.h"
 
 namespace xwb {
 
@@ -64,7 +65,8 @@ template <> __device__ __forceinline__ uint8_t zero_chunk<1>() { return 0; }
 
 // One call = one SimulatorInterface::take_actions (or reset_game) for every env.
 template <int G>
-__device__ __forceinline__ void sg_body(const SgParams &p, uint32_t policy_step, int &pos, uint32_t &flags, int &steps) {
+__device__ __forceinline__ void sg_body(const SgParams &p, uint32_t policy_step, int &pos, uint32_t &flags, int &steps,
+                                        uint32_t &episode, bool &dirty) {
     using chunk_t = typename ChunkT<G>::type;
     __shared__ int s_pos[256];      // -1: leave this env's observation untouched
     __shared__ uint8_t s_fresh[256];
@@ -106,15 +108,17 @@ __device__ __forceinline__ void sg_body(const SgParams &p, uint32_t policy_step,
         if (do_reset) {
             // SimpleGameEngine::reset_game cpp:31-38 ; GameSimulator::reset_game
             pos = A / 2; flags = 0; steps = 0;
-            p.episode[e] += 1;
+            episode += 1;
             if (p.mode != MODE_STEP) {
                 // game_over() right after reset (over at once for array_size <= 2)
                 p.done[e] = (uint8_t)(sg_over(pos, A) ? SUCCESS : ALIVE);   // num_steps_ == 0 < max_steps
             }
-            atomicAdd(p.reset_count, 1);
             obs_pos = pos; fresh = true;
         }
-        if (obs_pos >= 0) { p.pos[e] = pos; p.flags[e] = (uint8_t)flags; p.num_steps[e] = steps; }
+        // resets are counted once per wavefront
+        const unsigned long long rm = __ballot(do_reset);
+        if (rm && (int)(tid & 63) == __ffsll((long long)rm) - 1) atomicAdd(p.reset_count, __popcll(rm));
+        if (obs_pos >= 0) dirty = true;
     }
     s_pos[tid] = obs_pos;
     s_fresh[tid] = fresh ? 1 : 0;
@@ -146,15 +150,17 @@ __device__ __forceinline__ void sg_body(const SgParams &p, uint32_t policy_step,
 // reward / code / observation like a separate launch would -- one launch instead of n (a 6 MB step is launch-bound)
 template <int G>
 __global__ __launch_bounds__(256) void sg_kernel(SgParams p) {
-    // the env's state stays in registers across the steps of one launch (it is still written back every step)
+    // the env's state stays in registers across the steps of one launch and is written back once
     const int e = blockIdx.x * 256 + threadIdx.x;
     int pos = 0, steps = 0;
-    uint32_t flags = 0;
-    if (e < p.n) { pos = p.pos[e]; flags = p.flags[e]; steps = p.num_steps[e]; }
+    uint32_t flags = 0, episode = 0;
+    bool dirty = false;
+    if (e < p.n) { pos = p.pos[e]; flags = p.flags[e]; steps = p.num_steps[e]; episode = p.episode[e]; }
     for (int it = 0; it < p.n_steps; ++it) {
-        sg_body<G>(p, p.policy_step + (uint32_t)it, pos, flags, steps);      // (p stays in kernel-argument memory: never written)
+        sg_body<G>(p, p.policy_step + (uint32_t)it, pos, flags, steps, episode, dirty);   // (p stays in kernel-argument memory: never written)
         __syncthreads();                                   // the shared staging of this step is dead
     }
+    if (e < p.n && dirty) { p.pos[e] = pos; p.flags[e] = (uint8_t)flags; p.num_steps[e] = steps; p.episode[e] = episode; }
 }
 
 hipError_t launch_simple_game(const SgParams &p, hipStream_t s) {
@@ -214,11 +220,11 @@ __device__ __forceinline__ void race_tangent(const RaceParams &p, float x, float
     }
 }
 
-// RaceEngine::get_screen, cpp:412-430
-__device__ __forceinline__ float4 race_screen(const RaceParams &p, const RaceCar &c) {
+// RaceEngine::get_screen, cpp:412-430.  (ca, sa) = cos / sin of the car's angle as doubles: the reference evaluates
+// cos(angle) and sin(angle) twice here and twice more in BaseCar::move / get_reward, always of the same float angle.
+__device__ __forceinline__ float4 race_screen(const RaceParams &p, const RaceCar &c, double ca, double sa) {
     float tx, ty;
     race_tangent(p, c.x, c.y, tx, ty);
-    double ca = cos((double)c.angle), sa = sin((double)c.angle);
     double d = (double)tx * ca + (double)ty * sa;
     float cos_theta = (float)fmax(-1.0, fmin(1.0, d));
     float sin_theta = (float)sqrt((double)(1 - cos_theta * cos_theta));
@@ -245,8 +251,10 @@ __device__ __forceinline__ void race_reset(const RaceParams &p, RaceCar &c, uint
     if (p.track_type == 1) {               // cpp:86-89
         float theta = (float)((double)(u_a * 2) * RACE_PI);
         float r = p.inner_radius + u_b * p.width;
-        float qx = (float)((double)r * cos((double)theta));
-        float qy = (float)((double)r * sin((double)theta));
+        double ct, st;
+        xwb_sincos((double)theta, &st, &ct);
+        float qx = (float)((double)r * ct);
+        float qy = (float)((double)r * st);
         c.x = qx + p.center_x; c.y = qy + p.center_y;
     } else {                               // cpp:196-199
         float dy = u_a * p.length / 2;
@@ -256,11 +264,19 @@ __device__ __forceinline__ void race_reset(const RaceParams &p, RaceCar &c, uint
     c.angle = (float)((double)(u_ang * 2) * RACE_PI);   // BaseCar::set_angle(true) cpp:237-243
 }
 
-__device__ __forceinline__ void race_body(const RaceParams &p, uint32_t policy_step) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= p.n) return;
-    RaceCar c = {p.x[e], p.y[e], p.angle[e]};
-    int steps = p.num_steps[e];
+// per-lane state of one env, kept in registers across the steps of one launch
+struct RaceLane {
+    RaceCar c;
+    int steps;
+    uint32_t episode;
+    double ca, sa;           // cos / sin of c.angle, valid when `trig`
+    bool trig, dirty;
+};
+
+// One SimulatorInterface::take_actions (or reset_game) for this lane's env.  Outputs (reward, code, action, frame) go to
+// HBM here; the car itself stays in `L` (race_kernel writes it back once per launch).
+__device__ __forceinline__ void race_body(const RaceParams &p, uint32_t policy_step, int e, RaceLane &L) {
+    RaceCar &c = L.c;
     bool do_reset = false, touched = false;
     if (p.mode == MODE_STEP) {
         int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, policy_step, p.n_legal);
@@ -271,22 +287,26 @@ __device__ __forceinline__ void race_body(const RaceParams &p, uint32_t policy_s
             atomicAdd(p.err_count, 1);
         } else {
             int action = p.legal[a];               // _legal_actions[action_id], cpp:474
-            steps += 1;
+            L.steps += 1;
             float reward = 0.0f;
-            for (int i = 0; i < p.act_rep; ++i) {
-                // RaceEngine::act cpp:290-341
-                int id = action;
-                float d_forward = 0.0f, d_turn = 0.0f;
-                int m = id % 3;
+            // RaceEngine::act cpp:290-341: the action decodes to the same (d_forward, d_turn) on every repeat
+            float d_forward = 0.0f, d_turn = 0.0f;
+            {
+                int id = action, m = id % 3;
                 if (m == 1) d_forward = p.delta_fwd; else if (m == 2) d_forward = -p.delta_fwd;
                 id /= 3;
                 m = id % 3;
                 if (m == 1) d_turn = p.delta_ang; else if (m == 2) d_turn = -p.delta_ang;
+            }
+            for (int i = 0; i < p.act_rep; ++i) {
                 // BaseCar::move cpp:227-235
+                const float a0 = c.angle;
                 c.angle += d_turn;
                 if ((double)c.angle > 2 * RACE_PI) c.angle = (float)((double)c.angle - 2 * RACE_PI);
                 else if (c.angle < 0) c.angle = (float)((double)c.angle + 2 * RACE_PI);
-                float dirx = (float)cos((double)c.angle), diry = (float)sin((double)c.angle);
+                if (!L.trig || c.angle != a0) xwb_sincos((double)c.angle, &L.sa, &L.ca);   // one evaluation per new angle
+                L.trig = true;
+                float dirx = (float)L.ca, diry = (float)L.sa;
                 float sx = d_forward * dirx, sy = d_forward * diry;
                 c.x += sx; c.y += sy;
                 // RaceEngine::get_reward cpp:386-410
@@ -302,7 +322,7 @@ __device__ __forceinline__ void race_body(const RaceParams &p, uint32_t policy_s
                 reward += (float)((double)rwd * p.reward_scale);
             }
             float rr = 0.0f; rr += reward;
-            int code = ((p.max_steps > 0 && steps >= p.max_steps) ? MAX_STEP : ALIVE) |
+            int code = ((p.max_steps > 0 && L.steps >= p.max_steps) ? MAX_STEP : ALIVE) |
                        (race_oob(p, c.x, c.y) ? DEAD : ALIVE);
             p.reward[e] = rr;
             p.done[e] = (uint8_t)code;
@@ -315,17 +335,20 @@ __device__ __forceinline__ void race_body(const RaceParams &p, uint32_t policy_s
                    (p.mode == MODE_RESET_MASK && p.mask[e] != 0);
     }
     if (do_reset) {
-        uint32_t ep = p.episode[e] + 1;
-        p.episode[e] = ep;
-        race_reset(p, c, p.env_gid0 + (uint32_t)e, ep);
-        steps = 0;
+        L.episode += 1;
+        race_reset(p, c, p.env_gid0 + (uint32_t)e, L.episode);
+        L.trig = false;
+        L.steps = 0;
         if (p.mode != MODE_STEP)
             p.done[e] = (uint8_t)(race_oob(p, c.x, c.y) ? DEAD : ALIVE);
-        atomicAdd(p.reset_count, 1);
         touched = true;
     }
+    // resets are counted once per wavefront
+    const unsigned long long rm = __ballot(do_reset);
+    if (rm && (int)(threadIdx.x & 63) == __ffsll((long long)rm) - 1) atomicAdd(p.reset_count, __popcll(rm));
     if (!touched) return;
-    p.x[e] = c.x; p.y[e] = c.y; p.angle[e] = c.angle; p.num_steps[e] = steps;
+    L.dirty = true;
+    if (!L.trig) { xwb_sincos((double)c.angle, &L.sa, &L.ca); L.trig = true; }
     // make_context_screens: [env][context][4] floats, 16 bytes per frame -> one float4 per lane
     float4 *frames = reinterpret_cast<float4 *>(p.obs) + (size_t)e * p.context;
     if (do_reset) {
@@ -333,13 +356,20 @@ __device__ __forceinline__ void race_body(const RaceParams &p, uint32_t policy_s
     } else {
         for (int f = 0; f + 1 < p.context; ++f) frames[f] = frames[f + 1];
     }
-    frames[p.context - 1] = race_screen(p, c);
+    frames[p.context - 1] = race_screen(p, c, L.ca, L.sa);
 }
 
 __global__ __launch_bounds__(256) void race_kernel(RaceParams p) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const bool live = e < p.n;
+    RaceLane L;
+    L.trig = false; L.dirty = false; L.ca = L.sa = 0;
+    L.c.x = L.c.y = L.c.angle = 0; L.steps = 0; L.episode = 0;
+    if (live) { L.c.x = p.x[e]; L.c.y = p.y[e]; L.c.angle = p.angle[e]; L.steps = p.num_steps[e]; L.episode = p.episode[e]; }
     for (int it = 0; it < p.n_steps; ++it) {               // n_steps > 1: xwb_step_n, see sg_kernel
-        race_body(p, p.policy_step + (uint32_t)it);
+        if (live) race_body(p, p.policy_step + (uint32_t)it, e, L);
     }
+    if (live && L.dirty) { p.x[e] = L.c.x; p.y[e] = L.c.y; p.angle[e] = L.c.angle; p.num_steps[e] = L.steps; p.episode[e] = L.episode; }
 }
 
 hipError_t launch_simple_race(const RaceParams &p, hipStream_t s) {

@@ -19,6 +19,7 @@
 #define XWB_PHILOX_ATTR __noinline__
 #include "xwb_common.h"
 #include "xw_device.h"
+#include "../../include/xwb_trig.h"
 
 namespace xwb {
 
@@ -305,7 +306,9 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
                 const double scale = 0.5 + (1 - 0.5) * u1;
                 const double offset = 0 + ((1 - scale) - 0) * u2;
                 const double angle = (90 - yaw * 180 / 3.14159265358979323846) * 3.1415926535897932384626433832795 / 180;
-                const double alpha = cos(angle) * scale, beta = sin(angle) * scale;
+                double sn, cs;                                  // include/xwb_trig.h: the same bits on the host's checker
+                xwb_sincos(angle, &sn, &cs);
+                const double alpha = cs * scale, beta = sn * scale;
                 double M[6] = {alpha, beta, (1 - alpha) * 32.0 - beta * 32.0, -beta, alpha, beta * 32.0 + (1 - alpha) * 32.0};
                 M[2] += (offset + scale / 2 - 0.5) * 64;
                 M[5] += (offset + scale / 2 - 0.5) * 64;

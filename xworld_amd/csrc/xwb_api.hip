@@ -7,6 +7,7 @@
 // gfx950 device xwb_create fails.
 #include "../../include/xwb.h"
 #include "xwb_common.h"
+#include "../../include/xwb_trig.h"
 
 #include <cmath>
 #include <cstdio>
@@ -37,6 +38,22 @@ int fail(int code, const std::string &msg) {
 
 struct EventPair { hipEvent_t a, b; };
 
+// Every entry point that touches the device runs with the batch's device current and restores the caller's
+// device on return: two batches on different GPUs of one process, or a caller whose current device is not the
+// batch's, launch on the right device.
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define XWB_ON_DEVICE(s) DeviceGuard _device_guard((s)->device)
+
 struct KernelTimer {
     std::vector<EventPair> pool;
     size_t used = 0;
@@ -46,12 +63,14 @@ struct KernelTimer {
 
 struct xwb_sim {
     xwb_config cfg;
+    int device = 0;
     int n = 0;
     size_t obs_bytes_per_env = 0;
     int out_h = 0, out_w = 0, out_c = 0;
     int num_actions = 0;
     uint32_t policy_step = 0;
     bool list_valid = false;
+    bool autoreset_done = false;           // the last step call already reset the envs whose codes are still set
     int count_sel = 0;
     bool profiling = false;
     KernelTimer t_render, t_step, t_reset;
@@ -65,7 +84,8 @@ struct xwb_sim {
     float *d_reward = nullptr;
     uint8_t *d_done = nullptr, *d_success = nullptr;
     void *d_obs = nullptr, *d_obs_owned = nullptr;
-    float2 *d_packed = nullptr;            // caller-owned (xwb_bind_results)
+    float2 *d_packed = nullptr;            // caller-owned (xwb_bind_results): slot 0 of the ring
+    int64_t packed_slots = 1, packed_pos = 0;   // xwb_bind_results_ring: step call k writes slot k % slots
     // simple_game
     int32_t *d_pos = nullptr;
     uint8_t *d_flags = nullptr;
@@ -220,6 +240,10 @@ int xw_setup(xwb_sim *s) {
         if ((c.tasks[i] >= XWB_TASK2D_TARGET) != (c.tasks[0] >= XWB_TASK2D_TARGET))
             return fail(XWB_ERR_ARG, "xworld: a task group holds XWorld3DNav* tasks or 2-D-native XWorldNav* tasks, not both");
     const int n = s->n, cells = c.max_dim * c.max_dim, ch = c.color ? 3 : 1;
+    const bool group2d_cfg = c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET;
+    // goal_cells holds one byte per goal slot with 0xff = "no goal": cell 255 only exists on a 16x16 map
+    if (c.max_dim > 15 && (c.visible_radius > 0 || group2d_cfg))
+        return fail(XWB_ERR_ARG, "xworld: max_dim 16 is not available with visible_radius > 0 or the 2-D-native task group (<= 15)");
     // name tables (xworld_env.py:247-255): per type, names -> icon variants (icon order = path order)
     int n_names[3] = {0, 0, 0};
     for (int i = 0; i < c.n_icons; ++i) {
@@ -284,6 +308,9 @@ int xw_setup(xwb_sim *s) {
     if ((rc = dev_alloc(s, &s->d_cand2d, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_sent_names, n, 0xff))) return rc;
     const bool curriculum = c.curriculum != 0 && c.map_kind == XWB_MAP_NAV;       // XWorldWalls never reads the flag
+    // under the curriculum the levels place 2 or 4 goals whatever cfg.num_goals says (XWorldNav.py:27-34): the per-env
+    // goal-image cache and every kernel that indexes it use the levels' maximum
+    const int img_goals = curriculum ? 4 : c.num_goals;
     if (curriculum) {
         if ((rc = dev_alloc(s, &s->d_cur_level, n, c.start_level))) return rc;
         if ((rc = dev_alloc(s, &s->d_cur_counter, n))) return rc;
@@ -294,7 +321,7 @@ int xw_setup(xwb_sim *s) {
     if ((rc = dev_alloc(s, &s->d_agent_dir, n, 1))) return rc;                 // heading "down": yaw 1.5707963
     if (c.visible_radius > 0) {
         if ((rc = dev_alloc(s, &s->d_goal_warp, (size_t)n * XW_MAX_GOALS * 6))) return rc;
-        if ((rc = dev_alloc(s, &s->d_goal_img, (size_t)n * c.num_goals * 4096))) return rc;
+        if ((rc = dev_alloc(s, &s->d_goal_img, (size_t)n * img_goals * 4096))) return rc;
         const size_t npx = (size_t)c.n_icons * 64 * 64;
         std::vector<uint8_t> a4((npx + 2) * 4, 0);
         for (size_t i = 0; i < npx; ++i) for (int k = 0; k < 3; ++k) a4[i * 4 + k] = c.icons64[i * 3 + k];
@@ -351,7 +378,7 @@ int xw_setup(xwb_sim *s) {
 
     XwParams &p = s->xw;
     p.n = n; p.context = c.context; p.max_steps = c.max_steps; p.act_rep = 1; p.auto_reset = 0;
-    p.map_kind = c.map_kind; p.max_dim = c.max_dim; p.dim = c.dim; p.num_goals = c.num_goals;
+    p.map_kind = c.map_kind; p.max_dim = c.max_dim; p.dim = c.dim; p.num_goals = img_goals;
     p.num_blocks = c.num_blocks; p.max_steps_factor = c.max_steps_factor; p.task_mode = c.task_mode;
     p.channels = ch; p.n_icons = c.n_icons;
     p.obs_f32 = f32 ? 1 : 0;
@@ -375,7 +402,7 @@ int xw_setup(xwb_sim *s) {
     p.grid = s->d_grid; p.agent_xy = s->d_agent; p.task_steps = s->d_task_steps; p.task_state = s->d_task_state;
     p.num_steps = s->d_num_steps; p.episode = s->d_episode; p.success = s->d_success; p.fresh = s->d_fresh;
     p.reward = s->d_reward; p.done = s->d_done; p.obs = static_cast<uint8_t *>(s->d_obs);
-    p.packed = s->d_packed;
+    p.packed = nullptr;                     // set per call (xw_params)
     p.done_list = s->d_done_list; p.done_count = s->d_done_count; p.done_count_next = s->d_done_count + 1;
     p.err_count = s->d_err;
     if (c.visible_radius > 0) {
@@ -403,6 +430,11 @@ void timer_end(xwb_sim *s, KernelTimer &t, hipStream_t st) {
     t.used++;
 }
 
+// the results slot of the step call being queued (xwb_bind_results_ring)
+float2 *packed_slot(xwb_sim *s) {
+    return s->d_packed ? s->d_packed + (size_t)(s->packed_pos % s->packed_slots) * (size_t)s->n : nullptr;
+}
+
 SgParams sg_params(xwb_sim *s) {
     SgParams p{};
     const xwb_config &c = s->cfg;
@@ -412,7 +444,7 @@ SgParams sg_params(xwb_sim *s) {
     p.actions = nullptr; p.mask = nullptr; p.actions_out = s->d_actions;
     p.pos = s->d_pos; p.flags = s->d_flags; p.num_steps = s->d_num_steps; p.episode = s->d_episode;
     p.reward = s->d_reward; p.done = s->d_done; p.obs = static_cast<uint8_t *>(s->d_obs);
-    p.packed = s->d_packed;
+    p.packed = packed_slot(s);
     p.n_steps = 1;
     p.err_count = s->d_err; p.reset_count = s->d_reset_count;
     return p;
@@ -427,7 +459,7 @@ RaceParams race_params(xwb_sim *s) {
     p.actions = nullptr; p.mask = nullptr; p.actions_out = s->d_actions;
     p.x = s->d_x; p.y = s->d_y; p.angle = s->d_angle; p.num_steps = s->d_num_steps; p.episode = s->d_episode;
     p.reward = s->d_reward; p.done = s->d_done; p.obs = static_cast<float *>(s->d_obs);
-    p.packed = s->d_packed;
+    p.packed = packed_slot(s);
     p.n_steps = 1;
     p.err_count = s->d_err; p.reset_count = s->d_reset_count;
     return p;
@@ -453,7 +485,7 @@ int simple_reset(xwb_sim *s, int mode, const uint8_t *mask, hipStream_t st) {
 XwParams xw_params(xwb_sim *s) {
     XwParams p = s->xw;
     p.obs = static_cast<uint8_t *>(s->d_obs);
-    p.packed = s->d_packed;
+    p.packed = packed_slot(s);
     p.policy_step = s->policy_step;
     p.list_flag = 2;
     p.done_count = s->d_done_count + s->count_sel;
@@ -563,6 +595,8 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         if (autoreset) HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
     }
     s->policy_step += 1;
+    s->packed_pos += 1;
+    s->autoreset_done = autoreset;
     return XWB_OK;
 }
 
@@ -613,9 +647,10 @@ int xwb_create(const xwb_config *cfg, xwb_sim **out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(XWB_ERR_HIP, "no HIP device: libxwb.so has no CPU path");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(XWB_ERR_ARG, "bad device ordinal");
-    HIP_TRY(hipSetDevice(cfg->device));
+    DeviceGuard _device_guard(cfg->device);           // the caller's current device is restored on return
     xwb_sim *s = new xwb_sim();
     s->cfg = *cfg;
+    s->device = cfg->device;
     s->n = cfg->num_envs;
     const int n = s->n;
     int rc = XWB_OK;
@@ -694,6 +729,7 @@ int xwb_create(const xwb_config *cfg, xwb_sim **out) {
 
 int xwb_destroy(xwb_sim *s) {
     if (!s) return XWB_OK;
+    XWB_ON_DEVICE(s);
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->side) (void)hipStreamDestroy(s->side);
     if (s->ev_step) (void)hipEventDestroy(s->ev_step);
@@ -707,7 +743,9 @@ int xwb_destroy(xwb_sim *s) {
 
 int xwb_reset(xwb_sim *s, void *stream) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    XWB_ON_DEVICE(s);
     hipStream_t st = as_stream(stream);
+    s->autoreset_done = false;
     if (s->cfg.game != XWB_XWORLD2D) return simple_reset(s, MODE_RESET_ALL, nullptr, st);
     s->list_valid = false;
     return xw_reset_list(s, MODE_RESET_ALL, false, true, st);
@@ -715,7 +753,15 @@ int xwb_reset(xwb_sim *s, void *stream) {
 
 int xwb_reset_done(xwb_sim *s, void *stream) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    XWB_ON_DEVICE(s);
     hipStream_t st = as_stream(stream);
+    if (s->autoreset_done) {
+        // xwb_step_autoreset / xwb_step_n already reset every env whose code is set (the codes are kept for the caller
+        // to read): clearing them is all that is left -- resetting those envs again would skip an episode
+        s->autoreset_done = false;
+        HIP_TRY(hipMemsetAsync(s->d_done, 0, (size_t)s->n, st));
+        return XWB_OK;
+    }
     if (s->cfg.game != XWB_XWORLD2D) return simple_reset(s, MODE_RESET_DONE, nullptr, st);
     if (!s->list_valid) {                      // no step since the last reset: rebuild the list from done[]
         XwParams p = xw_params(s);
@@ -729,6 +775,7 @@ int xwb_reset_done(xwb_sim *s, void *stream) {
 
 int xwb_reset_masked(xwb_sim *s, const uint8_t *mask_dev, void *stream) {
     if (!s || !mask_dev) return fail(XWB_ERR_ARG, "NULL argument");
+    XWB_ON_DEVICE(s);
     hipStream_t st = as_stream(stream);
     if (s->cfg.game != XWB_XWORLD2D) return simple_reset(s, MODE_RESET_MASK, mask_dev, st);
     XwParams p = xw_params(s);
@@ -741,6 +788,7 @@ int xwb_reset_masked(xwb_sim *s, const uint8_t *mask_dev, void *stream) {
 
 int xwb_reset_env(xwb_sim *s, int32_t env, void *stream) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    XWB_ON_DEVICE(s);
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
     hipStream_t st = as_stream(stream);
     HIP_TRY(hipMemsetAsync(s->d_mask, 0, (size_t)s->n, st));
@@ -750,11 +798,13 @@ int xwb_reset_env(xwb_sim *s, int32_t env, void *stream) {
 
 int xwb_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, void *stream) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    XWB_ON_DEVICE(s);
     return do_step(s, actions_dev, act_rep, false, as_stream(stream));
 }
 
 int xwb_step_host(xwb_sim *s, const int32_t *actions_host, int32_t act_rep, void *stream) {
     if (!s || !actions_host) return fail(XWB_ERR_ARG, "NULL argument");
+    XWB_ON_DEVICE(s);
     hipStream_t st = as_stream(stream);
     HIP_TRY(hipMemcpyAsync(s->d_actions_in, actions_host, sizeof(int32_t) * (size_t)s->n, hipMemcpyHostToDevice, st));
     return do_step(s, s->d_actions_in, act_rep, false, st);
@@ -762,6 +812,7 @@ int xwb_step_host(xwb_sim *s, const int32_t *actions_host, int32_t act_rep, void
 
 int xwb_step_n(xwb_sim *s, int32_t n_steps, int32_t act_rep, void *stream) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    XWB_ON_DEVICE(s);
     if (n_steps < 1 || act_rep < 1) return fail(XWB_ERR_ARG, "n_steps and act_rep must be >= 1");
     hipStream_t st = as_stream(stream);
     if (s->cfg.game == XWB_XWORLD2D) {                      // one render per step is the work: nothing to fuse
@@ -781,16 +832,20 @@ int xwb_step_n(xwb_sim *s, int32_t n_steps, int32_t act_rep, void *stream) {
     }
     timer_end(s, s->t_step, st);
     s->policy_step += (uint32_t)n_steps;
+    s->packed_pos += 1;
+    s->autoreset_done = true;
     return XWB_OK;
 }
 
 int xwb_step_autoreset(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, void *stream) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    XWB_ON_DEVICE(s);
     return do_step(s, actions_dev, act_rep, true, as_stream(stream));
 }
 
 int xwb_check_errors(xwb_sim *s, void *stream, int32_t *n_bad) {
     if (!s || !n_bad) return fail(XWB_ERR_ARG, "NULL argument");
+    XWB_ON_DEVICE(s);
     hipStream_t st = as_stream(stream);
     HIP_TRY(hipMemcpyAsync(n_bad, s->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemsetAsync(s->d_err, 0, sizeof(int32_t), st));
@@ -805,10 +860,15 @@ int xwb_obs_dev(xwb_sim *s, void **ptr, size_t *bytes_per_env) {
     return XWB_OK;
 }
 
-int xwb_bind_results(xwb_sim *s, float *packed_dev) {
+int xwb_bind_results(xwb_sim *s, float *packed_dev) { return xwb_bind_results_ring(s, packed_dev, 1); }
+
+int xwb_bind_results_ring(xwb_sim *s, float *packed_dev, int64_t slots) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
     if (packed_dev && (reinterpret_cast<uintptr_t>(packed_dev) & 7u)) return fail(XWB_ERR_ARG, "results buffer must be 8-byte aligned");
+    if (slots < 1) return fail(XWB_ERR_ARG, "slots must be >= 1");
     s->d_packed = reinterpret_cast<float2 *>(packed_dev);
+    s->packed_slots = slots;
+    s->packed_pos = 0;
     return XWB_OK;
 }
 
@@ -841,6 +901,7 @@ int xwb_xw_grid_dev(xwb_sim *s, uint16_t **ptr) {
 
 int xwb_done_count(xwb_sim *s, void *stream, int32_t *n_done) {
     if (!s || !n_done) return fail(XWB_ERR_ARG, "NULL argument");
+    XWB_ON_DEVICE(s);
     hipStream_t st = as_stream(stream);
     const int32_t *src = s->cfg.game == XWB_XWORLD2D ? s->d_done_count + s->count_sel : s->d_reset_count;
     HIP_TRY(hipMemcpyAsync(n_done, src, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -880,6 +941,7 @@ int xwb_num_envs(const xwb_sim *s, int32_t *n) {
 
 int xwb_get_env_state(xwb_sim *s, int32_t env, void *stream, xwb_env_state *o) {
     if (!s || !o) return fail(XWB_ERR_ARG, "NULL argument");
+    XWB_ON_DEVICE(s);
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
     hipStream_t st = as_stream(stream);
     memset(o, 0, sizeof *o);
@@ -938,6 +1000,7 @@ int xwb_get_env_state(xwb_sim *s, int32_t env, void *stream, xwb_env_state *o) {
 namespace {
 int copy_out(xwb_sim *s, void *dst, const void *src, size_t bytes, void *stream) {
     if (!s || !dst) return fail(XWB_ERR_ARG, "NULL argument");
+    XWB_ON_DEVICE(s);
     hipStream_t st = as_stream(stream);
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st));
     hipPointerAttribute_t attr;
@@ -949,6 +1012,7 @@ int copy_out(xwb_sim *s, void *dst, const void *src, size_t bytes, void *stream)
 
 int xwb_get_obs(xwb_sim *s, void *dst, size_t bytes, void *stream) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    XWB_ON_DEVICE(s);
     if (bytes != (size_t)s->n * s->obs_bytes_per_env) return fail(XWB_ERR_ARG, "bytes must be num_envs * bytes_per_env");
     return copy_out(s, dst, s->d_obs, bytes, stream);
 }
@@ -957,6 +1021,7 @@ int xwb_get_done(xwb_sim *s, uint8_t *dst, void *stream) { return s ? copy_out(s
 
 int xwb_get_env_obs(xwb_sim *s, int32_t env, void *stream, void *out_host, size_t bytes) {
     if (!s || !out_host) return fail(XWB_ERR_ARG, "NULL argument");
+    XWB_ON_DEVICE(s);
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
     if (bytes != s->obs_bytes_per_env) return fail(XWB_ERR_ARG, "bytes must equal bytes_per_env");
     hipStream_t st = as_stream(stream);
@@ -967,6 +1032,7 @@ int xwb_get_env_obs(xwb_sim *s, int32_t env, void *stream, void *out_host, size_
 
 int xwb_get_env_grid(xwb_sim *s, int32_t env, void *stream, uint16_t *out_host) {
     if (!s || !out_host) return fail(XWB_ERR_ARG, "NULL argument");
+    XWB_ON_DEVICE(s);
     if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
     hipStream_t st = as_stream(stream);
@@ -979,6 +1045,7 @@ int xwb_get_env_grid(xwb_sim *s, int32_t env, void *stream, uint16_t *out_host) 
 int xwb_xw_load_map_task(xwb_sim *s, int32_t env, const uint16_t *grid_host, int32_t agent_x, int32_t agent_y,
                          int32_t dim, int32_t task, int32_t target) {
     if (!s || !grid_host) return fail(XWB_ERR_ARG, "NULL argument");
+    XWB_ON_DEVICE(s);
     if (task < XWB_TASK_TARGET || task > XWB_TASK2D_BETWEEN) return fail(XWB_ERR_ARG, "unknown task id");
     if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
@@ -1085,6 +1152,7 @@ int xwb_xw_load_map(xwb_sim *s, int32_t env, const uint16_t *grid_host, int32_t 
 
 int xwb_xw_set_agent_dir(xwb_sim *s, int32_t env, int32_t dir) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    XWB_ON_DEVICE(s);
     if (s->cfg.game != XWB_XWORLD2D || s->cfg.visible_radius == 0) return fail(XWB_ERR_STATE, "not an egocentric xworld batch");
     if (env < 0 || env >= s->n || dir < 0 || dir > 3) return fail(XWB_ERR_ARG, "env or dir out of range");
     HIP_TRY(hipDeviceSynchronize());
@@ -1095,6 +1163,7 @@ int xwb_xw_set_agent_dir(xwb_sim *s, int32_t env, int32_t dir) {
 
 int xwb_xw_set_goal_pose(xwb_sim *s, int32_t env, int32_t cell_x, int32_t cell_y, double yaw, double scale, double offset) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    XWB_ON_DEVICE(s);
     if (s->cfg.game != XWB_XWORLD2D || s->cfg.visible_radius == 0) return fail(XWB_ERR_STATE, "not an egocentric xworld batch");
     const int D = s->cfg.max_dim;
     if (env < 0 || env >= s->n || cell_x < 0 || cell_y < 0 || cell_x >= D || cell_y >= D) return fail(XWB_ERR_ARG, "env or cell out of range");
@@ -1106,7 +1175,9 @@ int xwb_xw_set_goal_pose(xwb_sim *s, int32_t env, int32_t cell_x, int32_t cell_y
     if (slot < 0) return fail(XWB_ERR_ARG, "no goal at that cell");
     // XItem::get_item_image (xitem.cpp:46-60) + the inversion cv::warpAffine performs
     const double angle = (90 - yaw * 180 / 3.14159265358979323846) * 3.1415926535897932384626433832795 / 180;
-    const double alpha = std::cos(angle) * scale, beta = std::sin(angle) * scale;
+    double sn, cs;                                  // include/xwb_trig.h: the reset kernel's arithmetic, bit for bit
+    xwb_sincos(angle, &sn, &cs);
+    const double alpha = cs * scale, beta = sn * scale;
     double M[6] = {alpha, beta, (1 - alpha) * 32.0 - beta * 32.0, -beta, alpha, beta * 32.0 + (1 - alpha) * 32.0};
     M[2] += (offset + scale / 2 - 0.5) * 64;
     M[5] += (offset + scale / 2 - 0.5) * 64;
@@ -1122,6 +1193,7 @@ int xwb_xw_set_goal_pose(xwb_sim *s, int32_t env, int32_t cell_x, int32_t cell_y
 
 int xwb_xw_refresh_obs(xwb_sim *s, int32_t env) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    XWB_ON_DEVICE(s);
     if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
     HIP_TRY(hipDeviceSynchronize());
@@ -1141,6 +1213,7 @@ int xwb_xw_refresh_obs(xwb_sim *s, int32_t env) {
 
 int xwb_race_set_car(xwb_sim *s, int32_t env, float x, float y, float angle) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    XWB_ON_DEVICE(s);
     if (s->cfg.game != XWB_SIMPLE_RACE) return fail(XWB_ERR_STATE, "not a simple_race batch");
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
     HIP_TRY(hipDeviceSynchronize());
@@ -1162,7 +1235,9 @@ int xwb_get_extra_info(xwb_sim *s, int32_t env, void *stream, char *out, size_t 
     static const char *events[] = {"", "correct_goal", "wrong_goal", "time_up"};
     const char *task = st.xw_task >= 0 && st.xw_task < 9 ? tasks[st.xw_task] : "";
     const char *event = st.xw_event >= 0 && st.xw_event < 4 ? events[st.xw_event] : "";
-    snprintf(out, cap, "%d|task:%s,event:%s,height:%d,width:%d", (int)getpid(), task, event, s->cfg.dim, s->cfg.dim);
+    // xworld_.actual_height() / actual_width() (xworld.h:59,70): the level's dims under FLAGS_curriculum
+    const int dim = s->d_cur_level ? 3 + st.xw_level : s->cfg.dim;
+    snprintf(out, cap, "%d|task:%s,event:%s,height:%d,width:%d", (int)getpid(), task, event, dim, dim);
     return XWB_OK;
 }
 
@@ -1221,6 +1296,7 @@ int xwb_state_bytes(xwb_sim *s, int32_t include_obs, size_t *bytes) {
 
 int xwb_save_state(xwb_sim *s, int32_t include_obs, uint8_t *out_host, size_t cap) {
     if (!s || !out_host) return fail(XWB_ERR_ARG, "NULL argument");
+    XWB_ON_DEVICE(s);
     size_t need = 0;
     xwb_state_bytes(s, include_obs, &need);
     if (cap < need) return fail(XWB_ERR_ARG, "buffer smaller than xwb_state_bytes");
@@ -1230,7 +1306,7 @@ int xwb_save_state(xwb_sim *s, int32_t include_obs, uint8_t *out_host, size_t ca
     memcpy(h.magic, "XWBSTATE", 8);
     h.version = 1; h.game = (uint32_t)s->cfg.game; h.num_envs = (uint32_t)s->n; h.include_obs = include_obs ? 1u : 0u;
     h.n_arrays = (uint32_t)arrays.size(); h.policy_step = s->policy_step; h.count_sel = (uint32_t)s->count_sel;
-    h.list_valid = s->list_valid ? 1u : 0u; h.obs_bytes_per_env = s->obs_bytes_per_env; h.cfg_hash = config_hash(s->cfg);
+    h.list_valid = (s->list_valid ? 1u : 0u) | (s->autoreset_done ? 2u : 0u); h.obs_bytes_per_env = s->obs_bytes_per_env; h.cfg_hash = config_hash(s->cfg);
     uint8_t *w = out_host;
     memcpy(w, &h, sizeof h); w += sizeof h;
     for (auto &a : arrays) {
@@ -1244,6 +1320,7 @@ int xwb_save_state(xwb_sim *s, int32_t include_obs, uint8_t *out_host, size_t ca
 
 int xwb_load_state(xwb_sim *s, const uint8_t *in_host, size_t bytes) {
     if (!s || !in_host) return fail(XWB_ERR_ARG, "NULL argument");
+    XWB_ON_DEVICE(s);
     if (bytes < sizeof(StateHeader)) return fail(XWB_ERR_ARG, "not a state blob");
     StateHeader h;
     memcpy(&h, in_host, sizeof h);
@@ -1263,7 +1340,7 @@ int xwb_load_state(xwb_sim *s, const uint8_t *in_host, size_t bytes) {
         HIP_TRY(hipMemcpy(a.ptr, r, a.bytes, hipMemcpyHostToDevice));
         r += b;
     }
-    s->policy_step = h.policy_step; s->count_sel = (int)h.count_sel; s->list_valid = h.list_valid != 0;
+    s->policy_step = h.policy_step; s->count_sel = (int)h.count_sel; s->list_valid = (h.list_valid & 1u) != 0; s->autoreset_done = (h.list_valid & 2u) != 0;
     if (s->cfg.game == XWB_XWORLD2D) {
         XwParams p = xw_params(s);
         if (p.visible_radius) HIP_TRY(launch_xw_warp_goals(p, false, nullptr));
@@ -1342,6 +1419,7 @@ int xwb_profile_begin(xwb_sim *s) {
 
 int xwb_profile_end(xwb_sim *s, void *stream, const char *kernel, double *avg_us, int64_t *launches) {
     if (!s || !kernel || !avg_us || !launches) return fail(XWB_ERR_ARG, "NULL argument");
+    XWB_ON_DEVICE(s);
     KernelTimer *t = nullptr;
     if (!strcmp(kernel, "render")) t = &s->t_render;
     else if (!strcmp(kernel, "step")) t = &s->t_step;

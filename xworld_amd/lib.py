@@ -66,6 +66,7 @@ _SIGS = [
     ("xwb_check_errors", C.c_int, [_vp, _vp, C.POINTER(C.c_int32)]),
     ("xwb_obs_dev", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     ("xwb_bind_results", C.c_int, [_vp, _vp]),
+    ("xwb_bind_results_ring", C.c_int, [_vp, _vp, C.c_int64]),
     ("xwb_bind_obs", C.c_int, [_vp, _vp]),
     ("xwb_reward_dev", C.c_int, [_vp, C.POINTER(_vp)]),
     ("xwb_game_over_dev", C.c_int, [_vp, C.POINTER(_vp)]),

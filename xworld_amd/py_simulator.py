@@ -92,8 +92,11 @@ class Simulator:
             events = {0: "", 1: "correct_goal", 2: "wrong_goal", 3: "time_up"}
             d["task"] = assets.TASK_NAMES[st.xw_task]
             d["event"] = events[st.xw_event]
-            d["height"] = str(self.batch.cfg.dim)                     # get_extra_info, xworld_simulator.cpp:495-504
-            d["width"] = str(self.batch.cfg.dim)
+            # get_extra_info, xworld_simulator.cpp:495-504: xworld_.actual_height() / actual_width() = the level's
+            # dims (3 + level) under FLAGS_curriculum
+            dim = 3 + st.xw_level if self.batch.cfg.curriculum != 0 and self.batch.cfg.map_kind == 0 else self.batch.cfg.dim
+            d["height"] = str(dim)
+            d["width"] = str(dim)
         return d
 
     def get_num_steps(self):

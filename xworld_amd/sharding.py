@@ -4,10 +4,13 @@ Envs are independent (the reference's own scale-out is one OS process per env,
 examples/demo_interface.cpp:67-95), so the batch is split into contiguous ranges of *global* env ids;
 every RNG stream is keyed by the global id, hence results do not depend on the number of shards.
 The only exchange is the per-step gather of results to rank 0:
-  * gather_results: (reward f32, game_over u8) of every shard, a few bytes per env;
-  * gather_screens: every shard's observation slab into one contiguous tensor on rank 0.  Each remote
-    shard crosses its one direct xGMI link to the root, so this is link-bound (DESIGN.md "multi-GPU").
-These helpers only move tensors; they work with any backend (tests use gloo on CPU).
+  * ResultGather: (reward f32, game_over u8) of every shard, a few bytes per env;
+  * ScreensGather: every shard's observation slab into one contiguous tensor on rank 0.  Each remote
+    shard crosses its one direct xGMI link to the root, so this is link-bound (DESIGN.md "multi-GPU");
+    it is double-buffered: the transfer of step t runs beside the kernels of step t + 1.
+These helpers only move tensors; they work with any backend.  The CPU tests use gloo; the single-GPU test of
+the N > 1 path runs several ranks on one device over gloo, whose device-tensor collectives are staged through
+host memory here (`_Staged`) -- RCCL refuses two ranks on one device.
 """
 import torch
 import torch.distributed as dist
@@ -27,6 +30,89 @@ def shard_counts(total_envs, world_size):
     return [shard_range(total_envs, world_size, r)[1] for r in range(world_size)]
 
 
+def backend_info(group=None):
+    """What the exchange runs on: {"world_size", "backend", "version"} (version = RCCL's for backend nccl)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"world_size": 1, "backend": "none", "version": None}
+    be = dist.get_backend(group)
+    ver = None
+    if be == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                                   # pragma: no cover
+            ver = None
+    return {"world_size": dist.get_world_size(group), "backend": be, "version": ver}
+
+
+def _needs_staging(t, group=None):
+    # gloo has no device-tensor send / recv / all_gather: stage through host memory (test transport only)
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+class _Staged:
+    """A finished-on-wait handle for an exchange that went through host staging buffers."""
+
+    def __init__(self, copies):
+        self.copies = copies          # [(device destination, host source)]
+
+    def wait(self):
+        for dst, src in self.copies:
+            dst.copy_(src)
+
+
+def _p2p_gather(local, out_root, counts, rank, dst, group):
+    """isend / irecv of every rank's slab into its slice of out_root on `dst`; returns the work handles."""
+    world = len(counts)
+    offsets = [sum(counts[:r]) for r in range(world)]
+    if _needs_staging(local, group):
+        handles = []
+        if rank == dst:
+            copies = []
+            for r in range(world):
+                if r == dst or counts[r] == 0:
+                    continue
+                host = torch.empty((counts[r],) + tuple(out_root.shape[1:]), dtype=out_root.dtype)
+                handles.append(dist.irecv(host, r, group=group))
+                copies.append((out_root[offsets[r]:offsets[r] + counts[r]], host))
+            handles.append(_Staged(copies))     # waited last: the receives above are complete by then
+            return _Ordered(handles)
+        if counts[rank] > 0:
+            handles.append(dist.isend(local.cpu(), dst, group=group))
+        return _Ordered(handles)
+    if rank == dst:
+        ops = [dist.P2POp(dist.irecv, out_root[offsets[r]:offsets[r] + counts[r]], r, group=group)
+               for r in range(world) if r != dst and counts[r] > 0]
+    else:
+        ops = [dist.P2POp(dist.isend, local, dst, group=group)] if counts[rank] > 0 else []
+    return _Ordered(dist.batch_isend_irecv(ops) if ops else [])
+
+
+class _Ordered:
+    def __init__(self, handles):
+        self.handles = list(handles)
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+
+
+def gather_slabs(local, out_root, counts, rank, dst=0, group=None, async_op=False):
+    """Every rank's `local` [count_r, ...] slab into out_root[offset_r : offset_r + count_r] on `dst`
+    (the root's own slab is copied unless it already aliases its slice).  async_op: returns a handle whose
+    wait() orders the current stream behind the transfer instead of waiting here."""
+    world = len(counts)
+    if rank == dst:
+        off = sum(counts[:dst])
+        mine = out_root[off:off + counts[dst]]
+        if mine.data_ptr() != local.data_ptr():
+            mine.copy_(local)
+    work = _p2p_gather(local, out_root, counts, rank, dst, group) if world > 1 else _Ordered([])
+    if async_op:
+        return work
+    work.wait()
+    return out_root if rank == dst else None
+
+
 class ResultGather:
     """Per-step gather of (reward, game_over) to `dst`.  Equal shard sizes -> one all_gather_into_tensor of a packed
     [n, 2] float tensor; ragged shards -> point-to-point into slices.
@@ -34,7 +120,9 @@ class ResultGather:
     `start()` enqueues the exchange of the step that just finished and returns at once; `finish()` waits for
     it (stream-side) and hands out the gathered tensors.  Calling finish() for step t only after step t+1 has
     been enqueued lets the (latency-bound, few-hundred-KB) collective run beside the next step's kernels --
-    two packed/out buffers alternate so the in-flight exchange is never overwritten.  `__call__` = start + finish."""
+    two packed/out buffers alternate so the in-flight exchange is never overwritten.  `start(packed=t)` ships a
+    caller-owned [n, 2] tensor instead (e.g. one row of a per-step record the simulator wrote through
+    bind_results); the caller then keeps it untouched until finish().  `__call__` = start + finish."""
 
     def __init__(self, counts, rank, device, dst=0, group=None):
         self.counts, self.rank, self.dst, self.group = list(counts), rank, dst, group
@@ -55,22 +143,28 @@ class ResultGather:
         (BatchedSimulator.bind_results) and call start() without arguments -- no packing kernels at all."""
         return self.packed[self.slot]
 
-    def start(self, reward=None, game_over=None):
+    def start(self, reward=None, game_over=None, packed=None):
         if self.pending is not None:
             raise RuntimeError("ResultGather.start() called twice without finish()")
         k = self.slot
         self.slot ^= 1
-        packed, out = self.packed[k], self.out[k]
-        if reward is not None:
-            packed[:, 0] = reward
-            packed[:, 1] = game_over.to(torch.float32)
+        out = self.out[k]
+        if packed is None:
+            packed = self.packed[k]
+            if reward is not None:
+                packed[:, 0] = reward
+                packed[:, 1] = game_over.to(torch.float32)
         work = None
         if self.world == 1:
             out.copy_(packed)
-        elif self.equal:
+        elif self.equal and not _needs_staging(packed, self.group):
             work = dist.all_gather_into_tensor(out, packed, group=self.group, async_op=True)
+        elif self.equal:
+            host_out = torch.empty(tuple(out.shape), dtype=out.dtype)
+            h = dist.all_gather_into_tensor(host_out, packed.cpu(), group=self.group, async_op=True)
+            work = _Ordered([h, _Staged([(out, host_out)])])
         else:
-            gather_slabs(packed, out, self.counts, self.rank, self.dst, self.group)
+            work = gather_slabs(packed, out, self.counts, self.rank, self.dst, self.group, async_op=True)
         self.pending = (work, k)
 
     def finish(self):
@@ -90,20 +184,71 @@ class ResultGather:
         return self.finish()
 
 
-def gather_slabs(local, out_root, counts, rank, dst=0, group=None):
-    """Every rank's `local` [count_r, ...] slab into out_root[offset_r : offset_r + count_r] on `dst`
-    (the root's own slab is copied unless it already aliases its slice)."""
-    world = len(counts)
-    offsets = [sum(counts[:r]) for r in range(world)]
-    if rank == dst:
-        mine = out_root[offsets[dst]:offsets[dst] + counts[dst]]
-        if mine.data_ptr() != local.data_ptr():
-            mine.copy_(local)
-        ops = [dist.P2POp(dist.irecv, out_root[offsets[r]:offsets[r] + counts[r]], r, group=group)
-               for r in range(world) if r != dst and counts[r] > 0]
-    else:
-        ops = [dist.P2POp(dist.isend, local, dst, group=group)] if counts[rank] > 0 else []
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-    return out_root if rank == dst else None
+class ScreensGather:
+    """Per-step gather of every shard's screens into ONE contiguous [total_envs, ...] tensor on `dst`, double-buffered
+    (SURVEY 8(e)): two destination tensors on the root and two observation buffers on every rank alternate, so the
+    transfer of step t (async point-to-point over each remote GPU's direct xGMI link to the root) runs beside the
+    kernels of step t + 1 and is only waited for when its buffers come up for reuse, two steps later.
+
+        sg = ScreensGather(sim, counts, rank)
+        loop:  sg.bind_next()            # the simulator renders this step into the free buffer pair
+               sim.step(); sim.reset_done()
+               sg.start()                # ship this step's screens
+               screens = sg.latest()     # (root) the newest COMPLETE gathered tensor: the previous step's; None at first
+        sg.drain()                       # -> the last step's gathered tensor
+
+    The root renders straight into its slice of the destination (BatchedSimulator.bind_obs), so its own slab is never
+    copied.  A context ring (context > 1) shifts frames in place and therefore needs ONE observation buffer: the gather
+    then is waited for before the next step (`depth` = 1)."""
+
+    def __init__(self, sim, counts, rank, dst=0, group=None):
+        self.sim, self.counts, self.rank, self.dst, self.group = sim, list(counts), rank, dst, group
+        self.world = len(counts)
+        self.depth = 2 if sim.cfg.context == 1 else 1
+        shape = tuple(sim.obs.shape[1:])
+        dtype, device = sim.obs.dtype, sim.obs.device
+        n = counts[rank]
+        self.off = sum(counts[:rank])
+        if rank == dst:
+            self.full = [torch.empty((sum(counts),) + shape, dtype=dtype, device=device) for _ in range(self.depth)]
+            self.local = [f[self.off:self.off + n] for f in self.full]
+        else:
+            self.full = [None] * self.depth
+            self.local = [torch.empty((n,) + shape, dtype=dtype, device=device) for _ in range(self.depth)]
+        self.work = [None] * self.depth
+        self.k = self.depth - 1          # buffer pair of the current step
+        self.done_k = None               # newest pair whose gather was waited for
+
+    def bind_next(self):
+        self.k = (self.k + 1) % self.depth
+        if self.work[self.k] is not None:             # its previous transfer must be over before it is rendered into
+            self.work[self.k].wait()
+            self.work[self.k] = None
+            self.done_k = self.k
+        self.sim.bind_obs(self.local[self.k])
+
+    def start(self):
+        self.work[self.k] = gather_slabs(self.local[self.k], self.full[self.k], self.counts, self.rank, self.dst,
+                                         self.group, async_op=True)
+        if self.depth == 1:
+            self.work[self.k].wait()
+            self.work[self.k] = None
+            self.done_k = self.k
+
+    def latest(self):
+        """root: newest gathered tensor that is complete in stream order (with depth 2: the previous step's)."""
+        k = self.k if self.depth == 1 else (self.k + 1) % self.depth
+        if self.depth == 2 and self.work[k] is not None:
+            self.work[k].wait()
+            self.work[k] = None
+            self.done_k = k
+        return self.full[k] if (self.rank == self.dst and self.done_k is not None) else None
+
+    def drain(self):
+        for i in range(self.depth):
+            k = (self.k + 1 + i) % self.depth
+            if self.work[k] is not None:
+                self.work[k].wait()
+                self.work[k] = None
+        self.done_k = self.k
+        return self.full[self.k] if self.rank == self.dst else None
