@@ -218,7 +218,7 @@ def test_simple_race_full_size_c3(oracle):
     sim = BatchedSimulator("simple_race", _race_opts({}), num_envs=n, seed=1, policy_seed=5)
     for t in range(steps):
         sim.reset_done()
-        obs = sim.obs.cpu().numpy().reshape(n, 16).view(np.uint8)
+        obs = sim.obs.cpu().numpy().reshape(n, 4).view(np.uint8)
         assert np.array_equal(oracle.obs_checksum_np(obs), ref.obs_ck[t]), t       # the frame each policy step sees
         sim.step()
         assert np.array_equal(sim.reward.cpu().numpy().view(np.uint32), ref.rewards[t].view(np.uint32)), t
