@@ -41,10 +41,24 @@ __device__ __forceinline__ void wave_append(bool flag, int value, int32_t *list,
 
 // ------------------------------------------------------------------- step --
 __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
+    // The kernel is a chain of dependent memory round trips for a few thousand wavefronts (it moves ~1 MB): everything
+    // that does not depend on a previous load is fetched in the first round trip -- the env's scalars, and the icon type
+    // table into LDS, which turns the "is the thing I bumped into a goal" lookup at the end of the chain into an LDS read.
+    __shared__ uint8_t s_icon_type[4096];                  // xw_setup: n_icons <= 4000
     const int e = blockIdx.x * 256 + threadIdx.x;
     int32_t *count_now = p.done_count;
     if (e == 0) *p.done_count_next = 0;        // double-buffered done counter: zero the next step's
     bool is_done = false;
+    int ld_axy = 0, ld_steps = 0, ld_ts = 0, ld_tsteps = 0, ld_dir = 1, ld_level = 0;
+    if (e < p.n) {
+        ld_axy = p.agent_xy[e]; ld_steps = p.num_steps[e]; ld_ts = p.task_state[e]; ld_tsteps = p.task_steps[e];
+        if (p.visible_radius) ld_dir = p.agent_dir[e];
+        if (p.curriculum != 0) ld_level = p.cur_level[e];
+    }
+    for (int i = threadIdx.x * 4; i < p.n_icons; i += 1024) {          // (the table is padded to a multiple of 4 bytes)
+        *reinterpret_cast<uint32_t *>(s_icon_type + i) = *reinterpret_cast<const uint32_t *>(p.icon_type + i);
+    }
+    __syncthreads();
     if (e < p.n) {
         const int NA = p.visible_radius ? 6 : 4;           // XAgent legal_actions_, xitem.cpp:80-87
         int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step, NA);
@@ -58,9 +72,9 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
         } else {
             const int D = p.max_dim;
             uint16_t *g = p.grid + (size_t)e * D * D;
-            const int axy = p.agent_xy[e];
+            const int axy = ld_axy;
             int ax = axy & 0xffff, ay = axy >> 16;
-            const int steps = p.num_steps[e] + 1;          // GameSimulator::take_actions: once per call
+            const int steps = ld_steps + 1;                // GameSimulator::take_actions: once per call
             const uint16_t agent_code = g[ay * D + ax];
             int ddx = a == 2 ? -1 : (a == 3 ? 1 : 0);         // MOVE_LEFT / MOVE_RIGHT
             int ddy = a == 0 ? -1 : (a == 1 ? 1 : 0);         // MOVE_UP / MOVE_DOWN
@@ -72,9 +86,10 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
                     // XAgent::act, xitem.cpp:103-155: MOVE_FORWARD, MOVE_BACKWARD, MOVE_LEFT_FPV, MOVE_RIGHT_FPV relative to
                     // the heading; TURN_LEFT / TURN_RIGHT change the yaw and "move" onto the agent's own cell, which
                     // XMap::move_item refuses (xmap.cpp:76-101): a turn is an unsuccessful action without contacts
-                    int dir = p.agent_dir[e];
+                    int dir = ld_dir;
                     if (a == 4) dir = (dir + 3) & 3;
                     else if (a == 5) dir = (dir + 1) & 3;
+                    ld_dir = dir;
                     p.agent_dir[e] = (uint8_t)dir;
                     vx = dir == 0 ? 1 : (dir == 2 ? -1 : 0);
                     vy = dir == 1 ? 1 : (dir == 3 ? -1 : 0);
@@ -99,10 +114,10 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
                 }
             }
             // Teacher::teach -> Task stage (one group, task XWorld3DNavTarget)
-            const int ts = p.task_state[e];
+            const int ts = ld_ts;
             int target = task_target(ts), kind = task_kind(ts);
             int stage = task_stage(ts);
-            int tsteps = p.task_steps[e];
+            int tsteps = ld_tsteps;
             int event = EV_NONE;
             int record = -1;                                // curriculum: the result this step adds to the task's window
             double rew = 0.0;
@@ -137,12 +152,12 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
             } else if (stage == STAGE_NAV) {
                 rew = -0.01;                                // time_penalty
                 tsteps += 1;
-                const int dim = p.curriculum != 0 ? 3 + p.cur_level[e] : p.dim;       // env.get_dims()
+                const int dim = p.curriculum != 0 ? 3 + ld_level : p.dim;             // env.get_dims()
                 if (tsteps >= dim * dim * p.max_steps_factor) {
                     event = EV_TIMEUP;
                     record = 0;
                     stage = STAGE_TERMINAL;
-                } else if (hit != 0 && ddx == vx && ddy == vy && p.icon_type[(hit & CELL_ICON_MASK) - 1] == 0) {
+                } else if (hit != 0 && ddx == vx && ddy == vy && s_icon_type[(hit & CELL_ICON_MASK) - 1] == 0) {
                     // _reach_object: id in collisions and |theta| < pi/4, i.e. the goal was bumped into along the
                     // heading: MOVE_DOWN under full observation (yaw stays 1.5707963), MOVE_FORWARD in egocentric mode.
                     // Target / Near / Avoid: the reached goal is in self.target (cell bit 15, set by the idle stage)
@@ -207,6 +222,24 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
 hipError_t launch_xw_step(const XwParams &p, hipStream_t s) {
     dim3 grid((p.n + 255) / 256), block(256);
     hipLaunchKernelGGL(xw_step_kernel, grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void xw_wait_kernel(const uint32_t *epoch_slot, uint32_t want) {
+    xw_wait_epoch(epoch_slot, want);
+}
+
+hipError_t launch_xw_wait(const uint32_t *epoch_slot, uint32_t want, hipStream_t s) {
+    hipLaunchKernelGGL(xw_wait_kernel, dim3(1), dim3(64), 0, s, epoch_slot, want);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void xw_signal_kernel(uint32_t *epoch_slot, uint32_t value) {
+    if (threadIdx.x == 0) xw_publish_epoch(epoch_slot, value);
+}
+
+hipError_t launch_xw_signal(uint32_t *epoch_slot, uint32_t value, hipStream_t s) {
+    hipLaunchKernelGGL(xw_signal_kernel, dim3(1), dim3(64), 0, s, epoch_slot, value);
     return hipGetLastError();
 }
 
@@ -292,6 +325,8 @@ __global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
     const unsigned long long b_lo = c_lo * 16, b_hi = c_hi * 16;
     const int e0 = (int)(b_lo / FB), e1 = (int)((b_hi - 1) / FB);
     const int ncode = (e1 - e0 + 1) * cells;
+    // this kernel running = the step kernel queued before it is complete: tell the reset kernel's queue (xw_device.h)
+    if (p.sig_epoch && blockIdx.x == 0 && tid == 0) xw_publish_epoch(p.sync + 1, p.sig_epoch);
     for (int i = tid; i < ncode; i += BS) {
         const size_t gi = (size_t)e0 * cells + i;
         const uint16_t *src = TERM && p.term_flag[e0 + i / cells] ? p.term_grid : p.grid;
@@ -369,9 +404,16 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
     const int cells = D * D;
     const int ctx = p.context;
     const int cpf = CH * 9 * cells * ES;
+    // first round trip: the count, this workgroup's first list entry (the list is the step kernel's, complete long ago) and
+    // the epoch, together
     const int cnt = *count_now;
+    const int e_first = p.done_list[(int)blockIdx.x < p.n ? blockIdx.x : 0];
+    if ((int)blockIdx.x >= cnt) return;                   // nothing to draw (and nothing to wait for)
+    // the listed envs were regenerated by a reset kernel on the other queue: its epoch instead of a barrier packet.  Only
+    // workgroups with work spin, and that kernel's workgroups have all been resident since long before this one starts.
+    if (p.wait_epoch) xw_wait_epoch(p.sync + 3, p.wait_epoch);
     for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
-        const int e = p.done_list[i];
+        const int e = i == (int)blockIdx.x ? e_first : p.done_list[i];
         __syncthreads();
         for (int k = threadIdx.x; k < cells; k += 256) s_grid[k] = p.grid[(size_t)e * cells + k] & CELL_ICON_MASK;
         __syncthreads();

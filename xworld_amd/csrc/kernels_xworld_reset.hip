@@ -685,34 +685,36 @@ __global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int 
     const int total = mode == MODE_RESET_ALL ? p.n : *count_now;
     int per_wave = (total + (int)gridDim.x - 1) / (int)gridDim.x;
     per_wave = per_wave < 1 ? 1 : (per_wave > 64 ? 64 : per_wave);
-    if ((int)blockIdx.x * per_wave >= total) return;                   // whole wavefront idle
-    LaneLds L;
-    L.lane = threadIdx.x;
-    L.stack = lds32;                                                   // 64 x 64 x 4 B
-    L.gname = reinterpret_cast<uint16_t *>(lds32 + 64 * 64);           // 16 x 64 x 2 B
-    L.ov_idx = L.gname + XW_MAX_GOALS * 64;
-    L.ov_val = L.ov_idx + XW_MAX_GOALS * 64;
-    L.gicon = L.ov_idx;
-    L.gcell = reinterpret_cast<uint8_t *>(L.ov_val + XW_MAX_GOALS * 64);   // 16 x 64 B
-    L.blk = L.gcell + XW_MAX_GOALS * 64;                               // D*D x 64 B
-    // name -> icon-variant tables staged in LDS once per wavefront: every lookup afterwards is an LDS read
-    // instead of a dependent chain of global loads queued behind render_all's write stream
-    const int lds_dim = p.curriculum != 0 ? p.max_dim : p.dim;          // a curriculum env may be at any level
-    int16_t *t_first = reinterpret_cast<int16_t *>(L.blk + lds_dim * lds_dim * 64);
-    int16_t *t_var = t_first + ((p.name_first_len + 1) & ~1);
-    for (int k = threadIdx.x; k < p.name_first_len; k += 64) t_first[k] = p.name_first[k];
-    for (int k = threadIdx.x; k < p.name_variants_len; k += 64) t_var[k] = p.name_variants[k];
-    __syncthreads();
-    if ((int)threadIdx.x >= per_wave) return;
-    IconTables T;
-    T.first[0] = t_first + p.name_first_off[0];
-    T.first[1] = t_first + p.name_first_off[1];
-    T.first[2] = t_first + p.name_first_off[2];
-    T.variants = t_var;
-    // the grid is capped (a short list should not cost the dispatch of one workgroup per env of the batch): loop
-    for (int i = blockIdx.x * per_wave + (int)threadIdx.x; i < total; i += gridDim.x * per_wave) {
-        const int e = mode == MODE_RESET_ALL ? i : p.done_list[i];
-        xw_reset_env<NW, KIND>(p, T, L, e, keep_done != 0);
+    if ((int)blockIdx.x * per_wave < total) {                          // else: whole wavefront idle
+        LaneLds L;
+        L.lane = threadIdx.x;
+        L.stack = lds32;                                                   // 64 x 64 x 4 B
+        L.gname = reinterpret_cast<uint16_t *>(lds32 + 64 * 64);           // 16 x 64 x 2 B
+        L.ov_idx = L.gname + XW_MAX_GOALS * 64;
+        L.ov_val = L.ov_idx + XW_MAX_GOALS * 64;
+        L.gicon = L.ov_idx;
+        L.gcell = reinterpret_cast<uint8_t *>(L.ov_val + XW_MAX_GOALS * 64);   // 16 x 64 B
+        L.blk = L.gcell + XW_MAX_GOALS * 64;                               // D*D x 64 B
+        // name -> icon-variant tables staged in LDS once per wavefront: every lookup afterwards is an LDS read
+        // instead of a dependent chain of global loads queued behind render_all's write stream
+        const int lds_dim = p.curriculum != 0 ? p.max_dim : p.dim;          // a curriculum env may be at any level
+        int16_t *t_first = reinterpret_cast<int16_t *>(L.blk + lds_dim * lds_dim * 64);
+        int16_t *t_var = t_first + ((p.name_first_len + 1) & ~1);
+        for (int k = threadIdx.x; k < p.name_first_len; k += 64) t_first[k] = p.name_first[k];
+        for (int k = threadIdx.x; k < p.name_variants_len; k += 64) t_var[k] = p.name_variants[k];
+        __syncthreads();
+        if ((int)threadIdx.x < per_wave) {
+            IconTables T;
+            T.first[0] = t_first + p.name_first_off[0];
+            T.first[1] = t_first + p.name_first_off[1];
+            T.first[2] = t_first + p.name_first_off[2];
+            T.variants = t_var;
+            // the grid is capped (a short list should not cost the dispatch of one workgroup per env of the batch): loop
+            for (int i = blockIdx.x * per_wave + (int)threadIdx.x; i < total; i += gridDim.x * per_wave) {
+                const int e = mode == MODE_RESET_ALL ? i : p.done_list[i];
+                xw_reset_env<NW, KIND>(p, T, L, e, keep_done != 0);
+            }
+        }
     }
 }
 

@@ -75,6 +75,8 @@ struct xwb_sim {
     bool profiling = false;
     KernelTimer t_render, t_step, t_reset;
     hipStream_t side = nullptr;            // reset of finished envs runs here, beside render_all
+    uint32_t *d_sync = nullptr;            // device-side epochs of the step / reset kernels (XwParams::sync)
+    uint32_t epoch_step = 0, epoch_reset = 0;
     hipEvent_t ev_step = nullptr, ev_reset = nullptr, ev_term = nullptr;
     // common device buffers
     int32_t *d_actions_in = nullptr;       // staging for xwb_step_host
@@ -302,7 +304,7 @@ int xw_setup(xwb_sim *s) {
     if ((rc = dev_alloc(s, &s->d_done_list, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_done_count, 2))) return rc;
     if ((rc = dev_alloc(s, &s->d_fresh, n))) return rc;
-    if ((rc = dev_alloc(s, &s->d_icon_type, c.n_icons))) return rc;
+    if ((rc = dev_alloc(s, &s->d_icon_type, ((size_t)c.n_icons + 3) & ~(size_t)3))) return rc;   // the step kernel stages it dword-wise
     if ((rc = dev_alloc(s, &s->d_icon_colored, c.n_icons))) return rc;
     if ((rc = dev_alloc(s, &s->d_goal_cells, (size_t)n * XW_MAX_GOALS, 0xff))) return rc;
     if ((rc = dev_alloc(s, &s->d_cand2d, n))) return rc;
@@ -316,6 +318,7 @@ int xw_setup(xwb_sim *s) {
         if ((rc = dev_alloc(s, &s->d_cur_counter, n))) return rc;
         if ((rc = dev_alloc(s, &s->d_cur_usage, (size_t)n * 9 * XW_USAGE_BYTES))) return rc;
     }
+    if ((rc = dev_alloc(s, &s->d_sync, 4))) return rc;
     if ((rc = dev_alloc(s, &s->d_term_grid, (size_t)n * cells))) return rc;
     if ((rc = dev_alloc(s, &s->d_term_flag, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_agent_dir, n, 1))) return rc;                 // heading "down": yaw 1.5707963
@@ -385,6 +388,7 @@ int xw_setup(xwb_sim *s) {
     p.n_tasks = c.n_tasks;
     p.group2d = c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET;
     p.curriculum = curriculum ? c.curriculum : 0.0; p.cur_level = s->d_cur_level; p.cur_counter = s->d_cur_counter; p.cur_usage = s->d_cur_usage;
+    p.sync = s->d_sync; p.sig_epoch = 0; p.wait_epoch = 0;
     p.sent_names = s->d_sent_names; p.term_grid = s->d_term_grid; p.term_flag = s->d_term_flag;
     p.goal_cells = s->d_goal_cells; p.cand2d = s->d_cand2d; p.icon_colored = s->d_icon_colored;
     p.visible_radius = c.visible_radius; p.out_dim = s->out_h; p.no_wall_shadow = c.no_wall_shadow;
@@ -505,10 +509,24 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
     // on `st` after that work, clears them instead
     p.auto_reset = keep_done ? 1 : (beside_render && render ? 2 : 0);
     hipStream_t rs = beside_render ? s->side : st;
-    if (beside_render) HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
+    // full observation: the two queues hand over through epochs in device memory (XwParams::sync) -- the side queue's
+    // kernel waits for the step kernel's epoch, the list render for the reset kernel's; no event / barrier packets
+    const bool by_epoch = beside_render && render && !p.visible_radius && mode != MODE_RESET_ALL;
+    if (by_epoch) {
+        HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->side));
+        if (++s->epoch_reset == 0) s->epoch_reset = 1;
+    } else if (beside_render) {
+        HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
+    }
     timer_begin(s, s->t_reset, rs);
     HIP_TRY(launch_xw_reset(p, mode, rs));
     timer_end(s, s->t_reset, rs);
+    if (by_epoch) {
+        HIP_TRY(launch_xw_signal(s->d_sync + 3, s->epoch_reset, s->side));     // queued behind the reset kernel
+        p.wait_epoch = s->epoch_reset;
+        HIP_TRY(launch_xw_render(p, 1, st));
+        return XWB_OK;
+    }
     if (beside_render && render && p.visible_radius && mode != MODE_RESET_ALL) {
         // egocentric: the first frames of the new episodes are drawn on the side stream too, beside the big render (which
         // skips these envs); only the done codes are cleared on the caller's stream, behind whatever still reads them
@@ -556,6 +574,8 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         s->count_sel ^= 1;                     // this step appends to the counter the previous one zeroed
         XwParams p = xw_params(s);
         p.actions = actions_dev; p.act_rep = act_rep;
+        if (++s->epoch_step == 0) s->epoch_step = 1;
+        p.sig_epoch = s->epoch_step;           // published by the render kernel queued behind the step kernel
         timer_begin(s, s->t_step, st);
         HIP_TRY(launch_xw_step(p, st));
         timer_end(s, s->t_step, st);
@@ -579,8 +599,8 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
             // The egocentric render reads more than the grid (heading, goal images): there the terminal frames are
             // rendered from the (short) list on the side stream, beside the big render, which skips those envs; a
             // following xwb_reset_done queues behind that list render.
-            HIP_TRY(hipEventRecord(s->ev_step, st));
             if (p.visible_radius) {
+                HIP_TRY(hipEventRecord(s->ev_step, st));
                 pr.list_flag = 1;
                 pr.ego_list_beside = 1;
                 HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));

@@ -198,8 +198,18 @@ struct XwParams {
     int32_t *done_count;         // counter the current step / compaction appends to
     int32_t *done_count_next;    // the other one of the pair; zeroed by the step kernel
     int32_t *err_count;
+    // device-side hand-off between the two queues of the step loop, instead of event / barrier packets (each costs the
+    // loop ~3-6 us of idle GPU): sync[1] = epoch of the last completed step kernel, sync[3] = of the last completed reset
+    // kernel (xw_device.h: xw_publish_epoch / xw_wait_epoch).  render_all with sig_epoch != 0 publishes it to sync[1] when it
+    // starts (= the step kernel before it in the queue is complete); the list render with wait_epoch != 0 waits for sync[3].
+    uint32_t *sync;
+    uint32_t sig_epoch, wait_epoch;
 };
 hipError_t launch_xw_step(const XwParams &p, hipStream_t s);
+// one wavefront that ends once *epoch_slot has reached `want`: orders the work queued behind it after the publisher
+hipError_t launch_xw_wait(const uint32_t *epoch_slot, uint32_t want, hipStream_t s);
+// one thread that publishes `value`: queued behind a kernel, it tells the other queue that kernel is complete
+hipError_t launch_xw_signal(uint32_t *epoch_slot, uint32_t value, hipStream_t s);
 // reset envs: mode RESET_ALL -> every env; otherwise the compacted done_list / done_count
 hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s);
 // compaction of done[] (mode RESET_DONE) or mask (RESET_MASK) into done_list / done_count
