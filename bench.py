@@ -234,8 +234,8 @@ def main():
     per_step, per_launch, kernel_name = algorithmic_bytes(args.workload, sim)
     is_xworld = WORKLOADS[args.workload][0] == "xworld"
     fused = args.fused if not is_xworld else 1
-    assert fused == 1 or (args.steps % fused == 0 and args.warmup % fused == 0), "--steps / --warmup must be multiples of --fused"
-    K, W, R = args.steps // fused, args.warmup // fused, max(1, args.repeats)       # in step CALLS
+    assert fused == 1 or args.steps % fused == 0, "--steps must be a multiple of --fused"
+    K, W, R = args.steps // fused, -(-args.warmup // fused), max(1, args.repeats)   # in step CALLS (warm-up rounded up)
 
     from xworld_amd import sharding
     counts = [n_local] * world

@@ -18,6 +18,15 @@
 
 namespace xwb {
 
+// Envs reset by this launch, counted into *counter with ONE atomic per wavefront per LAUNCH.  (One per wavefront per step
+// was 90 % of a fused SimpleRace launch: under a random policy nearly every wavefront holds an env that ends at any
+// given step, so a thousand wavefronts hit one address every step and L2 serialises same-address atomics.)
+__device__ __forceinline__ void count_resets(int32_t *counter, int n_reset) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n_reset += __shfl_down(n_reset, off);
+    if ((threadIdx.x & 63) == 0 && n_reset) atomicAdd(counter, n_reset);
+}
+
 // ============================================================ SimpleGame ====
 static constexpr float SG_MOVE_REWARD = -0.1f;   // simple_game_simulator.h:52
 static constexpr float SG_DEST_REWARD = 4.0f;    // simple_game_simulator.h:53
@@ -64,9 +73,11 @@ template <> __device__ __forceinline__ uint32_t zero_chunk<4>() { return 0u; }
 template <> __device__ __forceinline__ uint8_t zero_chunk<1>() { return 0; }
 
 // One call = one SimulatorInterface::take_actions (or reset_game) for every env.
-template <int G>
+// FAST = a step call under the built-in policy with context 1: nothing in the body loads from memory, so the compiler
+// has no reason to drain the outstanding stores (s_waitcnt vmcnt(0)) between the steps of a fused launch.
+template <int G, bool FAST>
 __device__ __forceinline__ void sg_body(const SgParams &p, uint32_t policy_step, int &pos, uint32_t &flags, int &steps,
-                                        uint32_t &episode, bool &dirty) {
+                                        uint32_t &episode, bool &dirty, int &n_reset) {
     using chunk_t = typename ChunkT<G>::type;
     __shared__ int s_pos[256];      // -1: leave this env's observation untouched
     __shared__ uint8_t s_fresh[256];
@@ -77,8 +88,8 @@ __device__ __forceinline__ void sg_body(const SgParams &p, uint32_t policy_step,
     bool fresh = false;
     if (e < p.n) {
         bool do_reset = false;
-        if (p.mode == MODE_STEP) {
-            int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, policy_step, 2);
+        if (FAST || p.mode == MODE_STEP) {
+            int a = (FAST || !p.actions) ? policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, policy_step, 2) : p.actions[e];
             p.actions_out[e] = a;
             if (a == ACTION_SKIP) {
                 // this env does not take part in the call
@@ -109,15 +120,13 @@ __device__ __forceinline__ void sg_body(const SgParams &p, uint32_t policy_step,
             // SimpleGameEngine::reset_game cpp:31-38 ; GameSimulator::reset_game
             pos = A / 2; flags = 0; steps = 0;
             episode += 1;
-            if (p.mode != MODE_STEP) {
+            if (!FAST && p.mode != MODE_STEP) {
                 // game_over() right after reset (over at once for array_size <= 2)
                 p.done[e] = (uint8_t)(sg_over(pos, A) ? SUCCESS : ALIVE);   // num_steps_ == 0 < max_steps
             }
             obs_pos = pos; fresh = true;
         }
-        // resets are counted once per wavefront
-        const unsigned long long rm = __ballot(do_reset);
-        if (rm && (int)(tid & 63) == __ffsll((long long)rm) - 1) atomicAdd(p.reset_count, __popcll(rm));
+        n_reset += do_reset ? 1 : 0;
         if (obs_pos >= 0) dirty = true;
     }
     s_pos[tid] = obs_pos;
@@ -131,7 +140,7 @@ __device__ __forceinline__ void sg_body(const SgParams &p, uint32_t policy_step,
     const int cpf = A / G;                                   // chunks per frame
     const int base_env = blockIdx.x * 256;
     const int n_here = min(256, p.n - base_env);
-    const int ctx = p.context;
+    const int ctx = FAST ? 1 : p.context;
     for (int i = tid; i < n_here * cpf; i += 256) {
         int le = i / cpf, j = i - le * cpf;
         int pos = s_pos[le];
@@ -148,26 +157,31 @@ __device__ __forceinline__ void sg_body(const SgParams &p, uint32_t policy_step,
 
 // n_steps > 1 (xwb_step_n): consecutive steps under the built-in policy with in-kernel auto-reset, each one writing its
 // reward / code / observation like a separate launch would -- one launch instead of n (a 6 MB step is launch-bound)
-template <int G>
+template <int G, bool FAST>
 __global__ __launch_bounds__(256) void sg_kernel(SgParams p) {
     // the env's state stays in registers across the steps of one launch and is written back once
     const int e = blockIdx.x * 256 + threadIdx.x;
     int pos = 0, steps = 0;
     uint32_t flags = 0, episode = 0;
     bool dirty = false;
+    int n_reset = 0;
     if (e < p.n) { pos = p.pos[e]; flags = p.flags[e]; steps = p.num_steps[e]; episode = p.episode[e]; }
     for (int it = 0; it < p.n_steps; ++it) {
-        sg_body<G>(p, p.policy_step + (uint32_t)it, pos, flags, steps, episode, dirty);   // (p stays in kernel-argument memory: never written)
+        sg_body<G, FAST>(p, p.policy_step + (uint32_t)it, pos, flags, steps, episode, dirty, n_reset);   // (p stays in kernel-argument memory: never written)
         __syncthreads();                                   // the shared staging of this step is dead
     }
     if (e < p.n && dirty) { p.pos[e] = pos; p.flags[e] = (uint8_t)flags; p.num_steps[e] = steps; p.episode[e] = episode; }
+    count_resets(p.reset_count, n_reset);
 }
 
 hipError_t launch_simple_game(const SgParams &p, hipStream_t s) {
     dim3 grid((p.n + 255) / 256), block(256);
-    if (p.array_size % 16 == 0) hipLaunchKernelGGL(sg_kernel<16>, grid, block, 0, s, p);
-    else if (p.array_size % 4 == 0) hipLaunchKernelGGL(sg_kernel<4>, grid, block, 0, s, p);
-    else hipLaunchKernelGGL(sg_kernel<1>, grid, block, 0, s, p);
+    const bool fast = p.mode == MODE_STEP && !p.actions && p.context == 1;
+#define SG_LAUNCH(GV) do { if (fast) hipLaunchKernelGGL((sg_kernel<GV, true>), grid, block, 0, s, p); else hipLaunchKernelGGL((sg_kernel<GV, false>), grid, block, 0, s, p); } while (0)
+    if (p.array_size % 16 == 0) SG_LAUNCH(16);
+    else if (p.array_size % 4 == 0) SG_LAUNCH(4);
+    else SG_LAUNCH(1);
+#undef SG_LAUNCH
     return hipGetLastError();
 }
 
@@ -271,22 +285,26 @@ struct RaceLane {
     uint32_t episode;
     double ca, sa;           // cos / sin of c.angle, valid when `trig`
     bool trig, dirty;
+    int n_reset;
 };
 
 // One SimulatorInterface::take_actions (or reset_game) for this lane's env.  Outputs (reward, code, action, frame) go to
 // HBM here; the car itself stays in `L` (race_kernel writes it back once per launch).
+template <bool FAST>        // see sg_body
 __device__ __forceinline__ void race_body(const RaceParams &p, uint32_t policy_step, int e, RaceLane &L) {
     RaceCar &c = L.c;
     bool do_reset = false, touched = false;
-    if (p.mode == MODE_STEP) {
-        int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, policy_step, p.n_legal);
+    if (FAST || p.mode == MODE_STEP) {
+        int a = (FAST || !p.actions) ? policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, policy_step, p.n_legal) : p.actions[e];
         p.actions_out[e] = a;
         if (a == ACTION_SKIP) {
             // this env does not take part in the call
         } else if ((unsigned)a >= (unsigned)p.n_legal) {
             atomicAdd(p.err_count, 1);
         } else {
-            int action = p.legal[a];               // _legal_actions[action_id], cpp:474
+            // _legal_actions[action_id], cpp:474.  The set is {4, 7} or 0..8 (race_setup): selected arithmetically rather than
+            // by a dynamically indexed p.legal[a], which is a vector load from the kernel-argument buffer
+            const int action = p.n_legal == 9 ? a : (a == 0 ? p.legal[0] : p.legal[1]);
             L.steps += 1;
             float reward = 0.0f;
             // RaceEngine::act cpp:290-341: the action decodes to the same (d_forward, d_turn) on every repeat
@@ -339,42 +357,44 @@ __device__ __forceinline__ void race_body(const RaceParams &p, uint32_t policy_s
         race_reset(p, c, p.env_gid0 + (uint32_t)e, L.episode);
         L.trig = false;
         L.steps = 0;
-        if (p.mode != MODE_STEP)
+        if (!FAST && p.mode != MODE_STEP)
             p.done[e] = (uint8_t)(race_oob(p, c.x, c.y) ? DEAD : ALIVE);
         touched = true;
     }
-    // resets are counted once per wavefront
-    const unsigned long long rm = __ballot(do_reset);
-    if (rm && (int)(threadIdx.x & 63) == __ffsll((long long)rm) - 1) atomicAdd(p.reset_count, __popcll(rm));
+    L.n_reset += do_reset ? 1 : 0;
     if (!touched) return;
     L.dirty = true;
     if (!L.trig) { xwb_sincos((double)c.angle, &L.sa, &L.ca); L.trig = true; }
     // make_context_screens: [env][context][4] floats, 16 bytes per frame -> one float4 per lane
-    float4 *frames = reinterpret_cast<float4 *>(p.obs) + (size_t)e * p.context;
+    const int ctx = FAST ? 1 : p.context;
+    float4 *frames = reinterpret_cast<float4 *>(p.obs) + (size_t)e * ctx;
     if (do_reset) {
-        for (int f = 0; f + 1 < p.context; ++f) frames[f] = make_float4(0, 0, 0, 0);
+        for (int f = 0; f + 1 < ctx; ++f) frames[f] = make_float4(0, 0, 0, 0);
     } else {
-        for (int f = 0; f + 1 < p.context; ++f) frames[f] = frames[f + 1];
+        for (int f = 0; f + 1 < ctx; ++f) frames[f] = frames[f + 1];
     }
-    frames[p.context - 1] = race_screen(p, c, L.ca, L.sa);
+    frames[ctx - 1] = race_screen(p, c, L.ca, L.sa);
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void race_kernel(RaceParams p) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     const bool live = e < p.n;
     RaceLane L;
-    L.trig = false; L.dirty = false; L.ca = L.sa = 0;
+    L.trig = false; L.dirty = false; L.ca = L.sa = 0; L.n_reset = 0;
     L.c.x = L.c.y = L.c.angle = 0; L.steps = 0; L.episode = 0;
     if (live) { L.c.x = p.x[e]; L.c.y = p.y[e]; L.c.angle = p.angle[e]; L.steps = p.num_steps[e]; L.episode = p.episode[e]; }
     for (int it = 0; it < p.n_steps; ++it) {               // n_steps > 1: xwb_step_n, see sg_kernel
-        if (live) race_body(p, p.policy_step + (uint32_t)it, e, L);
+        if (live) race_body<FAST>(p, p.policy_step + (uint32_t)it, e, L);
     }
     if (live && L.dirty) { p.x[e] = L.c.x; p.y[e] = L.c.y; p.angle[e] = L.c.angle; p.num_steps[e] = L.steps; p.episode[e] = L.episode; }
+    count_resets(p.reset_count, L.n_reset);
 }
 
 hipError_t launch_simple_race(const RaceParams &p, hipStream_t s) {
     dim3 grid((p.n + 255) / 256), block(256);
-    hipLaunchKernelGGL(race_kernel, grid, block, 0, s, p);
+    if (p.mode == MODE_STEP && !p.actions && p.context == 1) hipLaunchKernelGGL(race_kernel<true>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(race_kernel<false>, grid, block, 0, s, p);
     return hipGetLastError();
 }
 

@@ -46,6 +46,15 @@ __device__ __forceinline__ void idle_2d(int kind, uint32_t cand, const uint8_t *
     stage = STAGE_NAV;
 }
 
+// p.tasks[i] for a per-lane i: a select chain over the eight scalars instead of a vector load from the kernel-argument
+// buffer (which is not cached like device memory: a full memory round trip in the middle of a latency-bound kernel)
+__device__ __forceinline__ int task_at(const XwParams &p, int i) {
+    int r = p.tasks[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) r = i == k ? p.tasks[k] : r;
+    return r;
+}
+
 // Epochs in device memory order the two queues of the step loop without event / barrier packets.  The publisher is always
 // the FIRST thread of the kernel that FOLLOWS the producing kernel in its in-order queue: when that kernel starts, the
 // producer has completed and the queue's kernel-boundary release / acquire has made its writes visible device-wide, so
