@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define XWB_ABI_VERSION 1
+#define XWB_ABI_VERSION 2
 
 enum {
     XWB_OK = 0,
@@ -65,6 +65,10 @@ enum { XWB_EV_NONE = 0, XWB_EV_CORRECT_GOAL = 1, XWB_EV_WRONG_GOAL = 2, XWB_EV_T
 enum { XWB_OBS_U8 = 0, XWB_OBS_F32 = 1 };
 enum { XWB_SCHEDULE_RANDOM = 0, XWB_SCHEDULE_WEIGHTED = 1 };
 enum { XWB_ICON_GOAL = 0, XWB_ICON_BLOCK = 1, XWB_ICON_AGENT = 2 };  /* xworld_env.py:66 grid_types */
+/* where the decisions the reference takes with util::get_rand_ind / get_rand_range_val come from (simulator_util.cpp:38-73):
+ * the batch's own counter-based streams (default), or one libstdc++ minstd_rand0 per env, seeded and consumed exactly as the
+ * reference's thread-local engine (include/xwb_minstd.h) -- replays a reference run made with --simulator_seed != 0 */
+enum { XWB_RNG_PHILOX = 0, XWB_RNG_MINSTD = 1 };
 
 /*
  * Batch configuration.  Field names follow the reference's gflags / py_simulator
@@ -126,6 +130,10 @@ typedef struct xwb_config {
     double   task_weights[8];    /* the per-task numbers of the conf JSON (TaskGroup::add_task: > 0); read when weighted */
     int32_t  no_wall_shadow;     /* != 0: FLAGS_wall_shadow = false (xmap.cpp:19,170): the egocentric view keeps the cells
                                   * behind walls visible (a gflag of the C++ binaries; not settable from py_simulator) */
+    int32_t  rng_mode;           /* XWB_RNG_* */
+    int32_t  simulator_seed;     /* FLAGS_simulator_seed (simulator_util.cpp:26): must be != 0 with XWB_RNG_MINSTD */
+    int32_t  thread_base;        /* XWB_RNG_MINSTD: simulator threads the reference process had created before this batch's
+                                  * first env; global env g uses the engine of thread number thread_base + g + 1 */
 } xwb_config;
 
 typedef struct xwb_sim xwb_sim;
@@ -203,6 +211,7 @@ int xwb_num_steps_dev(xwb_sim *sim, int32_t **ptr);     /* int32[num_envs]: get_
 int xwb_success_dev(xwb_sim *sim, uint8_t **ptr);       /* uint8[num_envs]: last_action_success() */
 int xwb_episode_dev(xwb_sim *sim, uint32_t **ptr);      /* uint32[num_envs]: resets so far (RNG episode index) */
 int xwb_xw_grid_dev(xwb_sim *sim, uint16_t **ptr);      /* xworld: uint16[num_envs][max_dim*max_dim] cell codes */
+int xwb_minstd_state_dev(xwb_sim *sim, uint32_t **ptr); /* XWB_RNG_MINSTD: uint32[num_envs] engine states (else NULL) */
 int xwb_done_count(xwb_sim *sim, void *stream, int32_t *n_done);   /* envs reset by the last reset_done (sync) */
 
 /* The whole batch's outputs copied into caller-owned memory, host or device (hipMemcpyDefault), ordered on `stream`;
@@ -296,6 +305,13 @@ int xwb_xw_get_tile_table(const xwb_sim *sim, uint8_t *out_host, size_t cap, siz
 int xwb_profile_begin(xwb_sim *sim);
 int xwb_profile_end(xwb_sim *sim, void *stream, const char *kernel, double *avg_us, int64_t *launches);
 int xwb_profile_stop(xwb_sim *sim);
+
+/* ---- the reference's thread-local RNG on the host (include/xwb_minstd.h): what XWB_RNG_MINSTD runs per env on the device ----
+ * xwb_minstd_seed_thread: the engine state of the nth simulator thread under FLAGS_simulator_seed (simulator_util.cpp:44-52);
+ * xwb_minstd_rand_ind / rand_range: util::get_rand_ind / get_rand_range_val on a caller-held state. */
+uint32_t xwb_minstd_seed_thread(int32_t simulator_seed, int32_t nth_thread);
+int32_t  xwb_minstd_rand_ind(uint32_t *state, int32_t size);
+float    xwb_minstd_rand_range(uint32_t *state, float upper);
 
 const char *xwb_last_error(void);
 const char *xwb_version(void);

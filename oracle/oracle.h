@@ -151,6 +151,11 @@ typedef struct {
     int task_schedule;       /* 0 "random": util::get_rand_ind; 1 "weighted": util::simple_importance_sampling (teaching_task.cpp:204-213) */
     double task_weights[8];  /* TaskGroup::add_task weights, conf order */
     int no_wall_shadow;      /* FLAGS_wall_shadow = false (xmap.cpp:19,170) */
+    int simulator_seed;      /* FLAGS_simulator_seed != 0: the decisions the reference takes with util::get_rand_ind /
+                              * get_rand_range_val (the teacher's task draw, teaching_task.cpp:204-213) come from the env's
+                              * own minstd_rand0, seeded like the reference's thread number thread_base + env id + 1
+                              * (simulator_util.cpp:38-55); the xwb-rng-v1 draw they replace is still consumed */
+    int thread_base;
 } orc_xw_cfg;
 
 typedef struct {

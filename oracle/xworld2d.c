@@ -763,6 +763,9 @@ static void after_map(orc_xworld *w, int idle_pick) {
 void orc_xw_reset_game(orc_xworld *w, uint32_t env_gid, uint32_t episode) {
     w->env_gid = env_gid; w->episode = episode;
     w->forced = NULL; w->n_forced = 0;
+    /* one object may stand in for many envs in turn: an env's engine starts with its first episode */
+    if (w->cfg.simulator_seed && episode == 0)
+        orc_minstd_seed_thread(&w->reng, w->cfg.simulator_seed, w->cfg.thread_base + (int)env_gid + 1);
     orc_stream_init(&w->rs, w->cfg.seed, env_gid, episode, 0);
     if (w->cfg.map_kind == ORC_MAP_WALLS) gen_map_walls(w);
     else gen_map_nav(w);

@@ -11,6 +11,7 @@
 
 struct orc_xworld {
     orc_xw_cfg cfg;
+    orc_minstd reng;                 /* cfg.simulator_seed != 0: this env's thread-local engine */
     int n_icons;
     orc_icon_info *info;
     const uint8_t *icons64;          /* borrowed */

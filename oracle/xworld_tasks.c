@@ -384,10 +384,12 @@ void orc_task_idle(orc_xworld *w) {
         double acc[8], total = 0;
         for (int i = 0; i < n_tasks; ++i) { total += w->cfg.task_weights[i]; acc[i] = total; }
         float val = ((float)orc_xw_draw_below(w, 1 << 24) * (1.0f / 16777216.0f)) * (float)total;
+        if (w->cfg.simulator_seed) val = orc_minstd_rand_range(&w->reng, (float)total);      /* the reference's own engine */
         t = n_tasks - 1;
         for (int i = 0; i < n_tasks; ++i) if ((double)val <= acc[i]) { t = i; break; }
     } else {
         t = orc_xw_draw_below(w, n_tasks);
+        if (w->cfg.simulator_seed) t = orc_minstd_rand_ind(&w->reng, n_tasks);
     }
     w->task_kind = w->cfg.n_tasks > 0 ? w->cfg.tasks[t] : ORC_TASK_TARGET;
     if (w->task_kind >= ORC_TASK2D_TARGET) { idle_2d(w, &p); return; }

@@ -44,7 +44,8 @@ class XwCfg(C.Structure):
                 ("task_mode", C.c_int), ("color", C.c_int), ("context", C.c_int), ("seed", C.c_uint32),
                 ("visible_radius", C.c_int), ("n_tasks", C.c_int), ("tasks", C.c_int * 8),
                 ("curriculum", C.c_double), ("start_level", C.c_int),
-                ("task_schedule", C.c_int), ("task_weights", C.c_double * 8), ("no_wall_shadow", C.c_int)]
+                ("task_schedule", C.c_int), ("task_weights", C.c_double * 8), ("no_wall_shadow", C.c_int),
+                ("simulator_seed", C.c_int), ("thread_base", C.c_int)]
 
 
 class Entity(C.Structure):

@@ -134,3 +134,35 @@ def test_ctypes_offsets_match_the_c_header(tmp_path):
             assert getattr(cls, fname).offset == int(off), (cname, fname)
         seen += 1
     assert seen == sum(len(c._fields_) + 1 for c in structs.values())
+
+
+def test_reference_rng_known_answers_through_libxwb(oracle):
+    """The reference's tests/test_simulator_seed.cpp:22-50 through the product's own restatement (include/xwb_minstd.h,
+    exported as xwb_minstd_*): FLAGS_simulator_seed = 1 -> the first get_rand_ind(1000000) of threads 1..5; the test binary's
+    second case runs in the same process, so seed 2 meets threads 6..10.  Then the product's engines against the oracle's
+    (an independent restatement pinned by the same test) over long mixed draw sequences."""
+    from xworld_amd import lib
+    L = lib.load()
+    seq1 = [266148, 605992, 817626, 635637, 393423]
+    seq2 = [258945, 847424, 238883, 918571, 875562]
+    for seed, first, want in ((1, 1, seq1), (2, 6, seq2)):
+        got = []
+        for nth in range(first, first + 5):
+            st = C.c_uint32(L.xwb_minstd_seed_thread(seed, nth))
+            got.append(L.xwb_minstd_rand_ind(C.byref(st), 1000000))
+        assert got == want, (seed, got)
+    OL = oracle.lib()
+    for seed, nth in ((1, 1), (2, 9), (12345, 77), (-3, 4)):
+        st = C.c_uint32(L.xwb_minstd_seed_thread(seed, nth))
+        g = oracle.MinStd()
+        OL.orc_minstd_seed_thread(C.byref(g), seed, nth)
+        assert st.value == g.x
+        for k in range(3000):
+            if k % 3 == 0:
+                n = 1 + (k * 7919) % 1000
+                assert L.xwb_minstd_rand_ind(C.byref(st), n) == OL.orc_minstd_rand_ind(C.byref(g), n)
+            else:
+                u = float(1 + k % 5)
+                a, b = L.xwb_minstd_rand_range(C.byref(st), u), OL.orc_minstd_rand_range(C.byref(g), u)
+                assert a == b and 0 <= a <= u
+            assert st.value == g.x

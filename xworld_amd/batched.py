@@ -47,6 +47,13 @@ class BatchedSimulator:
         cfg.policy_seed = int(policy_seed) & 0xFFFFFFFF
         cfg.max_steps = int(opts.get("max_steps", 0))
         cfg.context = int(opts.get("context", 1))
+        # FLAGS_simulator_seed (simulator_util.cpp:26): rng = "minstd" replays the reference's thread-local engines
+        rng = opts.get("rng", "philox")
+        if rng not in ("philox", "minstd"):
+            raise RuntimeError("rng must be 'philox' or 'minstd'")
+        cfg.rng_mode = 1 if rng == "minstd" else 0
+        cfg.simulator_seed = int(opts.get("simulator_seed", 0))
+        cfg.thread_base = int(opts.get("thread_base", 0))
         self.palette = None
         self._keep = []
         if name == "simple_game":
@@ -207,6 +214,11 @@ class BatchedSimulator:
     @property
     def game_over_codes(self):
         return self._view("done", self.L.xwb_game_over_dev, (self.num_envs,), "|u1")
+
+    @property
+    def minstd_state(self):
+        """rng = "minstd": the per-env minstd_rand0 states, uint32 as an int32 view"""
+        return self._view("minstd", self.L.xwb_minstd_state_dev, (self.num_envs,), "<i4")
 
     @property
     def actions(self):

@@ -15,6 +15,7 @@
 // float/double rounding points as the reference (no FMA contraction).
 #include "xwb_common.h"
 #include "../../include/xwb_trig.h"
+#include "../../include/xwb_minstd.h"
 
 namespace xwb {
 
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(256) void sg_kernel(SgParams p) {
     uint32_t flags = 0, episode = 0;
     bool dirty = false;
     int n_reset = 0;
+    if (e == 0 && p.reset_count_next) *p.reset_count_next = 0;
     if (e < p.n) { pos = p.pos[e]; flags = p.flags[e]; steps = p.num_steps[e]; episode = p.episode[e]; }
     for (int it = 0; it < p.n_steps; ++it) {
         sg_body<G, FAST>(p, p.policy_step + (uint32_t)it, pos, flags, steps, episode, dirty, n_reset);   // (p stays in kernel-argument memory: never written)
@@ -247,7 +249,7 @@ __device__ __forceinline__ float4 race_screen(const RaceParams &p, const RaceCar
 }
 
 // RaceEngine::reset_game cpp:267-284 ; draws (random mode): track, start-pos #1, start-pos #2, angle
-__device__ __forceinline__ void race_reset(const RaceParams &p, RaceCar &c, uint32_t gid, uint32_t episode) {
+__device__ __forceinline__ void race_reset(const RaceParams &p, RaceCar &c, uint32_t gid, uint32_t episode, uint32_t *engine) {
     if (!p.random) {
         if (p.track_type == 1) {           // CircleTrack::get_start_pos cpp:81-85
             c.x = (p.inner_radius + p.width / 2) + p.center_x;
@@ -258,10 +260,22 @@ __device__ __forceinline__ void race_reset(const RaceParams &p, RaceCar &c, uint
         c.angle = (float)(RACE_PI / 2);    // BaseCar::set_angle(false)
         return;
     }
-    Stream s;
-    s.init(p.seed, gid, episode, 0);
-    float u_track = s.unit(); (void)u_track;       // one track in the pool -> index 0
-    float u_a = s.unit(), u_b = s.unit(), u_ang = s.unit();
+    float u_track, u_a, u_b, u_ang;
+    if (engine) {
+        // XWB_RNG_MINSTD: util::get_rand_range_val(1.0) four times from this env's engine, in the reference's call order
+        uint32_t x = *engine;
+        u_track = xwb_minstd_rand_range_state(&x, 1.0f);
+        u_a = xwb_minstd_rand_range_state(&x, 1.0f);
+        u_b = xwb_minstd_rand_range_state(&x, 1.0f);
+        u_ang = xwb_minstd_rand_range_state(&x, 1.0f);
+        *engine = x;
+    } else {
+        Stream s;
+        s.init(p.seed, gid, episode, 0);
+        u_track = s.unit();
+        u_a = s.unit(); u_b = s.unit(); u_ang = s.unit();
+    }
+    (void)u_track;                         // one track in the pool -> index 0
     if (p.track_type == 1) {               // cpp:86-89
         float theta = (float)((double)(u_a * 2) * RACE_PI);
         float r = p.inner_radius + u_b * p.width;
@@ -354,7 +368,7 @@ __device__ __forceinline__ void race_body(const RaceParams &p, uint32_t policy_s
     }
     if (do_reset) {
         L.episode += 1;
-        race_reset(p, c, p.env_gid0 + (uint32_t)e, L.episode);
+        race_reset(p, c, p.env_gid0 + (uint32_t)e, L.episode, (!FAST && p.minstd) ? p.minstd + e : nullptr);
         L.trig = false;
         L.steps = 0;
         if (!FAST && p.mode != MODE_STEP)
@@ -382,6 +396,7 @@ __global__ __launch_bounds__(256) void race_kernel(RaceParams p) {
     const bool live = e < p.n;
     RaceLane L;
     L.trig = false; L.dirty = false; L.ca = L.sa = 0; L.n_reset = 0;
+    if (e == 0 && p.reset_count_next) *p.reset_count_next = 0;
     L.c.x = L.c.y = L.c.angle = 0; L.steps = 0; L.episode = 0;
     if (live) { L.c.x = p.x[e]; L.c.y = p.y[e]; L.c.angle = p.angle[e]; L.steps = p.num_steps[e]; L.episode = p.episode[e]; }
     for (int it = 0; it < p.n_steps; ++it) {               // n_steps > 1: xwb_step_n, see sg_kernel
@@ -393,7 +408,7 @@ __global__ __launch_bounds__(256) void race_kernel(RaceParams p) {
 
 hipError_t launch_simple_race(const RaceParams &p, hipStream_t s) {
     dim3 grid((p.n + 255) / 256), block(256);
-    if (p.mode == MODE_STEP && !p.actions && p.context == 1) hipLaunchKernelGGL(race_kernel<true>, grid, block, 0, s, p);
+    if (p.mode == MODE_STEP && !p.actions && p.context == 1 && !p.minstd) hipLaunchKernelGGL(race_kernel<true>, grid, block, 0, s, p);
     else hipLaunchKernelGGL(race_kernel<false>, grid, block, 0, s, p);
     return hipGetLastError();
 }

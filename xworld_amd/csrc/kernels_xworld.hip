@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
                     Stream s2;
                     s2.init(p.seed, p.env_gid0 + (uint32_t)e, p.episode[e], 2u);
                     s2.blk = (uint32_t)steps;
-                    const int k2 = task_at(p, sample_task(p, s2));
+                    const int k2 = task_at(p, sample_task(p, s2, e));
                     kind = k2;
                     idle_2d(kind, p.cand2d[e], p.goal_cells + (size_t)e * XW_MAX_GOALS,
                             [&](uint32_t n) { return s2.below(n); }, target, stage, tsteps);

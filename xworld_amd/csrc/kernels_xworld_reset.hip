@@ -387,7 +387,7 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
     // ---- teacher idle stage (TaskGroup::run_stage samples one task of the group per episode, then its idle()):
     // decision order "xwb-taskgen-v1" (DESIGN.md).  Nothing is written to the grid before the stage has
     // succeeded, so the "map too crowded?" cases (the reference asserts) simply keep the generated map.
-    const int tsel = sample_task(p, s);
+    const int tsel = sample_task(p, s, e);
     const int kind = p.n_tasks > 0 ? task_at(p, tsel) : TASK_TARGET;
     uint32_t target_bits = 0;                              // goal slot i belongs to self.target
     int sent_a = 0xffff, sent_b = 0xffff;                  // names bound into the teacher's grammar (G / G1, G2)

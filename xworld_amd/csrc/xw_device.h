@@ -1,6 +1,7 @@
 // xw_device.h -- small device helpers shared by the XWorld2D kernels.
 #pragma once
 #include "xwb_common.h"
+#include "../../include/xwb_minstd.h"
 
 namespace xwb {
 
@@ -89,11 +90,19 @@ __device__ __forceinline__ int done_code(const XwParams &p, int num_steps, int e
 // TaskGroup::run_stage's sample_task (teaching_task.cpp:204-213): util::get_rand_ind, or for the "weighted" schedule
 // util::simple_importance_sampling (simulator_util.cpp:57-86): a float uniform in [0, float(total)), first task whose
 // accumulated weight is >= it.  One draw either way.
+// XWB_RNG_MINSTD: the decision comes from env e's own minstd_rand0 (the reference's thread-local engine); the stream's draw
+// is still consumed so that everything else the stream decides (the map) does not depend on the RNG mode.
 template <typename S>
-__device__ inline int sample_task(const XwParams &p, S &s) {
+__device__ inline int sample_task(const XwParams &p, S &s, int e) {
     const int n = p.n_tasks > 0 ? p.n_tasks : 1;
-    if (!p.task_weighted) return (int)s.below((uint32_t)n);
-    const double w = (double)(s.unit() * (float)p.task_acc[n - 1]);
+    if (!p.task_weighted) {
+        int t = (int)s.below((uint32_t)n);
+        if (p.minstd) { uint32_t x = p.minstd[e]; t = xwb_minstd_rand_ind_state(&x, n); p.minstd[e] = x; }
+        return t;
+    }
+    float val = s.unit() * (float)p.task_acc[n - 1];
+    if (p.minstd) { uint32_t x = p.minstd[e]; val = xwb_minstd_rand_range_state(&x, (float)p.task_acc[n - 1]); p.minstd[e] = x; }
+    const double w = (double)val;
     for (int i = 0; i < n; ++i) if (w <= p.task_acc[i]) return i;
     return n - 1;
 }

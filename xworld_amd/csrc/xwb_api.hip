@@ -8,6 +8,7 @@
 #include "../../include/xwb.h"
 #include "xwb_common.h"
 #include "../../include/xwb_trig.h"
+#include "../../include/xwb_minstd.h"
 
 #include <cmath>
 #include <cstdio>
@@ -70,11 +71,13 @@ struct xwb_sim {
     int num_actions = 0;
     uint32_t policy_step = 0;
     bool list_valid = false;
+    int rc_sel = 0;                        // simple games: the reset counter of the pair the last counting launch used
     bool autoreset_done = false;           // the last step call already reset the envs whose codes are still set
     int count_sel = 0;
     bool profiling = false;
     KernelTimer t_render, t_step, t_reset;
     hipStream_t side = nullptr;            // reset of finished envs runs here, beside render_all
+    uint32_t *d_minstd = nullptr;          // XWB_RNG_MINSTD: one engine state per env
     uint32_t *d_sync = nullptr;            // device-side epochs of the step / reset kernels (XwParams::sync)
     uint32_t epoch_step = 0, epoch_reset = 0;
     hipEvent_t ev_step = nullptr, ev_reset = nullptr, ev_term = nullptr;
@@ -389,6 +392,7 @@ int xw_setup(xwb_sim *s) {
     p.group2d = c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET;
     p.curriculum = curriculum ? c.curriculum : 0.0; p.cur_level = s->d_cur_level; p.cur_counter = s->d_cur_counter; p.cur_usage = s->d_cur_usage;
     p.sync = s->d_sync; p.sig_epoch = 0; p.wait_epoch = 0;
+    p.minstd = s->d_minstd;
     p.sent_names = s->d_sent_names; p.term_grid = s->d_term_grid; p.term_flag = s->d_term_flag;
     p.goal_cells = s->d_goal_cells; p.cand2d = s->d_cand2d; p.icon_colored = s->d_icon_colored;
     p.visible_radius = c.visible_radius; p.out_dim = s->out_h; p.no_wall_shadow = c.no_wall_shadow;
@@ -450,7 +454,7 @@ SgParams sg_params(xwb_sim *s) {
     p.reward = s->d_reward; p.done = s->d_done; p.obs = static_cast<uint8_t *>(s->d_obs);
     p.packed = packed_slot(s);
     p.n_steps = 1;
-    p.err_count = s->d_err; p.reset_count = s->d_reset_count;
+    p.err_count = s->d_err; p.reset_count = s->d_reset_count + s->rc_sel; p.reset_count_next = nullptr;
     return p;
 }
 
@@ -465,21 +469,32 @@ RaceParams race_params(xwb_sim *s) {
     p.reward = s->d_reward; p.done = s->d_done; p.obs = static_cast<float *>(s->d_obs);
     p.packed = packed_slot(s);
     p.n_steps = 1;
-    p.err_count = s->d_err; p.reset_count = s->d_reset_count;
+    p.err_count = s->d_err; p.reset_count = s->d_reset_count + s->rc_sel; p.reset_count_next = nullptr;
+    p.minstd = s->d_minstd;
     return p;
+}
+
+// A launch that counts the envs it resets takes the other counter of the pair, which the previous counting launch zeroed,
+// and zeroes that one's for the next (no memset per call in the queue).
+template <typename P>
+void take_reset_counter(xwb_sim *s, P &p) {
+    s->rc_sel ^= 1;
+    p.reset_count = s->d_reset_count + s->rc_sel;
+    p.reset_count_next = s->d_reset_count + (s->rc_sel ^ 1);
 }
 
 // reset for the simple games: one launch, mode selects the envs
 int simple_reset(xwb_sim *s, int mode, const uint8_t *mask, hipStream_t st) {
-    HIP_TRY(hipMemsetAsync(s->d_reset_count, 0, sizeof(int32_t), st));
     timer_begin(s, s->t_reset, st);
     if (s->cfg.game == XWB_SIMPLE_GAME) {
         SgParams p = sg_params(s);
         p.mode = mode; p.mask = mask;
+        take_reset_counter(s, p);
         HIP_TRY(launch_simple_game(p, st));
     } else {
         RaceParams p = race_params(s);
         p.mode = mode; p.mask = mask;
+        take_reset_counter(s, p);
         HIP_TRY(launch_simple_race(p, st));
     }
     timer_end(s, s->t_reset, st);
@@ -559,14 +574,14 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
     if (s->cfg.game == XWB_SIMPLE_GAME) {
         SgParams p = sg_params(s);
         p.actions = actions_dev; p.act_rep = act_rep; p.auto_reset = autoreset ? 1 : 0;
-        if (autoreset) HIP_TRY(hipMemsetAsync(s->d_reset_count, 0, sizeof(int32_t), st));
+        if (autoreset) take_reset_counter(s, p);
         timer_begin(s, s->t_step, st);
         HIP_TRY(launch_simple_game(p, st));
         timer_end(s, s->t_step, st);
     } else if (s->cfg.game == XWB_SIMPLE_RACE) {
         RaceParams p = race_params(s);
         p.actions = actions_dev; p.act_rep = act_rep; p.auto_reset = autoreset ? 1 : 0;
-        if (autoreset) HIP_TRY(hipMemsetAsync(s->d_reset_count, 0, sizeof(int32_t), st));
+        if (autoreset) take_reset_counter(s, p);
         timer_begin(s, s->t_step, st);
         HIP_TRY(launch_simple_race(p, st));
         timer_end(s, s->t_step, st);
@@ -711,12 +726,24 @@ int xwb_create(const xwb_config *cfg, xwb_sim **out) {
         default:
             return bail(fail(XWB_ERR_ARG, "Unrecognized game type"));     // simulator_interface.cpp:82
     }
+    if (cfg->rng_mode != XWB_RNG_PHILOX && cfg->rng_mode != XWB_RNG_MINSTD) return bail(fail(XWB_ERR_ARG, "unknown rng_mode"));
+    if (cfg->rng_mode == XWB_RNG_MINSTD) {
+        // the reference seeds an engine per thread only when FLAGS_simulator_seed != 0 (simulator_util.cpp:44-52); with 0
+        // its engines start from hash(thread id), which nobody can replay
+        if (cfg->simulator_seed == 0) return bail(fail(XWB_ERR_ARG, "rng_mode minstd needs simulator_seed != 0"));
+        if (cfg->thread_base < 0) return bail(fail(XWB_ERR_ARG, "thread_base must be >= 0"));
+        std::vector<uint32_t> st((size_t)n);
+        for (int e = 0; e < n; ++e)
+            st[(size_t)e] = xwb_minstd_seed_thread(cfg->simulator_seed, cfg->thread_base + (int32_t)(cfg->env_gid0 + (uint32_t)e) + 1);
+        if ((rc = dev_alloc(s, &s->d_minstd, n))) return bail(rc);
+        HIP_TRY(hipMemcpy(s->d_minstd, st.data(), st.size() * 4, hipMemcpyHostToDevice));
+    }
     if ((rc = dev_alloc(s, &s->d_actions, n, 0xff))) return bail(rc);
     if ((rc = dev_alloc(s, &s->d_actions_in, n, 0xff))) return bail(rc);
     if ((rc = dev_alloc(s, &s->d_mask, n))) return bail(rc);
     if ((rc = dev_alloc(s, &s->d_num_steps, n))) return bail(rc);
     if ((rc = dev_alloc(s, &s->d_err, 1))) return bail(rc);
-    if ((rc = dev_alloc(s, &s->d_reset_count, 1))) return bail(rc);
+    if ((rc = dev_alloc(s, &s->d_reset_count, 2))) return bail(rc);
     if ((rc = dev_alloc(s, &s->d_episode, n, 0xff))) return bail(rc);      // first reset -> episode 0
     if ((rc = dev_alloc(s, &s->d_reward, n))) return bail(rc);
     if ((rc = dev_alloc(s, &s->d_done, n))) return bail(rc);
@@ -839,15 +866,16 @@ int xwb_step_n(xwb_sim *s, int32_t n_steps, int32_t act_rep, void *stream) {
         for (int i = 0; i < n_steps; ++i) { int rc = do_step(s, nullptr, act_rep, true, st); if (rc) return rc; }
         return XWB_OK;
     }
-    HIP_TRY(hipMemsetAsync(s->d_reset_count, 0, sizeof(int32_t), st));
     timer_begin(s, s->t_step, st);
     if (s->cfg.game == XWB_SIMPLE_GAME) {
         SgParams p = sg_params(s);
         p.actions = nullptr; p.act_rep = act_rep; p.auto_reset = 1; p.n_steps = n_steps;
+        take_reset_counter(s, p);
         HIP_TRY(launch_simple_game(p, st));
     } else {
         RaceParams p = race_params(s);
         p.actions = nullptr; p.act_rep = act_rep; p.auto_reset = 1; p.n_steps = n_steps;
+        take_reset_counter(s, p);
         HIP_TRY(launch_simple_race(p, st));
     }
     timer_end(s, s->t_step, st);
@@ -911,6 +939,16 @@ XWB_GETTER(xwb_actions_dev, int32_t, d_actions)
 XWB_GETTER(xwb_num_steps_dev, int32_t, d_num_steps)
 XWB_GETTER(xwb_success_dev, uint8_t, d_success)
 XWB_GETTER(xwb_episode_dev, uint32_t, d_episode)
+XWB_GETTER(xwb_minstd_state_dev, uint32_t, d_minstd)
+
+uint32_t xwb_minstd_seed_thread(int32_t simulator_seed, int32_t nth_thread) {
+    // simulator_util.cpp:48-50: int seed = std::hash<std::string>()(std::to_string(FLAGS_simulator_seed + (++__num_threads)));
+    // reng_.seed(seed) -- libstdc++'s own hash, as in the reference's build
+    const int seed = (int)std::hash<std::string>()(std::to_string(simulator_seed + nth_thread));
+    return xwb_minstd_seed_value((int64_t)seed);
+}
+int32_t xwb_minstd_rand_ind(uint32_t *state, int32_t size) { return (state && size >= 1) ? xwb_minstd_rand_ind_state(state, size) : -1; }
+float xwb_minstd_rand_range(uint32_t *state, float upper) { return state ? xwb_minstd_rand_range_state(state, upper) : 0.0f; }
 
 int xwb_xw_grid_dev(xwb_sim *s, uint16_t **ptr) {
     if (!s || !ptr) return fail(XWB_ERR_ARG, "NULL argument");
@@ -923,7 +961,7 @@ int xwb_done_count(xwb_sim *s, void *stream, int32_t *n_done) {
     if (!s || !n_done) return fail(XWB_ERR_ARG, "NULL argument");
     XWB_ON_DEVICE(s);
     hipStream_t st = as_stream(stream);
-    const int32_t *src = s->cfg.game == XWB_XWORLD2D ? s->d_done_count + s->count_sel : s->d_reset_count;
+    const int32_t *src = s->cfg.game == XWB_XWORLD2D ? s->d_done_count + s->count_sel : s->d_reset_count + s->rc_sel;
     HIP_TRY(hipMemcpyAsync(n_done, src, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return XWB_OK;
@@ -1271,9 +1309,10 @@ std::vector<StateArray> state_arrays(xwb_sim *s, bool include_obs) {
     std::vector<StateArray> a;
     auto add = [&](void *p, size_t bytes) { if (p) a.push_back(StateArray{p, bytes}); };
     add(s->d_actions, n * 4); add(s->d_num_steps, n * 4); add(s->d_episode, n * 4); add(s->d_reward, n * 4);
-    add(s->d_done, n); add(s->d_success, n); add(s->d_err, 4); add(s->d_reset_count, 4);
+    add(s->d_done, n); add(s->d_success, n); add(s->d_err, 4); add(s->d_reset_count, 8);
     add(s->d_pos, n * 4); add(s->d_flags, n);
     add(s->d_x, n * 4); add(s->d_y, n * 4); add(s->d_angle, n * 4);
+    add(s->d_minstd, n * 4);
     if (s->cfg.game == XWB_XWORLD2D) {
         const size_t cells = (size_t)s->cfg.max_dim * s->cfg.max_dim;
         add(s->d_grid, n * cells * 2); add(s->d_agent, n * 4); add(s->d_task_steps, n * 4); add(s->d_task_state, n * 4);
@@ -1300,6 +1339,7 @@ uint64_t config_hash(const xwb_config &c) {            // everything that shapes
                          c.n_tasks, c.color, c.visible_radius, c.obs_format, c.n_icons};
     mix(v, sizeof v); mix(c.tasks, sizeof c.tasks);
     mix(&c.seed, 4); mix(&c.policy_seed, 4); mix(&c.env_gid0, 4);
+    mix(&c.rng_mode, 4); mix(&c.simulator_seed, 4); mix(&c.thread_base, 4);
     mix(&c.curriculum, 8); mix(&c.start_level, 4); mix(&c.task_schedule, 4); mix(c.task_weights, sizeof c.task_weights); mix(&c.no_wall_shadow, 4);
     return h;
 }
@@ -1324,8 +1364,8 @@ int xwb_save_state(xwb_sim *s, int32_t include_obs, uint8_t *out_host, size_t ca
     const auto arrays = state_arrays(s, include_obs != 0);
     StateHeader h{};
     memcpy(h.magic, "XWBSTATE", 8);
-    h.version = 1; h.game = (uint32_t)s->cfg.game; h.num_envs = (uint32_t)s->n; h.include_obs = include_obs ? 1u : 0u;
-    h.n_arrays = (uint32_t)arrays.size(); h.policy_step = s->policy_step; h.count_sel = (uint32_t)s->count_sel;
+    h.version = 2; h.game = (uint32_t)s->cfg.game; h.num_envs = (uint32_t)s->n; h.include_obs = include_obs ? 1u : 0u;
+    h.n_arrays = (uint32_t)arrays.size(); h.policy_step = s->policy_step; h.count_sel = (uint32_t)s->count_sel | ((uint32_t)s->rc_sel << 1);
     h.list_valid = (s->list_valid ? 1u : 0u) | (s->autoreset_done ? 2u : 0u); h.obs_bytes_per_env = s->obs_bytes_per_env; h.cfg_hash = config_hash(s->cfg);
     uint8_t *w = out_host;
     memcpy(w, &h, sizeof h); w += sizeof h;
@@ -1344,7 +1384,7 @@ int xwb_load_state(xwb_sim *s, const uint8_t *in_host, size_t bytes) {
     if (bytes < sizeof(StateHeader)) return fail(XWB_ERR_ARG, "not a state blob");
     StateHeader h;
     memcpy(&h, in_host, sizeof h);
-    if (memcmp(h.magic, "XWBSTATE", 8) != 0 || h.version != 1) return fail(XWB_ERR_ARG, "not a state blob of this version");
+    if (memcmp(h.magic, "XWBSTATE", 8) != 0 || h.version != 2) return fail(XWB_ERR_ARG, "not a state blob of this version");
     if (h.game != (uint32_t)s->cfg.game || h.num_envs != (uint32_t)s->n || h.obs_bytes_per_env != s->obs_bytes_per_env ||
         h.cfg_hash != config_hash(s->cfg))
         return fail(XWB_ERR_ARG, "state blob was saved from a batch with another configuration");
@@ -1360,7 +1400,7 @@ int xwb_load_state(xwb_sim *s, const uint8_t *in_host, size_t bytes) {
         HIP_TRY(hipMemcpy(a.ptr, r, a.bytes, hipMemcpyHostToDevice));
         r += b;
     }
-    s->policy_step = h.policy_step; s->count_sel = (int)h.count_sel; s->list_valid = (h.list_valid & 1u) != 0; s->autoreset_done = (h.list_valid & 2u) != 0;
+    s->policy_step = h.policy_step; s->count_sel = (int)(h.count_sel & 1u); s->rc_sel = (int)((h.count_sel >> 1) & 1u); s->list_valid = (h.list_valid & 1u) != 0; s->autoreset_done = (h.list_valid & 2u) != 0;
     if (s->cfg.game == XWB_XWORLD2D) {
         XwParams p = xw_params(s);
         if (p.visible_radius) HIP_TRY(launch_xw_warp_goals(p, false, nullptr));

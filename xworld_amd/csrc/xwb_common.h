@@ -90,7 +90,8 @@ struct SgParams {
     uint8_t *done;
     uint8_t *obs;               // [n][context][array_size]
     int32_t *err_count;
-    int32_t *reset_count;
+    int32_t *reset_count;       // envs reset by this launch are added here (one of a pair)
+    int32_t *reset_count_next;  // nullable: the pair's other counter, zeroed by this launch for the next counting one
 };
 hipError_t launch_simple_game(const SgParams &p, hipStream_t s);
 
@@ -117,7 +118,9 @@ struct RaceParams {
     uint8_t *done;
     float *obs;                 // [n][context][4]
     int32_t *err_count;
-    int32_t *reset_count;
+    int32_t *reset_count;       // see SgParams
+    int32_t *reset_count_next;
+    uint32_t *minstd;           // nullable: XWB_RNG_MINSTD, one libstdc++ minstd_rand0 state per env (include/xwb_minstd.h)
 };
 hipError_t launch_simple_race(const RaceParams &p, hipStream_t s);
 
@@ -204,6 +207,7 @@ struct XwParams {
     // starts (= the step kernel before it in the queue is complete); the list render with wait_epoch != 0 waits for sync[3].
     uint32_t *sync;
     uint32_t sig_epoch, wait_epoch;
+    uint32_t *minstd;            // nullable: XWB_RNG_MINSTD, one libstdc++ minstd_rand0 state per env: the teacher's task draw
 };
 hipError_t launch_xw_step(const XwParams &p, hipStream_t s);
 // one wavefront that ends once *epoch_slot has reached `want`: orders the work queued behind it after the publisher

@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libxwb.so")
 
-XWB_ABI_VERSION = 1
+XWB_ABI_VERSION = 2
 XWB_SIMPLE_GAME, XWB_SIMPLE_RACE, XWB_XWORLD2D = 0, 1, 2
 XWB_MAP_NAV, XWB_MAP_WALLS = 0, 1
 XWB_TASKMODE_LANG_ACQ, XWB_TASKMODE_ONE_CHANNEL = 0, 1
@@ -34,6 +34,7 @@ class XwbConfig(C.Structure):
         ("icons64", C.c_void_p), ("icon_type", C.c_void_p), ("icon_name", C.c_void_p), ("icon_colored", C.c_void_p),
         ("curriculum", C.c_double), ("start_level", C.c_int32),
         ("task_schedule", C.c_int32), ("task_weights", C.c_double * 8), ("no_wall_shadow", C.c_int32),
+        ("rng_mode", C.c_int32), ("simulator_seed", C.c_int32), ("thread_base", C.c_int32),
     ]
 
 
@@ -78,6 +79,10 @@ _SIGS = [
     ("xwb_success_dev", C.c_int, [_vp, C.POINTER(_vp)]),
     ("xwb_episode_dev", C.c_int, [_vp, C.POINTER(_vp)]),
     ("xwb_xw_grid_dev", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("xwb_minstd_state_dev", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("xwb_minstd_seed_thread", C.c_uint32, [C.c_int32, C.c_int32]),
+    ("xwb_minstd_rand_ind", C.c_int32, [C.POINTER(C.c_uint32), C.c_int32]),
+    ("xwb_minstd_rand_range", C.c_float, [C.POINTER(C.c_uint32), C.c_float]),
     ("xwb_done_count", C.c_int, [_vp, _vp, C.POINTER(C.c_int32)]),
     ("xwb_get_num_actions", C.c_int, [_vp, C.POINTER(C.c_int32)]),
     ("xwb_get_screen_out_dimensions", C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
