@@ -274,7 +274,12 @@ int xwb_race_set_car(xwb_sim *sim, int32_t env, float x, float y, float angle);
 
 /* SimulatorInterface::get_state(reward) of one env, serialised in the reference's StatePacket wire
  * layout (data_packet.h:313-319, data_packet.cpp:143-174, memory_util.h:307-333): keys "reward",
- * "screen" [, "sentence" for xworld].  Returns bytes needed in *need; writes when cap suffices. */
+ * "screen" [, "sentence" for xworld].  Returns bytes needed in *need; writes when cap suffices.
+ * KNOWN GAP: "sentence" is always "-" here.  The teacher's sentence of an env is a pure function of xwb_env_state
+ * (task, stage, event, xw_sentence_names, episode) and the goal-name strings, which this ABI never sees (it gets name
+ * ids); the Python host layer builds it (xworld_amd/language.py, BatchedSimulator.sentence / py_simulator get_state()),
+ * C / C++ callers and the TCP endpoint (include/xwb_endpoint.hpp) get "-" -- what the reference shows for an empty
+ * teacher sentence (xworld_simulator.cpp:486-493). */
 int xwb_get_state_packet(xwb_sim *sim, int32_t env, float reward, void *stream,
                          uint8_t *out_host, size_t cap, size_t *need);
 

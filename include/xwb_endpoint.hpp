@@ -79,26 +79,32 @@ class Message {
     void read(T &t) { need(sizeof(T)); memcpy(&t, b_.data() + at_, sizeof(T)); at_ += sizeof(T); }
     void read(std::string &s) {
         size_t n; read(n);
-        need(n + 1);
+        if (n >= b_.size() - at_) throw Error("wire::Message: truncated message");      // n + 1 bytes, without overflow
         s.assign(reinterpret_cast<const char *>(b_.data() + at_), n);
         at_ += n + 1;
     }
     template <typename T>
     void read(std::vector<T> &v) {                           // memory_util.h:362-369
         size_t n; read(n);
-        need(n * sizeof(T));
+        if (n > (b_.size() - at_) / sizeof(T)) throw Error("wire::Message: truncated message");   // before sizing anything by it
         v.resize(n);
         read(v.data(), n);
     }
     template <typename T>
-    void read(T *a, size_t n) { need(n * sizeof(T)); if (n) memcpy(a, b_.data() + at_, n * sizeof(T)); at_ += n * sizeof(T); }
+    void read(T *a, size_t n) {
+        if (n > (b_.size() - at_) / sizeof(T)) throw Error("wire::Message: truncated message");
+        if (n) memcpy(a, b_.data() + at_, n * sizeof(T));
+        at_ += n * sizeof(T);
+    }
     void read(StatePacket &p) { p.decode(b_.data() + at_, b_.size() - at_); at_ = b_.size(); }   // always last
 
   private:
-    void need(size_t n) const { if (at_ + n > b_.size()) throw Error("wire::Message: truncated message"); }
+    void need(size_t n) const { if (at_ > b_.size() || n > b_.size() - at_) throw Error("wire::Message: truncated message"); }
     std::vector<uint8_t> b_;
     size_t at_ = 0;
 };
+
+constexpr size_t kMaxMessageBytes = size_t(256) << 20;
 
 class Socket {
   public:
@@ -112,7 +118,9 @@ class Socket {
         lfd_ = ::socket(AF_INET, SOCK_STREAM, 0);
         if (lfd_ < 0) throw Error("socket() failed");
         sockaddr_in a{};
-        a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(INADDR_ANY); a.sin_port = 0;
+        // the reference's acceptor listens on every interface; its clients only ever connect to "localhost"
+        // (simulator_communication.cpp:63-91) and the protocol has no authentication: loopback only
+        a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(INADDR_LOOPBACK); a.sin_port = 0;
         socklen_t len = sizeof a;
         if (::bind(lfd_, reinterpret_cast<sockaddr *>(&a), sizeof a) != 0 || ::listen(lfd_, 1) != 0 ||
             ::getsockname(lfd_, reinterpret_cast<sockaddr *>(&a), &len) != 0)
@@ -151,7 +159,9 @@ class Socket {
     void receive(Message &m) {
         size_t n = 0;
         recv_all(&n, sizeof n);
-        if (n > (size_t(1) << 32)) throw Error("wire: implausible message size");
+        // the largest legitimate message is a state packet: a context ring of float frames (16 frames of 3 x 256 x 256
+        // floats = 12.6 MB); 256 MiB is far beyond it and far below what a hostile length could make us allocate
+        if (n > kMaxMessageBytes) throw Error("wire: implausible message size");
         m.clear();
         m.resize(n);
         recv_all(m.data_mutable(), n);

@@ -103,9 +103,11 @@ class StatePacket {
             std::string key = get_str(p, len, at);
             StateBuffer b;
             uint8_t flags = *take(p, len, at, 1);
-            if (flags & 1) { b.has_reals = true; uint64_t m = get_u64(p, len, at); b.reals.resize(m); if (m) memcpy(b.reals.data(), take(p, len, at, 4 * m), 4 * m); }
-            if (flags & 2) { b.has_pixels = true; uint64_t m = get_u64(p, len, at); b.pixels.resize(m); if (m) memcpy(b.pixels.data(), take(p, len, at, m), m); }
-            if (flags & 4) { b.has_id = true; uint64_t m = get_u64(p, len, at); b.id.resize(m); if (m) memcpy(b.id.data(), take(p, len, at, 4 * m), 4 * m); }
+            // element counts come from the peer: checked against the bytes that are left (without overflow) BEFORE anything
+            // is sized by them
+            if (flags & 1) { b.has_reals = true; const size_t m = get_count(p, len, at, 4); b.reals.resize(m); if (m) memcpy(b.reals.data(), take(p, len, at, 4 * m), 4 * m); }
+            if (flags & 2) { b.has_pixels = true; const size_t m = get_count(p, len, at, 1); b.pixels.resize(m); if (m) memcpy(b.pixels.data(), take(p, len, at, m), m); }
+            if (flags & 4) { b.has_id = true; const size_t m = get_count(p, len, at, 4); b.id.resize(m); if (m) memcpy(b.id.data(), take(p, len, at, 4 * m), 4 * m); }
             if (flags & 8) { b.has_str = true; b.str = get_str(p, len, at); }
             data_[key] = b;
         }
@@ -121,14 +123,21 @@ class StatePacket {
     static void put_u64(std::vector<uint8_t> &o, uint64_t v) { put(o, &v, 8); }
     static void put_str(std::vector<uint8_t> &o, const std::string &s) { put_u64(o, s.size()); put(o, s.c_str(), s.size() + 1); }
     static const uint8_t *take(const uint8_t *p, size_t len, size_t &at, size_t n) {
-        if (at + n > len) throw Error("StatePacket::decode: truncated buffer");
+        if (at > len || n > len - at) throw Error("StatePacket::decode: truncated buffer");
         const uint8_t *q = p + at;
         at += n;
         return q;
     }
     static uint64_t get_u64(const uint8_t *p, size_t len, size_t &at) { uint64_t v; memcpy(&v, take(p, len, at, 8), 8); return v; }
+    // a count of `elem`-byte elements that must still fit into the buffer
+    static size_t get_count(const uint8_t *p, size_t len, size_t &at, size_t elem) {
+        const uint64_t m = get_u64(p, len, at);
+        if (m > (uint64_t)(len - at) / elem) throw Error("StatePacket::decode: element count exceeds the buffer");
+        return (size_t)m;
+    }
     static std::string get_str(const uint8_t *p, size_t len, size_t &at) {
-        uint64_t n = get_u64(p, len, at);
+        const size_t n = get_count(p, len, at, 1);
+        if (n == len - at) throw Error("StatePacket::decode: truncated buffer");     // the terminating NUL
         const uint8_t *q = take(p, len, at, n + 1);
         return std::string(reinterpret_cast<const char *>(q), n);
     }

@@ -32,6 +32,21 @@ static int packet_tests() {
     bool threw = false;
     try { xwb::StatePacket s3; s3.decode(buf.data(), buf.size() - 1); } catch (const xwb::Error &) { threw = true; }
     EXPECT(threw);
+    // hostile counts: an element count or a string length far beyond the bytes that follow must be refused before anything
+    // is sized by it (and 4 * m / n + 1 must not wrap)
+    const uint64_t bad[] = {~0ull, ~0ull / 4 + 1, 1ull << 62, (uint64_t)buf.size()};
+    for (uint64_t v : bad) {
+        std::vector<uint8_t> evil = buf;
+        memcpy(evil.data() + 32, &v, 8);                   // the reals count of "internal_state"
+        threw = false;
+        try { xwb::StatePacket s3; s3.decode(evil); } catch (const xwb::Error &) { threw = true; } catch (...) { threw = false; }
+        EXPECT(threw);
+        evil = buf;
+        memcpy(evil.data() + 8, &v, 8);                    // the first key's length
+        threw = false;
+        try { xwb::StatePacket s3; s3.decode(evil); } catch (const xwb::Error &) { threw = true; } catch (...) { threw = false; }
+        EXPECT(threw);
+    }
     printf("packet ok (%zu bytes)\n", buf.size());
     return 0;
 }

@@ -1438,7 +1438,8 @@ int xwb_get_state_packet(xwb_sim *s, int32_t env, float reward, void *stream, ui
     w.str("screen");
     f = is_float ? 1 : 2; w.put(&f, 1); w.u64(n_screen); w.put(screen.data(), screen.size());
     if (xw) {
-        // XWorldSimulator::define_state_specs (:486-493): teacher sentence or "-" (language side channel is out of scope)
+        // XWorldSimulator::define_state_specs (:486-493): teacher sentence or "-".  The sentence itself is built by the
+        // Python host layer from xwb_env_state (include/xwb.h: "KNOWN GAP" at xwb_get_state_packet)
         w.str("sentence");
         f = 8; w.put(&f, 1); w.str("-");
     }
