@@ -134,6 +134,19 @@ typedef struct xwb_config {
     int32_t  simulator_seed;     /* FLAGS_simulator_seed (simulator_util.cpp:26): must be != 0 with XWB_RNG_MINSTD */
     int32_t  thread_base;        /* XWB_RNG_MINSTD: simulator threads the reference process had created before this batch's
                                   * first env; global env g uses the engine of thread number thread_base + g + 1 */
+    /* A second task group of the conf's "task_groups" (listed after the first; the teacher keeps conf order,
+     * teacher.cpp:56-98): n_tasks2 == 0 -> none.  One of the two groups holds XWorld3DNav* tasks, the other the 2-D-native
+     * XWorldNav* ones.  They run NON-exclusively -- Teacher::teach's else branch (teacher.cpp:221-225): every teach() runs
+     * each group's stage in conf order, rewards add up, the last group's event ("" included) is what game_over() sees, and
+     * only the first group's task sees the step's collision events (xworld_simulator.cpp:118-122). */
+    int32_t  n_tasks2;
+    int32_t  tasks2[8];
+    int32_t  task_schedule2;
+    double   task_weights2[8];
+    int32_t  task_groups_exclusive;  /* FLAGS_task_groups_exclusive (teacher.cpp:22-24).  task_mode lang_acquisition forces it
+                                      * off exactly as the reference does (simulator_interface.cpp:46-48); with one group it
+                                      * changes nothing; exclusive scheduling of TWO groups (weighted group shuffle, one group
+                                      * per teach(), 3-D idle stages in mid-episode) is not built: xwb_create refuses it */
 } xwb_config;
 
 typedef struct xwb_sim xwb_sim;
@@ -248,6 +261,8 @@ typedef struct xwb_env_state {
     int32_t  xw_check_counter;   /* curriculum: XWorldEnv.curriculum_check_counter */
     uint32_t xw_sentence_names;  /* goal-name ids the idle stage binds into the teacher's sentence: a | b << 16 (0xffff none):
                                   * TARGET G = the picked goal; NEAR G = g1; BETWEEN G1, G2; DIRECTION, AVOID G = the referent */
+    /* the second task group's Task FSM (n_tasks2 > 0; else zeros); xw_event / xw_event2 = what each group's task recorded */
+    int32_t  xw_task2, xw_stage2, xw_event2, xw_target2, xw_steps_in_task2;
 } xwb_env_state;
 int xwb_get_env_state(xwb_sim *sim, int32_t env, void *stream, xwb_env_state *out);
 /* copies env's "screen" (context frames) to host memory; bytes must equal bytes_per_env */

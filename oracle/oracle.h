@@ -156,6 +156,15 @@ typedef struct {
                               * own minstd_rand0, seeded like the reference's thread number thread_base + env id + 1
                               * (simulator_util.cpp:38-55); the xwb-rng-v1 draw they replace is still consumed */
     int thread_base;
+    /* a second task group of the teacher, listed after the first in the conf (teacher.cpp:56-98 keeps conf order); 0 = none.
+     * The groups run non-exclusively -- Teacher::teach's else branch (teacher.cpp:221-225), which lang_acquisition forces
+     * (simulator_interface.cpp:46-48): every teach() runs each group's stage in conf order; rewards add up in the teacher
+     * buffer, every task overwrites the buffer's event (also with ""), and only the first py_stage of a teach() sees this
+     * step's collision events (XWorldSimulator::get_events_of_game clears them, xworld_simulator.cpp:118-122). */
+    int n_tasks2;
+    int tasks2[8];
+    int task_schedule2;
+    double task_weights2[8];
 } orc_xw_cfg;
 
 typedef struct {
@@ -167,6 +176,9 @@ typedef struct {
 } orc_entity;
 
 typedef struct orc_xworld orc_xworld;
+/* Task FSM of task group g (0 or 1) after the last call; ev = the event ITS task recorded in that call */
+void   orc_xw_group_state(const orc_xworld *w, int g, int *kind, int *stage, int *steps_in_task, int *event,
+                          int *target2d_x, int *target2d_y);
 /* icons64: n_icons*64*64*3 BGR bytes (may be NULL when no rendering is asked for) */
 orc_xworld *orc_xw_create(const orc_xw_cfg *cfg, int n_icons, const orc_icon_info *info,
                           const uint8_t *icons64);

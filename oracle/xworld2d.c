@@ -520,10 +520,55 @@ static void task_navigation_reward(orc_xworld *w) {
     w->stage = next_stage;
 }
 
-/* Teacher::teach, teacher.cpp:207-230 (one task group) */
+static void group_save(orc_xworld *w, int g) {
+    orc_group_state *s = &w->grp[g];
+    s->stage = w->stage; s->steps_in_cur_task = w->steps_in_cur_task; s->target_name = w->target_name; s->task_kind = w->task_kind;
+    memcpy(s->target_ent, w->target_ent, sizeof s->target_ent);
+    s->between_x = w->between_x; s->between_y = w->between_y; s->sent_a = w->sent_a; s->sent_b = w->sent_b;
+    s->dir_ref_ent = w->dir_ref_ent; s->dir_word = w->dir_word; s->target2d_x = w->target2d_x; s->target2d_y = w->target2d_y;
+    s->last_event = w->event;
+}
+static void group_load(orc_xworld *w, int g) {
+    const orc_group_state *s = &w->grp[g];
+    w->stage = s->stage; w->steps_in_cur_task = s->steps_in_cur_task; w->target_name = s->target_name; w->task_kind = s->task_kind;
+    memcpy(w->target_ent, s->target_ent, sizeof s->target_ent);
+    w->between_x = s->between_x; w->between_y = s->between_y; w->sent_a = s->sent_a; w->sent_b = s->sent_b;
+    w->dir_ref_ent = s->dir_ref_ent; w->dir_word = s->dir_word; w->target2d_x = s->target2d_x; w->target2d_y = s->target2d_y;
+    w->act_n_tasks = g ? w->cfg.n_tasks2 : w->cfg.n_tasks;
+    w->act_tasks = g ? w->cfg.tasks2 : w->cfg.tasks;
+    w->act_schedule = g ? w->cfg.task_schedule2 : w->cfg.task_schedule;
+    w->act_weights = g ? w->cfg.task_weights2 : w->cfg.task_weights;
+}
+
+static void teacher_run_group(orc_xworld *w, int idle_pick);
+
+/* Teacher::teach, teacher.cpp:207-230, task_groups_exclusive_ == false: every group's stage in conf order.  Rewards add
+ * up in the buffer (add_teacher_reward); Task::py_stage ends with record_event_in_buffer(task.get_event()), so the buffer
+ * holds the LAST group's event, "" included; game_events_ is cleared by the first py_stage that reads it. */
 static void teacher_teach(orc_xworld *w, int idle_pick) {
     /* before_teach: clear_teacher_env_buffer */
     w->teacher_reward = 0; w->event = ORC_EV_NONE;
+    if (w->n_groups <= 1) {
+        group_load(w, 0);                         /* (the working fields already are group 0's: sets the task list) */
+        teacher_run_group(w, idle_pick);
+        group_save(w, 0);
+        return;
+    }
+    int last_event = ORC_EV_NONE;
+    for (int g = 0; g < w->n_groups; ++g) {
+        if (g > 0) group_save(w, g - 1);
+        if (g > 0) group_load(w, g);
+        else group_load(w, 0);
+        w->event = ORC_EV_NONE;
+        teacher_run_group(w, idle_pick);
+        last_event = w->event;                    /* record_event_in_buffer: overwrites */
+    }
+    group_save(w, w->n_groups - 1);
+    group_load(w, 0);                             /* accessors read group 0 */
+    w->event = last_event;
+}
+
+static void teacher_run_group(orc_xworld *w, int idle_pick) {
     switch (w->stage) {
         case ORC_STAGE_IDLE:
             (void)idle_pick;
@@ -751,11 +796,18 @@ static void after_map(orc_xworld *w, int idle_pick) {
     w->n_hits = 0;
     w->num_steps = 0;             /* last_action_success_ is NOT touched by reset_game */
     /* Teacher::reset_after_game_reset + teach(): lazy Task::reset then idle stage */
-    w->stage = ORC_STAGE_IDLE;
-    w->steps_in_cur_task = 0;
-    w->target_name = -1;
-    w->target2d_x = w->target2d_y = -1;
-    w->task_kind = ORC_TASK_TARGET;
+    w->n_groups = w->cfg.n_tasks2 > 0 ? 2 : 1;
+    for (int g = w->n_groups - 1; g >= 0; --g) {      /* TaskGroup::reset for every group; group 0's ends up in the working fields */
+        w->stage = ORC_STAGE_IDLE;
+        w->steps_in_cur_task = 0;
+        w->target_name = -1;
+        w->target2d_x = w->target2d_y = -1;
+        w->task_kind = ORC_TASK_TARGET;
+        memset(w->target_ent, 0, sizeof w->target_ent);
+        w->between_x = w->between_y = -1; w->sent_a = w->sent_b = -1; w->dir_ref_ent = -1; w->dir_word = 0;
+        w->event = ORC_EV_NONE;
+        group_save(w, g);
+    }
     teacher_teach(w, idle_pick);
     init_screen(w);
 }
@@ -878,6 +930,12 @@ int orc_xw_num_actions(const orc_xworld *w) { return w->cfg.visible_radius ? 6 :
 int64_t orc_xw_num_steps(const orc_xworld *w) { return w->num_steps; }
 int orc_xw_last_action_success(const orc_xworld *w) { return w->last_action_success; }
 int orc_xw_event(const orc_xworld *w) { return w->event; }
+void orc_xw_group_state(const orc_xworld *w, int g, int *kind, int *stage, int *steps_in_task, int *event,
+                        int *target2d_x, int *target2d_y) {
+    const orc_group_state *s = &w->grp[g < 0 || g >= w->n_groups ? 0 : g];
+    *kind = s->task_kind; *stage = s->stage; *steps_in_task = s->steps_in_cur_task; *event = s->last_event;
+    *target2d_x = s->target2d_x; *target2d_y = s->target2d_y;
+}
 int orc_xw_stage(const orc_xworld *w) { return w->stage; }
 int orc_xw_target_name(const orc_xworld *w) { return w->target_name; }
 int orc_xw_task_kind(const orc_xworld *w) { return w->task_kind; }

@@ -9,8 +9,23 @@
 #define MAXSTACK 4
 #define ITEM_SIZE 64          /* XItem::item_size_, xitem.h:151 */
 
+/* the Task FSM fields of one task group (teaching_task.h:63-69 + the Python task's own fields); the group that is running
+ * has them in orc_xworld's working fields, teacher_teach() swaps */
+typedef struct {
+    int stage, steps_in_cur_task, target_name, task_kind;
+    uint8_t target_ent[MAXENT];
+    int between_x, between_y, sent_a, sent_b, dir_ref_ent, dir_word, target2d_x, target2d_y;
+    int last_event;
+} orc_group_state;
+
 struct orc_xworld {
     orc_xw_cfg cfg;
+    orc_group_state grp[2];          /* saved FSMs; the working fields below always end a call holding group 0's */
+    int n_groups;
+    /* the running group's task list (orc_task_idle) */
+    int act_n_tasks, act_schedule;
+    const int *act_tasks;
+    const double *act_weights;
     orc_minstd reng;                 /* cfg.simulator_seed != 0: this env's thread-local engine */
     int n_icons;
     orc_icon_info *info;

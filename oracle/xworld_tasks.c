@@ -376,13 +376,13 @@ void orc_task_idle(orc_xworld *w) {
     w->dir_ref_ent = -1; w->dir_word = 0;
     w->sent_a = w->sent_b = -1;
     /* TaskGroup::run_stage: idx = get_rand_ind(task_list_.size()) */
-    int n_tasks = w->cfg.n_tasks > 0 ? w->cfg.n_tasks : 1;
+    int n_tasks = w->act_n_tasks > 0 ? w->act_n_tasks : 1;
     int t;
-    if (w->cfg.task_schedule == 1 && w->cfg.n_tasks > 0) {
+    if (w->act_schedule == 1 && w->act_n_tasks > 0) {
         /* util::simple_importance_sampling (simulator_util.cpp:57-86): float uniform in [0, float(acc.back())), the first
          * task whose accumulated weight is >= it; the draw is the 24-bit integer behind orc_stream_unit */
         double acc[8], total = 0;
-        for (int i = 0; i < n_tasks; ++i) { total += w->cfg.task_weights[i]; acc[i] = total; }
+        for (int i = 0; i < n_tasks; ++i) { total += w->act_weights[i]; acc[i] = total; }
         float val = ((float)orc_xw_draw_below(w, 1 << 24) * (1.0f / 16777216.0f)) * (float)total;
         if (w->cfg.simulator_seed) val = orc_minstd_rand_range(&w->reng, (float)total);      /* the reference's own engine */
         t = n_tasks - 1;
@@ -391,7 +391,7 @@ void orc_task_idle(orc_xworld *w) {
         t = orc_xw_draw_below(w, n_tasks);
         if (w->cfg.simulator_seed) t = orc_minstd_rand_ind(&w->reng, n_tasks);
     }
-    w->task_kind = w->cfg.n_tasks > 0 ? w->cfg.tasks[t] : ORC_TASK_TARGET;
+    w->task_kind = w->act_n_tasks > 0 ? w->act_tasks[t] : ORC_TASK_TARGET;
     if (w->task_kind >= ORC_TASK2D_TARGET) { idle_2d(w, &p); return; }
     if (w->task_kind == ORC_TASK_TARGET || w->task_kind == ORC_TASK_AVOID) {
         int cand[MAXENT];

@@ -45,7 +45,8 @@ class XwCfg(C.Structure):
                 ("visible_radius", C.c_int), ("n_tasks", C.c_int), ("tasks", C.c_int * 8),
                 ("curriculum", C.c_double), ("start_level", C.c_int),
                 ("task_schedule", C.c_int), ("task_weights", C.c_double * 8), ("no_wall_shadow", C.c_int),
-                ("simulator_seed", C.c_int), ("thread_base", C.c_int)]
+                ("simulator_seed", C.c_int), ("thread_base", C.c_int),
+                ("n_tasks2", C.c_int), ("tasks2", C.c_int * 8), ("task_schedule2", C.c_int), ("task_weights2", C.c_double * 8)]
 
 
 class Entity(C.Structure):
@@ -147,6 +148,7 @@ def lib():
     sig("orc_xw_load_map", None, vp, C.c_int, C.POINTER(Entity), C.c_int, C.c_int, C.c_uint32, C.c_uint32)
     sig("orc_xw_load_map_ex", None, vp, C.c_int, C.POINTER(Entity), C.c_int, i32p, C.c_int, C.c_uint32, C.c_uint32)
     sig("orc_xw_task_kind", C.c_int, vp)
+    sig("orc_xw_group_state", None, vp, C.c_int, *([C.POINTER(C.c_int)] * 6))
     sig("orc_xw_between_cell", None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
     sig("orc_xw_set_pose", None, vp, C.c_int, C.c_double, C.c_double, C.c_double)
     sig("orc_xw_get_pose", None, vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
@@ -355,6 +357,16 @@ def xw_cfg(**kw):
               max_steps_factor=10, task_mode=0, color=0, context=1, seed=0xC0FFEE, visible_radius=0)
     tasks = kw.pop("tasks", None)
     weights = kw.pop("task_weights", None)
+    tasks2 = kw.pop("tasks2", None)
+    weights2 = kw.pop("task_weights2", None)
+    if tasks2 is not None:                               # a second task group, after the first in conf order
+        c.n_tasks2 = len(tasks2)
+        for i, t in enumerate(tasks2):
+            c.tasks2[i] = TASK_ID.get(t, t)
+    if weights2 is not None:
+        c.task_schedule2 = 1
+        for i, x in enumerate(weights2):
+            c.task_weights2[i] = float(x)
     if weights is not None:
         c.task_schedule = 1
         for i, x in enumerate(weights):
@@ -471,6 +483,12 @@ class XWorld:
 
     def refresh_screen(self):
         self.L.orc_xw_refresh_screen(self.h)
+
+    def group_state(self, g):
+        """(task kind, stage, steps in task, the event its task recorded in the last call, 2-D target x, y) of task group g"""
+        v = [C.c_int() for _ in range(6)]
+        self.L.orc_xw_group_state(self.h, g, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)
 
     def task_kind(self):
         return self.L.orc_xw_task_kind(self.h)

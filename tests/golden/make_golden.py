@@ -40,6 +40,8 @@ Fixtures written:
   sentences.json the reference's CFG with each task's grammar: sentences for random bindings + the choices behind them
   tasks2d.json   the 2-D-native group of confs/walls.json (XWorldNavTarget / Near / ColorTarget / Between, rule D14b)
                  as a one-task group, both task modes, every teach() call of a 70-step episode
+  groups.json    two task groups (an XWorld3DNav* and an XWorldNav* task) run non-exclusively in both conf orders: every
+                 teach() call of 60-step episodes, per group and summed
   tasks.json     all five tasks of the XWorld3DNav group (Target, Near, Between, Direction, Avoid): the idle stage
                  driven by logged decisions (see DecisionRandom), the map after the teacher's rearrangement,
                  the target cells, and a random-action trace as in teacher.json
@@ -583,6 +585,95 @@ def gen_tasks2d(pals, n_maps, seed0, steps):
     return out
 
 
+
+# ------------------------------------------- two task groups, non-exclusive (D13) ----
+def gen_groups(pal, n_maps, seed0, steps):
+    """Teacher::teach with TWO task groups and task_groups_exclusive = false (teacher.cpp:207-230; lang_acquisition forces it,
+    simulator_interface.cpp:46-48): a one-task XWorld3DNav* group and a one-task XWorldNav* (2-D-native) group, in both conf
+    orders.  The ~15 lines of teacher.cpp / teaching_task.cpp restated here: per teach() every group in conf order -- if its
+    task is idle: Task::reset, then the current stage through Task::py_stage (Harness.py_stage: the FIRST group's call consumes
+    the step's collision events, get_events_of_game clears them; every call overwrites the event buffer, "" included);
+    rewards add up.  Logged per teach() and group: was it idle, the decisions its stage drew, reward, event, next stage; plus
+    the 2-D task's target cell, the summed reward and the event left in the buffer."""
+    import importlib
+    sys.path.insert(0, os.path.join(REF, "games", "xworld", "tasks"))
+    pairs = [("XWorld3DNavTarget", "XWorldNavTarget"), ("XWorld3DNavTargetNear", "XWorldNavColorTarget"),
+             ("XWorld3DNavTargetBetween", "XWorldNavTarget"), ("XWorld3DNavTargetDirection", "XWorldNavNear"),
+             ("XWorld3DNavTargetAvoid", "XWorldNavColorTarget")]
+    out = {}
+    rnd = random.Random(1357)
+    env = XWorldNav(ITEM_PATH)
+    for n3, n2 in pairs:
+        m3, m2 = importlib.import_module(n3), importlib.import_module(n2)
+        for order in ("3d_first", "2d_first"):
+            runs = []
+            k = 0
+            while len(runs) < n_maps and k < 6 * n_maps:
+                k += 1
+                random.seed(seed0 + k)
+                env.reset()
+                env.env_changed()
+                before = entity_records(env, pal)
+                h = Harness(env)
+                t3, t2 = getattr(m3, n3)(env), getattr(m2, n2)(env)
+                t2.directions = _ItDict(t2.directions)
+                fake = DecisionRandom(seed0 * 13 + k)
+                real3, real2 = m3.random, m2.random
+                m3.random = m2.random = fake
+                groups = [("3d", t3), ("2d", t2)] if order == "3d_first" else [("2d", t2), ("3d", t3)]
+                stage = {"3d": "idle", "2d": "idle"}
+
+                def teach():
+                    recs, total, buffer_event = [], 0.0, ""
+                    for fam, task in groups:
+                        was_idle = stage[fam] == "idle"
+                        if was_idle:
+                            task.reset()
+                        n0 = len(fake.log)
+                        # Task::py_stage, teaching_task.cpp:64-116 (Harness.py_stage reads env_changed() itself, which
+                        # clears the flag: restated here so that update_environment() below still sees it)
+                        env.update_entities_from_cpp([dict(e) for e in h.ents])
+                        env.update_agent_sentence_from_cpp("")
+                        env.update_agent_action_success_from_cpp(h.success)
+                        ev, h.game_events = h.game_events, ""
+                        env.update_game_event_from_cpp(ev)
+                        ret = getattr(task, stage[fam])()
+                        st, reward = ret[0], float(ret[1])
+                        stage[fam] = st
+                        changed = env.env_changed()
+                        event = task.get_event()
+                        if changed:                              # Task::py_stage -> game_->update_environment()
+                            h.ents = [dict(e) for e in env.cpp_get_entities()]
+                            for e in h.ents:
+                                e["loc"] = tuple(int(v) for v in e["loc"])
+                            h.agent = [e for e in h.ents if e["type"] == "agent"][0]
+                        total += reward
+                        buffer_event = event
+                        recs.append([fam, int(was_idle), list(fake.log[n0:]), reward, event, st])
+                    tgt = t2.target
+                    tx, ty = (int(tgt[0]) + env.offset_w, int(tgt[1]) + env.offset_h) if tgt[0] >= 0 else (-1, -1)
+                    return {"groups": recs, "reward": total, "event": buffer_event, "target2d": [tx, ty]}
+                try:
+                    try:
+                        first = teach()
+                    except AssertionError:                       # "map too crowded?": the reference process would die
+                        continue
+                    after = entity_records(env, pal)
+                    trace = []
+                    for t in range(steps):
+                        a = rnd.randrange(4)
+                        h.act(a)
+                        rec = teach()
+                        rec.update(action=a, agent=[int(h.agent["loc"][0]), int(h.agent["loc"][1])], success=int(bool(h.success)))
+                        trace.append(rec)
+                finally:
+                    m3.random, m2.random = real3, real2
+                runs.append({"py_seed": seed0 + k, "dim": env.get_dims()[0], "max_dim": env.get_max_dims()[0],
+                             "entities_before": before, "entities_after": after, "reset_teach": first, "trace": trace})
+            out["%s+%s/%s" % (n3, n2, order)] = runs
+    return out
+
+
 # ------------------------------------------------------------ teacher sentences ----
 def gen_sentences(n_per_task, seed0):
     """The reference's context_free_grammar.CFG (the real module, not the no-op stand-in above) fed with each task's own
@@ -758,6 +849,7 @@ def main():
         "sentences.json": lambda: gen_sentences(60, 31000),
         "tasks2d.json": lambda: gen_tasks2d({"nav": nav_pal, "walls": walls_pal}, 6, 12000, 70),
         "curriculum.json": lambda: gen_curriculum(nav_pal, 920, 41000, 0.33),
+        "groups.json": lambda: gen_groups(nav_pal, 6, 52000, 60),
     }
     only = sys.argv[1:]                      # optional: the fixtures to (re)generate
     out = {name: make() for name, make in makers.items() if not only or name in only}

@@ -1,0 +1,125 @@
+"""D13 on the GPU: two task groups run non-exclusively (Teacher::teach, teacher.cpp:207-230; forced by lang_acquisition,
+simulator_interface.cpp:46-48) against the oracle, which tests/test_oracle_groups.py pins to the reference's own Python
+tasks; the reference's confs/walls.json loaded unchanged; task_groups_exclusive honoured or refused, never ignored."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONF = os.path.join(ROOT, "xworld_amd", "confs")
+T3 = ["XWorld3DNavTarget", "XWorld3DNavTargetNear", "XWorld3DNavTargetBetween", "XWorld3DNavTargetDirection", "XWorld3DNavTargetAvoid"]
+T2 = ["XWorldNavTarget", "XWorldNavNear", "XWorldNavColorTarget", "XWorldNavBetween"]
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.mark.parametrize("first,second,w2,extra", [(T3, T2, None, {}), (T2, T3, None, {}), (T3, T2, [2, 1, 3, 1], {}),
+                                                   (T2[:1], T3[2:3], None, {}), (T3, T2, None, {"visible_radius": 3}),
+                                                   (T3, T2, None, {"curriculum": 0.1, "max_dim": 8})],
+                         ids=["3d+2d", "2d+3d", "weighted", "target+between", "ego", "curriculum"])
+def test_two_groups_reset_and_rollout(oracle, first, second, w2, extra):
+    _torch()
+    from xworld_amd.batched import BatchedSimulator
+    n, steps, gid0 = 512, 400, 30
+    md = extra.get("max_dim", 7)
+    opts = {"xwd_conf_path": os.path.join(CONF, "navigation2d.json"), "task_mode": "lang_acquisition", "max_dim": md,
+            "num_blocks": 16, "tasks": first, "tasks2": second}
+    opts.update(extra)
+    if w2:
+        opts["task_weights2"] = w2
+    sim = BatchedSimulator("xworld", opts, num_envs=n, seed=21, policy_seed=8, env_gid0=gid0)
+    pal = oracle.Palette(oracle.NAV_SUBTREES)
+    cfg = dict(map_kind=0, max_dim=md, dim=md, num_goals=4, num_blocks=16, seed=21, tasks=first, tasks2=second,
+               visible_radius=extra.get("visible_radius", 0), curriculum=extra.get("curriculum", 0.0))
+    if w2:
+        cfg["task_weights2"] = w2
+    ow = oracle.XWorld(pal, render=False, **cfg)
+    for e in range(0, n, 3):
+        ow.reset_game(gid0 + e, 0)
+        st = sim.env_state(e)
+        assert np.array_equal(sim.env_grid(e).astype(np.int32), ow.grid()), e
+        assert (st.xw_agent_x, st.xw_agent_y) == ow.agent_xy(), e
+        k0, s0, _, _, tx0, ty0 = ow.group_state(0)
+        k1, s1, _, _, tx1, ty1 = ow.group_state(1)
+        assert (st.xw_task, st.xw_stage, st.xw_task2, st.xw_stage2) == (k0, s0, k1, s1), e
+        for kind, target, tx, ty in ((k0, st.xw_target, tx0, ty0), (k1, st.xw_target2, tx1, ty1)):
+            if kind >= 5:                                   # the 2-D group's target cell
+                assert target == (ty * md + tx if tx >= 0 else -1), (e, kind)
+    ref = oracle.xw_rollout(n, oracle.xw_cfg(**cfg), pal, steps, policy_seed=8, env_gid0=gid0)
+    rewards = set()
+    for t in range(steps):
+        sim.reset_done()
+        sim.step()
+        r = sim.reward.cpu().numpy()
+        assert np.array_equal(r.view(np.uint32), ref.rewards[t].view(np.uint32)), t
+        assert np.array_equal(sim.game_over_codes.cpu().numpy(), ref.codes[t]), t
+        rewards.update(np.unique(r).tolist())
+    assert len(rewards) >= 4                                # sums of both groups' rewards
+    if first is T2 or first == T2[:1]:
+        assert ref.stats.resets >= 0
+    sim.close()
+
+
+def test_reference_walls_conf_loads_unchanged():
+    """The reference's confs/walls.json (byte-identical copy under tests/golden/): its navigation group runs, the language
+    group XWorldRec is skipped with a warning; python/examples/test_xworld.py:31-60's option dict."""
+    _torch()
+    from xworld_amd.py_simulator import Simulator
+    path = os.path.join(ROOT, "tests", "golden", "walls_reference.json")
+    options = {"xwd_conf_path": path, "curriculum": 0.1, "task_mode": "lang_acquisition", "context": 1, "pause_screen": True,
+               "task_groups_exclusive": False, "visible_radius": 0}
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        game = Simulator.create("xworld", options)
+    assert any("XWorldRec" in str(x.message) for x in w)
+    assert game.batch.task_groups == [("XWorldNav", [5, 6, 7, 8])] and game.batch.cfg.n_tasks2 == 0
+    game.reset_game()
+    total = 0.0
+    for i in range(60):
+        if game.game_over() != "alive":
+            game.reset_game()
+            continue
+        st = game.get_state()
+        assert st["height"] == st["width"] == "3"           # curriculum level 0: actual dims (xworld_simulator.cpp:495-504)
+        total += game.take_actions({"action": i % 4}, 1, False)
+    assert total < 0
+
+
+def test_two_group_conf_and_exclusive_flag():
+    _torch()
+    from xworld_amd.batched import BatchedSimulator
+    from xworld_amd.lib import XwbError
+    conf = os.path.join(CONF, "nav_two_groups.json")
+    sim = BatchedSimulator("xworld", {"xwd_conf_path": conf, "task_mode": "lang_acquisition"}, num_envs=64)
+    assert [g[0] for g in sim.task_groups] == ["XWorld3DNav", "XWorldNav"]
+    assert sim.cfg.n_tasks == 5 and sim.cfg.n_tasks2 == 4 and sim.cfg.task_schedule2 == 1 and sim.cfg.task_groups_exclusive == 0
+    for _ in range(30):
+        sim.step()
+        sim.reset_done()
+    st = sim.env_state(3)
+    assert st.xw_task in range(5) and st.xw_task2 in range(5, 9)
+    assert isinstance(sim.sentence(3), str)
+    sim.close()
+    # one_channel + exclusive (the Python defaults) with two built groups: refused, not silently run non-exclusively
+    with pytest.raises(XwbError, match="exclusive"):
+        BatchedSimulator("xworld", {"xwd_conf_path": conf}, num_envs=4)
+    sim = BatchedSimulator("xworld", {"xwd_conf_path": conf, "task_groups_exclusive": False}, num_envs=4)   # one_channel, both run
+    sim.close()
+    # one group: the flag changes nothing
+    one = os.path.join(CONF, "navigation2d.json")
+    a = BatchedSimulator("xworld", {"xwd_conf_path": one, "task_groups_exclusive": True}, num_envs=32, seed=4)
+    b = BatchedSimulator("xworld", {"xwd_conf_path": one, "task_groups_exclusive": False}, num_envs=32, seed=4)
+    for _ in range(40):
+        a.step(); b.step()
+        assert np.array_equal(a.reward.cpu().numpy(), b.reward.cpu().numpy())
+        a.reset_done(); b.reset_done()
+    a.close(); b.close()
+    with pytest.raises(XwbError, match="one must hold"):
+        BatchedSimulator("xworld", {"xwd_conf_path": one, "task_mode": "lang_acquisition", "tasks": T3[:2], "tasks2": T3[2:]}, num_envs=4)

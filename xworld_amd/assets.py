@@ -65,6 +65,42 @@ TASK_IDS = {"XWorld3DNavTarget": 0, "XWorld3DNavTargetNear": 1, "XWorld3DNavTarg
 TASK_NAMES = {v: k for k, v in TASK_IDS.items()}
 
 
+def conf_groups(conf, group=None):
+    """The task groups of the conf this build runs, in the order the JSON lists them (the teacher keeps that order,
+    teacher.cpp:56-98): [(group name, [task ids], [weights] or None for schedule "random")].
+
+    A group is built when every task it lists is (TASK_IDS).  Groups of other tasks -- the language question-answering
+    group XWorldRec of the reference's confs/walls.json, the dialog groups -- are skipped with a warning: the batch then
+    behaves as the reference does with those groups taken out of the conf.  `group` names one group to keep."""
+    import warnings
+    groups = conf.get("task_groups") or {}
+    if not groups:
+        return [("default", [0], None)]
+    if group is not None:
+        if group not in groups:
+            raise RuntimeError("task group %s is not in the conf" % group)
+        groups = {group: groups[group]}
+    out = []
+    for gname, g in groups.items():
+        names = list(g.get("tasks", {}))
+        missing = [t for t in names if t not in TASK_IDS]
+        if missing:
+            warnings.warn("task group %s is skipped: %s %s not built (navigation tasks only)" %
+                          (gname, ", ".join(missing[:3]) + (" ..." if len(missing) > 3 else ""), "is" if len(missing) == 1 else "are"))
+            continue
+        sched = g.get("schedule", "random")
+        if sched not in ("random", "weighted"):
+            raise RuntimeError("unknown task group schedule '%s'" % sched)
+        if not 1 <= len(names) <= 8:
+            raise RuntimeError("a task group needs 1..8 tasks")
+        out.append((gname, [TASK_IDS[t] for t in names], [float(w) for w in g["tasks"].values()] if sched == "weighted" else None))
+    if not out:
+        raise RuntimeError("the conf lists no task group this build runs")
+    if len(out) > 2:
+        raise RuntimeError("at most two task groups run per batch; pick with the 'task_group' option: " + ", ".join(n for n, _, _ in out))
+    return out
+
+
 def conf_tasks(conf, group=None):
     """Task ids of one task group of the conf, in the order the JSON lists them (`group` names it when the conf
     has several: confs/walls.json also lists the language group XWorldRec, which is out of scope).

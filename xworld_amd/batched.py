@@ -93,20 +93,41 @@ class BatchedSimulator:
             if fmt not in ("uint8", "float32"):
                 raise RuntimeError("obs_format must be 'uint8' or 'float32'")
             cfg.obs_format = 1 if fmt == "float32" else 0
-            tasks = opts.get("tasks")                                     # override: list of task class names / ids
-            tasks = assets.conf_tasks(conf, opts.get("task_group")) if tasks is None else [assets.TASK_IDS.get(t, t) for t in tasks]
-            cfg.n_tasks = len(tasks)
-            for i, t in enumerate(tasks):
-                cfg.tasks[i] = int(t)
-            # teaching_task.cpp:204-213: schedule "weighted" samples by the per-task numbers of the conf; "task_weights" overrides
-            weights = opts.get("task_weights", assets.conf_task_weights(conf, opts.get("task_group")) if opts.get("tasks") is None else None)
-            if weights is not None:
-                if len(weights) != len(tasks):
+            # the conf's task groups in conf order (unbuilt groups are skipped with a warning); "tasks" [+ "tasks2"] override
+            # them with lists of task class names / ids, "task_weights" [+ "task_weights2"] = schedule "weighted"
+            # (teaching_task.cpp:204-213)
+            if opts.get("tasks") is None:
+                groups = assets.conf_groups(conf, opts.get("task_group"))
+                if "task_weights" in opts:
+                    groups[0] = (groups[0][0], groups[0][1], opts["task_weights"])
+            else:
+                groups = [("tasks", [assets.TASK_IDS.get(t, t) for t in opts["tasks"]], opts.get("task_weights"))]
+                if opts.get("tasks2") is not None:
+                    groups.append(("tasks2", [assets.TASK_IDS.get(t, t) for t in opts["tasks2"]], opts.get("task_weights2")))
+            for gi, (gname, tasks, weights) in enumerate(groups):
+                if weights is not None and len(weights) != len(tasks):
                     raise RuntimeError("task_weights needs one weight per task")
-                cfg.task_schedule = 1
-                for i, x in enumerate(weights):
-                    cfg.task_weights[i] = float(x)
-            self.tasks = list(tasks)
+                if gi == 0:
+                    cfg.n_tasks = len(tasks)
+                    for i, t in enumerate(tasks):
+                        cfg.tasks[i] = int(t)
+                    if weights is not None:
+                        cfg.task_schedule = 1
+                        for i, x in enumerate(weights):
+                            cfg.task_weights[i] = float(x)
+                else:
+                    cfg.n_tasks2 = len(tasks)
+                    for i, t in enumerate(tasks):
+                        cfg.tasks2[i] = int(t)
+                    if weights is not None:
+                        cfg.task_schedule2 = 1
+                        for i, x in enumerate(weights):
+                            cfg.task_weights2[i] = float(x)
+            # FLAGS_task_groups_exclusive (py_simulator.cpp:132, default true); lang_acquisition turns it off as the
+            # reference does (simulator_interface.cpp:46-48)
+            cfg.task_groups_exclusive = int(bool(opts.get("task_groups_exclusive", True))) if mode != "lang_acquisition" else 0
+            self.tasks = list(groups[0][1])
+            self.task_groups = [(g[0], list(g[1])) for g in groups]
             cfg.visible_radius = int(opts.get("visible_radius", 0))         # py_simulator.cpp:133
             cfg.no_wall_shadow = 0 if opts.get("wall_shadow", True) else 1   # FLAGS_wall_shadow (xmap.cpp:19), C++ gflag only
             # py_simulator.cpp:127: FLAGS_curriculum.  XWorldNav.py:27-55: != 0 -> every env walks through the six levels
@@ -330,24 +351,34 @@ class BatchedSimulator:
         lib.check(self.L.xwb_xw_refresh_obs(self.h, int(env)))
 
     def sentence(self, env=0, stream=None):
-        """The teacher's sentence of one env after the last call (language.py); "" where the reference shows "-"."""
-        from . import language
+        """The teacher's sentence of one env after the last call (language.py); "" where the reference shows "-".  With two
+        task groups the first one (conf order) that speaks wins: Task::teacher_speak only records into an empty buffer
+        (teaching_task.cpp:118-127)."""
         st = self.env_state(env, stream)
-        if st.xw_task in (5, 7):
+        out = self._group_sentence(env, stream, st, st.xw_task, st.xw_stage, st.xw_event, st.xw_target, st.xw_steps_in_task)
+        if not out and self.cfg.n_tasks2 > 0:
+            out = self._group_sentence(env, stream, st, st.xw_task2, st.xw_stage2, st.xw_event2, st.xw_target2, st.xw_steps_in_task2)
+        return out
+
+    def _group_sentence(self, env, stream, st, task, stage, event, target, steps_in_task):
+        from . import language
+        if task in (5, 7):
             # 2-D-native Target / ColorTarget: they speak on the teach() call that picked the target, and "Time up ." on
             # the one_channel step that runs out of time (xworld_task.py:205-211): back to idle with the target still recorded
-            if st.xw_stage == 0 and st.xw_event == 0 and st.xw_target >= 0 and st.num_steps > 0 and self.cfg.task_mode == 1:
-                return language.sentence_2d_timeup(st.xw_task)
-            if st.xw_stage != 1 or st.xw_steps_in_task != 0 or st.xw_target < 0:
+            if stage == 0 and event == 0 and target >= 0 and st.num_steps > 0 and self.cfg.task_mode == 1:
+                return language.sentence_2d_timeup(task)
+            if stage != 1 or steps_in_task != 0 or target < 0:
                 return ""
             d = self.cfg.max_dim
-            icon = int(self.env_grid(env, stream)[st.xw_target // d, st.xw_target % d]) - 1
+            icon = int(self.env_grid(env, stream)[target // d, target % d]) - 1
+            if icon < 0:                                   # (two groups: the 3-D stage may have moved the goal away since)
+                return ""
             m = self.palette.meta[icon]
-            return language.sentence_2d(st.xw_task, m["name"], m.get("color", "na"), self.cfg.seed,
+            return language.sentence_2d(task, m["name"], m.get("color", "na"), self.cfg.seed,
                                         self.cfg.env_gid0 + int(env), st.episode, int(st.num_steps))
         sn = st.xw_sentence_names
-        return language.sentence(st.xw_task, st.xw_stage, st.xw_event, self.palette.names["goal"], sn & 0xffff, sn >> 16,
-                                 (st.xw_target >> 8) & 7 if st.xw_task == 3 and st.xw_target >= 0 else 0,
+        return language.sentence(task, stage, event, self.palette.names["goal"], sn & 0xffff, sn >> 16,
+                                 (target >> 8) & 7 if task == 3 and target >= 0 else 0,
                                  self.cfg.seed, self.cfg.env_gid0 + int(env), st.episode)
 
     def save_state(self, include_obs=True):

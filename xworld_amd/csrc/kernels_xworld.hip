@@ -39,6 +39,94 @@ __device__ __forceinline__ void wave_append(bool flag, int value, int32_t *list,
     if (flag) list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
 }
 
+// What one teach() call hands a task group's stage (Task::py_stage pushes the same into the Python env)
+struct StepCtx {
+    int e, D, ax, ay, steps, hit, hit_cell, ddx, ddy, vx, vy;
+    bool success;
+    int level;
+};
+
+// One task group's stage in one Teacher::teach call: group G's task FSM (ts_in / tsteps_in -> ts_out / tsteps_out), the
+// reward it adds to the teacher buffer and the event it leaves there (every py_stage overwrites it).
+template <int G>
+__device__ __forceinline__ void teach_group(const XwParams &p, const StepCtx &c, const uint8_t *s_icon_type, int ts, int tsteps_in,
+                                            double &rew, int &event, int &ts_out, int &tsteps_out) {
+    const int e = c.e, D = c.D, ax = c.ax, ay = c.ay, steps = c.steps, hit = c.hit, hit_cell = c.hit_cell;
+    const int ddx = c.ddx, ddy = c.ddy, vx = c.vx, vy = c.vy, ld_level = c.level;
+    const bool success = c.success;
+    const bool group2d = G ? p.group2d_2 != 0 : p.group2d != 0;
+    int target = task_target(ts), kind = task_kind(ts);
+    int stage = task_stage(ts);
+    int tsteps = tsteps_in;
+    event = EV_NONE;
+    int record = -1;                                // curriculum: the result this step adds to the task's window
+    rew = 0.0;
+    if (group2d) {
+        // rule D14b (games/xworld/tasks/xworld_task.py:184-223): the group draws a task whenever its busy
+        // task is idle (teaching_task.cpp:204-222), also at step time
+        if (stage == STAGE_IDLE) {
+            Stream s2;
+            s2.init(p.seed, p.env_gid0 + (uint32_t)e, p.episode[e], 2u);
+            s2.blk = (uint32_t)steps;
+            const int k2 = task_at<G>(p, sample_task<G>(p, s2, e));
+            kind = k2;
+            idle_2d(kind, p.cand2d[e], p.goal_cells + (size_t)e * XW_MAX_GOALS,
+                    [&](uint32_t n) { return s2.below(n); }, target, stage, tsteps);
+            rew = 0.0;
+        } else if (stage == STAGE_NAV) {
+            rew = -0.1;                             // time_penalty
+            if (!success) rew += -0.2;              // failed_action_penalty
+            tsteps += 1;
+            if (p.task_mode == 1 && tsteps >= D * D / 2) {           // one_channel: h*w / 2 (max dims)
+                tsteps = 0;
+                record = 0;                         // _record_failure
+                stage = STAGE_IDLE;                 // "S -> timeup"
+            } else if (ay * D + ax == target) {     // agent.loc == self.target
+                tsteps = 0;
+                record = 1;                         // _record_success
+                event = EV_CORRECT; rew += 1.0;
+                stage = STAGE_IDLE;
+            }
+            // `agent.loc in goal_locs` (-1.0) cannot hold: XMap::move_item never enters an occupied cell
+        }
+    } else if (stage == STAGE_NAV) {
+        rew = -0.01;                                // time_penalty
+        tsteps += 1;
+        const int dim = p.curriculum != 0 ? 3 + ld_level : p.dim;             // env.get_dims()
+        if (tsteps >= dim * dim * p.max_steps_factor) {
+            event = EV_TIMEUP;
+            record = 0;
+            stage = STAGE_TERMINAL;
+        } else if (hit != 0 && ddx == vx && ddy == vy && s_icon_type[(hit & CELL_ICON_MASK) - 1] == 0) {
+            // _reach_object: id in collisions and |theta| < pi/4, i.e. the goal was bumped into along the
+            // heading: MOVE_DOWN under full observation (yaw stays 1.5707963), MOVE_FORWARD in egocentric mode.
+            // Target / Near / Avoid: the reached goal is in self.target (cell bit 15, set by the idle stage)
+            // -> correct, else wrong.  Between: any reached goal is wrong.  Direction: (direction(g, referent,
+            // agent.yaw), near) is evaluated now, the yaw being the current heading.
+            bool good = kind != TASK_BETWEEN && (hit & CELL_TARGET_BIT);
+            if (kind == TASK_DIRECTION && target >= 0) {        // (a replayed map may carry the bits only)
+                const int rc = target & 0xff, word = (target >> 8) & 7;
+                const int v2x = rc % D - hit_cell % D, v2y = rc / D - hit_cell / D;
+                const int cs = vx * v2x + vy * v2y, sn = vy * v2x - vx * v2y;
+                const int dirw = cs > 0 ? DIR_FRONT : (cs < 0 ? DIR_BEHIND : (sn > 0 ? DIR_RIGHT : DIR_LEFT));
+                good = v2x * v2x + v2y * v2y == 1 && dirw == word;
+            }
+            if (good) { event = EV_CORRECT; rew += 1.0; }
+            else { event = EV_WRONG; rew += -1.0; }
+            record = good ? 1 : 0;                  // _successful_goal / _failed_goal
+            stage = STAGE_TERMINAL;
+        } else if (kind == TASK_BETWEEN && ay * D + ax == target) {
+            // XWorld3DNavTargetBetween.navigation_reward: dist(agent, middle) < threshold / 2
+            event = EV_CORRECT; rew += 1.0;
+            record = 1;
+            stage = STAGE_TERMINAL;
+        }
+    }
+    if (record >= 0 && p.curriculum != 0) usage_push(p.cur_usage + ((size_t)e * 9 + kind) * XW_USAGE_BYTES, record);
+    ts_out = pack_task(target, stage, event, kind);
+    tsteps_out = tsteps;
+}
+
 // ------------------------------------------------------------------- step --
 __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
     // The kernel is a chain of dependent memory round trips for a few thousand wavefronts (it moves ~1 MB): everything
@@ -49,9 +137,10 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
     int32_t *count_now = p.done_count;
     if (e == 0) *p.done_count_next = 0;        // double-buffered done counter: zero the next step's
     bool is_done = false;
-    int ld_axy = 0, ld_steps = 0, ld_ts = 0, ld_tsteps = 0, ld_dir = 1, ld_level = 0;
+    int ld_axy = 0, ld_steps = 0, ld_ts = 0, ld_tsteps = 0, ld_dir = 1, ld_level = 0, ld_ts2 = 0, ld_tsteps2 = 0;
     if (e < p.n) {
         ld_axy = p.agent_xy[e]; ld_steps = p.num_steps[e]; ld_ts = p.task_state[e]; ld_tsteps = p.task_steps[e];
+        if (p.n_tasks2 > 0) { ld_ts2 = p.task_state2[e]; ld_tsteps2 = p.task_steps2[e]; }
         if (p.visible_radius) ld_dir = p.agent_dir[e];
         if (p.curriculum != 0) ld_level = p.cur_level[e];
     }
@@ -113,83 +202,35 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
                     }
                 }
             }
-            // Teacher::teach -> Task stage (one group, task XWorld3DNavTarget)
-            const int ts = ld_ts;
-            int target = task_target(ts), kind = task_kind(ts);
-            int stage = task_stage(ts);
-            int tsteps = ld_tsteps;
-            int event = EV_NONE;
-            int record = -1;                                // curriculum: the result this step adds to the task's window
+            // Teacher::teach (teacher.cpp:207-230), groups run non-exclusively in conf order: each group's Task stage adds its
+            // reward to the teacher buffer and overwrites the buffer's event ("" included); only the first py_stage of a
+            // teach() sees this step's collisions (XWorldSimulator::get_events_of_game clears them, xworld_simulator.cpp:
+            // 118-122).  One group is the usual case.
+            StepCtx cx{e, D, ax, ay, steps, hit, hit_cell, ddx, ddy, vx, vy, success, ld_level};
             double rew = 0.0;
-            if (p.group2d) {
-                // rule D14b (games/xworld/tasks/xworld_task.py:184-223): the group draws a task whenever its busy
-                // task is idle (teaching_task.cpp:204-222), also at step time
-                if (stage == STAGE_IDLE) {
-                    Stream s2;
-                    s2.init(p.seed, p.env_gid0 + (uint32_t)e, p.episode[e], 2u);
-                    s2.blk = (uint32_t)steps;
-                    const int k2 = task_at(p, sample_task(p, s2, e));
-                    kind = k2;
-                    idle_2d(kind, p.cand2d[e], p.goal_cells + (size_t)e * XW_MAX_GOALS,
-                            [&](uint32_t n) { return s2.below(n); }, target, stage, tsteps);
-                    rew = 0.0;
-                } else if (stage == STAGE_NAV) {
-                    rew = -0.1;                             // time_penalty
-                    if (!success) rew += -0.2;              // failed_action_penalty
-                    tsteps += 1;
-                    if (p.task_mode == 1 && tsteps >= D * D / 2) {           // one_channel: h*w / 2 (max dims)
-                        tsteps = 0;
-                        record = 0;                         // _record_failure
-                        stage = STAGE_IDLE;                 // "S -> timeup"
-                    } else if (ay * D + ax == target) {     // agent.loc == self.target
-                        tsteps = 0;
-                        record = 1;                         // _record_success
-                        event = EV_CORRECT; rew += 1.0;
-                        stage = STAGE_IDLE;
-                    }
-                    // `agent.loc in goal_locs` (-1.0) cannot hold: XMap::move_item never enters an occupied cell
-                }
-            } else if (stage == STAGE_NAV) {
-                rew = -0.01;                                // time_penalty
-                tsteps += 1;
-                const int dim = p.curriculum != 0 ? 3 + ld_level : p.dim;             // env.get_dims()
-                if (tsteps >= dim * dim * p.max_steps_factor) {
-                    event = EV_TIMEUP;
-                    record = 0;
-                    stage = STAGE_TERMINAL;
-                } else if (hit != 0 && ddx == vx && ddy == vy && s_icon_type[(hit & CELL_ICON_MASK) - 1] == 0) {
-                    // _reach_object: id in collisions and |theta| < pi/4, i.e. the goal was bumped into along the
-                    // heading: MOVE_DOWN under full observation (yaw stays 1.5707963), MOVE_FORWARD in egocentric mode.
-                    // Target / Near / Avoid: the reached goal is in self.target (cell bit 15, set by the idle stage)
-                    // -> correct, else wrong.  Between: any reached goal is wrong.  Direction: (direction(g, referent,
-                    // agent.yaw), near) is evaluated now, the yaw being the current heading.
-                    bool good = kind != TASK_BETWEEN && (hit & CELL_TARGET_BIT);
-                    if (kind == TASK_DIRECTION && target >= 0) {        // (a replayed map may carry the bits only)
-                        const int rc = target & 0xff, word = (target >> 8) & 7;
-                        const int v2x = rc % D - hit_cell % D, v2y = rc / D - hit_cell / D;
-                        const int cs = vx * v2x + vy * v2y, sn = vy * v2x - vx * v2y;
-                        const int dirw = cs > 0 ? DIR_FRONT : (cs < 0 ? DIR_BEHIND : (sn > 0 ? DIR_RIGHT : DIR_LEFT));
-                        good = v2x * v2x + v2y * v2y == 1 && dirw == word;
-                    }
-                    if (good) { event = EV_CORRECT; rew += 1.0; }
-                    else { event = EV_WRONG; rew += -1.0; }
-                    record = good ? 1 : 0;                  // _successful_goal / _failed_goal
-                    stage = STAGE_TERMINAL;
-                } else if (kind == TASK_BETWEEN && ay * D + ax == target) {
-                    // XWorld3DNavTargetBetween.navigation_reward: dist(agent, middle) < threshold / 2
-                    event = EV_CORRECT; rew += 1.0;
-                    record = 1;
-                    stage = STAGE_TERMINAL;
-                }
+            int event = EV_NONE;
+            {
+                int ts_new, tsteps_new;
+                double r0;
+                teach_group<0>(p, cx, s_icon_type, ld_ts, ld_tsteps, r0, event, ts_new, tsteps_new);
+                rew = 0.0 + r0;                             // add_teacher_reward on a cleared buffer
+                p.task_state[e] = ts_new;
+                p.task_steps[e] = tsteps_new;
             }
-            if (record >= 0 && p.curriculum != 0) usage_push(p.cur_usage + ((size_t)e * 9 + kind) * XW_USAGE_BYTES, record);
+            if (p.n_tasks2 > 0) {
+                cx.hit = 0;                                 // game_events_ was consumed by the first group's py_stage
+                int ts_new, tsteps_new;
+                double r1;
+                teach_group<1>(p, cx, s_icon_type, ld_ts2, ld_tsteps2, r1, event, ts_new, tsteps_new);
+                rew += r1;
+                p.task_state2[e] = ts_new;
+                p.task_steps2[e] = tsteps_new;
+            }
             float r = 0.0f;                                 // SimulatorInterface::take_actions
             r += 0.0f;                                      // XWorldSimulator::take_action returns 0
             r = (float)((double)r + rew);                   // r += teacher_->give_reward() (double)
             const int code = done_code(p, steps, event);
             p.agent_xy[e] = ax | (ay << 16);
-            p.task_state[e] = pack_task(target, stage, event, kind);
-            p.task_steps[e] = tsteps;
             p.num_steps[e] = steps;
             p.success[e] = success ? 1 : 0;
             p.reward[e] = r;

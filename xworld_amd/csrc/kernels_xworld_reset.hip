@@ -387,16 +387,14 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
     // ---- teacher idle stage (TaskGroup::run_stage samples one task of the group per episode, then its idle()):
     // decision order "xwb-taskgen-v1" (DESIGN.md).  Nothing is written to the grid before the stage has
     // succeeded, so the "map too crowded?" cases (the reference asserts) simply keep the generated map.
-    const int tsel = sample_task(p, s, e);
-    const int kind = p.n_tasks > 0 ? task_at(p, tsel) : TASK_TARGET;
+    // One or two task groups (conf order), each: TaskGroup::run_stage draws a task, Task::reset, its idle stage.  The
+    // 3-D-family stage may rearrange the map; the 2-D-family stage only reads it (its candidate tables are refreshed below
+    // when it ran before a rearrangement: every later idle stage of the episode sees the final map).
     uint32_t target_bits = 0;                              // goal slot i belongs to self.target
     int sent_a = 0xffff, sent_b = 0xffff;                  // names bound into the teacher's grammar (G / G1, G2)
     int between = -1;                                      // NavTargetBetween: the middle cell (actual-dim index)
-    int target_field = -1;
 
-    int stage0 = STAGE_NAV;
-
-    if (p.group2d) {
+    auto idle_stage_2d = [&](int kind, bool draw, int &tf, int &st0) {
         // ---- the 2-D-native group (rule D14b).  XWorldTask._reachable: bfs with the BLOCKS as the only obstacles;
         // the agent never leaves its component and nothing else moves, so the candidate sets of every later idle
         // stage of this episode are fixed here: goal_cells + cand2d are what the step kernel's idle stage reads.
@@ -423,9 +421,13 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
             gc[i] = i < ng ? (uint8_t)((c / D + off) * MD + (c % D + off)) : (uint8_t)0xff;
         }
         p.cand2d[e] = cand;
-        int tsteps0;
-        idle_2d(kind, cand, gc, [&](uint32_t n) { return s.below(n); }, target_field, stage0, tsteps0);
-    } else if (kind == TASK_TARGET || kind == TASK_AVOID) {
+        if (draw) {
+            int tsteps0;
+            idle_2d(kind, cand, gc, [&](uint32_t n) { return s.below(n); }, tf, st0, tsteps0);
+        }
+    };
+    auto idle_stage_3d = [&](int kind, int &tf) {
+    if (kind == TASK_TARGET || kind == TASK_AVOID) {
         // goals reachable from the agent with blocks and the other goals as obstacles: flood the empty cells from
         // the agent by whole-board shifts; a goal is reachable iff one of its 4-neighbours is flooded
         const Mask<NW> free_cells = valid.andnot(occupied);          // agent cell included: it is the seed
@@ -452,7 +454,7 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
                 if ((cand_bits >> i) & 1u) { if (k == 0) { pick = i; break; } k--; }
             const int selname = L.gname[L.at(pick)];
             if (kind == TASK_TARGET) {
-                target_field = selname;
+                tf = selname;
                 sent_a = selname;
                 for (int i = 0; i < ng; ++i) if (L.gname[L.at(i)] == selname) target_bits |= 1u << i;
             } else {
@@ -623,6 +625,29 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
             agent_cell = al;
             sent_a = L.gname[L.at(kind == TASK_DIRECTION ? ref : g1)];
             if (kind == TASK_BETWEEN) sent_b = L.gname[L.at(g2)];
+            {
+                // env.entities: g1 and g2 were deleted and set again, so they now follow the other goals, in that order
+                // (xworld_env.py _delete_entity / _set_entity_inst).  A later idle stage that enumerates the goals -- the
+                // 2-D-native group's random.choice(targets) -- sees that order, so the goal slots take it too; the
+                // egocentric poses travel with their goals.
+                const uint8_t c1 = L.gcell[L.at(g1)], c2 = L.gcell[L.at(g2)];
+                const uint16_t i1 = L.gicon[L.at(g1)], i2 = L.gicon[L.at(g2)], n1 = L.gname[L.at(g1)], n2 = L.gname[L.at(g2)];
+                double *gw = p.visible_radius ? p.goal_warp + (size_t)e * XW_MAX_GOALS * 6 : nullptr;
+                double w1[6], w2[6];
+                if (gw) for (int q = 0; q < 6; ++q) { w1[q] = gw[g1 * 6 + q]; w2[q] = gw[g2 * 6 + q]; }
+                int k = 0;
+                for (int i = 0; i < ng; ++i) {
+                    if (i == g1 || i == g2) continue;
+                    if (k != i) {
+                        L.gcell[L.at(k)] = L.gcell[L.at(i)]; L.gicon[L.at(k)] = L.gicon[L.at(i)]; L.gname[L.at(k)] = L.gname[L.at(i)];
+                        if (gw) for (int q = 0; q < 6; ++q) gw[k * 6 + q] = gw[i * 6 + q];
+                    }
+                    ++k;
+                }
+                L.gcell[L.at(k)] = c1; L.gicon[L.at(k)] = i1; L.gname[L.at(k)] = n1;
+                L.gcell[L.at(k + 1)] = c2; L.gicon[L.at(k + 1)] = i2; L.gname[L.at(k + 1)] = n2;
+                if (gw) for (int q = 0; q < 6; ++q) { gw[k * 6 + q] = w1[q]; gw[(k + 1) * 6 + q] = w2[q]; }
+            }
             if (kind == TASK_NEAR) {
                 // _get_surrounding_goals(refer=g1.loc): dist < 1.5 + 1e-3 = the 8-neighbourhood, goals AT g1.loc skipped
                 for (int i = 0; i < ng; ++i) {
@@ -648,15 +673,31 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
                     const int dir = cs > 0 ? DIR_FRONT : (cs < 0 ? DIR_BEHIND : (sn > 0 ? DIR_RIGHT : DIR_LEFT));
                     if (dir == direction) target_bits |= 1u << i;
                 }
-                target_field = ((rl / D + off) * MD + (rl % D + off)) | (direction << 8);
+                tf = ((rl / D + off) * MD + (rl % D + off)) | (direction << 8);
             }
         }
     }
+        if (kind == TASK_BETWEEN && between >= 0) tf = (between / D + off) * MD + (between % D + off);
+    };
+    int kindv[2] = {TASK_TARGET, TASK_TARGET}, tfv[2] = {-1, -1}, st0v[2] = {STAGE_NAV, STAGE_NAV};
+    {
+        const int tsel = sample_task<0>(p, s, e);
+        kindv[0] = p.n_tasks > 0 ? task_at<0>(p, tsel) : TASK_TARGET;
+        if (p.group2d) idle_stage_2d(kindv[0], true, tfv[0], st0v[0]);
+        else idle_stage_3d(kindv[0], tfv[0]);
+    }
+    if (p.n_tasks2 > 0) {
+        const int tsel = sample_task<1>(p, s, e);
+        kindv[1] = task_at<1>(p, tsel);
+        if (p.group2d_2) idle_stage_2d(kindv[1], true, tfv[1], st0v[1]);
+        else idle_stage_3d(kindv[1], tfv[1]);
+        if (p.group2d) { int tf_unused, st_unused; idle_stage_2d(kindv[0], false, tf_unused, st_unused); }
+    }
+    const int kind = kindv[0];
     // goal cells carry bit 15 when the goal belongs to the target set (the step kernel's whole reward rule)
     for (int i = 0; i < ng; ++i)
         put_code(L.gcell[L.at(i)], (uint16_t)((L.gicon[L.at(i)] + 1) | (((target_bits >> i) & 1u) ? 0x8000u : 0u)));
-    if (kind == TASK_BETWEEN && between >= 0) target_field = (between / D + off) * MD + (between % D + off);
-    if (!p.group2d) {                                     // goal slot -> cell (the egocentric render finds a goal's pose by it)
+    if (!p.group2d && !(p.n_tasks2 > 0 && p.group2d_2)) {   // goal slot -> cell (the egocentric render finds a goal's pose by it)
         uint8_t *gc = p.goal_cells + (size_t)e * XW_MAX_GOALS;
         for (int i = 0; i < XW_MAX_GOALS; ++i) {
             const int c = i < ng ? L.gcell[L.at(i)] : 0;
@@ -665,7 +706,8 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
     }
 
     p.agent_xy[e] = (agent_cell % D + off) | ((agent_cell / D + off) << 16);
-    p.task_state[e] = pack_task(target_field, stage0, EV_NONE, kind);
+    p.task_state[e] = pack_task(tfv[0], st0v[0], EV_NONE, kind);
+    if (p.n_tasks2 > 0) { p.task_state2[e] = pack_task(tfv[1], st0v[1], EV_NONE, kindv[1]); p.task_steps2[e] = 0; }
     p.sent_names[e] = (uint32_t)sent_a | ((uint32_t)sent_b << 16);
     p.task_steps[e] = 0;
     p.num_steps[e] = 0;

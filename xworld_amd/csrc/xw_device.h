@@ -49,10 +49,12 @@ __device__ __forceinline__ void idle_2d(int kind, uint32_t cand, const uint8_t *
 
 // p.tasks[i] for a per-lane i: a select chain over the eight scalars instead of a vector load from the kernel-argument
 // buffer (which is not cached like device memory: a full memory round trip in the middle of a latency-bound kernel)
+template <int G = 0>
 __device__ __forceinline__ int task_at(const XwParams &p, int i) {
-    int r = p.tasks[0];
+    const int *tasks = G ? p.tasks2 : p.tasks;
+    int r = tasks[0];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) r = i == k ? p.tasks[k] : r;
+    for (int k = 1; k < 8; ++k) r = i == k ? tasks[k] : r;
     return r;
 }
 
@@ -92,18 +94,20 @@ __device__ __forceinline__ int done_code(const XwParams &p, int num_steps, int e
 // accumulated weight is >= it.  One draw either way.
 // XWB_RNG_MINSTD: the decision comes from env e's own minstd_rand0 (the reference's thread-local engine); the stream's draw
 // is still consumed so that everything else the stream decides (the map) does not depend on the RNG mode.
-template <typename S>
+template <int G = 0, typename S>
 __device__ inline int sample_task(const XwParams &p, S &s, int e) {
-    const int n = p.n_tasks > 0 ? p.n_tasks : 1;
-    if (!p.task_weighted) {
+    const int n_conf = G ? p.n_tasks2 : p.n_tasks;
+    const int n = n_conf > 0 ? n_conf : 1;
+    const double *task_acc = G ? p.task_acc2 : p.task_acc;
+    if (!(G ? p.task_weighted2 : p.task_weighted)) {
         int t = (int)s.below((uint32_t)n);
         if (p.minstd) { uint32_t x = p.minstd[e]; t = xwb_minstd_rand_ind_state(&x, n); p.minstd[e] = x; }
         return t;
     }
-    float val = s.unit() * (float)p.task_acc[n - 1];
-    if (p.minstd) { uint32_t x = p.minstd[e]; val = xwb_minstd_rand_range_state(&x, (float)p.task_acc[n - 1]); p.minstd[e] = x; }
+    float val = s.unit() * (float)task_acc[n - 1];
+    if (p.minstd) { uint32_t x = p.minstd[e]; val = xwb_minstd_rand_range_state(&x, (float)task_acc[n - 1]); p.minstd[e] = x; }
     const double w = (double)val;
-    for (int i = 0; i < n; ++i) if (w <= p.task_acc[i]) return i;
+    for (int i = 0; i < n; ++i) if (w <= task_acc[i]) return i;
     return n - 1;
 }
 

@@ -99,6 +99,7 @@ struct xwb_sim {
     RaceParams race{};
     // xworld
     uint16_t *d_grid = nullptr;
+    int32_t *d_task_steps2 = nullptr, *d_task_state2 = nullptr;
     int32_t *d_agent = nullptr, *d_task_steps = nullptr, *d_task_state = nullptr, *d_done_list = nullptr,
             *d_done_count = nullptr;
     uint8_t *d_fresh = nullptr, *d_icon_type = nullptr, *d_icon_colored = nullptr, *d_goal_cells = nullptr;
@@ -244,8 +245,27 @@ int xw_setup(xwb_sim *s) {
     for (int i = 1; i < c.n_tasks; ++i)
         if ((c.tasks[i] >= XWB_TASK2D_TARGET) != (c.tasks[0] >= XWB_TASK2D_TARGET))
             return fail(XWB_ERR_ARG, "xworld: a task group holds XWorld3DNav* tasks or 2-D-native XWorldNav* tasks, not both");
+    if (c.n_tasks2 < 0 || c.n_tasks2 > 8) return fail(XWB_ERR_ARG, "xworld: need 0 <= n_tasks2 <= 8");
+    if (c.n_tasks2 > 0) {
+        if (c.n_tasks < 1) return fail(XWB_ERR_ARG, "xworld: a second task group needs a first one");
+        for (int i = 0; i < c.n_tasks2; ++i) {
+            if (c.tasks2[i] < XWB_TASK_TARGET || c.tasks2[i] > XWB_TASK2D_BETWEEN) return fail(XWB_ERR_ARG, "xworld: unknown task id");
+            if ((c.tasks2[i] >= XWB_TASK2D_TARGET) != (c.tasks2[0] >= XWB_TASK2D_TARGET))
+                return fail(XWB_ERR_ARG, "xworld: a task group holds XWorld3DNav* tasks or 2-D-native XWorldNav* tasks, not both");
+        }
+        if ((c.tasks2[0] >= XWB_TASK2D_TARGET) == (c.tasks[0] >= XWB_TASK2D_TARGET))
+            return fail(XWB_ERR_ARG, "xworld: two task groups: one must hold XWorld3DNav* tasks, the other the 2-D-native ones");
+        if (c.task_schedule2 != XWB_SCHEDULE_RANDOM && c.task_schedule2 != XWB_SCHEDULE_WEIGHTED) return fail(XWB_ERR_ARG, "xworld: unknown task_schedule2");
+        if (c.task_schedule2 == XWB_SCHEDULE_WEIGHTED)
+            for (int i = 0; i < c.n_tasks2; ++i)
+                if (!(c.task_weights2[i] > 0)) return fail(XWB_ERR_ARG, "A task must have a positive weight");
+        // simulator_interface.cpp:46-48: lang_acquisition runs the groups non-exclusively whatever the flag says
+        if (c.task_groups_exclusive && c.task_mode != XWB_TASKMODE_LANG_ACQ)
+            return fail(XWB_ERR_ARG, "xworld: exclusive scheduling of two task groups is not built (teacher.cpp:209-220 would run "
+                                     "3-D idle stages in mid-episode); use task_groups_exclusive = 0 or task_mode lang_acquisition");
+    }
     const int n = s->n, cells = c.max_dim * c.max_dim, ch = c.color ? 3 : 1;
-    const bool group2d_cfg = c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET;
+    const bool group2d_cfg = (c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET) || (c.n_tasks2 > 0 && c.tasks2[0] >= XWB_TASK2D_TARGET);
     // goal_cells holds one byte per goal slot with 0xff = "no goal": cell 255 only exists on a 16x16 map
     if (c.max_dim > 15 && (c.visible_radius > 0 || group2d_cfg))
         return fail(XWB_ERR_ARG, "xworld: max_dim 16 is not available with visible_radius > 0 or the 2-D-native task group (<= 15)");
@@ -304,6 +324,10 @@ int xw_setup(xwb_sim *s) {
     if ((rc = dev_alloc(s, &s->d_agent, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_task_steps, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_task_state, n))) return rc;
+    if (c.n_tasks2 > 0) {
+        if ((rc = dev_alloc(s, &s->d_task_state2, n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_task_steps2, n))) return rc;
+    }
     if ((rc = dev_alloc(s, &s->d_done_list, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_done_count, 2))) return rc;
     if ((rc = dev_alloc(s, &s->d_fresh, n))) return rc;
@@ -399,6 +423,12 @@ int xw_setup(xwb_sim *s) {
     p.agent_dir = s->d_agent_dir; p.goal_warp = s->d_goal_warp; p.atlas64 = s->d_atlas64; p.ego_taps = s->d_ego_taps; p.goal_img = s->d_goal_img; p.ego_agent_rot = s->d_agent_rot;
     for (int i = 0; i < 8; ++i) p.tasks[i] = i < c.n_tasks ? c.tasks[i] : 0;
     p.task_weighted = c.task_schedule == XWB_SCHEDULE_WEIGHTED;
+    p.n_tasks2 = c.n_tasks2;
+    p.group2d_2 = c.n_tasks2 > 0 && c.tasks2[0] >= XWB_TASK2D_TARGET;
+    p.task_weighted2 = c.task_schedule2 == XWB_SCHEDULE_WEIGHTED;
+    for (int i = 0; i < 8; ++i) p.tasks2[i] = i < c.n_tasks2 ? c.tasks2[i] : 0;
+    for (int i = 0; i < 8; ++i) p.task_acc2[i] = (i ? p.task_acc2[i - 1] : 0.0) + (i < c.n_tasks2 && p.task_weighted2 ? c.task_weights2[i] : 0.0);
+    p.task_state2 = s->d_task_state2; p.task_steps2 = s->d_task_steps2;
     for (int i = 0; i < 8; ++i) p.task_acc[i] = (i ? p.task_acc[i - 1] : 0.0) + (i < c.n_tasks && p.task_weighted ? c.task_weights[i] : 0.0);
     p.policy_seed = c.policy_seed; p.env_gid0 = c.env_gid0; p.policy_step = 0; p.seed = c.seed;
     p.icon_type = s->d_icon_type; p.icon_name = s->d_icon_name;
@@ -1011,7 +1041,7 @@ int xwb_get_env_state(xwb_sim *s, int32_t env, void *stream, xwb_env_state *o) {
     HIP_TRY(hipMemcpyAsync(&steps, s->d_num_steps + env, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&act, s->d_actions + env, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&o->episode, s->d_episode + env, 4, hipMemcpyDeviceToHost, st));
-    int32_t axy = 0, ts = 0, tsteps = 0;
+    int32_t axy = 0, ts = 0, tsteps = 0, ts2 = 0, tsteps2 = 0;
     if (s->cfg.game == XWB_SIMPLE_GAME) {
         HIP_TRY(hipMemcpyAsync(&o->sg_pos, s->d_pos + env, 4, hipMemcpyDeviceToHost, st));
     } else if (s->cfg.game == XWB_SIMPLE_RACE) {
@@ -1022,6 +1052,10 @@ int xwb_get_env_state(xwb_sim *s, int32_t env, void *stream, xwb_env_state *o) {
         HIP_TRY(hipMemcpyAsync(&axy, s->d_agent + env, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(&ts, s->d_task_state + env, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(&tsteps, s->d_task_steps + env, 4, hipMemcpyDeviceToHost, st));
+        if (s->d_task_state2) {
+            HIP_TRY(hipMemcpyAsync(&ts2, s->d_task_state2 + env, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&tsteps2, s->d_task_steps2 + env, 4, hipMemcpyDeviceToHost, st));
+        }
     }
     HIP_TRY(hipStreamSynchronize(st));
     o->game_over = done;
@@ -1038,6 +1072,10 @@ int xwb_get_env_state(xwb_sim *s, int32_t env, void *stream, xwb_env_state *o) {
         o->xw_stage = (ts >> 16) & 0xf;
         o->xw_event = (ts >> 20) & 0xf;
         o->xw_steps_in_task = tsteps;
+        if (s->d_task_state2) {
+            o->xw_task2 = (ts2 >> 24) & 0xf; o->xw_target2 = (int16_t)(ts2 & 0xffff); o->xw_stage2 = (ts2 >> 16) & 0xf;
+            o->xw_event2 = (ts2 >> 20) & 0xf; o->xw_steps_in_task2 = tsteps2;
+        }
         uint8_t dir = 1;
         HIP_TRY(hipMemcpy(&dir, s->d_agent_dir + env, 1, hipMemcpyDeviceToHost));
         o->xw_agent_dir = dir;
@@ -1106,6 +1144,7 @@ int xwb_xw_load_map_task(xwb_sim *s, int32_t env, const uint16_t *grid_host, int
     XWB_ON_DEVICE(s);
     if (task < XWB_TASK_TARGET || task > XWB_TASK2D_BETWEEN) return fail(XWB_ERR_ARG, "unknown task id");
     if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
+    if (s->cfg.n_tasks2 > 0) return fail(XWB_ERR_STATE, "map replay is for batches with one task group");
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
     if (s->d_cur_level) {
         if (dim < 3 || dim > 8) return fail(XWB_ERR_ARG, "dim is not one of the curriculum's levels (3..8)");
@@ -1316,6 +1355,7 @@ std::vector<StateArray> state_arrays(xwb_sim *s, bool include_obs) {
     if (s->cfg.game == XWB_XWORLD2D) {
         const size_t cells = (size_t)s->cfg.max_dim * s->cfg.max_dim;
         add(s->d_grid, n * cells * 2); add(s->d_agent, n * 4); add(s->d_task_steps, n * 4); add(s->d_task_state, n * 4);
+        add(s->d_task_steps2, n * 4); add(s->d_task_state2, n * 4);
         add(s->d_done_list, n * 4); add(s->d_done_count, 8); add(s->d_fresh, n);
         add(s->d_goal_cells, n * XW_MAX_GOALS); add(s->d_cand2d, n * 4); add(s->d_agent_dir, n); add(s->d_sent_names, n * 4);
         add(s->d_goal_warp, n * XW_MAX_GOALS * 6 * sizeof(double));     // goal images are re-warped from these on load
@@ -1340,6 +1380,7 @@ uint64_t config_hash(const xwb_config &c) {            // everything that shapes
     mix(v, sizeof v); mix(c.tasks, sizeof c.tasks);
     mix(&c.seed, 4); mix(&c.policy_seed, 4); mix(&c.env_gid0, 4);
     mix(&c.rng_mode, 4); mix(&c.simulator_seed, 4); mix(&c.thread_base, 4);
+    mix(&c.n_tasks2, 4); mix(c.tasks2, sizeof c.tasks2); mix(&c.task_schedule2, 4); mix(c.task_weights2, sizeof c.task_weights2);
     mix(&c.curriculum, 8); mix(&c.start_level, 4); mix(&c.task_schedule, 4); mix(c.task_weights, sizeof c.task_weights); mix(&c.no_wall_shadow, 4);
     return h;
 }

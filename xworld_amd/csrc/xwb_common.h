@@ -141,6 +141,11 @@ struct XwParams {
     int n_tasks, tasks[8];       // tasks of the teacher's group, sampled whenever the group is idle: uniformly, or
     int task_weighted;           // schedule "weighted": util::simple_importance_sampling over the accumulated weights
     double task_acc[8];
+    // a second task group (conf order: after the first), run non-exclusively: Teacher::teach's else branch
+    // (teacher.cpp:221-225).  n_tasks2 == 0: none.  One group holds the XWorld3DNav* tasks, the other the 2-D-native ones.
+    int n_tasks2, tasks2[8], task_weighted2, group2d_2;
+    double task_acc2[8];
+    int32_t *task_state2, *task_steps2;   // [n] the second group's Task FSM (same encoding as task_state / task_steps)
     int list_flag;               // list render: 2 = first frame of a new episode (init_screen: older context frames zeroed,
                                  // fresh / done flags cleared); 1 = the terminal frame of a finished env (ring shift only)
     int group2d;                 // the group holds the 2-D-native tasks (rule D14b): idle stages also run at step time

@@ -35,6 +35,8 @@ class XwbConfig(C.Structure):
         ("curriculum", C.c_double), ("start_level", C.c_int32),
         ("task_schedule", C.c_int32), ("task_weights", C.c_double * 8), ("no_wall_shadow", C.c_int32),
         ("rng_mode", C.c_int32), ("simulator_seed", C.c_int32), ("thread_base", C.c_int32),
+        ("n_tasks2", C.c_int32), ("tasks2", C.c_int32 * 8), ("task_schedule2", C.c_int32), ("task_weights2", C.c_double * 8),
+        ("task_groups_exclusive", C.c_int32),
     ]
 
 
@@ -47,6 +49,8 @@ class XwbEnvState(C.Structure):
         ("xw_agent_x", C.c_int32), ("xw_agent_y", C.c_int32), ("xw_event", C.c_int32), ("xw_stage", C.c_int32),
         ("xw_target_name", C.c_int32), ("xw_steps_in_task", C.c_int32),
         ("episode", C.c_uint32), ("xw_task", C.c_int32), ("xw_target", C.c_int32), ("xw_agent_dir", C.c_int32), ("xw_level", C.c_int32), ("xw_check_counter", C.c_int32), ("xw_sentence_names", C.c_uint32),
+        ("xw_task2", C.c_int32), ("xw_stage2", C.c_int32), ("xw_event2", C.c_int32), ("xw_target2", C.c_int32),
+        ("xw_steps_in_task2", C.c_int32),
     ]
 
 
