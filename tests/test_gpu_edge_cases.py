@@ -204,3 +204,28 @@ def test_batch_copy_out_functions():
     assert np.array_equal(r, sim.reward.cpu().numpy()) and np.array_equal(d, sim.game_over_codes.cpu().numpy())
     assert sim.L.xwb_get_obs(sim.h, host.ctypes.data, host.size - 1, None) != 0
     sim.close()
+
+
+def test_queue_sync_modes_agree_and_pmc_env_falls_back():
+    """The step loop's two queues hand over through device-side epochs by default and through events when a tool that
+    serialises kernels is in sight (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION): both give the same rollout."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os, hashlib; sys.path.insert(0, %r); import torch\n"
+            "from xworld_amd.batched import BatchedSimulator\n"
+            "conf = os.path.join(%r, 'xworld_amd', 'confs', 'navigation2d.json')\n"
+            "sim = BatchedSimulator('xworld', {'xwd_conf_path': conf, 'task_mode': 'lang_acquisition', 'max_dim': 7, 'color': True}, num_envs=4096, seed=3, policy_seed=4)\n"
+            "h = hashlib.sha256()\n"
+            "for t in range(150):\n"
+            "    sim.step(); h.update(sim.reward.cpu().numpy().tobytes()); h.update(sim.game_over_codes.cpu().numpy().tobytes()); sim.reset_done()\n"
+            "h.update(sim.obs.cpu().numpy().tobytes()); assert sim.check_errors() == 0; print(h.hexdigest())\n") % (root, root)
+    outs = []
+    for env in ({"XWB_QUEUE_SYNC": "epochs"}, {"XWB_QUEUE_SYNC": "events"}, {"ROCPROF_COUNTER_COLLECTION": "1"}):
+        e = dict(os.environ)
+        e.pop("XWB_QUEUE_SYNC", None)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] == outs[2], outs

@@ -266,12 +266,12 @@ hipError_t launch_xw_step(const XwParams &p, hipStream_t s) {
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(64) void xw_wait_kernel(const uint32_t *epoch_slot, uint32_t want) {
-    xw_wait_epoch(epoch_slot, want);
+__global__ __launch_bounds__(64) void xw_wait_kernel(const uint32_t *epoch_slot, uint32_t want, uint32_t *timeout_flag) {
+    xw_wait_epoch(epoch_slot, want, timeout_flag);
 }
 
-hipError_t launch_xw_wait(const uint32_t *epoch_slot, uint32_t want, hipStream_t s) {
-    hipLaunchKernelGGL(xw_wait_kernel, dim3(1), dim3(64), 0, s, epoch_slot, want);
+hipError_t launch_xw_wait(const uint32_t *epoch_slot, uint32_t want, uint32_t *timeout_flag, hipStream_t s) {
+    hipLaunchKernelGGL(xw_wait_kernel, dim3(1), dim3(64), 0, s, epoch_slot, want, timeout_flag);
     return hipGetLastError();
 }
 
@@ -450,9 +450,12 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
     const int cnt = *count_now;
     const int e_first = p.done_list[(int)blockIdx.x < p.n ? blockIdx.x : 0];
     if ((int)blockIdx.x >= cnt) return;                   // nothing to draw (and nothing to wait for)
-    // the listed envs were regenerated by a reset kernel on the other queue: its epoch instead of a barrier packet.  Only
-    // workgroups with work spin, and that kernel's workgroups have all been resident since long before this one starts.
-    if (p.wait_epoch) xw_wait_epoch(p.sync + 3, p.wait_epoch);
+    // The listed envs were regenerated by a reset kernel on the other queue; its epoch stands in for a barrier packet.
+    // Normally that kernel finished long ago.  When it has not, the spinning workgroups must not be able to fill the machine:
+    // the kernels that publish the epoch need wave slots of their own.  render_list() therefore launches at most half the
+    // machine's wave slots when a wait is attached (a batch whose envs all finish on one step otherwise parks one spinning
+    // workgroup in every slot: seen as a 4 s stall on the 8x8 workload, where many envs time out on the same step).
+    if (p.wait_epoch) xw_wait_epoch(p.sync + 3, p.wait_epoch, p.sync + 4);
     for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
         const int e = i == (int)blockIdx.x ? e_first : p.done_list[i];
         __syncthreads();
@@ -495,7 +498,9 @@ static hipError_t render_all(const XwParams &p, hipStream_t s) {
 
 template <int DIM_T, int CH, int ES>
 static hipError_t render_list(const XwParams &p, hipStream_t s) {
-    dim3 grid(2048), block(256);       // looping workgroups; a long list (a whole batch finishing together) keeps 8 per CU busy
+    // looping workgroups; a long list (a whole batch finishing together) keeps 8 per CU busy -- 4 per CU (half the wave
+    // slots of the 256 CUs) when the kernel may have to spin on the other queue's epoch, see the kernel
+    dim3 grid(p.wait_epoch ? 1024 : 2048), block(256);
     hipLaunchKernelGGL((xw_render_list_kernel<DIM_T, CH, ES>), grid, block, 0, s, p, (const int32_t *)p.done_count);
     return hipGetLastError();
 }

@@ -23,6 +23,15 @@
 
 namespace xwb {
 
+#ifdef XWB_RESET_PROF
+__device__ unsigned long long g_reset_prof[16];   // [2k] = sum of phase k (100 MHz ticks), [2k+1] = max
+#define RP_T0() unsigned long long rp_last = wall_clock64()
+#define RP_T(k) do { const unsigned long long now = wall_clock64(); atomicAdd(&g_reset_prof[2 * (k)], now - rp_last); atomicMax(&g_reset_prof[2 * (k) + 1], now - rp_last); rp_last = now; } while (0)
+#else
+#define RP_T0()
+#define RP_T(k)
+#endif
+
 template <int NW>
 struct Mask {
     uint64_t w[NW];
@@ -212,8 +221,11 @@ __device__ __forceinline__ Mask<NW> xw_maze(Stream &s, int D, const LaneLds &L) 
     return mz;
 }
 
-template <int NW, int KIND>
-__device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneLds &L, int e, bool keep_done) {
+// GM (task groups, compile time so that the usual one-group batch carries none of the other paths): 0 = one XWorld3DNav*
+// group, 1 = one 2-D-native group, 2 = two groups
+template <int NW, int KIND, int GM>
+__device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneLds &L, int e, bool keep_done,
+                             const uint4 *pre_draws, uint32_t n_pre_draws) {
     int level_dim = p.dim, level_goals = p.num_goals, level_blocks = p.num_blocks;
     if (KIND == 0 && p.curriculum != 0) {
         // XWorldNav._configure: level -> dims, goals, blocks (XWorldNav.py:27-34)
@@ -223,10 +235,12 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
         level_blocks = level == 5 ? 16 : 3 * level;
     }
     const int MD = p.max_dim, D = level_dim, off = (MD - D) / 2;
+    RP_T0();
     const uint32_t ep = p.episode[e] + 1;
     p.episode[e] = ep;
     Stream s;
     s.init(p.seed, p.env_gid0 + (uint32_t)e, ep, 0);
+    s.pre = pre_draws; s.npre = n_pre_draws;
 
     // board masks
     Mask<NW> valid, col0, colN;
@@ -267,7 +281,9 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
             if (at_j >= 0) L.ov_val[L.at(at_j)] = (uint16_t)vl;               // names[j] = names[M-1-i]
             else { L.ov_idx[L.at(n_ov)] = (uint16_t)j; L.ov_val[L.at(n_ov)] = (uint16_t)vl; n_ov++; }
         }
+        RP_T(0);
         const Mask<NW> mz = xw_maze<NW>(s, D, L);
+        RP_T(1);
         int nb = 0;
 #pragma unroll
         for (int wi = 0; wi < NW; ++wi) {                     // '#' cells in row-major order
@@ -384,6 +400,7 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
         }
     }
 
+    RP_T(2);
     // ---- teacher idle stage (TaskGroup::run_stage samples one task of the group per episode, then its idle()):
     // decision order "xwb-taskgen-v1" (DESIGN.md).  Nothing is written to the grid before the stage has
     // succeeded, so the "map too crowded?" cases (the reference asserts) simply keep the generated map.
@@ -625,7 +642,8 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
             agent_cell = al;
             sent_a = L.gname[L.at(kind == TASK_DIRECTION ? ref : g1)];
             if (kind == TASK_BETWEEN) sent_b = L.gname[L.at(g2)];
-            {
+            if (GM == 2) {
+                // (only where a later idle stage enumerates the goals: a batch with a 2-D-native group beside this one)
                 // env.entities: g1 and g2 were deleted and set again, so they now follow the other goals, in that order
                 // (xworld_env.py _delete_entity / _set_entity_inst).  A later idle stage that enumerates the goals -- the
                 // 2-D-native group's random.choice(targets) -- sees that order, so the goal slots take it too; the
@@ -680,24 +698,26 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
         if (kind == TASK_BETWEEN && between >= 0) tf = (between / D + off) * MD + (between % D + off);
     };
     int kindv[2] = {TASK_TARGET, TASK_TARGET}, tfv[2] = {-1, -1}, st0v[2] = {STAGE_NAV, STAGE_NAV};
+    const bool first_2d = GM == 1 || (GM == 2 && p.group2d);
     {
         const int tsel = sample_task<0>(p, s, e);
         kindv[0] = p.n_tasks > 0 ? task_at<0>(p, tsel) : TASK_TARGET;
-        if (p.group2d) idle_stage_2d(kindv[0], true, tfv[0], st0v[0]);
-        else idle_stage_3d(kindv[0], tfv[0]);
+        if (GM != 0 && first_2d) idle_stage_2d(kindv[0], true, tfv[0], st0v[0]);
+        if (GM != 1 && !first_2d) idle_stage_3d(kindv[0], tfv[0]);
     }
-    if (p.n_tasks2 > 0) {
+    if (GM == 2) {
         const int tsel = sample_task<1>(p, s, e);
         kindv[1] = task_at<1>(p, tsel);
-        if (p.group2d_2) idle_stage_2d(kindv[1], true, tfv[1], st0v[1]);
+        if (!first_2d) idle_stage_2d(kindv[1], true, tfv[1], st0v[1]);
         else idle_stage_3d(kindv[1], tfv[1]);
-        if (p.group2d) { int tf_unused, st_unused; idle_stage_2d(kindv[0], false, tf_unused, st_unused); }
+        if (first_2d) { int tf_unused, st_unused; idle_stage_2d(kindv[0], false, tf_unused, st_unused); }
     }
     const int kind = kindv[0];
+    RP_T(3);
     // goal cells carry bit 15 when the goal belongs to the target set (the step kernel's whole reward rule)
     for (int i = 0; i < ng; ++i)
         put_code(L.gcell[L.at(i)], (uint16_t)((L.gicon[L.at(i)] + 1) | (((target_bits >> i) & 1u) ? 0x8000u : 0u)));
-    if (!p.group2d && !(p.n_tasks2 > 0 && p.group2d_2)) {   // goal slot -> cell (the egocentric render finds a goal's pose by it)
+    if (GM == 0) {                                        // goal slot -> cell (the egocentric render finds a goal's pose by it)
         uint8_t *gc = p.goal_cells + (size_t)e * XW_MAX_GOALS;
         for (int i = 0; i < XW_MAX_GOALS; ++i) {
             const int c = i < ng ? L.gcell[L.at(i)] : 0;
@@ -707,15 +727,16 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
 
     p.agent_xy[e] = (agent_cell % D + off) | ((agent_cell / D + off) << 16);
     p.task_state[e] = pack_task(tfv[0], st0v[0], EV_NONE, kind);
-    if (p.n_tasks2 > 0) { p.task_state2[e] = pack_task(tfv[1], st0v[1], EV_NONE, kindv[1]); p.task_steps2[e] = 0; }
+    if (GM == 2) { p.task_state2[e] = pack_task(tfv[1], st0v[1], EV_NONE, kindv[1]); p.task_steps2[e] = 0; }
     p.sent_names[e] = (uint32_t)sent_a | ((uint32_t)sent_b << 16);
     p.task_steps[e] = 0;
     p.num_steps[e] = 0;
     p.fresh[e] = 2;                                       // render: init_screen (zero the older context frames)
     if (!keep_done) p.done[e] = (uint8_t)done_code(p, 0, EV_NONE);
+    RP_T(4);
 }
 
-template <int NW, int KIND>
+template <int NW, int KIND, int GM>
 __global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int keep_done, const int32_t *count_now) {
     extern __shared__ uint32_t lds32[];
     // a handful of latency-bound wavefronts that run beside render_all's 16 waves per CU
@@ -745,26 +766,48 @@ __global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int 
         for (int k = threadIdx.x; k < p.name_first_len; k += 64) t_first[k] = p.name_first[k];
         for (int k = threadIdx.x; k < p.name_variants_len; k += 64) t_var[k] = p.name_variants[k];
         __syncthreads();
-        if ((int)threadIdx.x < per_wave) {
-            IconTables T;
-            T.first[0] = t_first + p.name_first_off[0];
-            T.first[1] = t_first + p.name_first_off[1];
-            T.first[2] = t_first + p.name_first_off[2];
-            T.variants = t_var;
+        IconTables T;
+        T.first[0] = t_first + p.name_first_off[0];
+        T.first[1] = t_first + p.name_first_off[1];
+        T.first[2] = t_first + p.name_first_off[2];
+        T.variants = t_var;
+        if (per_wave == 1) {
+            // One env per wavefront (the usual case): 63 lanes would idle while one walks the serial map generation, about
+            // half of whose instructions are Philox rounds.  The blocks of a counter-based stream are independent: every lane
+            // computes one block of this env's reset stream up front, the serial lane then reads its draws from LDS.
+            uint4 *s_pre = reinterpret_cast<uint4 *>((reinterpret_cast<uintptr_t>(t_var + p.name_variants_len) + 15) & ~(uintptr_t)15);
+            for (int i = blockIdx.x; i < total; i += gridDim.x) {
+                const int e = mode == MODE_RESET_ALL ? i : p.done_list[i];
+                const uint32_t ep = p.episode[e] + 1;                       // (lane 0 bumps it below; read before that)
+                __builtin_amdgcn_wave_barrier();
+                s_pre[threadIdx.x] = philox4x32_10(threadIdx.x, ep, 0u, 0u, p.seed, p.env_gid0 + (uint32_t)e);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (threadIdx.x == 0) xw_reset_env<NW, KIND, GM>(p, T, L, e, keep_done != 0, s_pre, 64u);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            }
+        } else if ((int)threadIdx.x < per_wave) {
             // the grid is capped (a short list should not cost the dispatch of one workgroup per env of the batch): loop
             for (int i = blockIdx.x * per_wave + (int)threadIdx.x; i < total; i += gridDim.x * per_wave) {
                 const int e = mode == MODE_RESET_ALL ? i : p.done_list[i];
-                xw_reset_env<NW, KIND>(p, T, L, e, keep_done != 0);
+                xw_reset_env<NW, KIND, GM>(p, T, L, e, keep_done != 0, nullptr, 0u);
             }
         }
     }
+    // (The epoch that tells the other queue's list render "every env of this launch is regenerated" is published by a
+    // one-thread kernel queued behind this one.  Publishing it from here -- a release fence per writing wavefront, the last
+    // one through stores the epoch -- saves that kernel's 5 us but the L2 write-backs cost the render running beside it 6 %:
+    // 0.122 -> 0.127 ms per step on C4.)
 }
 
 template <int NW>
 static void launch_reset_nw(const XwParams &p, int mode, dim3 grid, size_t lds, hipStream_t s) {
     const int32_t *cnt = p.done_count;
-    if (p.map_kind == 0) hipLaunchKernelGGL((xw_reset_kernel<NW, 0>), grid, dim3(64), lds, s, p, mode, p.auto_reset, cnt);
-    else hipLaunchKernelGGL((xw_reset_kernel<NW, 1>), grid, dim3(64), lds, s, p, mode, p.auto_reset, cnt);
+    const int gm = p.n_tasks2 > 0 ? 2 : (p.group2d ? 1 : 0);
+#define XW_RESET_LAUNCH(KINDV, GMV) hipLaunchKernelGGL((xw_reset_kernel<NW, KINDV, GMV>), grid, dim3(64), lds, s, p, mode, p.auto_reset, cnt)
+    if (p.map_kind == 0) { if (gm == 0) XW_RESET_LAUNCH(0, 0); else if (gm == 1) XW_RESET_LAUNCH(0, 1); else XW_RESET_LAUNCH(0, 2); }
+    else { if (gm == 0) XW_RESET_LAUNCH(1, 0); else if (gm == 1) XW_RESET_LAUNCH(1, 1); else XW_RESET_LAUNCH(1, 2); }
+#undef XW_RESET_LAUNCH
 }
 
 hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s) {
@@ -778,7 +821,7 @@ hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s) {
     const int lds_dim = p.curriculum != 0 ? p.max_dim : p.dim;
     const int cells = lds_dim * lds_dim;
     const size_t lds = 64 * 64 * 4 + 3 * XW_MAX_GOALS * 64 * 2 + XW_MAX_GOALS * 64 + (size_t)cells * 64 +
-                       2 * (size_t)(p.name_first_len + 2 + p.name_variants_len);
+                       2 * (size_t)(p.name_first_len + 2 + p.name_variants_len) + 32 + 64 * sizeof(uint4);
     if (lds > 65536) return hipErrorInvalidValue;
     if (cells <= 64) launch_reset_nw<1>(p, mode, grid, lds, s);
     else if (cells <= 128) launch_reset_nw<2>(p, mode, grid, lds, s);
@@ -791,3 +834,11 @@ hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s) {
 }
 
 }  // namespace xwb
+
+#ifdef XWB_RESET_PROF
+extern "C" int xwb_debug_reset_prof(unsigned long long *out) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(xwb::g_reset_prof), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(xwb::g_reset_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif

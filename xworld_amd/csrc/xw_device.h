@@ -68,10 +68,17 @@ __device__ __forceinline__ void xw_publish_epoch(uint32_t *epoch_slot, uint32_t 
 }
 
 // Wait (one lane spins, the workgroup follows through the barrier) until *epoch_slot has reached `want` (wrap-safe).
-__device__ __forceinline__ void xw_wait_epoch(const uint32_t *epoch_slot, uint32_t want) {
+// The publisher runs on another queue: this only terminates when the two queues really execute concurrently.  Tools that
+// serialise kernel execution (rocprofv3 --pmc, AMD_SERIALIZE_KERNEL) break that; the host falls back to events when it
+// sees them (xwb_api.hip: queue_sync_by_epochs), and as a last resort the spin gives up after ~4 s of wall clock, raises
+// `timeout_flag` (reported by xwb_check_errors) and lets the queue drain instead of hanging the device.
+__device__ __forceinline__ void xw_wait_epoch(const uint32_t *epoch_slot, uint32_t want, uint32_t *timeout_flag) {
     if (threadIdx.x == 0) {
-        while ((int32_t)(__hip_atomic_load(epoch_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0)
+        const unsigned long long t0 = wall_clock64();                  // 100 MHz
+        while ((int32_t)(__hip_atomic_load(epoch_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
             __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 400000000ull) { atomicExch(timeout_flag, 1u); break; }
+        }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     __syncthreads();

@@ -137,6 +137,24 @@ int dev_alloc(xwb_sim *s, T **p, size_t count, int fill = 0) {
 
 hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// The step loop's two queues hand over through epochs in device memory (XwParams::sync): kernels of one queue spin until a
+// kernel of the other has run, which needs the queues to execute concurrently.  Tools that serialise kernel execution make
+// that a deadlock, so events / barrier packets (3-6 us of idle GPU each) are used instead when one is in sight:
+// rocprofv3's counter collection (ROCPROF_COUNTER_COLLECTION / ROCPROF_COUNTERS), AMD_SERIALIZE_KERNEL,
+// HIP_LAUNCH_BLOCKING.  XWB_QUEUE_SYNC=events|epochs overrides.
+bool queue_sync_by_epochs() {
+    static int mode = -1;
+    if (mode < 0) {
+        auto on = [](const char *name) { const char *v = getenv(name); return v && *v && strcmp(v, "0") != 0; };
+        mode = 1;
+        if (on("ROCPROF_COUNTER_COLLECTION") || getenv("ROCPROF_COUNTERS") || on("AMD_SERIALIZE_KERNEL") || on("HIP_LAUNCH_BLOCKING") ||
+            on("CUDA_LAUNCH_BLOCKING"))
+            mode = 0;
+        if (const char *v = getenv("XWB_QUEUE_SYNC")) mode = strcmp(v, "events") == 0 ? 0 : (strcmp(v, "epochs") == 0 ? 1 : mode);
+    }
+    return mode == 1;
+}
+
 // ---- host restatement of the SimpleRace constructors (float/double conversion points matter) ----
 void race_setup(const xwb_config &c, RaceParams &r) {
     const double PI = 3.1415926;                       // simple_race_simulator.h:39
@@ -345,7 +363,7 @@ int xw_setup(xwb_sim *s) {
         if ((rc = dev_alloc(s, &s->d_cur_counter, n))) return rc;
         if ((rc = dev_alloc(s, &s->d_cur_usage, (size_t)n * 9 * XW_USAGE_BYTES))) return rc;
     }
-    if ((rc = dev_alloc(s, &s->d_sync, 4))) return rc;
+    if ((rc = dev_alloc(s, &s->d_sync, 8))) return rc;
     if ((rc = dev_alloc(s, &s->d_term_grid, (size_t)n * cells))) return rc;
     if ((rc = dev_alloc(s, &s->d_term_flag, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_agent_dir, n, 1))) return rc;                 // heading "down": yaw 1.5707963
@@ -556,9 +574,9 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
     hipStream_t rs = beside_render ? s->side : st;
     // full observation: the two queues hand over through epochs in device memory (XwParams::sync) -- the side queue's
     // kernel waits for the step kernel's epoch, the list render for the reset kernel's; no event / barrier packets
-    const bool by_epoch = beside_render && render && !p.visible_radius && mode != MODE_RESET_ALL;
+    const bool by_epoch = queue_sync_by_epochs() && beside_render && render && !p.visible_radius && mode != MODE_RESET_ALL;
     if (by_epoch) {
-        HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->side));
+        HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->d_sync + 4, s->side));
         if (++s->epoch_reset == 0) s->epoch_reset = 1;
     } else if (beside_render) {
         HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
@@ -639,6 +657,7 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
             HIP_TRY(hipEventRecord(s->ev_reset, s->side));
             s->list_valid = false;
         } else {
+            if (!p.visible_radius && !queue_sync_by_epochs()) HIP_TRY(hipEventRecord(s->ev_step, st));
             // Finished envs keep a terminal snapshot of their grid (step kernel) from which the big render draws their
             // last frame, so a following xwb_reset_done can regenerate the live state beside that render right away.
             // The egocentric render reads more than the grid (heading, goal images): there the terminal frames are
@@ -927,7 +946,16 @@ int xwb_check_errors(xwb_sim *s, void *stream, int32_t *n_bad) {
     hipStream_t st = as_stream(stream);
     HIP_TRY(hipMemcpyAsync(n_bad, s->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemsetAsync(s->d_err, 0, sizeof(int32_t), st));
+    uint32_t timed_out = 0;
+    if (s->d_sync) {
+        HIP_TRY(hipMemcpyAsync(&timed_out, s->d_sync + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemsetAsync(s->d_sync + 4, 0, sizeof(uint32_t), st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
+    if (timed_out)
+        return fail(XWB_ERR_STATE, "a device-side queue hand-off timed out (kernels of the two queues did not run concurrently: a tool "
+                                   "that serialises kernel execution?); results since the last check are unreliable -- run with "
+                                   "XWB_QUEUE_SYNC=events");
     return XWB_OK;
 }
 

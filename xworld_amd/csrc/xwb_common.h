@@ -36,12 +36,17 @@ struct Stream {
     uint32_t k0, k1, blk, episode, sid;
     uint4 buf;
     int have;
+    // optional: the stream's first `npre` blocks, already computed (by the other lanes of a wavefront that resets ONE env:
+    // Philox is half of that serial path's instructions and its blocks are independent of each other)
+    const uint4 *pre;
+    uint32_t npre;
     __device__ __forceinline__ void init(uint32_t seed, uint32_t gid, uint32_t ep, uint32_t stream_id) {
-        k0 = seed; k1 = gid; blk = 0; episode = ep; sid = stream_id; have = 0;
+        k0 = seed; k1 = gid; blk = 0; episode = ep; sid = stream_id; have = 0; pre = nullptr; npre = 0;
     }
     __device__ __forceinline__ uint32_t u32() {
         if (have == 0) {
-            buf = philox4x32_10(blk, episode, sid, 0u, k0, k1);
+            if (blk < npre) buf = pre[blk];
+            else buf = philox4x32_10(blk, episode, sid, 0u, k0, k1);
             blk += 1; have = 4;
         }
         const int i = 4 - have;
@@ -208,7 +213,7 @@ struct XwParams {
     int32_t *err_count;
     // device-side hand-off between the two queues of the step loop, instead of event / barrier packets (each costs the
     // loop ~3-6 us of idle GPU): sync[1] = epoch of the last completed step kernel, sync[3] = of the last completed reset
-    // kernel (xw_device.h: xw_publish_epoch / xw_wait_epoch).  render_all with sig_epoch != 0 publishes it to sync[1] when it
+    // kernel, sync[4] != 0: a wait gave up (xw_device.h: xw_publish_epoch / xw_wait_epoch).  render_all with sig_epoch != 0 publishes it to sync[1] when it
     // starts (= the step kernel before it in the queue is complete); the list render with wait_epoch != 0 waits for sync[3].
     uint32_t *sync;
     uint32_t sig_epoch, wait_epoch;
@@ -216,7 +221,7 @@ struct XwParams {
 };
 hipError_t launch_xw_step(const XwParams &p, hipStream_t s);
 // one wavefront that ends once *epoch_slot has reached `want`: orders the work queued behind it after the publisher
-hipError_t launch_xw_wait(const uint32_t *epoch_slot, uint32_t want, hipStream_t s);
+hipError_t launch_xw_wait(const uint32_t *epoch_slot, uint32_t want, uint32_t *timeout_flag, hipStream_t s);
 // one thread that publishes `value`: queued behind a kernel, it tells the other queue that kernel is complete
 hipError_t launch_xw_signal(uint32_t *epoch_slot, uint32_t value, hipStream_t s);
 // reset envs: mode RESET_ALL -> every env; otherwise the compacted done_list / done_count
