@@ -240,7 +240,7 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
     p.episode[e] = ep;
     Stream s;
     s.init(p.seed, p.env_gid0 + (uint32_t)e, ep, 0);
-    s.pre = pre_draws; s.npre = n_pre_draws;
+    s.pre = (Stream::lds_block_ptr)pre_draws; s.npre = n_pre_draws;
 
     // board masks
     Mask<NW> valid, col0, colN;
@@ -771,27 +771,25 @@ __global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int 
         T.first[1] = t_first + p.name_first_off[1];
         T.first[2] = t_first + p.name_first_off[2];
         T.variants = t_var;
-        if (per_wave == 1) {
-            // One env per wavefront (the usual case): 63 lanes would idle while one walks the serial map generation, about
-            // half of whose instructions are Philox rounds.  The blocks of a counter-based stream are independent: every lane
-            // computes one block of this env's reset stream up front, the serial lane then reads its draws from LDS.
-            uint4 *s_pre = reinterpret_cast<uint4 *>((reinterpret_cast<uintptr_t>(t_var + p.name_variants_len) + 15) & ~(uintptr_t)15);
-            for (int i = blockIdx.x; i < total; i += gridDim.x) {
-                const int e = mode == MODE_RESET_ALL ? i : p.done_list[i];
+        // One env per wavefront (the usual case): 63 lanes would idle while one walks the serial map generation, a large
+        // part of whose instructions are Philox rounds.  The blocks of a counter-based stream are independent: every lane
+        // computes one block of this env's reset stream up front, the serial lane then reads its draws from LDS.
+        const bool solo = per_wave == 1;
+        uint4 *s_pre = reinterpret_cast<uint4 *>((reinterpret_cast<uintptr_t>(t_var + p.name_variants_len) + 15) & ~(uintptr_t)15);
+        // the grid is capped (a short list should not cost the dispatch of one workgroup per env of the batch): loop
+        for (int base = blockIdx.x * per_wave; base < total; base += gridDim.x * per_wave) {
+            const int i = base + (solo ? 0 : (int)threadIdx.x);
+            const bool mine = (solo ? threadIdx.x == 0 : (int)threadIdx.x < per_wave) && i < total;
+            const int e = i < total ? (mode == MODE_RESET_ALL ? i : p.done_list[i]) : 0;
+            if (solo) {
                 const uint32_t ep = p.episode[e] + 1;                       // (lane 0 bumps it below; read before that)
                 __builtin_amdgcn_wave_barrier();
                 s_pre[threadIdx.x] = philox4x32_10(threadIdx.x, ep, 0u, 0u, p.seed, p.env_gid0 + (uint32_t)e);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
-                if (threadIdx.x == 0) xw_reset_env<NW, KIND, GM>(p, T, L, e, keep_done != 0, s_pre, 64u);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             }
-        } else if ((int)threadIdx.x < per_wave) {
-            // the grid is capped (a short list should not cost the dispatch of one workgroup per env of the batch): loop
-            for (int i = blockIdx.x * per_wave + (int)threadIdx.x; i < total; i += gridDim.x * per_wave) {
-                const int e = mode == MODE_RESET_ALL ? i : p.done_list[i];
-                xw_reset_env<NW, KIND, GM>(p, T, L, e, keep_done != 0, nullptr, 0u);
-            }
+            if (mine) xw_reset_env<NW, KIND, GM>(p, T, L, e, keep_done != 0, solo ? s_pre : nullptr, solo ? 64u : 0u);
+            if (solo) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         }
     }
     // (The epoch that tells the other queue's list render "every env of this launch is regenerated" is published by a

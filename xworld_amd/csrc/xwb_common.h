@@ -34,23 +34,32 @@ __device__ XWB_PHILOX_ATTR uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 
 struct Stream {
     uint32_t k0, k1, blk, episode, sid;
-    uint4 buf;
+    uint32_t b0, b1, b2, b3;     // the words of the current block that are still to be handed out, next one in b0 (plain
+                                 // scalars shifted down per draw: an indexed uint4 ends up in scratch memory)
     int have;
     // optional: the stream's first `npre` blocks, already computed (by the other lanes of a wavefront that resets ONE env:
-    // Philox is half of that serial path's instructions and its blocks are independent of each other)
-    const uint4 *pre;
+    // Philox is a large part of that serial path's instructions and its blocks are independent of each other)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const uint4 __attribute__((address_space(3))) *lds_block_ptr;   // always LDS: ds_read instead of a flat load
+#else
+    typedef const uint4 *lds_block_ptr;                                     // (the host pass only parses this)
+#endif
+    lds_block_ptr pre;
     uint32_t npre;
     __device__ __forceinline__ void init(uint32_t seed, uint32_t gid, uint32_t ep, uint32_t stream_id) {
         k0 = seed; k1 = gid; blk = 0; episode = ep; sid = stream_id; have = 0; pre = nullptr; npre = 0;
+        b0 = b1 = b2 = b3 = 0;
     }
     __device__ __forceinline__ uint32_t u32() {
         if (have == 0) {
+            uint4 buf;
             if (blk < npre) buf = pre[blk];
             else buf = philox4x32_10(blk, episode, sid, 0u, k0, k1);
+            b0 = buf.x; b1 = buf.y; b2 = buf.z; b3 = buf.w;
             blk += 1; have = 4;
         }
-        const int i = 4 - have;
-        const uint32_t v = i == 0 ? buf.x : (i == 1 ? buf.y : (i == 2 ? buf.z : buf.w));
+        const uint32_t v = b0;
+        b0 = b1; b1 = b2; b2 = b3;
         have -= 1;
         return v;
     }
