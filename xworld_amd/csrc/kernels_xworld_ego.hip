@@ -31,7 +31,7 @@
 namespace xwb {
 
 #ifdef XWB_EGO_PROF
-__device__ unsigned long long g_ego_prof[8];
+__device__ unsigned long long g_ego_prof[12];
 #define EGO_T0() unsigned long long t_last = wall_clock64()
 #define EGO_T(i) do { if (tid == 0) { const unsigned long long now = wall_clock64(); atomicAdd(&g_ego_prof[i], now - t_last); t_last = now; } } while (0)
 #else
@@ -159,17 +159,25 @@ __device__ __forceinline__ void ego_pixel(const EgoCtx &c, const EgoTap (*s_row)
 //   then 4 words       number of border rows, of border columns, largest edge of a cell's pixel rectangle, 0
 //   then O4, O4        the border rows, the border columns
 //   then r * r * 4     per view cell: x0, y0, width, height of its interior pixels in the frame
+//   then 3 * (O4 / 4)  column segments (x4 start, dwords, column term): maximal runs of dwords of a frame row that show the
+//                      same view-cell column -- the unit of the interior copy; their number is the header's 4th word
+// Term flags: 0x8000 = border (the taps straddle two cells: every pixel evaluated), 0x4000 = edge (some taps fall outside
+// the view -- the black line the quarter turn leaves -- but the rest lie in ONE cell: still a function of that cell's image
+// alone, so the table frame of that image holds the pixel; only goal cells, whose images are per env, evaluate it).
 struct EgoLayout {
-    const uint16_t *rt, *ct, *ct4, *br, *bc, *rect;
-    int nbr, nbc, cw;
+    const uint16_t *rt, *ct, *ct4, *br, *bc, *rect, *seg;
+    int nbr, nbc, cw, nseg;
 };
-__host__ __device__ inline int ego_layout_words(int O4, int r) { return 2 * O4 + ((O4 / 4 + 3) & ~3) + 4 + 2 * O4 + 4 * r * r; }
+constexpr uint32_t EGO_BORDER = 0x8000u, EGO_EDGE = 0x4000u, EGO_TERM = 0x3fffu;
+__host__ __device__ inline int ego_layout_words(int O4, int r) {
+    return 2 * O4 + ((O4 / 4 + 3) & ~3) + 4 + 2 * O4 + 4 * r * r + 3 * (O4 / 4);
+}
 __device__ __forceinline__ EgoLayout ego_layout(const uint16_t *base, int O4, int r) {
     EgoLayout l;
     l.rt = base; l.ct = base + O4; l.ct4 = base + 2 * O4;
     const uint16_t *h = l.ct4 + ((O4 / 4 + 3) & ~3);
-    l.nbr = h[0]; l.nbc = h[1]; l.cw = h[2];
-    l.br = h + 4; l.bc = l.br + O4; l.rect = l.bc + O4;
+    l.nbr = h[0]; l.nbc = h[1]; l.cw = h[2]; l.nseg = h[3];
+    l.br = h + 4; l.bc = l.br + O4; l.rect = l.bc + O4; l.seg = l.rect + 4 * r * r;
     return l;
 }
 
@@ -200,7 +208,7 @@ __device__ __forceinline__ void ego_pixels(const EgoCtx &c, const EgoTap (*s_row
         } else {
             const int j = i - n_row_px, q = ego_div(j, inv_O);
             ox = l.bc[q]; oy = j - q * O;
-            ok = !(l.rt[oy] & 0x8000u);                         // already done with its row
+            ok = !(l.rt[oy] & EGO_BORDER);                      // already done with its row
         }
         if (ok) ego_pixel<CH, DIR, false>(c, s_row, s_col, s_frame, O, ox, oy, 0);
     }
@@ -211,8 +219,12 @@ __device__ __forceinline__ void ego_pixels(const EgoCtx &c, const EgoTap (*s_row
         const int py = ego_div(jj, inv_cw), px = jj - py * l.cw;
         bool ok = px < (int)rc[2] && py < (int)rc[3];
         const int ox = ok ? (int)rc[0] + px : 0, oy = ok ? (int)rc[1] + py : 0;
-        ok = ok && !((l.rt[oy] | l.ct[ox]) & 0x8000u);
-        if (ok) ego_pixel<CH, DIR, true>(c, s_row, s_col, s_frame, O, ox, oy, k);
+        const uint32_t fl = (uint32_t)l.rt[oy] | (uint32_t)l.ct[ox];
+        ok = ok && !(fl & EGO_BORDER);
+        if (ok) {
+            if (fl & EGO_EDGE) ego_pixel<CH, DIR, false>(c, s_row, s_col, s_frame, O, ox, oy, 0);   // some taps are outside the view
+            else ego_pixel<CH, DIR, true>(c, s_row, s_col, s_frame, O, ox, oy, k);
+        }
     }
 }
 
@@ -227,40 +239,47 @@ __device__ __forceinline__ void ego_pixels_dir(int dir, const EgoCtx &ctx, const
     }
 }
 
-// Interior pixels: every dword of the frame (4 pixels of one row and plane) is copied from the table frame of the view
-// cell it falls into.  All loads of a thread are issued before its first LDS write; pixels of border rows / columns and
-// of goal cells get whatever the table holds there and are overwritten by ego_pixels.
-// (oy0, x40): row and dword-in-row of this thread's first dword; (sy, sx): the same for a stride of BS dwords.
+// Interior pixels are copied from the table frame of the view cell they fall into.  The unit is a column segment: the
+// dwords of one frame row (and plane) that show the same cell column -- 28 bytes at r = 3 -- fetched with dwordx4 / x3 /
+// x2 loads (global loads only need dword alignment) instead of one gather per dword: 3.5 x fewer load instructions, which
+// is what this phase is bound by (it was 44 % of the kernel).  All loads of an item are issued before its LDS writes;
+// pixels of border rows / columns and of goal cells get whatever the table holds there and are overwritten by ego_pixels.
 template <int CH, int BS>
 __device__ __forceinline__ void ego_copy_interior(const EgoCell *s_cells, const EgoLayout &l, const uint8_t *tab, uint32_t frame_bytes,
-                                                  uint8_t *s_frame, int O, int tid, int oy0, int x40, int sy, int sx) {
-    constexpr int IT = (84 * 21 + BS - 1) / BS, HALF = (IT + 1) / 2;    // two batches: 12 live registers instead of 21
-    const int rowd = O >> 2, nd = O * rowd;
+                                                  uint8_t *s_frame, int O, int tid) {
+    const int nseg = l.nseg, per_plane = O * nseg, items = CH * per_plane, rowd = O >> 2;
+    const float inv_pp = __builtin_amdgcn_rcpf((float)per_plane), inv_ns = __builtin_amdgcn_rcpf((float)nseg);
     uint32_t *f32 = reinterpret_cast<uint32_t *>(s_frame);
-    int oy = oy0, x4 = x40;
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef const unsigned int __attribute__((address_space(1))) *g_u32;
+    typedef const u32x2 __attribute__((address_space(1))) *g_u32x2;
+    typedef const u32x4 __attribute__((address_space(1))) *g_u32x4;
+    for (int it = tid; it < items; it += BS) {
+        const int ch = ego_div(it, inv_pp), rem = it - ch * per_plane;
+        const int oy = ego_div(rem, inv_ns), sg = rem - oy * nseg;
+        const int x4 = l.seg[3 * sg], ndw = l.seg[3 * sg + 1], cterm = l.seg[3 * sg + 2];
+        const int cell = (int)(l.rt[oy] & EGO_TERM) + cterm;
+        const int t = s_cells[cell].tab;
+        const int d0 = ch * (O * rowd) + oy * rowd + x4;                      // dword index in the planar frame
+        const uint8_t *src = tab + (uint32_t)(t < 0 ? 0 : t) * frame_bytes + 4u * (uint32_t)d0;
+        u32x4 q[6];
 #pragma unroll
-    for (int b = 0; b < IT; b += HALF) {
-        uint32_t v[HALF][CH];
-#pragma unroll
-        for (int it = b; it < b + HALF && it < IT; ++it) {
-            const int d = it * BS + tid;
-            if (d < nd) {
-                const int cell = (int)(l.rt[oy] & 0x7fffu) + (int)l.ct4[x4];
-                const int t = s_cells[cell].tab;
-                const uint8_t *src = tab + (uint32_t)(t < 0 ? 0 : t) * frame_bytes + 4u * (uint32_t)d;
-#pragma unroll
-                for (int ch = 0; ch < CH; ++ch) v[it - b][ch] = *reinterpret_cast<const uint32_t *>(src + (uint32_t)(ch * O * O));
-            }
-            x4 += sx; oy += sy;
-            if (x4 >= rowd) { x4 -= rowd; ++oy; }
+        for (int pc = 0; pc < 6; ++pc) {
+            const int left = ndw - 4 * pc;
+            q[pc] = (u32x4)(0u);
+            if (left >= 4) q[pc] = *(g_u32x4)(src + 16 * pc);
+            else if (left == 3) { const u32x2 a = *(g_u32x2)(src + 16 * pc); q[pc].x = a.x; q[pc].y = a.y; q[pc].z = *(g_u32)(src + 16 * pc + 8); }
+            else if (left == 2) { const u32x2 a = *(g_u32x2)(src + 16 * pc); q[pc].x = a.x; q[pc].y = a.y; }
+            else if (left == 1) q[pc].x = *(g_u32)(src + 16 * pc);
         }
 #pragma unroll
-        for (int it = b; it < b + HALF && it < IT; ++it) {
-            const int d = it * BS + tid;
-            if (d < nd) {
-#pragma unroll
-                for (int ch = 0; ch < CH; ++ch) f32[ch * nd + d] = v[it - b][ch];
-            }
+        for (int pc = 0; pc < 6; ++pc) {
+            const int left = ndw - 4 * pc;
+            if (left >= 1) f32[d0 + 4 * pc] = q[pc].x;
+            if (left >= 2) f32[d0 + 4 * pc + 1] = q[pc].y;
+            if (left >= 3) f32[d0 + 4 * pc + 2] = q[pc].z;
+            if (left >= 4) f32[d0 + 4 * pc + 3] = q[pc].w;
         }
     }
 }
@@ -334,10 +353,14 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
     uint8_t *s_ray = s_shadow + ((r * r + 3) & ~3);
     uint8_t *s_gc = s_ray + ((r + 3) & ~3);
     uint8_t *s_goal_k = s_gc + XW_MAX_GOALS;                                     // [XW_MAX_GOALS] view cells that show a goal
+    uint8_t *s_goal_slot = s_goal_k + XW_MAX_GOALS;                              // [XW_MAX_GOALS] their goal slots
+    uint8_t *s_miss_k = s_goal_slot + XW_MAX_GOALS;                              // [XW_MAX_GOALS] those not in the cache yet
+    uint8_t *s_miss_slot = s_miss_k + XW_MAX_GOALS;
     // composed taps of one output row / column: the two intermediate indices' taps and the output tap (static: O <= 84)
     __shared__ EgoTap s_row[84][3], s_col[84][3];
     __shared__ uint16_t s_code[XW_MAX_DIM * XW_MAX_DIM];                         // the env's grid, target bit stripped
-    __shared__ int s_ngoal;
+    __shared__ int s_ngoal, s_nmiss;
+    __shared__ uint32_t s_valid[64];                                             // the env's cache bits (ego_cache_words <= 64)
     const int tid = threadIdx.x;
     const int n_items = MODE == 1 ? *count_now : p.n;
     if ((int)blockIdx.x >= n_items) return;                    // the done list is short: most of its workgroups leave here
@@ -345,14 +368,13 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
     for (int i = tid; i < p.n_icons; i += BS) { s_itype[i] = p.icon_type[i]; s_rot[i] = p.ego_agent_rot[i]; }
     if (FAST) for (int i = tid; i < 4 * lw; i += BS) s_layout[i] = layout[i];
     const int cells = D * D;
-    const int rowd = O >> 2, copy_oy0 = tid / rowd, copy_x40 = tid - copy_oy0 * rowd, copy_sy = BS / rowd, copy_sx = BS - copy_sy * rowd;
     // Everything the env's setup reads from global memory is fetched one env ahead and staged in LDS, so the serial part
     // -- shadow rays, scan lines, cell table -- never waits for HBM / L2.  The setup is the first wavefront's job alone
     // (its lanes hold the grid: cells <= 256 = 4 per lane): it is scalar-heavy code that every wavefront would otherwise
     // repeat, and inside one wavefront its phases need no workgroup barrier (LDS operations of a wave complete in order).
     constexpr int CPL = XW_MAX_DIM * XW_MAX_DIM / 64;           // grid cells per lane of the first wavefront
     const bool wave0 = tid < 64;
-    struct Fetch { int e, axy, dir, skip; uint32_t code[CPL], gc; };
+    struct Fetch { int e, axy, dir, skip; uint32_t code[CPL], gc, valid; };
     auto fetch = [&](int item) {
         Fetch f;
         f.e = MODE == 1 ? p.done_list[item] : item;
@@ -361,6 +383,8 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
 #pragma unroll
         for (int k = 0; k < CPL; ++k) f.code[k] = wave0 && tid + 64 * k < cells ? (uint32_t)p.grid[(size_t)f.e * cells + tid + 64 * k] : 0u;
         f.gc = tid < XW_MAX_GOALS ? (uint32_t)p.goal_cells[(size_t)f.e * XW_MAX_GOALS + tid] : 0xffu;
+        // the env's goal-cell cache bits, lane i = word i (fetched with the rest, one env ahead: the look-up never waits)
+        f.valid = (FAST && p.ego_cache_valid && tid < (int)p.ego_cache_words && tid < 64) ? p.ego_cache_valid[(size_t)f.e * p.ego_cache_words + tid] : 0u;
         return f;
     };
     auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); };
@@ -382,6 +406,7 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
                 }
             }
             if (tid < XW_MAX_GOALS) s_gc[tid] = (uint8_t)f.gc;
+            if (FAST && tid < (int)p.ego_cache_words) s_valid[tid] = f.valid;
             if (tid < r) s_ray[tid] = 1;
             if (tid == 0) s_ngoal = 0;
         }
@@ -438,7 +463,7 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
                             for (int i = 0; i < XW_MAX_GOALS; ++i) if (s_gc[i] == gy * D + gx) slot = i;
                             c.img = gimg + slot * 4096;
                             c.tab = -1;
-                            if (FAST) s_goal_k[atomicAdd(&s_ngoal, 1)] = (uint8_t)k;
+                            if (FAST) { const int j = atomicAdd(&s_ngoal, 1); s_goal_k[j] = (uint8_t)k; s_goal_slot[j] = (uint8_t)slot; }
                         }
                     }
                 }
@@ -449,12 +474,62 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
         EGO_T(3);
         EgoCtx ctx{s_cells, white, black, r, S};
         if (FAST) {
-            ego_copy_interior<CH, BS>(s_cells, lay, tab, frame_bytes, s_frame, O, tid, copy_oy0, copy_x40, copy_sy, copy_sx);
+            ego_copy_interior<CH, BS>(s_cells, lay, tab, frame_bytes, s_frame, O, tid);
             __syncthreads();
             EGO_T(4);
         }
-        ego_pixels_dir<CH, BS, FAST>(dir, ctx, s_row, s_col, s_frame, O, tid, lay, s_goal_k, s_ngoal);
+        const uint8_t *eval_k = s_goal_k;
+        int n_eval = s_ngoal;
+        // (four frames in five show no goal at all: nothing to look up, nothing to evaluate, no barrier)
+        const bool cached = FAST && p.ego_cache != nullptr && s_ngoal > 0;
+        uint8_t *cache_env = nullptr;
+        uint32_t *valid_env = nullptr;
+        if (cached) {
+            // goal cells: copy the ones this env has already rendered in this place and heading, evaluate the rest (and keep them)
+            cache_env = p.ego_cache + (size_t)e * p.num_goals * (r * r * 4) * p.ego_cache_entry;
+            valid_env = p.ego_cache_valid + (size_t)e * p.ego_cache_words;
+            if (tid == 0) {
+                int nm = 0;
+                for (int j = 0; j < s_ngoal; ++j) {
+                    const int bit = (s_goal_slot[j] * r * r + s_goal_k[j]) * 4 + dir;
+                    if (!((s_valid[bit >> 5] >> (bit & 31)) & 1u)) { s_miss_k[nm] = s_goal_k[j]; s_miss_slot[nm] = s_goal_slot[j]; nm++; s_goal_k[j] = 0xff; }
+                }
+                s_nmiss = nm;
+            }
+            __syncthreads();
+            for (int j = 0; j < s_ngoal; ++j) {
+                const int k = s_goal_k[j];
+                if (k == 0xff) continue;                                 // a miss
+                const uint16_t *rc = lay.rect + 4 * k;
+                const int x0 = rc[0], y0 = rc[1], w = rc[2], h = rc[3], wh = w * h;
+                const uint8_t *src = cache_env + (size_t)((s_goal_slot[j] * r * r + k) * 4 + dir) * p.ego_cache_entry;
+                for (int i = tid; i < wh * CH; i += BS) {
+                    const int ch = i / wh, rem = i - ch * wh, py = rem / w, px = rem - py * w;
+                    s_frame[ch * O * O + (y0 + py) * O + x0 + px] = src[i];
+                }
+            }
+            eval_k = s_miss_k;
+            n_eval = s_nmiss;
+#ifdef XWB_EGO_PROF
+            if (tid == 0) { atomicAdd(&g_ego_prof[8], (unsigned long long)s_ngoal); atomicAdd(&g_ego_prof[9], (unsigned long long)s_nmiss); atomicAdd(&g_ego_prof[10], 1ull); }
+#endif
+        }
+        ego_pixels_dir<CH, BS, FAST>(dir, ctx, s_row, s_col, s_frame, O, tid, lay, eval_k, n_eval);
         __syncthreads();
+        if (cached && n_eval > 0) {
+            for (int j = 0; j < n_eval; ++j) {
+                const int k = s_miss_k[j];
+                const uint16_t *rc = lay.rect + 4 * k;
+                const int x0 = rc[0], y0 = rc[1], w = rc[2], h = rc[3], wh = w * h;
+                const int entry = (s_miss_slot[j] * r * r + k) * 4 + dir;
+                uint8_t *dst = cache_env + (size_t)entry * p.ego_cache_entry;
+                for (int i = tid; i < wh * CH; i += BS) {
+                    const int ch = i / wh, rem = i - ch * wh, py = rem / w, px = rem - py * w;
+                    dst[i] = s_frame[ch * O * O + (y0 + py) * O + x0 + px];
+                }
+                if (tid == 0) atomicOr(valid_env + (entry >> 5), 1u << (entry & 31));
+            }
+        }
         EGO_T(5);
         const int flag = p.context > 1 ? (MODE == 1 ? p.list_flag : (int)p.fresh[e]) : 1;
         const float scale = (float)(1 / 255.0);   // float32 frames: pixel * (1 / 255.0f), the product py_simulator.cpp:262-272 computes
@@ -506,6 +581,9 @@ __global__ __launch_bounds__(256) void xw_warp_goals_kernel(XwParams p, const ui
         const int e = LIST ? p.done_list[ei] : ei;
         const int cell = p.goal_cells[(size_t)e * XW_MAX_GOALS + slot];
         uint32_t *out = p.goal_img + ((size_t)e * G + slot) * 4096;
+        // new poses: whatever the render cached of this env's goal cells is stale
+        if (slot == 0 && p.ego_cache_valid)
+            for (int q = threadIdx.x; q < (int)p.ego_cache_words; q += 256) p.ego_cache_valid[(size_t)e * p.ego_cache_words + q] = 0;
         if (cell == 0xff) continue;
         const int icon = (int)(p.grid[(size_t)e * D * D + cell] & CELL_ICON_MASK) - 1;
         if (icon < 0) continue;
@@ -580,7 +658,8 @@ static void resize_taps(int src, int dst, std::vector<EgoTap> &h, std::vector<Eg
 // tables (EgoLayout).  An output row is interior when the four view rows behind it exist and lie in one cell row (or
 // column, for the sideways headings).  *fast_out: frame rows are whole dwords and no dword holds interior pixels of two
 // cells -- the condition for copying interior pixels from the table.
-hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int *fast_out) {
+hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int *fast_out, int *cell_edge_out) {
+    int cell_edge = 1;
     std::vector<EgoTap> h1, v1, h2, v2;
     resize_taps(64 * r, 64 * max_dim, h1, v1);
     resize_taps(64 * max_dim, out_dim, h2, v2);
@@ -593,6 +672,7 @@ hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int 
     for (int dir = 0; dir < 4; ++dir) {
         uint16_t *L = lay.data() + (size_t)dir * lw;
         uint16_t *rt = L, *ct = L + O4, *ct4 = L + 2 * O4, *hd = ct4 + q4, *br = hd + 4, *bc = br + O4, *rect = bc + O4;
+        uint16_t *seg = rect + 4 * r * r;
         const bool row_is_y = dir == 3 || dir == 1;
         std::vector<int> cell_of[2];                           // per axis: the cell coordinate of an interior row / column, -1 border
         for (int axis = 0; axis < 2; ++axis) {                 // 0: output rows, 1: output columns
@@ -605,26 +685,36 @@ hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int 
             for (int o = 0; o < O; ++o) {
                 const int idx[4] = {t1[t2[o].s0].s0, t1[t2[o].s0].s1, t1[t2[o].s1].s0, t1[t2[o].s1].s1};
                 int cell = -1;
-                bool ok = true;
+                bool ok = true, edge = false;
                 for (int i = 0; i < 4; ++i) {
                     const int f = flip ? S - idx[i] : idx[i];
-                    if (f < 0 || f >= S) { ok = false; break; }
+                    if (f < 0 || f >= S) { edge = true; continue; }       // outside the view: black whatever the cells show
                     if (cell < 0) cell = f >> 6;
                     else if (cell != (f >> 6)) ok = false;
                 }
-                if (ok) { term[o] = (uint16_t)(times_r ? cell * r : cell); cell_of[axis][o] = cell; }
-                else { term[o] = 0x8000; border[nb++] = (uint16_t)o; }
+                if (cell < 0) cell = 0;                                   // (all four outside: cannot happen, taps are adjacent pairs)
+                if (ok) { term[o] = (uint16_t)((times_r ? cell * r : cell) | (edge ? EGO_EDGE : 0u)); cell_of[axis][o] = cell; }
+                else { term[o] = (uint16_t)EGO_BORDER; border[nb++] = (uint16_t)o; }
             }
             hd[axis] = (uint16_t)nb;
         }
         for (int x4 = 0; x4 < O4 / 4; ++x4) {                  // the column term of a dword
             int term = -1;
             for (int j = 0; j < 4 && 4 * x4 + j < O; ++j) {
-                if (ct[4 * x4 + j] & 0x8000) continue;
-                if (term < 0) term = ct[4 * x4 + j];
-                else if (term != ct[4 * x4 + j]) fast = false;
+                if (ct[4 * x4 + j] & EGO_BORDER) continue;
+                const int tj = ct[4 * x4 + j] & EGO_TERM;
+                if (term < 0) term = tj;
+                else if (term != tj) fast = false;
             }
             ct4[x4] = (uint16_t)(term < 0 ? 0 : term);
+        }
+        {   // column segments: maximal runs of dwords with the same column term (at most 24 dwords: six x4 loads per item)
+            int ns = 0;
+            for (int x4 = 0; x4 < O4 / 4; ++x4) {
+                if (ns > 0 && seg[3 * (ns - 1) + 2] == ct4[x4] && seg[3 * (ns - 1) + 1] < 24) seg[3 * (ns - 1) + 1]++;
+                else { seg[3 * ns] = (uint16_t)x4; seg[3 * ns + 1] = 1; seg[3 * ns + 2] = ct4[x4]; ns++; }
+            }
+            hd[3] = (uint16_t)ns;
         }
         int cw = 1;
         for (int k = 0; k < r * r; ++k) {                       // view cell k = vy * r + vx: where its interior pixels are
@@ -641,7 +731,8 @@ hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int 
             if (w > cw) cw = w;
             if (h > cw) cw = h;
         }
-        hd[2] = (uint16_t)cw; hd[3] = 0;
+        hd[2] = (uint16_t)cw;
+        if (cw > cell_edge) cell_edge = cw;
     }
     const size_t tap_bytes = all.size() * sizeof(EgoTap), lay_bytes = lay.size() * sizeof(uint16_t);
     uint8_t *d = nullptr;
@@ -651,6 +742,7 @@ hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int 
     if (err == hipSuccess) err = hipMemcpy(d + tap_bytes, lay.data(), lay_bytes, hipMemcpyHostToDevice);
     *dev_out = reinterpret_cast<EgoTap *>(d);
     *fast_out = fast ? 1 : 0;
+    if (cell_edge_out) *cell_edge_out = cell_edge;
     return err;
 }
 
@@ -665,6 +757,9 @@ EgoTables ego_tables_of(const XwParams &p) {
 }
 size_t ego_frame_bytes(const XwParams &p) { return (size_t)((p.channels * p.out_dim * p.out_dim + 15) & ~15); }
 }  // namespace
+
+// bytes of one cache entry: the largest cell rectangle of any heading, all channels
+size_t xw_ego_cache_entry_bytes(const XwParams &p, int cell_edge) { return (size_t)((cell_edge * cell_edge * p.channels + 15) & ~15); }
 
 size_t xw_ego_tab_bytes(const XwParams &p) { return (size_t)(p.n_icons + 2) * 4 * ego_frame_bytes(p); }
 
@@ -688,7 +783,7 @@ hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s) {
     const bool fast = p.ego_fast != 0;
     const size_t lds = ego_frame_bytes(p) + (size_t)r * r * sizeof(EgoCell) + (fast ? (size_t)ego_layout_words(O4, r) * 8 : 0) +
                        (size_t)p.n_icons * 4 + (size_t)((p.n_icons + 3) & ~3) + (size_t)((D * D + 3) & ~3) +
-                       (size_t)((r * r + 3) & ~3) + (size_t)((r + 3) & ~3) + 2 * XW_MAX_GOALS + 16;
+                       (size_t)((r * r + 3) & ~3) + (size_t)((r + 3) & ~3) + 5 * XW_MAX_GOALS + 16;
     // whole batch: looping workgroups, each with its next env's state in flight, so the per-workgroup prologue (taps and
     // layout tables -> LDS) is amortised; 8192 of them rather than the 1024 that are resident at once: a shorter tail, and
     // a reset_done running on the side stream finds free slots (MI355X, C4 batch: 0.518 ms per step with 1024, 0.494 with 8192)
@@ -709,7 +804,7 @@ hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s) {
 
 #ifdef XWB_EGO_PROF
 extern "C" int xwb_debug_ego_prof(unsigned long long *out) {
-    unsigned long long z[8] = {0};
+    unsigned long long z[12] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(xwb::g_ego_prof), sizeof(z)) != hipSuccess) return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(xwb::g_ego_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }

@@ -112,6 +112,9 @@ struct xwb_sim {
     uint32_t *d_goal_img = nullptr, *d_agent_rot = nullptr;
     EgoTap *d_ego_taps = nullptr;
     uint8_t *d_ego_tab = nullptr;
+    int ego_cell_edge = 1;
+    uint8_t *d_ego_cache = nullptr;        // lazily filled cache of rendered goal cells (XwParams::ego_cache)
+    uint32_t *d_ego_cache_valid = nullptr;
     double *d_goal_warp = nullptr;
     int16_t *d_icon_name = nullptr, *d_name_first = nullptr, *d_name_variants = nullptr;
     uint32_t *d_atlas = nullptr;
@@ -393,7 +396,7 @@ int xw_setup(xwb_sim *s) {
         HIP_TRY(hipMemcpy(s->d_atlas64, a4.data(), a4.size(), hipMemcpyHostToDevice));
         if ((rc = dev_alloc(s, &s->d_agent_rot, (size_t)c.n_icons))) return rc;
         HIP_TRY(hipMemcpy(s->d_agent_rot, rot_off.data(), rot_off.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(xw_ego_tables(c.visible_radius, c.max_dim, s->out_h, &s->d_ego_taps, &s->xw.ego_fast));
+        HIP_TRY(xw_ego_tables(c.visible_radius, c.max_dim, s->out_h, &s->d_ego_taps, &s->xw.ego_fast, &s->ego_cell_edge));
         s->allocs.push_back(s->d_ego_taps);
     }
     if ((rc = dev_alloc(s, &s->d_icon_name, c.n_icons))) return rc;
@@ -464,6 +467,28 @@ int xw_setup(xwb_sim *s) {
     if (c.visible_radius > 0) {
         if ((rc = dev_alloc(s, &s->d_ego_tab, xw_ego_tab_bytes(p)))) return rc;
         p.ego_tab = s->d_ego_tab;
+        p.ego_cache = nullptr; p.ego_cache_valid = nullptr; p.ego_cache_entry = 0; p.ego_cache_words = 0;
+        if (p.ego_fast && !getenv("XWB_EGO_NO_CACHE")) {
+            // rendered goal cells, [env][goal slot][view cell][heading]: ~340 KB per env at r = 3 (11 GB for a C4-sized batch;
+            // the GPU has 288 GB).  Taken only if it leaves at least half of the free memory to the caller.
+            const size_t entry = xw_ego_cache_entry_bytes(p, s->ego_cell_edge);
+            const size_t per_env = (size_t)p.num_goals * c.visible_radius * c.visible_radius * 4;
+            const size_t bytes = (size_t)n * per_env * entry;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes < free_b / 2 && (per_env + 31) / 32 <= 64) {
+                void *q = nullptr;
+                if (hipMalloc(&q, bytes) == hipSuccess) {
+                    s->allocs.push_back(q);
+                    s->d_ego_cache = static_cast<uint8_t *>(q);
+                    const size_t words = (per_env + 31) / 32;
+                    if ((rc = dev_alloc(s, &s->d_ego_cache_valid, (size_t)n * words))) return rc;
+                    p.ego_cache = s->d_ego_cache; p.ego_cache_valid = s->d_ego_cache_valid;
+                    p.ego_cache_entry = (uint32_t)entry; p.ego_cache_words = (uint32_t)words;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+        }
         HIP_TRY(launch_xw_ego_build_tab(p, nullptr));
         HIP_TRY(hipStreamSynchronize(nullptr));
     }

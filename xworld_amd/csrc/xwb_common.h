@@ -204,6 +204,13 @@ struct XwParams {
                                  // the slots it frees (a 1024-thread group needs a whole idle CU and would wait for the end)
     int ego_fast;                // egocentric: interior pixels can be copied from ego_tab (kernels_xworld_ego.hip)
     const uint8_t *ego_tab;      // egocentric: [(n_icons + 2) * 4] frames "every cell shows icon i", per heading (interior pixels)
+    // egocentric: rendered goal cells, filled lazily.  The interior pixels of a view cell that shows a goal depend only on
+    // the goal's warped image (fixed for the episode), the cell's place in the view and the heading: entry
+    // [env][goal slot][view cell][heading] = those pixels ([channel][row][col], ego_cache_entry bytes), valid when its bit
+    // in ego_cache_valid ([env][ego_cache_words]) is set; the warp kernel clears an env's bits when its goals get new poses.
+    uint8_t *ego_cache;          // nullable (not enough free memory: every goal cell is evaluated every frame)
+    uint32_t *ego_cache_valid;
+    uint32_t ego_cache_entry, ego_cache_words;
     uint32_t *cand2d;            // [n] goal slots the agent can reach, blocks as the only obstacles: bits 0..15
                                  //     any goal (XWorldNavTarget), bits 16..31 coloured goals (XWorldNavColorTarget)
     const uint8_t *icon_colored; // [n_icons] properties.txt colour != "na"
@@ -246,7 +253,8 @@ hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s);
 hipError_t launch_xw_clear_done(const XwParams &p, hipStream_t s);
 hipError_t launch_xw_warp_goals(const XwParams &p, bool list, hipStream_t s);
 struct EgoTap;
-hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int *fast_out);
+hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int *fast_out, int *cell_edge_out);
+size_t xw_ego_cache_entry_bytes(const XwParams &p, int cell_edge);
 size_t xw_ego_tab_bytes(const XwParams &p);
 hipError_t launch_xw_ego_build_tab(const XwParams &p, hipStream_t s);
 
