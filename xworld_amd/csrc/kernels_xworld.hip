@@ -515,8 +515,8 @@ static hipError_t render_dispatch(const XwParams &p, int indexed, hipStream_t s)
 #undef XW_CASE
 }
 
-hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s) {
-    if (p.visible_radius) return launch_xw_render_ego(p, indexed == 3 ? 0 : indexed, s);
+hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s, hipEvent_t ev_front, hipEvent_t ev_list, hipEvent_t ev_cells) {
+    if (p.visible_radius) return launch_xw_render_ego(p, indexed == 3 ? 0 : indexed, s, ev_front, ev_list, ev_cells);
     if (p.obs_f32) return p.channels == 3 ? render_dispatch<3, 4>(p, indexed, s) : render_dispatch<1, 4>(p, indexed, s);
     return p.channels == 3 ? render_dispatch<3, 1>(p, indexed, s) : render_dispatch<1, 1>(p, indexed, s);
 }

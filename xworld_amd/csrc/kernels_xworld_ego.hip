@@ -26,6 +26,7 @@
 #include "xw_device.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace xwb {
@@ -56,6 +57,7 @@ struct EgoCtx {
     const EgoCell *cells;        // LDS, r * r
     const uint32_t *white, *black;
     int r, S;
+    int dir;                     // the heading, where it is not a template argument (ego_pixel<.., -1, ..>)
 };
 
 // cv::resize INTER_LINEAR on 8-bit data, one output value: HResizeLinear (11-bit) then VResizeLinear<uchar>
@@ -67,11 +69,12 @@ __device__ __forceinline__ int vresize(int b0, int h0, int b1, int h1) {
 // One output pixel.  DIR = the agent's heading: cv::warpAffine(view, rot(centre S/2, 90 + yaw deg)) is undone per tap
 // row / column -- quarter turns are exact integer maps, separable in x and y; the source index S falls outside and
 // leaves one black row / column (borderValue 0).
+// (DIR = -1: the heading is c.dir, a run-time value -- the same arithmetic with selects, for lanes of mixed headings)
 // ONE: all sixteen view pixels lie in the view cell `one` (an interior pixel of that cell, whose image is indexed: a goal)
 template <int CH, int DIR, bool ONE>
 __device__ __forceinline__ void ego_pixel(const EgoCtx &c, const EgoTap (*s_row)[3], const EgoTap (*s_col)[3],
-                                          uint8_t *s_frame, int O, int ox, int oy, int one) {
-    const int S = c.S, o = oy * O + ox;
+                                          uint8_t *s_frame, int plane, int o, int ox, int oy, int one) {
+    const int S = c.S;
     {
         // the 2 x 2 intermediate pixels this output pixel blends, and the 4 x 4 view pixels behind them
         const EgoTap ty = s_row[oy][2], tx = s_col[ox][2];
@@ -80,13 +83,14 @@ __device__ __forceinline__ void ego_pixel(const EgoCtx &c, const EgoTap (*s_row)
         // source coordinate contributed by a view row (vr) and by a view column (vc):
         //   up (3): sx = vc, sy = vr;  right (0): sx = S - vr, sy = vc;  down (1): sx = S - vc, sy = S - vr;  left (2): sx = vr, sy = S - vc
         int fr[4], fc[4];                                   // coordinate from the row index, from the column index
+        const int dir = DIR >= 0 ? DIR : c.dir;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            fr[i] = (DIR == 3 || DIR == 2) ? R[i] : S - R[i];
-            fc[i] = (DIR == 3 || DIR == 0) ? C[i] : S - C[i];
+            fr[i] = (dir == 3 || dir == 2) ? R[i] : S - R[i];
+            fc[i] = (dir == 3 || dir == 0) ? C[i] : S - C[i];
         }
         // fr is sy for headings up / down and sx for right / left (and fc the other one)
-        constexpr bool ROW_IS_Y = DIR == 3 || DIR == 1;
+        const bool ROW_IS_Y = dir == 3 || dir == 1;
         const uint32_t *src[16];
         if (ONE) {
             const uint32_t *img = c.cells[one].img;
@@ -142,7 +146,7 @@ __device__ __forceinline__ void ego_pixel(const EgoCtx &c, const EgoTap (*s_row)
             out[ch] = vresize(ty.w0, hB[0], ty.w1, hB[1]);
         }
         if (CH == 3) {
-            s_frame[o] = (uint8_t)out[0]; s_frame[O * O + o] = (uint8_t)out[1]; s_frame[2 * O * O + o] = (uint8_t)out[2];
+            s_frame[o] = (uint8_t)out[0]; s_frame[plane + o] = (uint8_t)out[1]; s_frame[2 * plane + o] = (uint8_t)out[2];
         } else {
             s_frame[o] = (uint8_t)((out[0] * 1868 + out[1] * 9617 + out[2] * 4899 + (1 << 13)) >> 14);   // cvtColor BGR2GRAY
         }
@@ -192,7 +196,7 @@ __device__ __forceinline__ void ego_pixels(const EgoCtx &c, const EgoTap (*s_row
     if (!FAST) {
         for (int i = tid; i < O * O; i += BS) {
             const int oy = ego_div(i, inv_O);
-            ego_pixel<CH, DIR, false>(c, s_row, s_col, s_frame, O, i - oy * O, oy, 0);
+            ego_pixel<CH, DIR, false>(c, s_row, s_col, s_frame, O * O, i, i - oy * O, oy, 0);
         }
         return;
     }
@@ -210,7 +214,7 @@ __device__ __forceinline__ void ego_pixels(const EgoCtx &c, const EgoTap (*s_row
             ox = l.bc[q]; oy = j - q * O;
             ok = !(l.rt[oy] & EGO_BORDER);                      // already done with its row
         }
-        if (ok) ego_pixel<CH, DIR, false>(c, s_row, s_col, s_frame, O, ox, oy, 0);
+        if (ok) ego_pixel<CH, DIR, false>(c, s_row, s_col, s_frame, O * O, oy * O + ox, ox, oy, 0);
     }
     // goal cells: interior pixels only
     for (int j = tid; j < n_goal * cw2; j += BS) {
@@ -222,8 +226,8 @@ __device__ __forceinline__ void ego_pixels(const EgoCtx &c, const EgoTap (*s_row
         const uint32_t fl = (uint32_t)l.rt[oy] | (uint32_t)l.ct[ox];
         ok = ok && !(fl & EGO_BORDER);
         if (ok) {
-            if (fl & EGO_EDGE) ego_pixel<CH, DIR, false>(c, s_row, s_col, s_frame, O, ox, oy, 0);   // some taps are outside the view
-            else ego_pixel<CH, DIR, true>(c, s_row, s_col, s_frame, O, ox, oy, k);
+            if (fl & EGO_EDGE) ego_pixel<CH, DIR, false>(c, s_row, s_col, s_frame, O * O, oy * O + ox, ox, oy, 0);   // some taps are outside the view
+            else ego_pixel<CH, DIR, true>(c, s_row, s_col, s_frame, O * O, oy * O + ox, ox, oy, k);
         }
     }
 }
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
         const uint8_t *eval_k = s_goal_k;
         int n_eval = s_ngoal;
         // (four frames in five show no goal at all: nothing to look up, nothing to evaluate, no barrier)
-        const bool cached = FAST && p.ego_cache != nullptr && s_ngoal > 0;
+        const bool cached = FAST && p.ego_cache != nullptr && p.ego_cellinfo == nullptr && s_ngoal > 0;   // (the span path keeps another entry layout)
         uint8_t *cache_env = nullptr;
         uint32_t *valid_env = nullptr;
         if (cached) {
@@ -569,58 +573,630 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
 }
 
 
+// ------------------------------------------------------------------------------------------------ span path ----
+// The whole-batch render when the frame is a grid of r x r equal squares, one per view cell (U = O / r pixels), and the only
+// rows / columns whose taps straddle two cells are first rows / columns of a square (xw_ego_tables checks; true of r = 3,
+// 5, 7 on every map size tried): then a frame is U-byte runs, each copied from the table frame of what its view cell
+// shows or from the env's rendered goal cell, plus at most r - 1 border rows and r - 1 border columns per frame, which are
+// evaluated pixel by pixel into a small per-env buffer first.  The one-workgroup-per-env kernel above spends its time waiting (three barriers and a serial set-up per
+// frame, four workgroups per CU: 14 us per frame and workgroup, 0.20 of the HBM roofline); split by what is parallel in:
+//   xw_ego_cells_kernel   lane per env: shadow rays and scan lines on bit masks -> cellinfo[env][view cell], and the list
+//                         of goal cells the cache does not hold yet
+//   xw_ego_eval_kernel    the pixels that have to be evaluated: four workgroups per listed goal cell (its U x U pixels ->
+//                         cache entry, valid bit), and, eight envs per workgroup, the border-line runs next to goal cells and
+//                         the pixels where border lines cross -> ego_border
+//   xw_ego_gather_kernel  one-shot workgroups over 16-byte chunk spans of the batch's frame bytes, cut by the global chunk
+//                         index exactly like the full-observation render (kernels_xworld.hip): U-byte runs gathered through
+//                         L2, assembled in LDS in output order, border-column bytes patched in, one non-temporal 16-byte
+//                         store per lane
+// The done-list render (new episodes, terminal frames) stays with the kernel above: short lists, latency-bound either way.
+
+// a square's pixels in the span path's sources (ego_tab3, the goal-cell cache): [channel][U rows][UP bytes], rows padded to whole
+// 16-byte pieces
+template <int R>
+struct EgoSq {
+    static constexpr int U = 84 / R, UD = U / 4, UDP = (UD + 3) & ~3, UP = 4 * UDP, CBP = U * UP, RR = R * R, PBP = RR * CBP;
+};
+
+// lane j of the wavefront appends (a, b) when flag: one atomic per wavefront
+__device__ __forceinline__ void ego_wave_append(bool flag, uint32_t a, uint32_t b, uint2 *list, int32_t *count) {
+    const unsigned long long m = __ballot(flag);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, leader);
+    if (flag) list[base + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(a, b);
+}
+
+// 64 envs per workgroup: all four wavefronts stage their grids (and the entity types) in LDS, the first one then walks them
+template <int R>
+__global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uint8_t *map, int skip_term) {
+    extern __shared__ uint4 smem4[];
+    const int D = p.max_dim, cells = D * D, tid = threadIdx.x, lane = tid;
+    uint16_t *s_code = reinterpret_cast<uint16_t *>(smem4);                // [64][cells]
+    uint8_t *s_type = reinterpret_cast<uint8_t *>(s_code + 64 * cells);    // [64][cells] type of the entity in a cell, 3 = none
+    __shared__ uint4 s_gc[64];                                             // the envs' goal slot -> cell tables
+    __shared__ uint32_t s_sq[64][R * R];                                   // the cell words, frame order
+    const int e_base = blockIdx.x * 64;
+    const int n_here = p.n - e_base < 64 ? p.n - e_base : 64;
+    uint8_t *s_itype = s_type + 64 * cells;                                // [n_icons]
+    uint8_t *s_cls = s_itype + ((p.n_icons + 15) & ~15);                   // [n_icons + 2]
+    __shared__ uint8_t s_map[8 * R * R + 8 * R];
+    const int e = e_base + lane, ec = e < p.n ? e : p.n - 1;
+    int axy = 0, dir = 0, term = 0;
+    int fresh = 0;
+    if (tid < 64) { axy = p.agent_xy[ec]; dir = p.agent_dir[ec] & 3; term = p.term_flag[ec]; fresh = p.fresh[ec]; }
+    for (int i = tid; i < p.n_icons; i += 256) s_itype[i] = p.icon_type[i];
+    for (int i = tid; i < p.n_icons + 2; i += 256) s_cls[i] = p.ego_cls[i];
+    for (int i = tid; i < 8 * R * R + 8 * R; i += 256) s_map[i] = map[i];
+    for (int i = tid; i < n_here * cells; i += 256) s_code[i] = (uint16_t)(p.grid[(size_t)e_base * cells + i] & CELL_ICON_MASK);
+    static_assert(XW_MAX_GOALS == 16, "one uint4 per env");
+    if (tid >= 64 && tid < 64 + n_here) s_gc[tid - 64] = reinterpret_cast<const uint4 *>(p.goal_cells)[e_base + tid - 64];
+    __syncthreads();
+    for (int i = tid; i < n_here * cells; i += 256) { const int code = s_code[i]; s_type[i] = code ? s_itype[code - 1] : (uint8_t)3; }
+    __syncthreads();
+    if (tid >= 64) return;
+    const bool active = e < p.n && !(skip_term && term);
+    const int ax = axy & 0xffff, ay = axy >> 16;
+    const uint16_t *code_e = s_code + lane * cells;
+    const uint8_t *type_e = s_type + lane * cells;
+    const uint8_t *gc_e = reinterpret_cast<const uint8_t *>(&s_gc[lane]);
+    auto is_block = [&](int x, int y) { return (unsigned)x < (unsigned)D && (unsigned)y < (unsigned)D && type_e[y * D + x] == 1; };
+    // XMap::image_masking (xmap.cpp:273-362), as in the kernel above
+    constexpr int r = R;
+    int major_x = 0, major_y = 0, minor_x = 0, minor_y = 0, scan_x0 = 0, scan_y0 = 0, xa = ax + r, ya = ay + r;
+    if (dir == 0) { xa += r / 2; major_y = 1; minor_x = 1; }
+    else if (dir == 3) { ya -= r / 2; major_x = 1; minor_y = -1; scan_y0 = r - 1; }
+    else if (dir == 2) { xa -= r / 2; major_y = 1; minor_x = -1; scan_x0 = r - 1; }
+    else { ya += r / 2; major_x = 1; minor_y = 1; }
+    const int x_st = xa - r / 2, y_st = ya - r / 2;
+    uint32_t ray = (1u << r) - 1u;                              // bit t: scan line t starts in the light
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const int o = side ? 1 : -1;
+        bool block = false;
+        int rx = ax, ry = ay;
+#pragma unroll
+        for (int k = 1; k <= r / 2; ++k) {
+            rx += o * major_x; ry += o * major_y;
+            if (block) ray &= ~(1u << (r / 2 + o * k));
+            if (is_block(rx, ry)) block = true;
+        }
+    }
+    unsigned long long shadow = 0;                              // bit k: view cell k lies behind a wall
+#pragma unroll
+    for (int t = 0; t < r; ++t) {
+        bool block = !((ray >> t) & 1u);
+        int cx = scan_x0 + t * major_x, cy = scan_y0 + t * major_y;
+#pragma unroll
+        for (int j = 0; j < r; ++j) {
+            if (block) shadow |= 1ull << (cy * r + cx);
+            if (is_block(x_st - r + cx, y_st - r + cy)) block = true;
+            cx += minor_x; cx = cx < 0 ? cx + r : (cx >= r ? cx - r : cx);
+            cy += minor_y; cy = cy < 0 ? cy + r : (cy >= r ? cy - r : cy);
+        }
+    }
+    if (p.no_wall_shadow) shadow = 0;
+    uint32_t *info_e = p.ego_cellinfo + (size_t)ec * (r * r);
+    const uint32_t *valid_e = p.ego_cache_valid + (size_t)ec * p.ego_cache_words;
+    const uint32_t cls_white = s_cls[p.n_icons], cls_black = s_cls[p.n_icons + 1];
+    // The words are stored in FRAME order (square fy * r + fx) and each carries all the gather needs beside the image:
+    // bits 24-25 the heading, 26 "finished by this step", 27-28 fresh[], 29 / 30 the square's first row / column is a border
+    // line of this heading -- the gather reads nothing else of the env, which a reset on the other queue may be rewriting.
+    // A goal: bit 15, bits 0-3 its slot, bits 4-9 the view cell (the cache is indexed by it).
+    constexpr int RL = 4 * r * r, CL = RL + 4 * r, INV = CL + 4 * r;
+    const uint32_t hd = (uint32_t)dir << 24 | (term ? 1u << 26 : 0u) | ((uint32_t)fresh & 3u) << 27;
+    uint32_t goal_mask_lo = 0, goal_mask_hi = 0;                // view cells that show a goal (r * r <= 49)
+    uint8_t gslot[r * r];
+#pragma unroll
+    for (int k = 0; k < r * r; ++k) {
+        const int gx = x_st - r + k % r, gy = y_st - r + k / r;
+        uint32_t info = (uint32_t)((p.n_icons + 1) * 4 + dir) | cls_black << 16;   // outside the map, or in a wall's shadow: black
+        int slot = 0;
+        if (active && (unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && !((shadow >> k) & 1ull)) {
+            const int code = code_e[gy * D + gx];
+            if (code == 0) info = (uint32_t)(p.n_icons * 4 + dir) | cls_white << 16;
+            else if (type_e[gy * D + gx] != 0) info = (uint32_t)((code - 1) * 4 + dir) | (uint32_t)s_cls[code - 1] << 16;
+            else {                                              // a goal: this env's warped copy, through the cache
+#pragma unroll
+                for (int i = 0; i < XW_MAX_GOALS; ++i) if (gc_e[i] == gy * D + gx) slot = i;
+                info = 0x8000u | (uint32_t)slot | (uint32_t)k << 4 | 0xffu << 16;
+                if (k < 32) goal_mask_lo |= 1u << k; else goal_mask_hi |= 1u << (k - 32);
+            }
+        }
+        gslot[k] = (uint8_t)slot;
+        const int f = s_map[INV + dir * (r * r) + k];
+        const uint32_t lines = (s_map[RL + dir * r + f / r] != 0xff ? 1u << 29 : 0u) | (s_map[CL + dir * r + f % r] != 0xff ? 1u << 30 : 0u);
+        s_sq[lane][f] = info | hd | lines;
+        if (active) info_e[f] = info | hd | lines;
+    }
+    // what the gather reads, per square: where its pixels come from (16-byte units: into ego_tab3, keyed by the classes of the
+    // cell, the one above and the one to the left -- the cell's own where the neighbour does not show in this square -- or, bit
+    // 23, into this env's part of the goal-cell cache), bit 24 / 25 its border row / column is evaluated for this env (a goal
+    // in or next to the cell), 26 a border row crosses a border column here, 27 finished by this step, 28-29 fresh[]
+    if (!active && e < p.n) {
+        for (int f = 0; f < r * r; ++f) p.ego_cellsrc[(size_t)e * (r * r) + f] = 1u << 27;      // (skipped: finished by this step)
+    }
+    if (active) {
+        typedef EgoSq<r> Q;
+        const uint32_t nc = (uint32_t)p.ego_ncls, ch_n = (uint32_t)p.channels, entry16 = p.ego_cache_entry / 16;
+        uint32_t *src_e = p.ego_cellsrc + (size_t)e * (r * r);
+#pragma unroll
+        for (int f = 0; f < r * r; ++f) {
+            const uint32_t w = s_sq[lane][f], wa = f >= r ? s_sq[lane][f - r] : w, wl = f % r ? s_sq[lane][f - 1] : w;
+            const bool rowb = (w >> 29 & 1u) != 0, colb = (w >> 30 & 1u) != 0, goal = (w & 0x8000u) != 0;
+            const bool row_dirty = rowb && ((wa | w) & 0x8000u), col_dirty = colb && ((wl | w) & 0x8000u);
+            const uint32_t c = (w >> 16) & 0xffu, ca = rowb && !row_dirty ? (wa >> 16) & 0xffu : c, cl = colb && !col_dirty ? (wl >> 16) & 0xffu : c;
+            const uint32_t off = goal ? (((w & 0xfu) * (r * r) + ((w >> 4) & 0x3fu)) * 4 + dir) * entry16
+                                      : ((((uint32_t)dir * nc + c) * nc + ca) * nc + cl) * ch_n * (Q::PBP / 16) + f * (Q::CBP / 16);
+            src_e[f] = off | (goal ? 1u << 23 : 0u) | (row_dirty ? 1u << 24 : 0u) | (col_dirty ? 1u << 25 : 0u) | (rowb && colb ? 1u << 26 : 0u) |
+                       (term ? 1u << 27 : 0u) | ((uint32_t)fresh & 3u) << 28;
+        }
+    }
+    // the cache bits of the goal cells, fetched together, then one list append per view cell across the wavefront
+    uint32_t vbit[r * r];
+#pragma unroll
+    for (int k = 0; k < r * r; ++k) {
+        const bool goal = ((k < 32 ? goal_mask_lo >> k : goal_mask_hi >> (k - 32)) & 1u) != 0;
+        const int bit = (gslot[k] * r * r + k) * 4 + dir;
+        vbit[k] = goal ? (valid_e[bit >> 5] >> (bit & 31)) & 1u : 1u;
+    }
+#pragma unroll
+    for (int k = 0; k < r * r; ++k)
+        ego_wave_append(vbit[k] == 0, (uint32_t)e, (uint32_t)(k | gslot[k] << 8 | dir << 16), p.ego_miss, p.ego_miss_count);
+}
+
+// (cache entries hold the whole square of the frame the cell occupies, in EgoSq's layout; its border row / column, if it has
+// one, is left as it is: the gather overwrites those bytes.  This is not the layout the kernel above keeps -- it leaves the
+// cache alone when the span path is on.)
+template <int CH, int R>
+__device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t *atlas4, const EgoTap *tap_h1, const EgoTap *tap_v1,
+                                              const EgoTap *tap_h2, const EgoTap *tap_v2, const uint16_t *layout, const uint8_t *map,
+                                              int block, int nblocks) {
+    constexpr int U = 84 / R, O = R * U, O4 = O;
+    constexpr int PARTS = 4, PP = (U * U + PARTS - 1) / PARTS;       // a goal cell is shared by four workgroups: <= one pixel per lane
+    static_assert(PP <= 256, "one pixel per lane");
+    __shared__ EgoTap s_row[84][3], s_col[84][3];
+    __shared__ EgoCell s_cells[R * R];
+    const int cnt = *p.ego_miss_count, tid = threadIdx.x, part = block % PARTS;
+    if (block / PARTS >= cnt) return;
+    ego_compose_taps(s_row, s_col, tap_h1, tap_v1, tap_h2, tap_v2, O, tid, 256);
+    const int lw = ego_layout_words(O4, R);
+    const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
+    for (int it = block / PARTS; it < cnt; it += nblocks / PARTS) {
+        const uint2 item = p.ego_miss[it];
+        const int e = (int)item.x, k = item.y & 0xff, slot = (item.y >> 8) & 0xff, dir = (item.y >> 16) & 3;
+        __syncthreads();
+        // every tap that falls inside the view falls into cell k: the whole table shows the goal's image
+        if (tid < R * R) s_cells[tid] = EgoCell{p.goal_img + ((size_t)e * p.num_goals + slot) * 4096, -1, -1};
+        __syncthreads();
+        const int f = map[8 * R + (4 + dir) * (R * R) + k];                  // the square view cell k occupies
+        const int x0 = (f % R) * U, y0 = (f / R) * U;
+        const uint16_t *rt = layout + dir * lw, *ct = rt + O4;
+        EgoCtx ctx{s_cells, white, black, R, 64 * R, dir};
+        const int entry = (slot * R * R + k) * 4 + dir;
+        uint8_t *dst = p.ego_cache + ((size_t)e * p.num_goals * (R * R * 4) + entry) * p.ego_cache_entry;
+        const int j = part * PP + tid;
+        if (tid < PP && j < U * U) {
+            const int py = j / U, px = j - py * U, ox = x0 + px, oy = y0 + py;
+            const uint32_t fl = (uint32_t)rt[oy] | (uint32_t)ct[ox];
+            if (!(fl & EGO_BORDER)) {
+                if (fl & EGO_EDGE) ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, 0);
+                else ego_pixel<CH, -1, true>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, 0);
+            }
+        }
+        // (the bit is read by kernels launched after this one: all four parts are complete by then)
+        if (tid == 0 && part == 0) atomicOr(p.ego_cache_valid + (size_t)e * p.ego_cache_words + (entry >> 5), 1u << (entry & 31));
+    }
+}
+
+// ego_border[env][line][channel][O], line fy - 1 = the border row at frame row fy * U, line r - 1 + fx - 1 = the border column
+// at frame column fx * U (indexed by output row): the pixels of those lines that the square table (ego_tab3: the cell and its
+// neighbour show images every env shares) cannot hold -- a run of U pixels next to a goal cell, and the pixels where a
+// border row crosses a border column (four cells).  EPW envs per workgroup, lanes = consecutive pixels of a run.
+__device__ __forceinline__ EgoCell ego_cell_of_info(const XwParams &p, const uint32_t *atlas4, uint32_t info, int e, int dir) {
+    const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
+    EgoCell c{black, 0, -1};
+    const int t = (int)((info & 0x7fffu) >> 2);
+    if (info & 0x8000u) c = EgoCell{p.goal_img + ((size_t)e * p.num_goals + (info & 0xfu)) * 4096, -1, -1};
+    else if (t == p.n_icons) c.img = white;
+    else if (t < p.n_icons) c = ego_icon_cell(p.icon_type, p.ego_agent_rot, atlas4, t, dir);
+    return c;
+}
+
+template <int CH, int R>
+__device__ __forceinline__ void ego_border_body(const XwParams &p, const uint32_t *atlas4, const EgoTap *tap_h1, const EgoTap *tap_v1,
+                                                const EgoTap *tap_h2, const EgoTap *tap_v2, const uint8_t *map, int skip_term, int block) {
+    constexpr int U = 84 / R, O = R * U, EPW = 8, NL = 2 * (R - 1);
+    constexpr int NSEG = R * (R - 1), NITEM = 2 * NSEG + (R - 1) * (R - 1);   // row runs, column runs, crossings
+    constexpr int RL = 4 * R * R, CL = RL + 4 * R;
+    __shared__ EgoTap s_row[84][3], s_col[84][3];
+    __shared__ EgoCell s_cells[EPW][R * R];
+    __shared__ uint8_t s_goal[EPW][R * R];               // view cell shows a goal
+    __shared__ uint8_t s_map[4 * R * R + 8 * R], s_edir[EPW];
+    __shared__ uint16_t s_runs[EPW * 2 * NSEG], s_cross[EPW * (R - 1) * (R - 1)];
+    __shared__ int s_nrun, s_ncross;
+    const int tid = threadIdx.x, e_base = block * EPW;
+    if (tid == 0) { s_nrun = 0; s_ncross = 0; }
+    ego_compose_taps(s_row, s_col, tap_h1, tap_v1, tap_h2, tap_v2, O, tid, 256);
+    for (int i = tid; i < 4 * R * R + 8 * R; i += 256) s_map[i] = map[i];
+    for (int i = tid; i < EPW * R * R; i += 256) {
+        const int le = i / (R * R), f = i - le * (R * R), e = e_base + le < p.n ? e_base + le : p.n - 1;
+        const uint32_t info = p.ego_cellinfo[(size_t)e * (R * R) + f];
+        const int dir = (int)(info >> 24) & 3, k = map[dir * (R * R) + f];
+        s_cells[le][k] = ego_cell_of_info(p, atlas4, info, e, dir);
+        s_goal[le][k] = (info & 0x8000u) ? 1 : 0;
+        if (f == 0) s_edir[le] = (uint8_t)(e_base + le < p.n && !(skip_term && p.term_flag[e]) ? dir : 4);   // 4: nothing to do
+    }
+    __syncthreads();
+    // which runs / crossings this workgroup has to evaluate
+    for (int i = tid; i < EPW * NITEM; i += 256) {
+        const int le = i / NITEM, it = i - le * NITEM, dir = s_edir[le];
+        bool need = false;
+        if (dir < 4) {
+            const uint8_t *cm = s_map + dir * (R * R);
+            if (it < NSEG) {                              // the run of border row fy over square column fx
+                const int fy = it / R + 1, fx = it % R;
+                need = s_map[RL + dir * R + fy] != 0xff && (s_goal[le][cm[(fy - 1) * R + fx]] | s_goal[le][cm[fy * R + fx]]);
+            } else if (it < 2 * NSEG) {                   // the run of border column fx over square row fy
+                const int q = it - NSEG, fx = q / R + 1, fy = q % R;
+                need = s_map[CL + dir * R + fx] != 0xff && (s_goal[le][cm[fy * R + fx - 1]] | s_goal[le][cm[fy * R + fx]]);
+            } else {
+                const int q = it - 2 * NSEG, fy = q / (R - 1) + 1, fx = q % (R - 1) + 1;
+                need = s_map[RL + dir * R + fy] != 0xff && s_map[CL + dir * R + fx] != 0xff;
+            }
+        }
+        // compacted: a run gets UP consecutive lanes, a crossing one (evaluating straight off the sparse item table kept one
+        // lane in a few busy and cost ~450 VALU instructions per pass: 1 235 per wave, the kernel was VALU-bound)
+        if (need) {
+            if (it < 2 * NSEG) s_runs[atomicAdd(&s_nrun, 1)] = (uint16_t)i;
+            else s_cross[atomicAdd(&s_ncross, 1)] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+    const int nrun = s_nrun, ncross = s_ncross;
+    if (nrun + ncross == 0) return;
+    const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
+    constexpr int UP = U <= 16 ? 16 : 32;                 // lanes per run
+    for (int i = tid; i < nrun * UP + ncross; i += 256) {
+        const bool is_run = i < nrun * UP;
+        const int gi = is_run ? s_runs[i / UP] : s_cross[i - nrun * UP], j = is_run ? i % UP : 0;
+        if (j >= U) continue;
+        const int le = gi / NITEM, it = gi - le * NITEM, dir = s_edir[le];
+        int ox, oy, line, o;
+        if (it < NSEG) {
+            const int fy = it / R + 1, fx = it % R;
+            ox = fx * U + j; oy = fy * U; line = fy - 1; o = ox;
+        } else if (it < 2 * NSEG) {
+            const int q = it - NSEG, fx = q / R + 1, fy = q % R;
+            ox = fx * U; oy = fy * U + j; line = R - 1 + fx - 1; o = oy;
+        } else {
+            const int q = it - 2 * NSEG, fy = q / (R - 1) + 1, fx = q % (R - 1) + 1;
+            ox = fx * U; oy = fy * U; line = R - 1 + fx - 1; o = oy;
+        }
+        EgoCtx ctx{s_cells[le], white, black, R, 64 * R, dir};
+        uint8_t *dst = p.ego_border + ((size_t)(e_base + le) * NL + line) * (CH * O);
+        ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst, O, o, ox, oy, 0);
+    }
+}
+
+// Both in one launch (they are independent, short and latency-bound: side by side they take the time of the longer one): the
+// first nb_border workgroups evaluate border lines, the rest listed goal cells.
+template <int CH, int R>
+__global__ __launch_bounds__(256) void xw_ego_eval_kernel(XwParams p, const uint32_t *atlas4, const EgoTap *tap_h1, const EgoTap *tap_v1,
+                                                          const EgoTap *tap_h2, const EgoTap *tap_v2, const uint16_t *layout, const uint8_t *map,
+                                                          int skip_term, int nb_border) {
+    if ((int)blockIdx.x < nb_border) ego_border_body<CH, R>(p, atlas4, tap_h1, tap_v1, tap_h2, tap_v2, map, skip_term, blockIdx.x);
+    else ego_miss_body<CH, R>(p, atlas4, tap_h1, tap_v1, tap_h2, tap_v2, layout, map, (int)blockIdx.x - nb_border, (int)gridDim.x - nb_border);
+}
+
+// ego_tab3: the squares of every constant-image neighbourhood.  Entry (heading, c, a, l, channel, square) = the pixels of that
+// square of the frame when its cell shows class c's image, the cell above class a's and the cell to the left class l's: the
+// square's first row / column, where that is a border line, blends two cells (the pixel where both cross blends four and is
+// not in the table).  One workgroup per (heading, c, a, l, square).
+template <int CH, int R>
+__global__ __launch_bounds__(256) void xw_ego_build_squares_kernel(XwParams p, const uint32_t *atlas4, const EgoTap *tap_h1, const EgoTap *tap_v1,
+                                                                 const EgoTap *tap_h2, const EgoTap *tap_v2, const uint8_t *map, uint8_t *tab3) {
+    typedef EgoSq<R> Q;
+    constexpr int U = Q::U, O = R * U, RR = R * R;
+    __shared__ EgoTap s_row[84][3], s_col[84][3];
+    __shared__ EgoCell s_cells[RR];
+    const int tid = threadIdx.x, nc = p.ego_ncls;
+    int id = blockIdx.x;
+    const int sq = id % RR; id /= RR;
+    const int l = id % nc; id /= nc;
+    const int a = id % nc; id /= nc;
+    const int c = id % nc, dir = id / nc;
+    const int fy = sq / R, fx = sq % R;
+    ego_compose_taps(s_row, s_col, tap_h1, tap_v1, tap_h2, tap_v2, O, tid, 256);
+    if (tid < RR) {
+        const int gy = tid / R, gx = tid % R;
+        const int cls = (gy == fy - 1 && gx == fx) ? a : ((gy == fy && gx == fx - 1) ? l : c);
+        s_cells[map[dir * RR + tid]] = ego_cell_of_info(p, atlas4, (uint32_t)p.ego_cls_icon[cls] << 2, 0, dir);
+    }
+    __syncthreads();
+    const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
+    EgoCtx ctx{s_cells, white, black, R, 64 * R, dir};
+    uint8_t *dst = tab3 + (((((size_t)dir * nc + c) * nc + a) * nc + l) * CH) * Q::PBP + (size_t)sq * Q::CBP;
+    for (int j = tid; j < U * U; j += 256) {
+        const int py = j / U, px = j - py * U;
+        ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst, Q::PBP, py * Q::UP + px, fx * U + px, fy * U + py, 0);
+    }
+}
+
+template <int CH, int R, int ES, int PER_>
+struct EgoSpanGeom {
+    static constexpr int BS = 128, PER = PER_, SPAN = BS * PER;
+    static constexpr int U = 84 / R, O = R * U;
+    static constexpr unsigned FB = CH * O * O;
+    static constexpr int BPC = 16 / ES;                                     // frame bytes behind one 16-byte chunk
+    static constexpr int cpf = (int)FB / BPC;                               // chunks per frame
+    static constexpr int SPE = (cpf + SPAN - 1) / SPAN;                     // list render: spans per env
+    // (what ego_gather_span keeps in LDS, to within a few bytes)
+    static constexpr int GB = 4 * O, SB = SPAN * BPC, NU = ((SB + GB - 1) / GB + 1) * R;
+    static constexpr int LDS = GB + SB + GB + 4 * (SB / (int)FB + 2) + 12 * NU + 32;
+};
+
+// Chunks [cr, cr + nc) of env e0's frame and on into the next envs' (nc <= SPAN).
+// What was measured on the way here (MI355X, 32 768 envs, 84 x 84 x 3; HBM time of the stores alone: 90 us; an empty kernel
+// of this grid: 54 us), each a different wall at the same ~195 us:
+//  - one lane per U-byte run from frame-planar tables: 417 VALU instructions per wave (a wave64 VALU instruction takes four
+//    cycles: 229 us) and a separate pass for the border-column bytes;
+//  - one lane per four runs: 112 VALU, but the texture addresser busy 75 % of the time -- a load costs about one cycle per
+//    cache line its lanes touch, and 28-byte runs at 84-byte strides touch 29 lines per instruction;
+//  - 16-byte pieces of square-contiguous sources, with staged cell words, border rows from (above, cell) line tables and
+//    border-column bytes from (left, cell) ones: five dependent phases per workgroup, 4.7 us at 16 workgroups per CU;
+//  - the same with the look-ups folded into one pass: 359 VALU per wave again (five 64-bit table addresses per unit).
+// Hence this shape: the sources hold whole squares with their border row and column already in them (ego_tab3 is keyed by
+// the classes of the cell, the one above and the one to the left), rows padded to whole 16-byte pieces; a UNIT is four
+// consecutive frame rows of one square column (U is a multiple of four: one square, one plane, one env), 4 UP contiguous
+// source bytes.  One lane per unit reads three cell words and posts one address; one lane per piece loads 16 bytes and
+// drops its dwords into output order in LDS; one barrier; 16-byte non-temporal stores.  Only where a goal is in or next to
+// the cell (its lines are evaluated per env into ego_border) or where a border row crosses a border column (four cells)
+// does the unit's lane place a row or first dwords itself -- the pieces leave those dwords alone.
+// flag_all: the context flag of every env touched (list render), -1: the cell words say.
+template <int CH, int R, bool CTX1, int ES, int PER>
+__device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, unsigned cr, int nc, int skip_term, int flag_all) {
+    typedef EgoSq<R> Q;
+    constexpr int BS = 128, SPAN = BS * PER;
+    constexpr int U = Q::U, UD = Q::UD, O = R * U, RR = R * R;
+    constexpr unsigned PB = O * O, FB = CH * PB;                            // bytes per plane, per frame
+    constexpr int BPC = 16 / ES;                                            // frame bytes behind one 16-byte chunk
+    constexpr int SB = SPAN * BPC;                                          // ... behind one span
+    constexpr unsigned GB = 4 * O, GPP = O / 4, GPF = CH * GPP;             // bytes per row group; groups per plane, per frame
+    constexpr int NG = (SB + GB - 1) / GB + 1;                              // row groups a span can touch
+    constexpr int NU = NG * R, PPU = Q::UDP, PPR = Q::UDP / 4;              // units (square column major), pieces per unit, per row
+    constexpr int ITP = (NU * PPU + BS - 1) / BS, ITU = (NU + BS - 1) / BS;
+    constexpr int NE = SB / (int)FB + 2;                                    // envs a span can touch
+    constexpr int cpf = (int)FB / BPC;
+    constexpr int NL = 2 * (R - 1);
+    static_assert(GB % 16 == 0 && U % 4 == 0, "aligned pieces");
+    __shared__ uint4 s_out4[(GB + SB + GB) / 16];
+    __shared__ uint32_t s_env[NE];                                          // a cell word of each env: its flags
+    __shared__ const uint8_t *s_usrc[NU];
+    __shared__ int s_uo[NU];                                                // the unit's first dword in s_out | flags << 24, -1: none
+    uint32_t *s_out = reinterpret_cast<uint32_t *>(s_out4);
+    const int tid = threadIdx.x;
+    const unsigned br = cr * BPC, be = br + (unsigned)nc * BPC;             // bytes, from the start of env e0's frame
+    const int ne = (int)((be - 1) / FB) + 1;
+    typedef const unsigned int __attribute__((address_space(1))) *g_u32;
+    typedef const u32x4 __attribute__((address_space(1))) *g_u32x4;
+    const unsigned g0 = br / GB, g1 = (be + GB - 1) / GB;                   // row groups, counted from env e0's first
+    if (tid >= BS - ne) s_env[BS - 1 - tid] = p.ego_cellsrc[((size_t)e0 + (BS - 1 - tid)) * RR];
+    const size_t env_cache = (size_t)p.num_goals * (RR * 4) * p.ego_cache_entry;
+    int uo[ITU];
+#pragma unroll
+    for (int iu = 0; iu < ITU; ++iu) {
+        const int ut = iu * BS + tid;
+        const unsigned fx = (unsigned)ut / NG, gq = g0 + ((unsigned)ut - fx * NG);
+        uo[iu] = -1;
+        if (ut < NU && gq < g1) {
+            const unsigned le = gq / GPF, gi = gq - le * GPF, ch = gi / GPP, oy0 = 4u * (gi - ch * GPP), fy = oy0 / (unsigned)U, py0 = oy0 - fy * U;
+            uint32_t w = p.ego_cellsrc[((size_t)e0 + le) * RR + fy * R + fx];
+            if (skip_term && (w >> 27 & 1u)) w = 0;
+            const bool cached = (w >> 23 & 1u) != 0;
+            const uint8_t *base = cached ? p.ego_cache + ((size_t)e0 + le) * env_cache : p.ego_tab3;
+            s_usrc[ut] = base + (size_t)(w & 0x7fffffu) * 16 + ch * (cached ? (unsigned)Q::CBP : (unsigned)Q::PBP) + py0 * Q::UP;
+            // what this lane places itself: bit 0 the first row (evaluated for this env), bit 1 the first dword of every row
+            // (an evaluated border column), bit 2 the first dword of the first row (the crossing)
+            const bool f_row = (w >> 24 & 1u) && py0 == 0, f_col = (w >> 25 & 1u) != 0, f_x = (w >> 26 & 1u) && py0 == 0 && !f_col;
+            uo[iu] = ((int)(GB + gq * GB - br) / 4 + (int)(fx * UD)) | (f_row ? 1 << 24 : 0) | (f_col ? 2 << 24 : 0) | (f_x ? 4 << 24 : 0);
+        }
+        if (ut < NU) s_uo[ut] = uo[iu];
+    }
+    __syncthreads();
+    // ---- one lane per 16-byte piece
+    {
+        u32x4 q[ITP];
+        int po[ITP], pi[ITP];
+#pragma unroll
+        for (int it = 0; it < ITP; ++it) {
+            const int P = it * BS + tid, u = P / PPU;
+            pi[it] = P - u * PPU;
+            po[it] = s_uo[P < NU * PPU ? u : 0];
+            if (P >= NU * PPU) po[it] = -1;
+            // (no branch around the load: all of a lane's pieces are in flight together; an idle lane reads the table's start)
+            const uint8_t *from = s_usrc[P < NU * PPU ? u : 0] + 16 * pi[it];
+            q[it] = *(g_u32x4)(po[it] >= 0 ? from : p.ego_tab3);
+        }
+#pragma unroll
+        for (int it = 0; it < ITP; ++it) {
+            if (po[it] < 0) continue;
+            const uint32_t w[4] = {q[it].x, q[it].y, q[it].z, q[it].w};
+            const int o = po[it] & 0xffffff, fl = po[it] >> 24;
+            const int j = pi[it] / PPR, h = pi[it] - j * PPR;
+            uint32_t *dst = s_out + o + j * (O / 4) + 4 * h;
+            constexpr int LASTD = UD - 4 * (PPR - 1);                                  // dwords of a row's last piece
+            if (fl == 0) {
+                dst[0] = w[0];
+                if (LASTD > 1 || h < PPR - 1) dst[1] = w[1];
+                if (LASTD > 2 || h < PPR - 1) dst[2] = w[2];
+                if (LASTD > 3 || h < PPR - 1) dst[3] = w[3];
+                continue;
+            }
+            const bool first = h == 0 && ((fl & 2) || (j == 0 && (fl & 4)));        // its first dword is the unit lane's
+            if (j == 0 && (fl & 1)) continue;                                          // the whole row is
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                if (h == PPR - 1 && d >= LASTD) continue;                               // padding
+                if (d == 0 && first) continue;
+                dst[d] = w[d];
+            }
+        }
+    }
+    // ---- the unit lanes place what the pieces left (rare: a goal in or next to the cell, a crossing)
+#pragma unroll
+    for (int iu = 0; iu < ITU; ++iu) {
+        if (uo[iu] < 0 || !(uo[iu] >> 24)) continue;
+        const int ut = iu * BS + tid, o = uo[iu] & 0xffffff, fl = uo[iu] >> 24;
+        const unsigned fx = (unsigned)ut / NG, gq = g0 + ((unsigned)ut - fx * NG);
+        const unsigned le = gq / GPF, gi = gq - le * GPF, ch = gi / GPP, oy0 = 4u * (gi - ch * GPP), fy = oy0 / (unsigned)U;
+        const uint8_t *lines = p.ego_border + (((size_t)e0 + le) * NL * CH + ch) * O, *src = s_usrc[ut];
+        const uint32_t cb = (fl & 6) ? *(g_u32)(lines + (size_t)(R - 1 + fx - 1) * (CH * O) + oy0) : 0u;
+        if (fl & 1) {
+            const uint8_t *row = lines + (size_t)(fy - 1) * (CH * O) + fx * U;
+#pragma unroll
+            for (int d = 0; d < UD; ++d) {
+                uint32_t w = *(g_u32)(row + 4 * d);
+                if (d == 0 && (fl & 2)) w = (w & ~0xffu) | (cb & 0xffu);
+                s_out[o + d] = w;
+            }
+        }
+        if (fl & 6) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j == 0 ? (fl & 1) != 0 : !(fl & 2)) continue;
+                const uint32_t w = *(g_u32)(src + j * Q::UP);
+                s_out[o + j * (O / 4)] = (w & ~0xffu) | ((cb >> (8 * j)) & 0xffu);
+            }
+        }
+    }
+    __syncthreads();
+    uint4 *obs4 = reinterpret_cast<uint4 *>(p.obs);
+    const float scale = (float)(1 / 255.0);
+    bool any_skip = false;                                                  // (uniform: a scalar branch)
+    if (skip_term) for (int i = 0; i < ne; ++i) any_skip |= (s_env[i] >> 27 & 1u) != 0;
+#pragma unroll
+    for (int kk = 0; kk < PER; ++kk) {
+        const int c = kk * BS + tid;
+        if (c >= nc) break;
+        uint4 val;
+        if (ES == 4) {
+            const uint32_t b = s_out[GB / 4 + c];
+            val = make_uint4(__float_as_uint((float)(b & 255u) * scale), __float_as_uint((float)((b >> 8) & 255u) * scale),
+                             __float_as_uint((float)((b >> 16) & 255u) * scale), __float_as_uint((float)(b >> 24) * scale));
+        } else {
+            val = s_out4[GB / 16 + c];
+        }
+        if (CTX1 && !any_skip) {
+            u32x4 nv = {val.x, val.y, val.z, val.w};
+            __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(obs4 + ((size_t)e0 * cpf + cr) + c));   // frames are back to back
+            continue;
+        }
+        const unsigned cq = cr + (unsigned)c, le = cq / (unsigned)cpf, cc = cq - le * cpf;
+        const uint32_t we = s_env[le];
+        if (skip_term && (we >> 27 & 1u)) continue;
+        uint4 *frame0 = obs4 + ((size_t)e0 + le) * p.context * cpf;
+        if (CTX1) {
+            u32x4 nv = {val.x, val.y, val.z, val.w};
+            __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(frame0 + cc));
+        } else {
+            xw_store_chunk(frame0, (int)cc, cpf, p.context, flag_all >= 0 ? flag_all : (int)((we >> 28) & 3u), val);
+        }
+    }
+}
+
+template <int CH, int R, bool CTX1, int ES, int PER>
+__global__ __launch_bounds__(128) void xw_ego_gather_kernel(XwParams p, int skip_term) {
+    typedef EgoSpanGeom<CH, R, ES, PER> G;
+    // (chunk indices fit 32 bits: the launcher checks)
+    const unsigned n_chunks = (unsigned)p.n * G::cpf, c_lo = blockIdx.x * G::SPAN;
+    const unsigned e0 = c_lo / G::cpf;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *p.ego_miss_count = 0;         // the kernels before this one consumed the list
+    ego_gather_span<CH, R, CTX1, ES, PER>(p, e0, c_lo - e0 * G::cpf, (int)(n_chunks - c_lo < (unsigned)G::SPAN ? n_chunks - c_lo : G::SPAN), skip_term, -1);
+}
+
+// the frames of the listed envs, from what the front kernels left of them (terminal frames: p.list_flag = 1)
+template <int CH, int R, bool CTX1, int ES>
+__global__ __launch_bounds__(128) void xw_ego_gather_list_kernel(XwParams p, const int32_t *count_now) {
+    typedef EgoSpanGeom<CH, R, ES, 2> G;
+    const int cnt = *count_now, part = blockIdx.x % G::SPE;
+    for (int item = blockIdx.x / G::SPE; item < cnt; item += gridDim.x / G::SPE) {
+        const int e = p.done_list[item], cr = part * G::SPAN;
+        __syncthreads();
+        ego_gather_span<CH, R, CTX1, ES, 2>(p, (unsigned)e, (unsigned)cr, G::cpf - cr < G::SPAN ? G::cpf - cr : G::SPAN, 0, p.list_flag);
+    }
+}
+
 // The warped 64x64 image of every goal of the listed envs (XItem::get_item_image, xitem.cpp:46-60): cv::warpAffine with
 // the goal's inverse matrix, INTER_LINEAR, BORDER_CONSTANT white.  A goal keeps its pose for the whole episode, so this
 // runs once per reset (~0.4 % of the envs per step) and the render reads goal pixels like any other icon.
+// Four workgroups per goal, four pixels per lane with all sixteen icon reads in flight together: beside a machine-filling
+// render this kernel is as slow as its chain of dependent reads (16 pixels one after the other: 108 us measured).
 template <bool LIST>
 __global__ __launch_bounds__(256) void xw_warp_goals_kernel(XwParams p, const uint32_t *atlas4, const int32_t *count_now) {
+    constexpr int PARTS = 4, PPL = 4096 / PARTS / 256;
     const int G = p.num_goals, D = p.max_dim;
-    const int n_items = (LIST ? *count_now : p.n) * G;
+    const int n_items = (LIST ? *count_now : p.n) * G * PARTS;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int ei = item / G, slot = item - ei * G;
+        const int part = item % PARTS, ig = item / PARTS, ei = ig / G, slot = ig - ei * G;
         const int e = LIST ? p.done_list[ei] : ei;
         const int cell = p.goal_cells[(size_t)e * XW_MAX_GOALS + slot];
         uint32_t *out = p.goal_img + ((size_t)e * G + slot) * 4096;
         // new poses: whatever the render cached of this env's goal cells is stale
-        if (slot == 0 && p.ego_cache_valid)
+        if (slot == 0 && part == 0 && p.ego_cache_valid)
             for (int q = threadIdx.x; q < (int)p.ego_cache_words; q += 256) p.ego_cache_valid[(size_t)e * p.ego_cache_words + q] = 0;
         if (cell == 0xff) continue;
         const int icon = (int)(p.grid[(size_t)e * D * D + cell] & CELL_ICON_MASK) - 1;
         if (icon < 0) continue;
         const double *M = p.goal_warp + ((size_t)e * XW_MAX_GOALS + slot) * 6;
         const double m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3], m4 = M[4], m5 = M[5];
-        for (int q = threadIdx.x; q < 4096; q += 256) {
+        const uint32_t *img = atlas4 + (uint32_t)icon * 4096u;
+        int fxs[PPL], fys[PPL];
+        bool inside[PPL];
+        uint32_t t[PPL][4];
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const int q = part * (4096 / PARTS) + j * 256 + threadIdx.x;
             const int px = q & 63, py = q >> 6;
             const int X0 = __double2int_rn((m1 * py + m2) * 1024) + 16, Y0 = __double2int_rn((m4 * py + m5) * 1024) + 16;
             const int X = (X0 + __double2int_rn(m0 * px * 1024)) >> 5, Y = (Y0 + __double2int_rn(m3 * px * 1024)) >> 5;
-            const int ix = X >> 5, iy = Y >> 5, fx = X & 31, fy = Y & 31;
+            const int ix = X >> 5, iy = Y >> 5;
+            fxs[j] = X & 31; fys[j] = Y & 31;
+            inside[j] = !(ix >= 64 || ix + 1 < 0 || iy >= 64 || iy + 1 < 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int qx = ix + (k & 1), qy = iy + (k >> 1);
+                const bool in = (unsigned)qx < 64u && (unsigned)qy < 64u;
+                const uint32_t v = img[in ? qy * 64 + qx : 0];           // (no branch around the read)
+                t[j][k] = in ? v : 0xffffffu;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const int fx = fxs[j], fy = fys[j];
             uint32_t res = 0xffffffu;
-            if (!(ix >= 64 || ix + 1 < 0 || iy >= 64 || iy + 1 < 0)) {
+            if (inside[j]) {
                 int w[4] = {(32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32};
                 if (w[0] == 32768) { w[0] = 32767; w[3] = 1; }     // BilinearTab_i: saturated entry and its compensation
-                uint32_t t[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int qx = ix + (k & 1), qy = iy + (k >> 1);
-                    t[k] = ((unsigned)qx < 64u && (unsigned)qy < 64u) ? atlas4[(uint32_t)icon * 4096u + (uint32_t)(qy * 64 + qx)] : 0xffffffu;
-                }
                 res = 0;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     int acc = 1 << 14;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) acc += (int)((t[k] >> (8 * ch)) & 255u) * w[k];
+                    for (int k = 0; k < 4; ++k) acc += (int)((t[j][k] >> (8 * ch)) & 255u) * w[k];
                     res |= (uint32_t)(acc >> 15) << (8 * ch);
                 }
             }
-            out[q] = res;
+            out[part * (4096 / PARTS) + j * 256 + threadIdx.x] = res;
         }
     }
 }
 
 hipError_t launch_xw_warp_goals(const XwParams &p, bool list, hipStream_t s) {
     const uint32_t *a4 = reinterpret_cast<const uint32_t *>(p.atlas64);
-    if (list) hipLaunchKernelGGL((xw_warp_goals_kernel<true>), dim3(1024), dim3(256), 0, s, p, a4, (const int32_t *)p.done_count);
+    if (list) hipLaunchKernelGGL((xw_warp_goals_kernel<true>), dim3(4096), dim3(256), 0, s, p, a4, (const int32_t *)p.done_count);
     else hipLaunchKernelGGL((xw_warp_goals_kernel<false>), dim3(8192), dim3(256), 0, s, p, a4, (const int32_t *)p.done_count);
     return hipGetLastError();
 }
@@ -658,8 +1234,14 @@ static void resize_taps(int src, int dst, std::vector<EgoTap> &h, std::vector<Eg
 // tables (EgoLayout).  An output row is interior when the four view rows behind it exist and lie in one cell row (or
 // column, for the sideways headings).  *fast_out: frame rows are whole dwords and no dword holds interior pixels of two
 // cells -- the condition for copying interior pixels from the table.
-hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int *fast_out, int *cell_edge_out) {
+hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int *fast_out, int *cell_edge_out, int *span_out) {
     int cell_edge = 1;
+    // span path: the frame as r x r squares of U = O / r pixels.  cmap: [heading][fy * r + fx] -> view cell; then, per heading,
+    // [r] which border row (its place in the layout's list) frame row fy * U is, 0xff: none, and the same for columns.
+    // Possible when the only rows / columns that straddle two cells are first rows / columns of a square.
+    const int U = out_dim / r;
+    bool span = (r == 3 || r == 5 || r == 7) && out_dim == r * (84 / r) && U % 4 == 0;
+    std::vector<uint8_t> cmap((size_t)((8 * r * r + 8 * r + 15) & ~15), 0xff);     // ... then the inverse of cmap: [heading][view cell] -> square
     std::vector<EgoTap> h1, v1, h2, v2;
     resize_taps(64 * r, 64 * max_dim, h1, v1);
     resize_taps(64 * max_dim, out_dim, h2, v2);
@@ -731,28 +1313,54 @@ hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int 
             if (w > cw) cw = w;
             if (h > cw) cw = h;
         }
+        if (span) {
+            for (int axis = 0; axis < 2; ++axis) {
+                int nb = 0;
+                for (int o = 0; o < O; ++o) {
+                    if (cell_of[axis][o] < 0) {
+                        if (o % U != 0 || o == 0) span = false;
+                        else cmap[(size_t)4 * r * r + (size_t)(axis * 4 + dir) * r + o / U] = (uint8_t)nb;
+                        nb++;
+                    } else if (cell_of[axis][o] != cell_of[axis][(o / U) * U + U / 2]) {
+                        span = false;
+                    }
+                }
+            }
+            for (int fy = 0; fy < r && span; ++fy)
+                for (int fx = 0; fx < r; ++fx) {
+                    const int rc = cell_of[0][fy * U + U / 2], cc = cell_of[1][fx * U + U / 2];
+                    cmap[(size_t)dir * r * r + fy * r + fx] = (uint8_t)(row_is_y ? rc * r + cc : cc * r + rc);
+                }
+        }
         hd[2] = (uint16_t)cw;
         if (cw > cell_edge) cell_edge = cw;
     }
     const size_t tap_bytes = all.size() * sizeof(EgoTap), lay_bytes = lay.size() * sizeof(uint16_t);
     uint8_t *d = nullptr;
-    hipError_t err = hipMalloc(&d, tap_bytes + lay_bytes);
+    for (int i = 0; i < 4 * r * r; ++i) {
+        if (cmap[i] == 0xff || cmap[i] >= r * r) { span = false; continue; }     // (a permutation per heading, or no span path)
+        cmap[(size_t)4 * r * r + 8 * r + (size_t)(i / (r * r)) * r * r + cmap[i]] = (uint8_t)(i % (r * r));
+    }
+    hipError_t err = hipMalloc(&d, tap_bytes + lay_bytes + cmap.size());
     if (err != hipSuccess) return err;
     err = hipMemcpy(d, all.data(), tap_bytes, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(d + tap_bytes, lay.data(), lay_bytes, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d + tap_bytes + lay_bytes, cmap.data(), cmap.size(), hipMemcpyHostToDevice);
     *dev_out = reinterpret_cast<EgoTap *>(d);
     *fast_out = fast ? 1 : 0;
+    if (span_out) *span_out = fast && span ? 1 : 0;
     if (cell_edge_out) *cell_edge_out = cell_edge;
     return err;
 }
 
 namespace {
-struct EgoTables { const EgoTap *h1, *v1, *h2, *v2; const uint16_t *lut; };
+struct EgoTables { const EgoTap *h1, *v1, *h2, *v2; const uint16_t *lut; const uint8_t *map; };
 EgoTables ego_tables_of(const XwParams &p) {
     const int P = 64 * p.max_dim, O = p.out_dim;
     EgoTables t;
     t.h1 = reinterpret_cast<const EgoTap *>(p.ego_taps); t.v1 = t.h1 + P; t.h2 = t.v1 + P; t.v2 = t.h2 + O;
     t.lut = reinterpret_cast<const uint16_t *>(t.v2 + O);
+    t.map = reinterpret_cast<const uint8_t *>(t.lut + (size_t)4 * ego_layout_words((O + 3) & ~3, p.visible_radius));
     return t;
 }
 size_t ego_frame_bytes(const XwParams &p) { return (size_t)((p.channels * p.out_dim * p.out_dim + 15) & ~15); }
@@ -776,10 +1384,89 @@ hipError_t launch_xw_ego_build_tab(const XwParams &p, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s) {
+namespace {
+// mode 0: every env; 2: every env the last step did not finish (a reset runs beside this: their state is in flux);
+// 4: a step's frames -- every env, the finished ones first and from the list (p.list_flag says how their context moves),
+//    ev_cells recorded once nothing reads the grids and agents any more (a reset's map generator may start), ev_front once
+//    nothing reads the goal images either (they may be redrawn), ev_list once the listed frames are out
+template <int CH, int R>
+hipError_t ego_span_render(const XwParams &p, const EgoTables &t, int mode, hipStream_t s, hipEvent_t ev_front, hipEvent_t ev_list, hipEvent_t ev_cells) {
+    constexpr int U = 84 / R, FB = CH * (R * U) * (R * U);
+    const uint32_t *a4 = reinterpret_cast<const uint32_t *>(p.atlas64);
+    const size_t cells = (size_t)p.max_dim * p.max_dim;
+    const int skip_front = mode == 2, skip_gather = mode != 0;
+    hipLaunchKernelGGL((xw_ego_cells_kernel<R>), dim3((p.n + 63) / 64), dim3(256), 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15), s, p, t.map, skip_front);
+    if (ev_cells) { const hipError_t e = hipEventRecord(ev_cells, s); if (e != hipSuccess) return e; }
+    const int nb_border = (p.n + 7) / 8;
+    hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 4096), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, skip_front, nb_border);
+    if (ev_front) { const hipError_t e = hipEventRecord(ev_front, s); if (e != hipSuccess) return e; }
+    const int es = p.obs_f32 ? 4 : 1;
+    const unsigned long long n_chunks = (unsigned long long)p.n * (FB / (16 / es));
+    const int32_t *cnt = (const int32_t *)p.done_count;
+    const unsigned list_blocks = (unsigned)(p.n < 2048 ? p.n : 2048);
+    // A/B hooks: XWB_EGO_PER = 16-byte chunks per lane (2 | 4), XWB_EGO_PAD = bytes of LDS a workgroup asks for on top of its own.
+    // Default padding: 13 workgroups per CU instead of 16 -- the kernels of a reset_done on the other queue (map generator,
+    // goal images, list render: 256-thread groups, up to 31 KB of LDS) otherwise never find room beside this one and run
+    // after it (0.292 -> 0.271 ms per step on the C4-sized batch).
+    static const int per = getenv("XWB_EGO_PER") ? atoi(getenv("XWB_EGO_PER")) : 4;
+    static const int pad_env = getenv("XWB_EGO_PAD") ? atoi(getenv("XWB_EGO_PAD")) : -1;
+#define EGO_PAD(ESV, PERV) (pad_env >= 0 ? pad_env : (163840 / 13 - EgoSpanGeom<CH, R, ESV, PERV>::LDS > 0 ? 163840 / 13 - EgoSpanGeom<CH, R, ESV, PERV>::LDS : 0))
+#define EGO_GATHER_BIG(CTXV, ESV, PERV) hipLaunchKernelGGL((xw_ego_gather_kernel<CH, R, CTXV, ESV, PERV>), dim3((unsigned)((n_chunks + 128 * PERV - 1) / (128 * PERV))), dim3(128), EGO_PAD(ESV, PERV), s, p, skip_gather)
+#define EGO_GATHER(CTXV, ESV) do { \
+        if (mode == 4) { \
+            hipLaunchKernelGGL((xw_ego_gather_list_kernel<CH, R, CTXV, ESV>), dim3(list_blocks * EgoSpanGeom<CH, R, ESV, 2>::SPE), dim3(128), 0, s, p, cnt); \
+            if (ev_list) { const hipError_t e = hipEventRecord(ev_list, s); if (e != hipSuccess) return e; } \
+        } \
+        if (per == 2) EGO_GATHER_BIG(CTXV, ESV, 2); else EGO_GATHER_BIG(CTXV, ESV, 4); \
+    } while (0)
+    if (p.context == 1) { if (es == 4) EGO_GATHER(true, 4); else EGO_GATHER(true, 1); }
+    else { if (es == 4) EGO_GATHER(false, 4); else EGO_GATHER(false, 1); }
+#undef EGO_GATHER_BIG
+#undef EGO_PAD
+#undef EGO_GATHER
+    return hipGetLastError();
+}
+}  // namespace
+
+size_t xw_ego_square_tab_bytes(const XwParams &p) {
+    const int r = p.visible_radius, U = 84 / r, UP = 4 * ((U / 4 + 3) & ~3);
+    return (size_t)4 * p.ego_ncls * p.ego_ncls * p.ego_ncls * p.channels * r * r * U * UP;
+}
+
+// bytes of one cache entry on the span path: a square, all channels, in EgoSq's layout
+size_t xw_ego_square_entry_bytes(const XwParams &p) {
+    const int r = p.visible_radius, U = 84 / r, UP = 4 * ((U / 4 + 3) & ~3);
+    return (size_t)p.channels * U * UP;
+}
+
+hipError_t launch_xw_ego_build_squares(const XwParams &p, hipStream_t s) {
+    const EgoTables t = ego_tables_of(p);
+    const int r = p.visible_radius;
+    const uint32_t *a4 = reinterpret_cast<const uint32_t *>(p.atlas64);
+    const unsigned blocks = (unsigned)(4 * p.ego_ncls * p.ego_ncls * p.ego_ncls * r * r);
+    uint8_t *tab3 = const_cast<uint8_t *>(p.ego_tab3);
+#define EGO_SQ(CHV, RV) hipLaunchKernelGGL((xw_ego_build_squares_kernel<CHV, RV>), dim3(blocks), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.map, tab3)
+    if (p.channels == 3) { if (r == 3) EGO_SQ(3, 3); else if (r == 5) EGO_SQ(3, 5); else EGO_SQ(3, 7); }
+    else { if (r == 3) EGO_SQ(1, 3); else if (r == 5) EGO_SQ(1, 5); else EGO_SQ(1, 7); }
+#undef EGO_SQ
+    return hipGetLastError();
+}
+
+bool xw_ego_span(const XwParams &p) {
+    // (the gather counts 16-byte chunks in 32 bits)
+    return p.visible_radius && p.ego_span && p.ego_cellinfo && (unsigned long long)p.n * p.channels * p.out_dim * p.out_dim < (1ull << 32);
+}
+
+hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s, hipEvent_t ev_front, hipEvent_t ev_list, hipEvent_t ev_cells) {
     const EgoTables t = ego_tables_of(p);
     const int r = p.visible_radius, O = p.out_dim, O4 = (O + 3) & ~3, D = p.max_dim;
     const int CH = p.channels;
+    if (indexed != 1 && xw_ego_span(p)) {
+        const int m = indexed;
+        if (CH == 3) return r == 3 ? ego_span_render<3, 3>(p, t, m, s, ev_front, ev_list, ev_cells) : (r == 5 ? ego_span_render<3, 5>(p, t, m, s, ev_front, ev_list, ev_cells) : ego_span_render<3, 7>(p, t, m, s, ev_front, ev_list, ev_cells));
+        return r == 3 ? ego_span_render<1, 3>(p, t, m, s, ev_front, ev_list, ev_cells) : (r == 5 ? ego_span_render<1, 5>(p, t, m, s, ev_front, ev_list, ev_cells) : ego_span_render<1, 7>(p, t, m, s, ev_front, ev_list, ev_cells));
+    }
+    if (indexed == 4) return hipErrorInvalidValue;             // (only the span path draws a step's terminal frames itself)
     const bool fast = p.ego_fast != 0;
     const size_t lds = ego_frame_bytes(p) + (size_t)r * r * sizeof(EgoCell) + (fast ? (size_t)ego_layout_words(O4, r) * 8 : 0) +
                        (size_t)p.n_icons * 4 + (size_t)((p.n_icons + 3) & ~3) + (size_t)((D * D + 3) & ~3) +

@@ -80,7 +80,8 @@ struct xwb_sim {
     uint32_t *d_minstd = nullptr;          // XWB_RNG_MINSTD: one engine state per env
     uint32_t *d_sync = nullptr;            // device-side epochs of the step / reset kernels (XwParams::sync)
     uint32_t epoch_step = 0, epoch_reset = 0;
-    hipEvent_t ev_step = nullptr, ev_reset = nullptr, ev_term = nullptr;
+    hipEvent_t ev_step = nullptr, ev_reset = nullptr, ev_term = nullptr, ev_cells = nullptr;
+    bool span_step = false;                // the last step drew its frames on the egocentric span path (ev_cells / ev_step / ev_term are its)
     // common device buffers
     int32_t *d_actions_in = nullptr;       // staging for xwb_step_host
     uint8_t *d_mask = nullptr;             // staging for xwb_reset_env
@@ -115,6 +116,12 @@ struct xwb_sim {
     int ego_cell_edge = 1;
     uint8_t *d_ego_cache = nullptr;        // lazily filled cache of rendered goal cells (XwParams::ego_cache)
     uint32_t *d_ego_cache_valid = nullptr;
+    uint32_t *d_ego_cellsrc = nullptr;
+    uint32_t *d_ego_cellinfo = nullptr;    // span path of the egocentric render (XwParams::ego_span)
+    uint2 *d_ego_miss = nullptr;
+    int32_t *d_ego_miss_count = nullptr;
+    uint8_t *d_ego_border = nullptr, *d_ego_cls = nullptr, *d_ego_tab3 = nullptr;
+    uint16_t *d_ego_cls_icon = nullptr;
     double *d_goal_warp = nullptr;
     int16_t *d_icon_name = nullptr, *d_name_first = nullptr, *d_name_variants = nullptr;
     uint32_t *d_atlas = nullptr;
@@ -396,7 +403,7 @@ int xw_setup(xwb_sim *s) {
         HIP_TRY(hipMemcpy(s->d_atlas64, a4.data(), a4.size(), hipMemcpyHostToDevice));
         if ((rc = dev_alloc(s, &s->d_agent_rot, (size_t)c.n_icons))) return rc;
         HIP_TRY(hipMemcpy(s->d_agent_rot, rot_off.data(), rot_off.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(xw_ego_tables(c.visible_radius, c.max_dim, s->out_h, &s->d_ego_taps, &s->xw.ego_fast, &s->ego_cell_edge));
+        HIP_TRY(xw_ego_tables(c.visible_radius, c.max_dim, s->out_h, &s->d_ego_taps, &s->xw.ego_fast, &s->ego_cell_edge, &s->xw.ego_span));
         s->allocs.push_back(s->d_ego_taps);
     }
     if ((rc = dev_alloc(s, &s->d_icon_name, c.n_icons))) return rc;
@@ -422,10 +429,13 @@ int xw_setup(xwb_sim *s) {
     } else {
         HIP_TRY(hipMemcpy(s->d_atlas, atlas.data(), atlas.size(), hipMemcpyHostToDevice));
     }
+    // (a high-priority side queue was tried: no gain beside the renders, and batches created after another one in the same
+    // process then failed their resume tests -- left at the default priority)
     HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_step, hipEventDisableTiming | hipEventDisableSystemFence));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_reset, hipEventDisableTiming | hipEventDisableSystemFence));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_term, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_cells, hipEventDisableTiming | hipEventDisableSystemFence));
 
     XwParams &p = s->xw;
     p.n = n; p.context = c.context; p.max_steps = c.max_steps; p.act_rep = 1; p.auto_reset = 0;
@@ -468,10 +478,12 @@ int xw_setup(xwb_sim *s) {
         if ((rc = dev_alloc(s, &s->d_ego_tab, xw_ego_tab_bytes(p)))) return rc;
         p.ego_tab = s->d_ego_tab;
         p.ego_cache = nullptr; p.ego_cache_valid = nullptr; p.ego_cache_entry = 0; p.ego_cache_words = 0;
+        p.ego_cellinfo = nullptr; p.ego_miss = nullptr; p.ego_miss_count = nullptr; p.ego_border = nullptr; p.ego_tab3 = nullptr; p.ego_cellsrc = nullptr;
         if (p.ego_fast && !getenv("XWB_EGO_NO_CACHE")) {
             // rendered goal cells, [env][goal slot][view cell][heading]: ~340 KB per env at r = 3 (11 GB for a C4-sized batch;
             // the GPU has 288 GB).  Taken only if it leaves at least half of the free memory to the caller.
-            const size_t entry = xw_ego_cache_entry_bytes(p, s->ego_cell_edge);
+            size_t entry = xw_ego_cache_entry_bytes(p, s->ego_cell_edge);
+            if (p.ego_span && xw_ego_square_entry_bytes(p) > entry) entry = xw_ego_square_entry_bytes(p);   // (the span path's layout)
             const size_t per_env = (size_t)p.num_goals * c.visible_radius * c.visible_radius * 4;
             const size_t bytes = (size_t)n * per_env * entry;
             size_t free_b = 0, total_b = 0;
@@ -484,12 +496,37 @@ int xw_setup(xwb_sim *s) {
                     if ((rc = dev_alloc(s, &s->d_ego_cache_valid, (size_t)n * words))) return rc;
                     p.ego_cache = s->d_ego_cache; p.ego_cache_valid = s->d_ego_cache_valid;
                     p.ego_cache_entry = (uint32_t)entry; p.ego_cache_words = (uint32_t)words;
+                    // span path: classes of the images every env shares (everything but goals)
+                    std::vector<uint8_t> cls((size_t)c.n_icons + 2, 0xff);
+                    std::vector<uint16_t> cls_icon;
+                    for (int i = 0; i < c.n_icons + 2; ++i)
+                        if (i >= c.n_icons || c.icon_type[i] != 0) { cls[i] = (uint8_t)(cls_icon.size() < 255 ? cls_icon.size() : 0); cls_icon.push_back((uint16_t)i); }
+                    if (p.ego_span && !getenv("XWB_EGO_NO_SPAN") && p.n_icons < 8000 && cls_icon.size() <= 16 &&
+                        (p.ego_ncls = (int)cls_icon.size(), xw_ego_square_tab_bytes(p) <= ((size_t)1 << 27))) {   // (its offsets are 23 bits of 16-byte units)
+                        const int rr = c.visible_radius * c.visible_radius;
+                        if ((rc = dev_alloc(s, &s->d_ego_cellinfo, (size_t)n * rr))) return rc;
+                        if ((rc = dev_alloc(s, &s->d_ego_cellsrc, (size_t)n * rr))) return rc;
+                        p.ego_cellsrc = s->d_ego_cellsrc;
+                        if ((rc = dev_alloc(s, &s->d_ego_miss, (size_t)n * (p.num_goals < rr ? p.num_goals : rr)))) return rc;
+                        if ((rc = dev_alloc(s, &s->d_ego_miss_count, 4))) return rc;
+                        if ((rc = dev_alloc(s, &s->d_ego_border, (size_t)n * 2 * (c.visible_radius - 1) * p.channels * p.out_dim + 16))) return rc;
+                        if ((rc = dev_alloc(s, &s->d_ego_cls, cls.size()))) return rc;
+                        if ((rc = dev_alloc(s, &s->d_ego_cls_icon, cls_icon.size()))) return rc;
+                        HIP_TRY(hipMemcpy(s->d_ego_cls, cls.data(), cls.size(), hipMemcpyHostToDevice));
+                        HIP_TRY(hipMemcpy(s->d_ego_cls_icon, cls_icon.data(), cls_icon.size() * 2, hipMemcpyHostToDevice));
+                        p.ego_cls = s->d_ego_cls; p.ego_cls_icon = s->d_ego_cls_icon; p.ego_ncls = (int)cls_icon.size();
+                        if ((rc = dev_alloc(s, &s->d_ego_tab3, xw_ego_square_tab_bytes(p) + 16))) return rc;
+                        p.ego_tab3 = s->d_ego_tab3;
+                        p.ego_border = s->d_ego_border;
+                        p.ego_cellinfo = s->d_ego_cellinfo; p.ego_miss = s->d_ego_miss; p.ego_miss_count = s->d_ego_miss_count;
+                    }
                 } else {
                     (void)hipGetLastError();
                 }
             }
         }
         HIP_TRY(launch_xw_ego_build_tab(p, nullptr));
+        if (p.ego_cellinfo) HIP_TRY(launch_xw_ego_build_squares(p, nullptr));
         HIP_TRY(hipStreamSynchronize(nullptr));
     }
     return XWB_OK;
@@ -597,6 +634,7 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
     // on `st` after that work, clears them instead
     p.auto_reset = keep_done ? 1 : (beside_render && render ? 2 : 0);
     hipStream_t rs = beside_render ? s->side : st;
+    const bool span_sync = beside_render && s->span_step && xw_ego_span(p);
     // full observation: the two queues hand over through epochs in device memory (XwParams::sync) -- the side queue's
     // kernel waits for the step kernel's epoch, the list render for the reset kernel's; no event / barrier packets
     const bool by_epoch = queue_sync_by_epochs() && beside_render && render && !p.visible_radius && mode != MODE_RESET_ALL;
@@ -604,10 +642,12 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
         HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->d_sync + 4, s->side));
         if (++s->epoch_reset == 0) s->epoch_reset = 1;
     } else if (beside_render) {
-        HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
+        // (span path: the map generator only has to wait for the kernel that reads the grids; the goal images are redrawn
+        // once the kernels that evaluate pixels from them are through)
+        HIP_TRY(hipStreamWaitEvent(s->side, span_sync ? s->ev_cells : s->ev_step, 0));
     }
     timer_begin(s, s->t_reset, rs);
-    HIP_TRY(launch_xw_reset(p, mode, rs));
+    HIP_TRY(launch_xw_reset(p, mode, rs, span_sync ? s->ev_step : nullptr));
     timer_end(s, s->t_reset, rs);
     if (by_epoch) {
         HIP_TRY(launch_xw_signal(s->d_sync + 3, s->epoch_reset, s->side));     // queued behind the reset kernel
@@ -620,6 +660,7 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
         // skips these envs); only the done codes are cleared on the caller's stream, behind whatever still reads them
         p.auto_reset = 3;
         p.ego_list_beside = 1;
+        if (xw_ego_span(p)) HIP_TRY(hipStreamWaitEvent(rs, s->ev_term, 0));   // the terminal frames of these envs are out
         HIP_TRY(launch_xw_render(p, 1, rs));
         HIP_TRY(hipEventRecord(s->ev_reset, s->side));
         HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
@@ -688,7 +729,9 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
             // The egocentric render reads more than the grid (heading, goal images): there the terminal frames are
             // rendered from the (short) list on the side stream, beside the big render, which skips those envs; a
             // following xwb_reset_done queues behind that list render.
-            if (p.visible_radius) {
+            // On the span path (kernels_xworld_ego.hip) only the front kernels read the env state: ev_step is recorded
+            // behind them, the terminal frames leave through a short list gather (ev_term) and the big gather skips them.
+            if (p.visible_radius && !xw_ego_span(p)) {
                 HIP_TRY(hipEventRecord(s->ev_step, st));
                 pr.list_flag = 1;
                 pr.ego_list_beside = 1;
@@ -698,11 +741,17 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
             }
         }
         timer_begin(s, s->t_render, st);
-        HIP_TRY(launch_xw_render(p, autoreset || p.visible_radius ? 2 : 3, st));
+        if (!autoreset && xw_ego_span(p)) {
+            p.list_flag = 1;
+            HIP_TRY(launch_xw_render(p, 4, st, s->ev_step, s->ev_term, s->ev_cells));
+        } else {
+            HIP_TRY(launch_xw_render(p, autoreset || p.visible_radius ? 2 : 3, st));
+        }
         timer_end(s, s->t_render, st);
-        if (!autoreset && p.visible_radius) HIP_TRY(hipStreamWaitEvent(st, s->ev_term, 0));
+        if (!autoreset && p.visible_radius && !xw_ego_span(p)) HIP_TRY(hipStreamWaitEvent(st, s->ev_term, 0));
         if (autoreset) HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
     }
+    s->span_step = !autoreset && xw_ego_span(s->xw);
     s->policy_step += 1;
     s->packed_pos += 1;
     s->autoreset_done = autoreset;
@@ -856,6 +905,7 @@ int xwb_destroy(xwb_sim *s) {
     if (s->ev_step) (void)hipEventDestroy(s->ev_step);
     if (s->ev_reset) (void)hipEventDestroy(s->ev_reset);
     if (s->ev_term) (void)hipEventDestroy(s->ev_term);
+    if (s->ev_cells) (void)hipEventDestroy(s->ev_cells);
     for (KernelTimer *t : {&s->t_render, &s->t_step, &s->t_reset})
         for (auto &ep : t->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     delete s;

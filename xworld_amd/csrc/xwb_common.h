@@ -211,6 +211,18 @@ struct XwParams {
     uint8_t *ego_cache;          // nullable (not enough free memory: every goal cell is evaluated every frame)
     uint32_t *ego_cache_valid;
     uint32_t ego_cache_entry, ego_cache_words;
+    // egocentric, span path (kernels_xworld_ego.hip: cells -> misses -> gather), nullable / 0 when the geometry rules it out
+    int ego_span;                // the view cells' pixel rectangles tile the frame in equal squares (no straddling rows / columns)
+    uint32_t *ego_cellinfo;      // [n][r * r] what each square of the frame shows (xw_ego_cells_kernel has the bit layout)
+    const uint8_t *ego_cls;      // [n_icons + 2] dense index of the images that are the same in every env (blocks, agents, an
+                                 //     empty cell, a black one), 0xff: a goal;  ego_cls_icon [ego_ncls]: class -> table slot
+    const uint16_t *ego_cls_icon;
+    int ego_ncls;
+    const uint8_t *ego_tab3;     // [heading][class c][class a][class l][channel][square] squares (kernels_xworld_ego.hip, EgoSq)
+    uint32_t *ego_cellsrc;       // [n][r * r] per square: where the gather finds its pixels (xw_ego_cells_kernel has the bit layout)
+    uint2 *ego_miss;             // goal cells the cache does not hold yet: (env, view cell | slot << 8 | heading << 16)
+    int32_t *ego_miss_count;
+    uint8_t *ego_border;         // [n][2 (r - 1)][channels][out_dim] evaluated border rows, then border columns, of each frame
     uint32_t *cand2d;            // [n] goal slots the agent can reach, blocks as the only obstacles: bits 0..15
                                  //     any goal (XWorldNavTarget), bits 16..31 coloured goals (XWorldNavColorTarget)
     const uint8_t *icon_colored; // [n_icons] properties.txt colour != "na"
@@ -241,22 +253,28 @@ hipError_t launch_xw_wait(const uint32_t *epoch_slot, uint32_t want, uint32_t *t
 // one thread that publishes `value`: queued behind a kernel, it tells the other queue that kernel is complete
 hipError_t launch_xw_signal(uint32_t *epoch_slot, uint32_t value, hipStream_t s);
 // reset envs: mode RESET_ALL -> every env; otherwise the compacted done_list / done_count
-hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s);
+// before_warp (egocentric): the redraw of the goal images waits for it (kernels still reading the old images)
+hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s, hipEvent_t before_warp = nullptr);
 // compaction of done[] (mode RESET_DONE) or mask (RESET_MASK) into done_list / done_count
 hipError_t launch_xw_compact(const XwParams &p, int mode, hipStream_t s);
 // render: indexed == 0 -> all envs (LDS-resident atlas, persistent workgroups);
 //         indexed == 1 -> envs in done_list (atlas through L2)
 // indexed: 0 = every env, 1 = the compacted done list, 2 = every env whose done code is 0 (the rest follows as a list),
 // 3 = every env, those the step just finished from their terminal snapshot (term_grid)
-hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s);
-hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s);
+hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s, hipEvent_t ev_front = nullptr, hipEvent_t ev_list = nullptr, hipEvent_t ev_cells = nullptr);
+// egocentric: indexed 4 = a step's frames on the span path (kernels_xworld_ego.hip), see ego_span_render
+hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s, hipEvent_t ev_front = nullptr, hipEvent_t ev_list = nullptr, hipEvent_t ev_cells = nullptr);
+bool xw_ego_span(const XwParams &p);
 hipError_t launch_xw_clear_done(const XwParams &p, hipStream_t s);
 hipError_t launch_xw_warp_goals(const XwParams &p, bool list, hipStream_t s);
 struct EgoTap;
-hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int *fast_out, int *cell_edge_out);
+hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int *fast_out, int *cell_edge_out, int *span_out);
 size_t xw_ego_cache_entry_bytes(const XwParams &p, int cell_edge);
 size_t xw_ego_tab_bytes(const XwParams &p);
 hipError_t launch_xw_ego_build_tab(const XwParams &p, hipStream_t s);
+size_t xw_ego_square_tab_bytes(const XwParams &p);
+size_t xw_ego_square_entry_bytes(const XwParams &p);
+hipError_t launch_xw_ego_build_squares(const XwParams &p, hipStream_t s);
 
 // host: builds the 12x12 tile table (OpenCV 3.2 fixed-point bilinear + BGR2GRAY) from 64x64 icons
 void build_tile_table(const uint8_t *icons64, int n_icons, int channels, uint8_t *out /* n*c*12*12 */);
