@@ -82,10 +82,13 @@ def algorithmic_bytes(workload, sim):
     d = sim.cfg.max_dim
     c = sim.screen_dims[2]
     if sim.cfg.visible_radius:
-        # egocentric: the frame is (r * (84 / r))^2 pixels; the render is compute-bound (16 view-pixel evaluations per
-        # output pixel), its algorithmic bytes are the frame written + the grid read
+        # egocentric: the frame is (r * (84 / r))^2 pixels; its algorithmic bytes are the frame written + the grid read.  The
+        # whole-batch render is four launches on the span path (timed together, on the stream they run on: cell table,
+        # evaluated pixels, terminal frames, gather -- the gather alone moves ~ all the bytes), one otherwise
         obs = c * sim.screen_dims[0] * sim.screen_dims[1]
-        return 33 + 2 * d * d + obs, 2 * d * d + obs, "xw_render_ego_kernel"
+        name = ("xw_ego_cells_kernel + xw_ego_eval_kernel + xw_ego_gather_list_kernel + xw_ego_gather_kernel"
+                if sim.ego_render_path == "span" else "xw_render_ego_kernel")
+        return 33 + 2 * d * d + obs, 2 * d * d + obs, name
     obs = c * 144 * d * d * (4 if sim.obs_is_float else 1)      # float32 variant: obs term x 4
     return 33 + 2 * d * d + obs, 2 * d * d + obs, "xw_render_all_kernel"
 

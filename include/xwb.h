@@ -226,6 +226,10 @@ int xwb_episode_dev(xwb_sim *sim, uint32_t **ptr);      /* uint32[num_envs]: res
 int xwb_xw_grid_dev(xwb_sim *sim, uint16_t **ptr);      /* xworld: uint16[num_envs][max_dim*max_dim] cell codes */
 int xwb_minstd_state_dev(xwb_sim *sim, uint32_t **ptr); /* XWB_RNG_MINSTD: uint32[num_envs] engine states (else NULL) */
 int xwb_done_count(xwb_sim *sim, void *stream, int32_t *n_done);   /* envs reset by the last reset_done (sync) */
+/* xworld, egocentric: which kernels draw the whole-batch frames: 1 = the span path (cells -> evaluated pixels -> gather,
+ * kernels_xworld_ego.hip), 0 = one workgroup per env (geometries / palettes the span path cannot take, or not enough free
+ * memory for its tables).  Both are bit-exact; callers that report kernel times need to know which ran. */
+int xwb_ego_render_path(xwb_sim *sim, int32_t *path);
 
 /* The whole batch's outputs copied into caller-owned memory, host or device (hipMemcpyDefault), ordered on `stream`;
  * host destinations are complete when the call returns.  obs: num_envs * bytes_per_env (see xwb_obs_dev);

@@ -227,6 +227,48 @@ def test_ego_autoreset_skip_and_context(oracle):
     b.close()
 
 
+@pytest.mark.parametrize("key,r,opts", [("nav7", 3, dict(color=True)), ("nav8", 3, dict(color=False, context=2)),
+                                        ("nav7", 5, dict(color=True, obs_format="float32")), ("nav11", 7, dict(color=True, context=3))])
+def test_ego_span_path_equals_per_env_path(oracle, key, r, opts, monkeypatch):
+    """The two egocentric renders (the span path -- cells, evaluated pixels, gather -- and one workgroup per env) draw the same
+    frames through every verb: step + reset_done, step_autoreset, masked resets; context rings and float32 frames included."""
+    torch = _torch()
+    n = 700                                                # not a multiple of the kernels' env groups (64, 8)
+    a, _, _ = _make(oracle, key, n, r, seed=11, policy_seed=3, **opts)
+    monkeypatch.setenv("XWB_EGO_NO_SPAN", "1")
+    b, _, _ = _make(oracle, key, n, r, seed=11, policy_seed=3, **opts)
+    monkeypatch.delenv("XWB_EGO_NO_SPAN")
+    assert a.ego_render_path == "span" and b.ego_render_path == "per_env"
+    for sim in (a, b):
+        sim.reset()
+    assert torch.equal(a.obs, b.obs)
+    mask = (torch.arange(n, device="cuda") % 7 == 3)
+    for t in range(50):
+        for sim in (a, b):
+            if t % 3 == 2:
+                sim.step_autoreset()
+            else:
+                sim.step()
+        assert torch.equal(a.obs, b.obs), ("terminal / stepped frames", t)
+        for sim in (a, b):
+            if t % 3 != 2:
+                sim.reset_done()
+            if t == 20:
+                sim.reset_masked(mask)
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward) and torch.equal(a.game_over_codes, b.game_over_codes), t
+    a.close()
+    b.close()
+
+
+def test_ego_render_path_by_geometry(oracle):
+    """r = 3, 5, 7: the frame is r x r equal squares -> span path; r = 1 and r >= 9 (81, 77 pixel edges): one workgroup per env."""
+    _torch()
+    for key, r, want in (("nav7", 3, "span"), ("nav7", 5, "span"), ("nav11", 7, "span"), ("nav7", 1, "per_env"), ("nav11", 9, "per_env")):
+        sim, _, _ = _make(oracle, key, 8, r)
+        assert sim.ego_render_path == want, (key, r)
+        sim.close()
+
+
 def test_ego_config_errors():
     _torch()
     from xworld_amd.batched import BatchedSimulator

@@ -53,13 +53,21 @@ def main(out, bench_args):
             print("%-70s dispatches %5d  %.0f B per dispatch = %.3f x buffer" % (k[:70], n, b, b / FILL_BYTES))
             cal.setdefault(counter, {})[k[:60]] = b / FILL_BYTES
     dom = [k for k in per_kernel if "render_all" in k or "sg_kernel" in k or "race_kernel" in k or "render_ego" in k]
-    if dom:
-        k = max(dom, key=lambda name: per_kernel[name].get("WRITE_SIZE", 0.0) * agg_count.get(name, 1))   # the step loop's kernel
+    span = [k for k in per_kernel if "xw_ego_gather_kernel" in k]
+    if dom or span:
         # write side: the fill kernels of the calibration report ~1.0 x -> WRITE_SIZE taken at face value;
         # read side: FETCH_SIZE x 2 (gfx950 correction for 16 B/lane streaming reads, MI355X_MICROARCH.md "HBM")
-        w = per_kernel[k].get("WRITE_SIZE", 0.0)
-        f = per_kernel[k].get("FETCH_SIZE", 0.0)
-        traffic = {"workload": workload, "kernel": k[:80], "write_bytes_per_launch": w, "fetch_bytes_per_launch_raw": f,
+        if span:
+            # the egocentric span path: the whole-batch render is four launches per step (bench.py times them together)
+            group = [name for name in per_kernel if any(t in name for t in ("xw_ego_cells_kernel", "xw_ego_eval_kernel", "xw_ego_gather_list_kernel", "xw_ego_gather_kernel"))]
+            k = " + ".join(sorted(name.split("(")[0].replace("void xwb::", "") for name in group))
+            w = sum(per_kernel[name].get("WRITE_SIZE", 0.0) for name in group)
+            f = sum(per_kernel[name].get("FETCH_SIZE", 0.0) for name in group)
+        else:
+            k = max(dom, key=lambda name: per_kernel[name].get("WRITE_SIZE", 0.0) * agg_count.get(name, 1))   # the step loop's kernel
+            w = per_kernel[k].get("WRITE_SIZE", 0.0)
+            f = per_kernel[k].get("FETCH_SIZE", 0.0)
+        traffic = {"workload": workload, "kernel": k[:200], "write_bytes_per_launch": w, "fetch_bytes_per_launch_raw": f,
                    "fetch_bytes_per_launch_corrected": 2 * f, "traffic_bytes_per_launch": w + 2 * f,
                    "calibration": cal, "source": os.path.basename(out)}
         with open(os.path.join(out, "traffic.json"), "w") as fh:

@@ -242,6 +242,13 @@ class BatchedSimulator:
         return self._view("minstd", self.L.xwb_minstd_state_dev, (self.num_envs,), "<i4")
 
     @property
+    def ego_render_path(self):
+        """egocentric xworld: "span" (cells -> evaluated pixels -> gather) or "per_env" (one workgroup per env)"""
+        v = C.c_int32(0)
+        lib.check(self.L.xwb_ego_render_path(self.h, C.byref(v)))
+        return "span" if v.value else "per_env"
+
+    @property
     def actions(self):
         return self._view("actions", self.L.xwb_actions_dev, (self.num_envs,), "<i4")
 

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
 //                         index exactly like the full-observation render (kernels_xworld.hip): U-byte runs gathered through
 //                         L2, assembled in LDS in output order, border-column bytes patched in, one non-temporal 16-byte
 //                         store per lane
-// The done-list render (new episodes, terminal frames) stays with the kernel above: short lists, latency-bound either way.
+// The frames of the done list's envs (new episodes) take the same three stages over the list, on the reset's queue.
 
 // a square's pixels in the span path's sources (ego_tab3, the goal-cell cache): [channel][U rows][UP bytes], rows padded to whole
 // 16-byte pieces
@@ -610,34 +610,45 @@ __device__ __forceinline__ void ego_wave_append(bool flag, uint32_t a, uint32_t 
 }
 
 // 64 envs per workgroup: all four wavefronts stage their grids (and the entity types) in LDS, the first one then walks them
-template <int R>
-__global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uint8_t *map, int skip_term) {
+// LIST: the envs of the done list (the frames of new episodes, drawn on the reset's queue) instead of the whole batch
+template <int R, bool LIST>
+__global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uint8_t *map, int skip_term, const int32_t *count_now) {
     extern __shared__ uint4 smem4[];
     const int D = p.max_dim, cells = D * D, tid = threadIdx.x, lane = tid;
     uint16_t *s_code = reinterpret_cast<uint16_t *>(smem4);                // [64][cells]
     uint8_t *s_type = reinterpret_cast<uint8_t *>(s_code + 64 * cells);    // [64][cells] type of the entity in a cell, 3 = none
     __shared__ uint4 s_gc[64];                                             // the envs' goal slot -> cell tables
     __shared__ uint32_t s_sq[64][R * R];                                   // the cell words, frame order
-    const int e_base = blockIdx.x * 64;
-    const int n_here = p.n - e_base < 64 ? p.n - e_base : 64;
+    const int e_base = blockIdx.x * 64, total = LIST ? *count_now : p.n;
+    if (e_base >= total) return;
+    const int n_here = total - e_base < 64 ? total - e_base : 64;
     uint8_t *s_itype = s_type + 64 * cells;                                // [n_icons]
     uint8_t *s_cls = s_itype + ((p.n_icons + 15) & ~15);                   // [n_icons + 2]
     __shared__ uint8_t s_map[8 * R * R + 8 * R];
-    const int e = e_base + lane, ec = e < p.n ? e : p.n - 1;
+    const bool valid = e_base + lane < total;
+    const int li = valid ? e_base + lane : total - 1;
+    const int e = LIST ? p.done_list[tid < 64 ? li : total - 1] : li, ec = e;
     int axy = 0, dir = 0, term = 0;
     int fresh = 0;
     if (tid < 64) { axy = p.agent_xy[ec]; dir = p.agent_dir[ec] & 3; term = p.term_flag[ec]; fresh = p.fresh[ec]; }
     for (int i = tid; i < p.n_icons; i += 256) s_itype[i] = p.icon_type[i];
     for (int i = tid; i < p.n_icons + 2; i += 256) s_cls[i] = p.ego_cls[i];
     for (int i = tid; i < 8 * R * R + 8 * R; i += 256) s_map[i] = map[i];
-    for (int i = tid; i < n_here * cells; i += 256) s_code[i] = (uint16_t)(p.grid[(size_t)e_base * cells + i] & CELL_ICON_MASK);
+    if (LIST) {
+        for (int i = tid; i < n_here * cells; i += 256) {
+            const int le = i / cells;
+            s_code[i] = (uint16_t)(p.grid[(size_t)p.done_list[e_base + le] * cells + (i - le * cells)] & CELL_ICON_MASK);
+        }
+    } else {
+        for (int i = tid; i < n_here * cells; i += 256) s_code[i] = (uint16_t)(p.grid[(size_t)e_base * cells + i] & CELL_ICON_MASK);
+    }
     static_assert(XW_MAX_GOALS == 16, "one uint4 per env");
-    if (tid >= 64 && tid < 64 + n_here) s_gc[tid - 64] = reinterpret_cast<const uint4 *>(p.goal_cells)[e_base + tid - 64];
+    if (tid >= 64 && tid < 64 + n_here) s_gc[tid - 64] = reinterpret_cast<const uint4 *>(p.goal_cells)[LIST ? p.done_list[e_base + tid - 64] : e_base + tid - 64];
     __syncthreads();
     for (int i = tid; i < n_here * cells; i += 256) { const int code = s_code[i]; s_type[i] = code ? s_itype[code - 1] : (uint8_t)3; }
     __syncthreads();
     if (tid >= 64) return;
-    const bool active = e < p.n && !(skip_term && term);
+    const bool active = valid && !(skip_term && term);
     const int ax = axy & 0xffff, ay = axy >> 16;
     const uint16_t *code_e = s_code + lane * cells;
     const uint8_t *type_e = s_type + lane * cells;
@@ -715,7 +726,7 @@ __global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uin
     // cell, the one above and the one to the left -- the cell's own where the neighbour does not show in this square -- or, bit
     // 23, into this env's part of the goal-cell cache), bit 24 / 25 its border row / column is evaluated for this env (a goal
     // in or next to the cell), 26 a border row crosses a border column here, 27 finished by this step, 28-29 fresh[]
-    if (!active && e < p.n) {
+    if (!active && valid) {
         for (int f = 0; f < r * r; ++f) p.ego_cellsrc[(size_t)e * (r * r) + f] = 1u << 27;      // (skipped: finished by this step)
     }
     if (active) {
@@ -807,7 +818,8 @@ __device__ __forceinline__ EgoCell ego_cell_of_info(const XwParams &p, const uin
 
 template <int CH, int R>
 __device__ __forceinline__ void ego_border_body(const XwParams &p, const uint32_t *atlas4, const EgoTap *tap_h1, const EgoTap *tap_v1,
-                                                const EgoTap *tap_h2, const EgoTap *tap_v2, const uint8_t *map, int skip_term, int block) {
+                                                const EgoTap *tap_h2, const EgoTap *tap_v2, const uint8_t *map, int skip_term, int block,
+                                                const int32_t *count_now) {
     constexpr int U = 84 / R, O = R * U, EPW = 8, NL = 2 * (R - 1);
     constexpr int NSEG = R * (R - 1), NITEM = 2 * NSEG + (R - 1) * (R - 1);   // row runs, column runs, crossings
     constexpr int RL = 4 * R * R, CL = RL + 4 * R;
@@ -817,17 +829,20 @@ __device__ __forceinline__ void ego_border_body(const XwParams &p, const uint32_
     __shared__ uint8_t s_map[4 * R * R + 8 * R], s_edir[EPW];
     __shared__ uint16_t s_runs[EPW * 2 * NSEG], s_cross[EPW * (R - 1) * (R - 1)];
     __shared__ int s_nrun, s_ncross;
-    const int tid = threadIdx.x, e_base = block * EPW;
+    __shared__ int s_eid[EPW];
+    const int tid = threadIdx.x, e_base = block * EPW, total = count_now ? *count_now : p.n;      // (a count: the done list's envs)
+    if (e_base >= total) return;
     if (tid == 0) { s_nrun = 0; s_ncross = 0; }
     ego_compose_taps(s_row, s_col, tap_h1, tap_v1, tap_h2, tap_v2, O, tid, 256);
     for (int i = tid; i < 4 * R * R + 8 * R; i += 256) s_map[i] = map[i];
     for (int i = tid; i < EPW * R * R; i += 256) {
-        const int le = i / (R * R), f = i - le * (R * R), e = e_base + le < p.n ? e_base + le : p.n - 1;
+        const int le = i / (R * R), f = i - le * (R * R), ix = e_base + le < total ? e_base + le : total - 1;
+        const int e = count_now ? p.done_list[ix] : ix;
         const uint32_t info = p.ego_cellinfo[(size_t)e * (R * R) + f];
         const int dir = (int)(info >> 24) & 3, k = map[dir * (R * R) + f];
         s_cells[le][k] = ego_cell_of_info(p, atlas4, info, e, dir);
         s_goal[le][k] = (info & 0x8000u) ? 1 : 0;
-        if (f == 0) s_edir[le] = (uint8_t)(e_base + le < p.n && !(skip_term && p.term_flag[e]) ? dir : 4);   // 4: nothing to do
+        if (f == 0) { s_edir[le] = (uint8_t)(e_base + le < total && !(skip_term && p.term_flag[e]) ? dir : 4); s_eid[le] = e; }   // 4: nothing to do
     }
     __syncthreads();
     // which runs / crossings this workgroup has to evaluate
@@ -876,7 +891,7 @@ __device__ __forceinline__ void ego_border_body(const XwParams &p, const uint32_
             ox = fx * U; oy = fy * U; line = R - 1 + fx - 1; o = oy;
         }
         EgoCtx ctx{s_cells[le], white, black, R, 64 * R, dir};
-        uint8_t *dst = p.ego_border + ((size_t)(e_base + le) * NL + line) * (CH * O);
+        uint8_t *dst = p.ego_border + ((size_t)s_eid[le] * NL + line) * (CH * O);
         ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst, O, o, ox, oy, 0);
     }
 }
@@ -886,8 +901,8 @@ __device__ __forceinline__ void ego_border_body(const XwParams &p, const uint32_
 template <int CH, int R>
 __global__ __launch_bounds__(256) void xw_ego_eval_kernel(XwParams p, const uint32_t *atlas4, const EgoTap *tap_h1, const EgoTap *tap_v1,
                                                           const EgoTap *tap_h2, const EgoTap *tap_v2, const uint16_t *layout, const uint8_t *map,
-                                                          int skip_term, int nb_border) {
-    if ((int)blockIdx.x < nb_border) ego_border_body<CH, R>(p, atlas4, tap_h1, tap_v1, tap_h2, tap_v2, map, skip_term, blockIdx.x);
+                                                          int skip_term, int nb_border, const int32_t *list_count) {
+    if ((int)blockIdx.x < nb_border) ego_border_body<CH, R>(p, atlas4, tap_h1, tap_v1, tap_h2, tap_v2, map, skip_term, blockIdx.x, list_count);
     else ego_miss_body<CH, R>(p, atlas4, tap_h1, tap_v1, tap_h2, tap_v2, layout, map, (int)blockIdx.x - nb_border, (int)gridDim.x - nb_border);
 }
 
@@ -1126,7 +1141,11 @@ __global__ __launch_bounds__(128) void xw_ego_gather_list_kernel(XwParams p, con
         const int e = p.done_list[item], cr = part * G::SPAN;
         __syncthreads();
         ego_gather_span<CH, R, CTX1, ES, 2>(p, (unsigned)e, (unsigned)cr, G::cpf - cr < G::SPAN ? G::cpf - cr : G::SPAN, 0, p.list_flag);
+        // (as the list render of the other path: the first frame of a new episode consumes fresh[] and, where the reset left
+        // that to the render, the done code)
+        if (part == 0 && threadIdx.x == 0 && p.list_flag == 2) { p.fresh[e] = 0; if (p.auto_reset == 2) p.done[e] = 0; }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *p.ego_miss_count = 0;          // (the list this path's cells kernel filled is consumed)
 }
 
 // The warped 64x64 image of every goal of the listed envs (XItem::get_item_image, xitem.cpp:46-60): cv::warpAffine with
@@ -1395,10 +1414,11 @@ hipError_t ego_span_render(const XwParams &p, const EgoTables &t, int mode, hipS
     const uint32_t *a4 = reinterpret_cast<const uint32_t *>(p.atlas64);
     const size_t cells = (size_t)p.max_dim * p.max_dim;
     const int skip_front = mode == 2, skip_gather = mode != 0;
-    hipLaunchKernelGGL((xw_ego_cells_kernel<R>), dim3((p.n + 63) / 64), dim3(256), 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15), s, p, t.map, skip_front);
+    const size_t cells_lds = 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15);
+    hipLaunchKernelGGL((xw_ego_cells_kernel<R, false>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, skip_front, nullptr);
     if (ev_cells) { const hipError_t e = hipEventRecord(ev_cells, s); if (e != hipSuccess) return e; }
     const int nb_border = (p.n + 7) / 8;
-    hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 4096), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, skip_front, nb_border);
+    hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 4096), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, skip_front, nb_border, (const int32_t *)nullptr);
     if (ev_front) { const hipError_t e = hipEventRecord(ev_front, s); if (e != hipSuccess) return e; }
     const int es = p.obs_f32 ? 4 : 1;
     const unsigned long long n_chunks = (unsigned long long)p.n * (FB / (16 / es));
@@ -1457,6 +1477,32 @@ bool xw_ego_span(const XwParams &p) {
     return p.visible_radius && p.ego_span && p.ego_cellinfo && (unsigned long long)p.n * p.channels * p.out_dim * p.out_dim < (1ull << 32);
 }
 
+namespace {
+// the frames of the done list's envs on the span path (new episodes: on the reset's queue, beside the whole-batch gather): the
+// same three stages over the list, with their own source words and goal-cell list (XwParams::ego_cellsrc_list, ...) -- the
+// whole-batch gather may still be reading the batch's
+template <int CH, int R>
+hipError_t ego_span_render_list(const XwParams &p0, const EgoTables &t, hipStream_t s) {
+    XwParams p = p0;
+    p.ego_cellsrc = p0.ego_cellsrc_list; p.ego_miss = p0.ego_miss_list; p.ego_miss_count = p0.ego_miss_count_list;
+    const uint32_t *a4 = reinterpret_cast<const uint32_t *>(p.atlas64);
+    const size_t cells = (size_t)p.max_dim * p.max_dim;
+    const int32_t *cnt = (const int32_t *)p.done_count;
+    const size_t cells_lds = 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15);
+    const int n_cap = p.n < 16384 ? p.n : 16384;               // (workgroups beyond the list leave at once)
+    hipLaunchKernelGGL((xw_ego_cells_kernel<R, true>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, 0, cnt);
+    const int nb_border = (p.n + 7) / 8;
+    hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 1024), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, 0, nb_border, cnt);
+    const int es = p.obs_f32 ? 4 : 1;
+    const unsigned list_blocks = (unsigned)(n_cap < 2048 ? n_cap : 2048);
+#define EGO_LIST(CTXV, ESV) hipLaunchKernelGGL((xw_ego_gather_list_kernel<CH, R, CTXV, ESV>), dim3(list_blocks * EgoSpanGeom<CH, R, ESV, 2>::SPE), dim3(128), 0, s, p, cnt)
+    if (p.context == 1) { if (es == 4) EGO_LIST(true, 4); else EGO_LIST(true, 1); }
+    else { if (es == 4) EGO_LIST(false, 4); else EGO_LIST(false, 1); }
+#undef EGO_LIST
+    return hipGetLastError();
+}
+}  // namespace
+
 hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s, hipEvent_t ev_front, hipEvent_t ev_list, hipEvent_t ev_cells) {
     const EgoTables t = ego_tables_of(p);
     const int r = p.visible_radius, O = p.out_dim, O4 = (O + 3) & ~3, D = p.max_dim;
@@ -1465,6 +1511,10 @@ hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s, h
         const int m = indexed;
         if (CH == 3) return r == 3 ? ego_span_render<3, 3>(p, t, m, s, ev_front, ev_list, ev_cells) : (r == 5 ? ego_span_render<3, 5>(p, t, m, s, ev_front, ev_list, ev_cells) : ego_span_render<3, 7>(p, t, m, s, ev_front, ev_list, ev_cells));
         return r == 3 ? ego_span_render<1, 3>(p, t, m, s, ev_front, ev_list, ev_cells) : (r == 5 ? ego_span_render<1, 5>(p, t, m, s, ev_front, ev_list, ev_cells) : ego_span_render<1, 7>(p, t, m, s, ev_front, ev_list, ev_cells));
+    }
+    if (indexed == 1 && xw_ego_span(p) && p.ego_cellsrc_list) {
+        if (CH == 3) return r == 3 ? ego_span_render_list<3, 3>(p, t, s) : (r == 5 ? ego_span_render_list<3, 5>(p, t, s) : ego_span_render_list<3, 7>(p, t, s));
+        return r == 3 ? ego_span_render_list<1, 3>(p, t, s) : (r == 5 ? ego_span_render_list<1, 5>(p, t, s) : ego_span_render_list<1, 7>(p, t, s));
     }
     if (indexed == 4) return hipErrorInvalidValue;             // (only the span path draws a step's terminal frames itself)
     const bool fast = p.ego_fast != 0;

@@ -116,7 +116,9 @@ struct xwb_sim {
     int ego_cell_edge = 1;
     uint8_t *d_ego_cache = nullptr;        // lazily filled cache of rendered goal cells (XwParams::ego_cache)
     uint32_t *d_ego_cache_valid = nullptr;
-    uint32_t *d_ego_cellsrc = nullptr;
+    uint32_t *d_ego_cellsrc = nullptr, *d_ego_cellsrc_list = nullptr;
+    uint2 *d_ego_miss_list = nullptr;
+    int32_t *d_ego_miss_count_list = nullptr;
     uint32_t *d_ego_cellinfo = nullptr;    // span path of the egocentric render (XwParams::ego_span)
     uint2 *d_ego_miss = nullptr;
     int32_t *d_ego_miss_count = nullptr;
@@ -479,6 +481,7 @@ int xw_setup(xwb_sim *s) {
         p.ego_tab = s->d_ego_tab;
         p.ego_cache = nullptr; p.ego_cache_valid = nullptr; p.ego_cache_entry = 0; p.ego_cache_words = 0;
         p.ego_cellinfo = nullptr; p.ego_miss = nullptr; p.ego_miss_count = nullptr; p.ego_border = nullptr; p.ego_tab3 = nullptr; p.ego_cellsrc = nullptr;
+        p.ego_cellsrc_list = nullptr; p.ego_miss_list = nullptr; p.ego_miss_count_list = nullptr;
         if (p.ego_fast && !getenv("XWB_EGO_NO_CACHE")) {
             // rendered goal cells, [env][goal slot][view cell][heading]: ~340 KB per env at r = 3 (11 GB for a C4-sized batch;
             // the GPU has 288 GB).  Taken only if it leaves at least half of the free memory to the caller.
@@ -507,6 +510,10 @@ int xw_setup(xwb_sim *s) {
                         if ((rc = dev_alloc(s, &s->d_ego_cellinfo, (size_t)n * rr))) return rc;
                         if ((rc = dev_alloc(s, &s->d_ego_cellsrc, (size_t)n * rr))) return rc;
                         p.ego_cellsrc = s->d_ego_cellsrc;
+                        if ((rc = dev_alloc(s, &s->d_ego_cellsrc_list, (size_t)n * rr))) return rc;
+                        if ((rc = dev_alloc(s, &s->d_ego_miss_list, (size_t)n * (p.num_goals < rr ? p.num_goals : rr)))) return rc;
+                        if ((rc = dev_alloc(s, &s->d_ego_miss_count_list, 4))) return rc;
+                        p.ego_cellsrc_list = s->d_ego_cellsrc_list; p.ego_miss_list = s->d_ego_miss_list; p.ego_miss_count_list = s->d_ego_miss_count_list;
                         if ((rc = dev_alloc(s, &s->d_ego_miss, (size_t)n * (p.num_goals < rr ? p.num_goals : rr)))) return rc;
                         if ((rc = dev_alloc(s, &s->d_ego_miss_count, 4))) return rc;
                         if ((rc = dev_alloc(s, &s->d_ego_border, (size_t)n * 2 * (c.visible_radius - 1) * p.channels * p.out_dim + 16))) return rc;
@@ -1013,6 +1020,13 @@ int xwb_step_autoreset(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, 
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
     XWB_ON_DEVICE(s);
     return do_step(s, actions_dev, act_rep, true, as_stream(stream));
+}
+
+int xwb_ego_render_path(xwb_sim *s, int32_t *path) {
+    if (!s || !path) return fail(XWB_ERR_ARG, "NULL argument");
+    if (s->cfg.game != XWB_XWORLD2D || s->cfg.visible_radius == 0) return fail(XWB_ERR_STATE, "not an egocentric xworld batch");
+    *path = xw_ego_span(s->xw) ? 1 : 0;
+    return XWB_OK;
 }
 
 int xwb_check_errors(xwb_sim *s, void *stream, int32_t *n_bad) {

@@ -222,6 +222,9 @@ struct XwParams {
     uint32_t *ego_cellsrc;       // [n][r * r] per square: where the gather finds its pixels (xw_ego_cells_kernel has the bit layout)
     uint2 *ego_miss;             // goal cells the cache does not hold yet: (env, view cell | slot << 8 | heading << 16)
     int32_t *ego_miss_count;
+    uint32_t *ego_cellsrc_list;  // the same three for the done-list render, which runs beside the whole-batch gather
+    uint2 *ego_miss_list;
+    int32_t *ego_miss_count_list;
     uint8_t *ego_border;         // [n][2 (r - 1)][channels][out_dim] evaluated border rows, then border columns, of each frame
     uint32_t *cand2d;            // [n] goal slots the agent can reach, blocks as the only obstacles: bits 0..15
                                  //     any goal (XWorldNavTarget), bits 16..31 coloured goals (XWorldNavColorTarget)
