@@ -591,6 +591,10 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
 //                         store per lane
 // The frames of the done list's envs (new episodes) take the same three stages over the list, on the reset's queue.
 
+// envs per workgroup of the border-line evaluation (8: 49 us for the evaluation kernel on the C4-sized batch -- four rounds
+// of workgroups that mostly wait for their staging loads; 32: one round)
+constexpr int EGO_BORDER_EPW = 32;
+
 // a square's pixels in the span path's sources (ego_tab3, the goal-cell cache): [channel][U rows][UP bytes], rows padded to whole
 // 16-byte pieces
 template <int R>
@@ -820,7 +824,7 @@ template <int CH, int R>
 __device__ __forceinline__ void ego_border_body(const XwParams &p, const uint32_t *atlas4, const EgoTap *tap_h1, const EgoTap *tap_v1,
                                                 const EgoTap *tap_h2, const EgoTap *tap_v2, const uint8_t *map, int skip_term, int block,
                                                 const int32_t *count_now) {
-    constexpr int U = 84 / R, O = R * U, EPW = 8, NL = 2 * (R - 1);
+    constexpr int U = 84 / R, O = R * U, EPW = EGO_BORDER_EPW, NL = 2 * (R - 1);
     constexpr int NSEG = R * (R - 1), NITEM = 2 * NSEG + (R - 1) * (R - 1);   // row runs, column runs, crossings
     constexpr int RL = 4 * R * R, CL = RL + 4 * R;
     __shared__ EgoTap s_row[84][3], s_col[84][3];
@@ -1417,7 +1421,7 @@ hipError_t ego_span_render(const XwParams &p, const EgoTables &t, int mode, hipS
     const size_t cells_lds = 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15);
     hipLaunchKernelGGL((xw_ego_cells_kernel<R, false>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, skip_front, nullptr);
     if (ev_cells) { const hipError_t e = hipEventRecord(ev_cells, s); if (e != hipSuccess) return e; }
-    const int nb_border = (p.n + 7) / 8;
+    const int nb_border = (p.n + EGO_BORDER_EPW - 1) / EGO_BORDER_EPW;
     hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 4096), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, skip_front, nb_border, (const int32_t *)nullptr);
     if (ev_front) { const hipError_t e = hipEventRecord(ev_front, s); if (e != hipSuccess) return e; }
     const int es = p.obs_f32 ? 4 : 1;
@@ -1491,7 +1495,7 @@ hipError_t ego_span_render_list(const XwParams &p0, const EgoTables &t, hipStrea
     const size_t cells_lds = 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15);
     const int n_cap = p.n < 16384 ? p.n : 16384;               // (workgroups beyond the list leave at once)
     hipLaunchKernelGGL((xw_ego_cells_kernel<R, true>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, 0, cnt);
-    const int nb_border = (p.n + 7) / 8;
+    const int nb_border = (p.n + EGO_BORDER_EPW - 1) / EGO_BORDER_EPW;
     hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 1024), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, 0, nb_border, cnt);
     const int es = p.obs_f32 ? 4 : 1;
     const unsigned list_blocks = (unsigned)(n_cap < 2048 ? n_cap : 2048);
