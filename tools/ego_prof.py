@@ -1,5 +1,6 @@
-"""Per-phase time of the egocentric render (a build with XWB_EXTRA_FLAGS=-DXWB_EGO_PROF only):
-    XWB_EXTRA_FLAGS=-DXWB_EGO_PROF python -m xworld_amd.build --force && python tools/ego_prof.py [r] [map key]
+"""Per-phase time of the one-workgroup-per-env egocentric render (a build with XWB_EXTRA_FLAGS=-DXWB_EGO_PROF only; the span
+path is switched off for the measurement):
+    XWB_EXTRA_FLAGS=-DXWB_EGO_PROF python -m xworld_amd.build --force && XWB_EGO_NO_SPAN=1 python tools/ego_prof.py [r] [map key]
 Prints the 100 MHz wall-clock ticks workgroup leaders spent between the barriers of xw_render_ego_kernel, summed over
 workgroups, as a share of the total."""
 import ctypes as C
@@ -15,7 +16,7 @@ r = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 conf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xworld_amd", "confs", "nav_target.json")
 sim = BatchedSimulator("xworld", {"xwd_conf_path": conf, "max_dim": 7, "dim": 7, "visible_radius": r, "color": True,
                                   "task_mode": "lang_acquisition"}, num_envs=32768)
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 12)()              # g_ego_prof[12]: seven phase timers, then the goal-cell cache's hit statistics
 for _ in range(5):
     sim.step(); sim.reset_done()
 torch.cuda.synchronize()

@@ -77,7 +77,8 @@ def main(out, bench_args):
     log = os.path.join(out, "bench_under_rocprof.log")
     if os.path.exists(log):
         print("== bench line under rocprof ==")
-        print(open(log).read().strip().splitlines()[-1][:2500])
+        lines = [l for l in open(log).read().splitlines() if l.startswith('{"metric"')]     # (rocprofv3 logs after the line)
+        print(lines[-1][:2500] if lines else "(no bench line)")
 
 
 if __name__ == "__main__":
