@@ -291,14 +291,21 @@ int xwb_xw_refresh_obs(xwb_sim *sim, int32_t env);
 /* simple_race: overwrite the car state of env (test hook).  Synchronous. */
 int xwb_race_set_car(xwb_sim *sim, int32_t env, float x, float y, float angle);
 
+/* xworld: the strings behind the palette's name ids -- goal_names[id] for xwb_config.icon_name of goal icons, and per icon its
+ * name and its colour ("na": none; properties.txt).  With them the library builds the teacher's sentences itself
+ * (xworld_amd/csrc/xwb_language.h: the reference's per-task context-free grammars, python/context_free_grammar.py and the
+ * tasks' _define_grammar, expanded with xwb-rng-v1 stream 3); the strings are copied. */
+int xwb_set_names(xwb_sim *sim, const char *const *goal_names, int32_t n_goal_names, const char *const *icon_names,
+                  const char *const *icon_colors, int32_t n_icons);
+/* The teacher's sentence of one env after the last call, NUL-terminated ("" where the reference's get_state() shows "-").
+ * Returns the bytes needed in *need; writes when cap suffices.  Needs xwb_set_names.  Synchronises `stream`. */
+int xwb_sentence(xwb_sim *sim, int32_t env, void *stream, char *out, size_t cap, size_t *need);
+
 /* SimulatorInterface::get_state(reward) of one env, serialised in the reference's StatePacket wire
  * layout (data_packet.h:313-319, data_packet.cpp:143-174, memory_util.h:307-333): keys "reward",
  * "screen" [, "sentence" for xworld].  Returns bytes needed in *need; writes when cap suffices.
- * KNOWN GAP: "sentence" is always "-" here.  The teacher's sentence of an env is a pure function of xwb_env_state
- * (task, stage, event, xw_sentence_names, episode) and the goal-name strings, which this ABI never sees (it gets name
- * ids); the Python host layer builds it (xworld_amd/language.py, BatchedSimulator.sentence / py_simulator get_state()),
- * C / C++ callers and the TCP endpoint (include/xwb_endpoint.hpp) get "-" -- what the reference shows for an empty
- * teacher sentence (xworld_simulator.cpp:486-493). */
+ * "sentence" is the teacher's sentence (xworld_simulator.cpp:486-493), "-" when the teacher is silent -- and always "-" until
+ * xwb_set_names has handed over the strings behind the name ids (the config only carries ids). */
 int xwb_get_state_packet(xwb_sim *sim, int32_t env, float reward, void *stream,
                          uint8_t *out_host, size_t cap, size_t *need);
 

@@ -161,6 +161,15 @@ class BatchedSimulator {
         if ((int)actions.size() != n_) throw Error("step_host: need one action per env");
         check(xwb_step_host(sim_, actions.data(), act_rep, stream));
     }
+    // xworld: the strings behind the palette's name ids (goal names by id; per icon its name and colour, "na" = none): with
+    // them get_state()'s "sentence" is the teacher's sentence, without them "-"
+    void set_names(const std::vector<std::string> &goal_names, const std::vector<std::string> &icon_names, const std::vector<std::string> &icon_colors) {
+        std::vector<const char *> g, n, c;
+        for (const std::string &x : goal_names) g.push_back(x.c_str());
+        for (const std::string &x : icon_names) n.push_back(x.c_str());
+        for (const std::string &x : icon_colors) c.push_back(x.c_str());
+        check(xwb_set_names(sim_, g.data(), (int32_t)g.size(), n.data(), c.data(), (int32_t)n.size()));
+    }
     xwb_env_state env_state(int env, void *stream = nullptr) const { xwb_env_state s; check(xwb_get_env_state(sim_, env, stream, &s)); return s; }
 
   private:

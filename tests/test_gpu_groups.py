@@ -106,6 +106,7 @@ def test_two_group_conf_and_exclusive_flag():
     st = sim.env_state(3)
     assert st.xw_task in range(5) and st.xw_task2 in range(5, 9)
     assert isinstance(sim.sentence(3), str)
+    assert all(sim.sentence(e) == sim.sentence_c(e) for e in range(0, sim.num_envs, 9))      # the first speaking group wins, on both sides of the ABI
     sim.close()
     # one_channel + exclusive (the Python defaults) with two built groups: refused, not silently run non-exclusively
     with pytest.raises(XwbError, match="exclusive"):

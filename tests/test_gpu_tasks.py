@@ -275,6 +275,13 @@ def test_conf_walls_json_navigation_group(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------ the teacher's sentences
+def _sent(sim, e):
+    """The sentence of env e from the Python layer (language.py) -- and the same one built inside libxwb.so (xwb_sentence)."""
+    s = sim.sentence(e)
+    assert sim.sentence_c(e) == s, (e, s, sim.sentence_c(e))
+    return s
+
+
 def test_sentences_follow_the_episode(oracle):
     """The names the idle stage binds (vs the oracle), one instruction per episode that contains them, the closing
     message on the step that ends the episode, silence afterwards, a new instruction after the reset."""
@@ -292,7 +299,7 @@ def test_sentences_follow_the_episode(oracle):
         st = sim.env_state(e)
         a, b = ow.sentence_names()
         assert (st.xw_sentence_names & 0xffff, st.xw_sentence_names >> 16) == (a & 0xffff, b & 0xffff), (e, st.xw_task)
-        s = sim.sentence(e)
+        s = _sent(sim, e)
         first[e] = s
         if a >= 0:
             assert names[a] in s.split() and (b < 0 or names[b] in s.split()), (e, s)
@@ -306,7 +313,7 @@ def test_sentences_follow_the_episode(oracle):
         sim.step()
         for e in range(0, n, 7):
             st = sim.env_state(e)
-            s = sim.sentence(e)
+            s = _sent(sim, e)
             if st.xw_event:
                 assert s == closing[st.xw_event]
                 seen.add(st.xw_event)
@@ -318,13 +325,23 @@ def test_sentences_follow_the_episode(oracle):
         for e in range(0, n, 7):
             st = sim.env_state(e)
             if st.num_steps == 0 and st.episode > 0:
-                first[e] = sim.sentence(e)
+                first[e] = _sent(sim, e)
     assert {1, 2} <= seen
     # the py_simulator surface shows it under "sentence"
     from xworld_amd.py_simulator import Simulator
     g = Simulator.create("xworld", {"xwd_conf_path": os.path.join(CONF, "navigation2d.json"), "task_mode": "lang_acquisition"})
     g.reset_game()
-    assert g.get_state()["sentence"] == g.batch.sentence(0) != ""
+    assert g.get_state()["sentence"] == g.batch.sentence(0) == g.batch.sentence_c(0) != ""
+    # ... and so does the state packet the C / C++ / TCP callers get (reference wire layout), "-" once the teacher is silent
+    L = oracle.lib()
+    for e in (0, 7, 14):
+        raw = sim.state_packet(env=e, reward=0.5)
+        buf = np.frombuffer(raw, np.uint8).copy()
+        out = (oracle.PacketField * 4)()
+        assert L.orc_packet_decode(oracle.ptr(buf, oracle.u8p), len(raw), out, 4) == 3
+        keys = {out[i].key: out[i] for i in range(3)}
+        want = sim.sentence(e) or "-"
+        assert want.encode() in raw and set(keys) == {b"reward", b"screen", b"sentence"}, (e, want)
     sim.close()
 
 
@@ -338,7 +355,7 @@ def test_sentences_of_the_2d_native_group(oracle):
     spoke = 0
     for e in range(n):
         st = sim.env_state(e)
-        s = sim.sentence(e)
+        s = _sent(sim, e)
         if st.xw_stage == 1:
             icon = int(sim.env_grid(e)[st.xw_target // md, st.xw_target % md]) - 1
             m = sim.palette.meta[icon]
@@ -350,20 +367,20 @@ def test_sentences_of_the_2d_native_group(oracle):
             assert s == ""
     assert spoke > n // 2
     sim.step()
-    assert all(sim.sentence(e) == "" for e in range(0, n, 5))      # the navigation stage says nothing
+    assert all(_sent(sim, e) == "" for e in range(0, n, 5))      # the navigation stage says nothing
     sim.close()
     # one_channel: the task runs out of time after h * w / 2 = 32 steps and says so on that step (xworld_task.py:205-211)
     sim, pal, cfg = _make(oracle, "nav8", 64, [KINDS2D[0]], seed=5, task_mode="one_channel")
     busy = [e for e in range(64) if sim.env_state(e).xw_stage == 1]
     assert len(busy) > 32
     for t in range(32):
-        assert all(sim.sentence(e) == "" for e in busy[:4]) or t == 0
+        assert all(_sent(sim, e) == "" for e in busy[:4]) or t == 0
         sim.step()
     for e in busy:
         st = sim.env_state(e)
-        assert st.xw_stage == 0 and st.xw_steps_in_task == 0 and sim.sentence(e) == "Time up ."
+        assert st.xw_stage == 0 and st.xw_steps_in_task == 0 and _sent(sim, e) == "Time up ."
     sim.step()                                                      # the next teach() call picks a new target and speaks
-    assert all(sim.sentence(e) not in ("", "Time up .") for e in busy)
+    assert all(_sent(sim, e) not in ("", "Time up .") for e in busy)
     sim.close()
 
 

@@ -145,6 +145,12 @@ class BatchedSimulator:
         h = C.c_void_p()
         lib.check(self.L.xwb_create(C.byref(cfg), C.byref(h)))
         self.h = h
+        if self.palette is not None:
+            # the strings behind the name ids: the library builds the teacher's sentences for C / C++ / TCP callers too
+            enc = lambda xs: (C.c_char_p * len(xs))(*[x.encode() for x in xs])
+            goals = self.palette.names["goal"]
+            lib.check(self.L.xwb_set_names(self.h, enc(goals), len(goals), enc([m["name"] for m in self.palette.meta]),
+                                           enc([m.get("color", "na") for m in self.palette.meta]), len(self.palette)))
         self.num_envs = int(num_envs)
         self.device = int(device)
         n = C.c_int32()
@@ -366,6 +372,14 @@ class BatchedSimulator:
         if not out and self.cfg.n_tasks2 > 0:
             out = self._group_sentence(env, stream, st, st.xw_task2, st.xw_stage2, st.xw_event2, st.xw_target2, st.xw_steps_in_task2)
         return out
+
+    def sentence_c(self, env=0, stream=None):
+        """The same sentence built inside libxwb.so (xwb_sentence: what state packets and the TCP endpoint carry)."""
+        need = C.c_size_t()
+        lib.check(self.L.xwb_sentence(self.h, int(env), self._stream(stream), None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value)
+        lib.check(self.L.xwb_sentence(self.h, int(env), self._stream(stream), buf, need.value, C.byref(need)))
+        return buf.value.decode()
 
     def _group_sentence(self, env, stream, st, task, stage, event, target, steps_in_task):
         from . import language

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libxwb.so")
 SOURCES = ["kernels_simple.hip", "kernels_xworld.hip", "kernels_xworld_reset.hip", "kernels_xworld_ego.hip", "xwb_api.hip"]
-HEADERS = [os.path.join(CSRC, "xwb_common.h"), os.path.join(CSRC, "xw_device.h"), os.path.join(os.path.dirname(HERE), "include", "xwb.h")]
+HEADERS = [os.path.join(CSRC, "xwb_common.h"), os.path.join(CSRC, "xw_device.h"), os.path.join(CSRC, "xwb_language.h"), os.path.join(os.path.dirname(HERE), "include", "xwb.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
 

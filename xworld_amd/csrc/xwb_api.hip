@@ -7,6 +7,7 @@
 // gfx950 device xwb_create fails.
 #include "../../include/xwb.h"
 #include "xwb_common.h"
+#include "xwb_language.h"
 #include "../../include/xwb_trig.h"
 #include "../../include/xwb_minstd.h"
 
@@ -129,6 +130,9 @@ struct xwb_sim {
     uint32_t *d_atlas = nullptr;
     std::vector<uint8_t> tile_table;   // host copy, n_icons x c x 12 x 12
     std::vector<int32_t> icon_type_h, icon_name_h, icon_colored_h;
+    // xwb_set_names: the strings behind the name ids (the teacher's sentences are built from them)
+    std::vector<std::string> goal_names, icon_names, icon_colors;
+    bool have_names = false;
     XwParams xw{};
     std::vector<void *> allocs;
 };
@@ -1571,6 +1575,80 @@ int xwb_load_state(xwb_sim *s, const uint8_t *in_host, size_t bytes) {
     return XWB_OK;
 }
 
+// BatchedSimulator.sentence / _group_sentence (xworld_amd/batched.py), on this side of the ABI
+static int group_sentence(xwb_sim *s, int32_t env, void *stream, const xwb_env_state &st, int task, int stage, int event, int target,
+                          int steps_in_task, std::string *out) {
+    out->clear();
+    const uint32_t gid = s->cfg.env_gid0 + (uint32_t)env;
+    if (task == 5 || task == 7) {
+        // 2-D-native Target / ColorTarget: they speak on the teach() call that picked the target, and "Time up ." on the
+        // one_channel step that runs out of time (xworld_task.py:205-211): back to idle with the target still recorded
+        if (stage == 0 && event == 0 && target >= 0 && st.num_steps > 0 && s->cfg.task_mode == XWB_TASKMODE_ONE_CHANNEL) {
+            *out = xwb::lang::sentence_2d_timeup(task);
+            return XWB_OK;
+        }
+        if (stage != 1 || steps_in_task != 0 || target < 0) return XWB_OK;
+        uint16_t code = 0;
+        const int cells = s->cfg.max_dim * s->cfg.max_dim;
+        if (target >= cells) return XWB_OK;
+        HIP_TRY(hipMemcpyAsync(&code, s->d_grid + (size_t)env * cells + target, 2, hipMemcpyDeviceToHost, as_stream(stream)));
+        HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+        const int icon = (int)(code & 0x7fffu) - 1;           // (xw_device.h CELL_ICON_MASK: bit 15 marks target goals)
+        if (icon < 0 || icon >= (int)s->icon_names.size()) return XWB_OK;   // (two groups: the 3-D stage may have moved the goal away since)
+        *out = xwb::lang::sentence_2d(task, s->icon_names[icon], s->icon_colors[icon], s->cfg.seed, gid, st.episode, (uint32_t)st.num_steps);
+        return XWB_OK;
+    }
+    const uint32_t sn = st.xw_sentence_names;
+    *out = xwb::lang::sentence(task, stage, event, s->goal_names, sn & 0xffffu, sn >> 16, task == 3 && target >= 0 ? (target >> 8) & 7 : 0,
+                               s->cfg.seed, gid, st.episode);
+    return XWB_OK;
+}
+
+static int env_sentence(xwb_sim *s, int32_t env, void *stream, std::string *out) {
+    xwb_env_state st;
+    int rc = xwb_get_env_state(s, env, stream, &st);
+    if (rc) return rc;
+    rc = group_sentence(s, env, stream, st, st.xw_task, st.xw_stage, st.xw_event, st.xw_target, st.xw_steps_in_task, out);
+    if (rc) return rc;
+    // two task groups: the first one (conf order) that speaks wins -- Task::teacher_speak only records into an empty
+    // buffer (teaching_task.cpp:118-127)
+    if (out->empty() && s->cfg.n_tasks2 > 0)
+        rc = group_sentence(s, env, stream, st, st.xw_task2, st.xw_stage2, st.xw_event2, st.xw_target2, st.xw_steps_in_task2, out);
+    return rc;
+}
+
+int xwb_set_names(xwb_sim *s, const char *const *goal_names, int32_t n_goal_names, const char *const *icon_names,
+                  const char *const *icon_colors, int32_t n_icons) {
+    if (!s || !goal_names || !icon_names || !icon_colors) return fail(XWB_ERR_ARG, "NULL argument");
+    if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
+    if (n_icons != s->cfg.n_icons || n_goal_names < 0) return fail(XWB_ERR_ARG, "one name and one colour per icon of the palette");
+    for (int i = 0; i < n_icons; ++i) {
+        if (!icon_names[i] || !icon_colors[i]) return fail(XWB_ERR_ARG, "NULL name");
+        if (s->icon_type_h[i] == 0 && (s->icon_name_h[i] < 0 || s->icon_name_h[i] >= n_goal_names))
+            return fail(XWB_ERR_ARG, "a goal icon's name id has no string");
+    }
+    for (int i = 0; i < n_goal_names; ++i) if (!goal_names[i]) return fail(XWB_ERR_ARG, "NULL name");
+    s->goal_names.assign(goal_names, goal_names + n_goal_names);
+    s->icon_names.assign(icon_names, icon_names + n_icons);
+    s->icon_colors.assign(icon_colors, icon_colors + n_icons);
+    s->have_names = true;
+    return XWB_OK;
+}
+
+int xwb_sentence(xwb_sim *s, int32_t env, void *stream, char *out, size_t cap, size_t *need) {
+    if (!s || !need) return fail(XWB_ERR_ARG, "NULL argument");
+    if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
+    if (!s->have_names) return fail(XWB_ERR_STATE, "xwb_set_names has not been called: the library only has name ids");
+    if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
+    XWB_ON_DEVICE(s);
+    std::string str;
+    const int rc = env_sentence(s, env, stream, &str);
+    if (rc) return rc;
+    *need = str.size() + 1;
+    if (out && cap >= str.size() + 1) memcpy(out, str.c_str(), str.size() + 1);
+    return XWB_OK;
+}
+
 int xwb_get_state_packet(xwb_sim *s, int32_t env, float reward, void *stream, uint8_t *out_host, size_t cap,
                          size_t *need) {
     if (!s || !need) return fail(XWB_ERR_ARG, "NULL argument");
@@ -1583,7 +1661,17 @@ int xwb_get_state_packet(xwb_sim *s, int32_t env, float reward, void *stream, ui
     size_t total = 8;
     total += 8 + 7 + 1 + 8 + 4;                                  // "reward": flags reals, 1 float
     total += 8 + 7 + 1 + 8 + s->obs_bytes_per_env;               // "screen"
-    if (xw) total += 8 + 9 + 1 + 8 + 2;                          // "sentence": str "-"
+    // XWorldSimulator::define_state_specs (:486-493): the teacher's sentence, "-" when it is silent (or when the strings behind
+    // the name ids were never handed over: xwb_set_names)
+    std::string sent = "-";
+    if (xw && s->have_names) {
+        XWB_ON_DEVICE(s);
+        std::string str;
+        const int rcs = env_sentence(s, env, stream, &str);
+        if (rcs) return rcs;
+        if (!str.empty()) sent = str;
+    }
+    if (xw) total += 8 + 9 + 1 + 8 + sent.size() + 1;           // "sentence": str
     *need = total;
     if (!out_host || cap < total) return XWB_OK;
     std::vector<uint8_t> screen(s->obs_bytes_per_env);
@@ -1596,10 +1684,8 @@ int xwb_get_state_packet(xwb_sim *s, int32_t env, float reward, void *stream, ui
     w.str("screen");
     f = is_float ? 1 : 2; w.put(&f, 1); w.u64(n_screen); w.put(screen.data(), screen.size());
     if (xw) {
-        // XWorldSimulator::define_state_specs (:486-493): teacher sentence or "-".  The sentence itself is built by the
-        // Python host layer from xwb_env_state (include/xwb.h: "KNOWN GAP" at xwb_get_state_packet)
         w.str("sentence");
-        f = 8; w.put(&f, 1); w.str("-");
+        f = 8; w.put(&f, 1); w.str(sent.c_str());
     }
     return XWB_OK;
 }

@@ -85,6 +85,8 @@ _SIGS = [
     ("xwb_xw_grid_dev", C.c_int, [_vp, C.POINTER(_vp)]),
     ("xwb_minstd_state_dev", C.c_int, [_vp, C.POINTER(_vp)]),
     ("xwb_ego_render_path", C.c_int, [_vp, C.POINTER(C.c_int32)]),
+    ("xwb_set_names", C.c_int, [_vp, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int32]),
+    ("xwb_sentence", C.c_int, [_vp, C.c_int32, _vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("xwb_minstd_seed_thread", C.c_uint32, [C.c_int32, C.c_int32]),
     ("xwb_minstd_rand_ind", C.c_int32, [C.POINTER(C.c_uint32), C.c_int32]),
     ("xwb_minstd_rand_range", C.c_float, [C.POINTER(C.c_uint32), C.c_float]),
