@@ -721,17 +721,28 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         timer_end(s, s->t_step, st);
         s->list_valid = true;
         XwParams pr = xw_params(s);
+        bool auto_epochs = false;
         if (autoreset) {
             // finished envs: reset + first frame of the new episode on the side stream, beside the render of everyone
             // else; their terminal frames are not materialised
-            HIP_TRY(hipEventRecord(s->ev_step, st));
-            HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
+            // (full observation: the hand-overs are epochs in device memory, as in xwb_reset_done -- the side queue's first
+            // kernel waits for the step kernel's epoch, which the render publishes; a one-wavefront kernel at the end of
+            // this call waits for the side queue's)
+            auto_epochs = queue_sync_by_epochs() && !p.visible_radius;
+            if (auto_epochs) {
+                HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->d_sync + 4, s->side));
+                if (++s->epoch_reset == 0) s->epoch_reset = 1;
+            } else {
+                HIP_TRY(hipEventRecord(s->ev_step, st));
+                HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
+            }
             pr.auto_reset = 1;
             timer_begin(s, s->t_reset, s->side);
             HIP_TRY(launch_xw_reset(pr, MODE_RESET_DONE, s->side));
             timer_end(s, s->t_reset, s->side);
             HIP_TRY(launch_xw_render(pr, 1, s->side));
-            HIP_TRY(hipEventRecord(s->ev_reset, s->side));
+            if (auto_epochs) HIP_TRY(launch_xw_signal(s->d_sync + 3, s->epoch_reset, s->side));      // queued behind the list render
+            else HIP_TRY(hipEventRecord(s->ev_reset, s->side));
             s->list_valid = false;
         } else {
             if (!p.visible_radius && !queue_sync_by_epochs()) HIP_TRY(hipEventRecord(s->ev_step, st));
@@ -760,7 +771,10 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         }
         timer_end(s, s->t_render, st);
         if (!autoreset && p.visible_radius && !xw_ego_span(p)) HIP_TRY(hipStreamWaitEvent(st, s->ev_term, 0));
-        if (autoreset) HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
+        if (autoreset) {
+            if (auto_epochs) HIP_TRY(launch_xw_wait(s->d_sync + 3, s->epoch_reset, s->d_sync + 4, st));
+            else HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
+        }
     }
     s->span_step = !autoreset && xw_ego_span(s->xw);
     s->policy_step += 1;
