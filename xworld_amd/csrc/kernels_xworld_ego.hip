@@ -905,7 +905,9 @@ __device__ __forceinline__ void ego_border_body(const XwParams &p, const uint32_
 template <int CH, int R>
 __global__ __launch_bounds__(256) void xw_ego_eval_kernel(XwParams p, const uint32_t *atlas4, const EgoTap *tap_h1, const EgoTap *tap_v1,
                                                           const EgoTap *tap_h2, const EgoTap *tap_v2, const uint16_t *layout, const uint8_t *map,
-                                                          int skip_term, int nb_border, const int32_t *list_count) {
+                                                          int skip_term, int nb_border, const int32_t *list_count, int publish) {
+    // (this kernel running = the cells kernel queued before it is complete: xw_device.h, epochs instead of event packets)
+    if (publish && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 5, p.sig_epoch);
     if ((int)blockIdx.x < nb_border) ego_border_body<CH, R>(p, atlas4, tap_h1, tap_v1, tap_h2, tap_v2, map, skip_term, blockIdx.x, list_count);
     else ego_miss_body<CH, R>(p, atlas4, tap_h1, tap_v1, tap_h2, tap_v2, layout, map, (int)blockIdx.x - nb_border, (int)gridDim.x - nb_border);
 }
@@ -1127,8 +1129,9 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
 }
 
 template <int CH, int R, bool CTX1, int ES, int PER>
-__global__ __launch_bounds__(128) void xw_ego_gather_kernel(XwParams p, int skip_term) {
+__global__ __launch_bounds__(128) void xw_ego_gather_kernel(XwParams p, int skip_term, int publish) {
     typedef EgoSpanGeom<CH, R, ES, PER> G;
+    if (publish && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 7, p.sig_epoch);      // the listed frames are out
     // (chunk indices fit 32 bits: the launcher checks)
     const unsigned n_chunks = (unsigned)p.n * G::cpf, c_lo = blockIdx.x * G::SPAN;
     const unsigned e0 = c_lo / G::cpf;
@@ -1138,8 +1141,9 @@ __global__ __launch_bounds__(128) void xw_ego_gather_kernel(XwParams p, int skip
 
 // the frames of the listed envs, from what the front kernels left of them (terminal frames: p.list_flag = 1)
 template <int CH, int R, bool CTX1, int ES>
-__global__ __launch_bounds__(128) void xw_ego_gather_list_kernel(XwParams p, const int32_t *count_now) {
+__global__ __launch_bounds__(128) void xw_ego_gather_list_kernel(XwParams p, const int32_t *count_now, int publish) {
     typedef EgoSpanGeom<CH, R, ES, 2> G;
+    if (publish && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 6, p.sig_epoch);      // the evaluation kernel is through
     const int cnt = *count_now, part = blockIdx.x % G::SPE;
     for (int item = blockIdx.x / G::SPE; item < cnt; item += gridDim.x / G::SPE) {
         const int e = p.done_list[item], cr = part * G::SPAN;
@@ -1418,11 +1422,13 @@ hipError_t ego_span_render(const XwParams &p, const EgoTables &t, int mode, hipS
     const uint32_t *a4 = reinterpret_cast<const uint32_t *>(p.atlas64);
     const size_t cells = (size_t)p.max_dim * p.max_dim;
     const int skip_front = mode == 2, skip_gather = mode != 0;
+    // mode 4 without events: the hand-overs to the reset's queue are epochs, published by the kernel that FOLLOWS the producer
+    const int publish = mode == 4 && !ev_front && p.sig_epoch != 0;
     const size_t cells_lds = 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15);
     hipLaunchKernelGGL((xw_ego_cells_kernel<R, false>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, skip_front, nullptr);
     if (ev_cells) { const hipError_t e = hipEventRecord(ev_cells, s); if (e != hipSuccess) return e; }
     const int nb_border = (p.n + EGO_BORDER_EPW - 1) / EGO_BORDER_EPW;
-    hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 4096), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, skip_front, nb_border, (const int32_t *)nullptr);
+    hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 4096), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, skip_front, nb_border, (const int32_t *)nullptr, publish);
     if (ev_front) { const hipError_t e = hipEventRecord(ev_front, s); if (e != hipSuccess) return e; }
     const int es = p.obs_f32 ? 4 : 1;
     const unsigned long long n_chunks = (unsigned long long)p.n * (FB / (16 / es));
@@ -1435,10 +1441,10 @@ hipError_t ego_span_render(const XwParams &p, const EgoTables &t, int mode, hipS
     static const int per = getenv("XWB_EGO_PER") ? atoi(getenv("XWB_EGO_PER")) : 4;
     static const int pad_env = getenv("XWB_EGO_PAD") ? atoi(getenv("XWB_EGO_PAD")) : -1;
 #define EGO_PAD(ESV, PERV) (pad_env >= 0 ? pad_env : (163840 / 13 - EgoSpanGeom<CH, R, ESV, PERV>::LDS > 0 ? 163840 / 13 - EgoSpanGeom<CH, R, ESV, PERV>::LDS : 0))
-#define EGO_GATHER_BIG(CTXV, ESV, PERV) hipLaunchKernelGGL((xw_ego_gather_kernel<CH, R, CTXV, ESV, PERV>), dim3((unsigned)((n_chunks + 128 * PERV - 1) / (128 * PERV))), dim3(128), EGO_PAD(ESV, PERV), s, p, skip_gather)
+#define EGO_GATHER_BIG(CTXV, ESV, PERV) hipLaunchKernelGGL((xw_ego_gather_kernel<CH, R, CTXV, ESV, PERV>), dim3((unsigned)((n_chunks + 128 * PERV - 1) / (128 * PERV))), dim3(128), EGO_PAD(ESV, PERV), s, p, skip_gather, publish)
 #define EGO_GATHER(CTXV, ESV) do { \
         if (mode == 4) { \
-            hipLaunchKernelGGL((xw_ego_gather_list_kernel<CH, R, CTXV, ESV>), dim3(list_blocks * EgoSpanGeom<CH, R, ESV, 2>::SPE), dim3(128), 0, s, p, cnt); \
+            hipLaunchKernelGGL((xw_ego_gather_list_kernel<CH, R, CTXV, ESV>), dim3(list_blocks * EgoSpanGeom<CH, R, ESV, 2>::SPE), dim3(128), 0, s, p, cnt, publish); \
             if (ev_list) { const hipError_t e = hipEventRecord(ev_list, s); if (e != hipSuccess) return e; } \
         } \
         if (per == 2) EGO_GATHER_BIG(CTXV, ESV, 2); else EGO_GATHER_BIG(CTXV, ESV, 4); \
@@ -1496,10 +1502,10 @@ hipError_t ego_span_render_list(const XwParams &p0, const EgoTables &t, hipStrea
     const int n_cap = p.n < 16384 ? p.n : 16384;               // (workgroups beyond the list leave at once)
     hipLaunchKernelGGL((xw_ego_cells_kernel<R, true>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, 0, cnt);
     const int nb_border = (p.n + EGO_BORDER_EPW - 1) / EGO_BORDER_EPW;
-    hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 1024), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, 0, nb_border, cnt);
+    hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 1024), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, 0, nb_border, cnt, 0);
     const int es = p.obs_f32 ? 4 : 1;
     const unsigned list_blocks = (unsigned)(n_cap < 2048 ? n_cap : 2048);
-#define EGO_LIST(CTXV, ESV) hipLaunchKernelGGL((xw_ego_gather_list_kernel<CH, R, CTXV, ESV>), dim3(list_blocks * EgoSpanGeom<CH, R, ESV, 2>::SPE), dim3(128), 0, s, p, cnt)
+#define EGO_LIST(CTXV, ESV) hipLaunchKernelGGL((xw_ego_gather_list_kernel<CH, R, CTXV, ESV>), dim3(list_blocks * EgoSpanGeom<CH, R, ESV, 2>::SPE), dim3(128), 0, s, p, cnt, 0)
     if (p.context == 1) { if (es == 4) EGO_LIST(true, 4); else EGO_LIST(true, 1); }
     else { if (es == 4) EGO_LIST(false, 4); else EGO_LIST(false, 1); }
 #undef EGO_LIST

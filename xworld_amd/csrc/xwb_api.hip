@@ -82,6 +82,7 @@ struct xwb_sim {
     uint32_t *d_sync = nullptr;            // device-side epochs of the step / reset kernels (XwParams::sync)
     uint32_t epoch_step = 0, epoch_reset = 0;
     hipEvent_t ev_step = nullptr, ev_reset = nullptr, ev_term = nullptr, ev_cells = nullptr;
+    bool span_epochs = false;              // ... and handed over through epochs (d_sync[5..7]) rather than those events
     bool span_step = false;                // the last step drew its frames on the egocentric span path (ev_cells / ev_step / ev_term are its)
     // common device buffers
     int32_t *d_actions_in = nullptr;       // staging for xwb_step_host
@@ -655,10 +656,12 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
     } else if (beside_render) {
         // (span path: the map generator only has to wait for the kernel that reads the grids; the goal images are redrawn
         // once the kernels that evaluate pixels from them are through)
-        HIP_TRY(hipStreamWaitEvent(s->side, span_sync ? s->ev_cells : s->ev_step, 0));
+        if (span_sync && s->span_epochs) HIP_TRY(launch_xw_wait(s->d_sync + 5, s->epoch_step, s->d_sync + 4, s->side));
+        else HIP_TRY(hipStreamWaitEvent(s->side, span_sync ? s->ev_cells : s->ev_step, 0));
     }
     timer_begin(s, s->t_reset, rs);
-    HIP_TRY(launch_xw_reset(p, mode, rs, span_sync ? s->ev_step : nullptr));
+    if (span_sync && s->span_epochs) HIP_TRY(launch_xw_reset(p, mode, rs, nullptr, s->d_sync + 6, s->epoch_step, s->d_sync + 4));
+    else HIP_TRY(launch_xw_reset(p, mode, rs, span_sync ? s->ev_step : nullptr));
     timer_end(s, s->t_reset, rs);
     if (by_epoch) {
         HIP_TRY(launch_xw_signal(s->d_sync + 3, s->epoch_reset, s->side));     // queued behind the reset kernel
@@ -671,6 +674,15 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
         // skips these envs); only the done codes are cleared on the caller's stream, behind whatever still reads them
         p.auto_reset = 3;
         p.ego_list_beside = 1;
+        if (span_sync && s->span_epochs) {
+            HIP_TRY(launch_xw_wait(s->d_sync + 7, s->epoch_step, s->d_sync + 4, rs));      // the terminal frames of these envs are out
+            HIP_TRY(launch_xw_render(p, 1, rs));
+            if (++s->epoch_reset == 0) s->epoch_reset = 1;
+            HIP_TRY(launch_xw_signal(s->d_sync + 3, s->epoch_reset, rs));
+            HIP_TRY(launch_xw_wait(s->d_sync + 3, s->epoch_reset, s->d_sync + 4, st));
+            HIP_TRY(launch_xw_clear_done(p, st));
+            return XWB_OK;
+        }
         if (xw_ego_span(p)) HIP_TRY(hipStreamWaitEvent(rs, s->ev_term, 0));   // the terminal frames of these envs are out
         HIP_TRY(launch_xw_render(p, 1, rs));
         HIP_TRY(hipEventRecord(s->ev_reset, s->side));
@@ -765,7 +777,9 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         timer_begin(s, s->t_render, st);
         if (!autoreset && xw_ego_span(p)) {
             p.list_flag = 1;
-            HIP_TRY(launch_xw_render(p, 4, st, s->ev_step, s->ev_term, s->ev_cells));
+            s->span_epochs = queue_sync_by_epochs();
+            if (s->span_epochs) HIP_TRY(launch_xw_render(p, 4, st));          // (p.sig_epoch = this step's epoch: d_sync[5..7])
+            else HIP_TRY(launch_xw_render(p, 4, st, s->ev_step, s->ev_term, s->ev_cells));
         } else {
             HIP_TRY(launch_xw_render(p, autoreset || p.visible_radius ? 2 : 3, st));
         }
