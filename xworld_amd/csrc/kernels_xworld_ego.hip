@@ -639,10 +639,19 @@ __global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uin
     for (int i = tid; i < p.n_icons + 2; i += 256) s_cls[i] = p.ego_cls[i];
     for (int i = tid; i < 8 * R * R + 8 * R; i += 256) s_map[i] = map[i];
     if (LIST) {
+#pragma unroll 4
         for (int i = tid; i < n_here * cells; i += 256) {
             const int le = i / cells;
             s_code[i] = (uint16_t)(p.grid[(size_t)p.done_list[e_base + le] * cells + (i - le * cells)] & CELL_ICON_MASK);
         }
+    } else if (n_here == 64) {
+        // 64 consecutive grids = 128 * cells contiguous bytes, a multiple of 16: a few 16-byte loads per lane, all in flight
+        // (the element-wise loop below is a chain of a dozen dependent round trips)
+        const uint4 *g4 = reinterpret_cast<const uint4 *>(p.grid + (size_t)e_base * cells);
+        uint4 *s4 = reinterpret_cast<uint4 *>(s_code);
+        const uint32_t m2 = CELL_ICON_MASK | CELL_ICON_MASK << 16;
+#pragma unroll 4
+        for (int i = tid; i < 8 * cells; i += 256) { uint4 v = g4[i]; v.x &= m2; v.y &= m2; v.z &= m2; v.w &= m2; s4[i] = v; }
     } else {
         for (int i = tid; i < n_here * cells; i += 256) s_code[i] = (uint16_t)(p.grid[(size_t)e_base * cells + i] & CELL_ICON_MASK);
     }
@@ -651,13 +660,20 @@ __global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uin
     __syncthreads();
     for (int i = tid; i < n_here * cells; i += 256) { const int code = s_code[i]; s_type[i] = code ? s_itype[code - 1] : (uint8_t)3; }
     __syncthreads();
+    // the goal slot of a cell rides in its type byte (bits 2-5): one LDS read in the walk below instead of a search through the
+    // env's sixteen slots per visible goal (that search was a third of the kernel's instructions)
+    for (int i = tid; i < n_here * XW_MAX_GOALS; i += 256) {
+        const int le = i / XW_MAX_GOALS, slot = i - le * XW_MAX_GOALS;
+        const int cell = reinterpret_cast<const uint8_t *>(&s_gc[le])[slot];
+        if (cell < cells) s_type[le * cells + cell] |= (uint8_t)(slot << 2);
+    }
+    __syncthreads();
     if (tid >= 64) return;
     const bool active = valid && !(skip_term && term);
     const int ax = axy & 0xffff, ay = axy >> 16;
     const uint16_t *code_e = s_code + lane * cells;
     const uint8_t *type_e = s_type + lane * cells;
-    const uint8_t *gc_e = reinterpret_cast<const uint8_t *>(&s_gc[lane]);
-    auto is_block = [&](int x, int y) { return (unsigned)x < (unsigned)D && (unsigned)y < (unsigned)D && type_e[y * D + x] == 1; };
+    auto is_block = [&](int x, int y) { return (unsigned)x < (unsigned)D && (unsigned)y < (unsigned)D && (type_e[y * D + x] & 3) == 1; };
     // XMap::image_masking (xmap.cpp:273-362), as in the kernel above
     constexpr int r = R;
     int major_x = 0, major_y = 0, minor_x = 0, minor_y = 0, scan_x0 = 0, scan_y0 = 0, xa = ax + r, ya = ay + r;
@@ -710,12 +726,11 @@ __global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uin
         uint32_t info = (uint32_t)((p.n_icons + 1) * 4 + dir) | cls_black << 16;   // outside the map, or in a wall's shadow: black
         int slot = 0;
         if (active && (unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && !((shadow >> k) & 1ull)) {
-            const int code = code_e[gy * D + gx];
+            const int code = code_e[gy * D + gx], ty = type_e[gy * D + gx];
             if (code == 0) info = (uint32_t)(p.n_icons * 4 + dir) | cls_white << 16;
-            else if (type_e[gy * D + gx] != 0) info = (uint32_t)((code - 1) * 4 + dir) | (uint32_t)s_cls[code - 1] << 16;
+            else if ((ty & 3) != 0) info = (uint32_t)((code - 1) * 4 + dir) | (uint32_t)s_cls[code - 1] << 16;
             else {                                              // a goal: this env's warped copy, through the cache
-#pragma unroll
-                for (int i = 0; i < XW_MAX_GOALS; ++i) if (gc_e[i] == gy * D + gx) slot = i;
+                slot = ty >> 2;
                 info = 0x8000u | (uint32_t)slot | (uint32_t)k << 4 | 0xffu << 16;
                 if (k < 32) goal_mask_lo |= 1u << k; else goal_mask_hi |= 1u << (k - 32);
             }
@@ -757,9 +772,20 @@ __global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uin
         const int bit = (gslot[k] * r * r + k) * 4 + dir;
         vbit[k] = goal ? (valid_e[bit >> 5] >> (bit & 31)) & 1u : 1u;
     }
+    // one atomic for the wavefront's whole lot (one per view cell was up to r * r dependent round trips)
+    unsigned long long mk[r * r];
+    int total_miss = 0;
 #pragma unroll
-    for (int k = 0; k < r * r; ++k)
-        ego_wave_append(vbit[k] == 0, (uint32_t)e, (uint32_t)(k | gslot[k] << 8 | dir << 16), p.ego_miss, p.ego_miss_count);
+    for (int k = 0; k < r * r; ++k) { mk[k] = __ballot(vbit[k] == 0); total_miss += __popcll(mk[k]); }
+    if (total_miss == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(p.ego_miss_count, total_miss);
+    base = __shfl(base, 0);
+#pragma unroll
+    for (int k = 0; k < r * r; ++k) {
+        if (vbit[k] == 0) p.ego_miss[base + __popcll(mk[k] & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)e, (uint32_t)(k | gslot[k] << 8 | dir << 16));
+        base += __popcll(mk[k]);
+    }
 }
 
 // (cache entries hold the whole square of the frame the cell occupies, in EgoSq's layout; its border row / column, if it has
@@ -768,27 +794,36 @@ __global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uin
 template <int CH, int R>
 __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t *atlas4, const EgoTap *tap_h1, const EgoTap *tap_v1,
                                               const EgoTap *tap_h2, const EgoTap *tap_v2, const uint16_t *layout, const uint8_t *map,
-                                              int block, int nblocks) {
+                                              int block, int nblocks, EgoTap (*s_row)[3], EgoTap (*s_col)[3]) {
     constexpr int U = 84 / R, O = R * U, O4 = O;
     constexpr int PARTS = 4, PP = (U * U + PARTS - 1) / PARTS;       // a goal cell is shared by four workgroups: <= one pixel per lane
     static_assert(PP <= 256, "one pixel per lane");
-    __shared__ EgoTap s_row[84][3], s_col[84][3];
+    // (s_row / s_col: the kernel's, shared with the other body)
+    // The count and (speculatively) the first item come in one round trip, the taps, the flag rows of all four headings and
+    // the view-cell -> square map in the next: per goal cell the chain is item -> pixel reads -> stores
     __shared__ EgoCell s_cells[R * R];
-    const int cnt = *p.ego_miss_count, tid = threadIdx.x, part = block % PARTS;
-    if (block / PARTS >= cnt) return;
-    ego_compose_taps(s_row, s_col, tap_h1, tap_v1, tap_h2, tap_v2, O, tid, 256);
+    __shared__ uint16_t s_flags[4][2][84];                 // [heading][row terms | column terms]
+    __shared__ uint8_t s_inv[4 * R * R];
+    const int tid = threadIdx.x, part = block % PARTS, first = block / PARTS;
+    const int cap = p.n * (p.num_goals < R * R ? p.num_goals : R * R);
+    uint2 item = p.ego_miss[first < cap ? first : cap - 1];
+    const int cnt = *p.ego_miss_count;
+    if (first >= cnt) return;                              // (most workgroups: the list is short)
     const int lw = ego_layout_words(O4, R);
+    for (int i = tid; i < 4 * 2 * O; i += 256) { const int d = i / (2 * O), rem = i - d * 2 * O; s_flags[d][rem / O][rem % O] = layout[d * lw + (rem / O) * O4 + rem % O]; }
+    if (tid < 4 * R * R) s_inv[tid] = map[8 * R + 4 * R * R + tid];
+    ego_compose_taps(s_row, s_col, tap_h1, tap_v1, tap_h2, tap_v2, O, tid, 256);
     const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
-    for (int it = block / PARTS; it < cnt; it += nblocks / PARTS) {
-        const uint2 item = p.ego_miss[it];
+    for (int it = first; it < cnt; it += nblocks / PARTS) {
+        if (it != first) item = p.ego_miss[it];
         const int e = (int)item.x, k = item.y & 0xff, slot = (item.y >> 8) & 0xff, dir = (item.y >> 16) & 3;
         __syncthreads();
         // every tap that falls inside the view falls into cell k: the whole table shows the goal's image
         if (tid < R * R) s_cells[tid] = EgoCell{p.goal_img + ((size_t)e * p.num_goals + slot) * 4096, -1, -1};
         __syncthreads();
-        const int f = map[8 * R + (4 + dir) * (R * R) + k];                  // the square view cell k occupies
+        const int f = s_inv[dir * (R * R) + k];                              // the square view cell k occupies
         const int x0 = (f % R) * U, y0 = (f / R) * U;
-        const uint16_t *rt = layout + dir * lw, *ct = rt + O4;
+        const uint16_t *rt = s_flags[dir][0], *ct = s_flags[dir][1];
         EgoCtx ctx{s_cells, white, black, R, 64 * R, dir};
         const int entry = (slot * R * R + k) * 4 + dir;
         uint8_t *dst = p.ego_cache + ((size_t)e * p.num_goals * (R * R * 4) + entry) * p.ego_cache_entry;
@@ -823,11 +858,11 @@ __device__ __forceinline__ EgoCell ego_cell_of_info(const XwParams &p, const uin
 template <int CH, int R>
 __device__ __forceinline__ void ego_border_body(const XwParams &p, const uint32_t *atlas4, const EgoTap *tap_h1, const EgoTap *tap_v1,
                                                 const EgoTap *tap_h2, const EgoTap *tap_v2, const uint8_t *map, int skip_term, int block,
-                                                const int32_t *count_now) {
+                                                const int32_t *count_now, EgoTap (*s_row)[3], EgoTap (*s_col)[3]) {
     constexpr int U = 84 / R, O = R * U, EPW = EGO_BORDER_EPW, NL = 2 * (R - 1);
     constexpr int NSEG = R * (R - 1), NITEM = 2 * NSEG + (R - 1) * (R - 1);   // row runs, column runs, crossings
     constexpr int RL = 4 * R * R, CL = RL + 4 * R;
-    __shared__ EgoTap s_row[84][3], s_col[84][3];
+    // (s_row / s_col: the kernel's, shared with the other body)
     __shared__ EgoCell s_cells[EPW][R * R];
     __shared__ uint8_t s_goal[EPW][R * R];               // view cell shows a goal
     __shared__ uint8_t s_map[4 * R * R + 8 * R], s_edir[EPW];
@@ -908,8 +943,9 @@ __global__ __launch_bounds__(256) void xw_ego_eval_kernel(XwParams p, const uint
                                                           int skip_term, int nb_border, const int32_t *list_count, int publish) {
     // (this kernel running = the cells kernel queued before it is complete: xw_device.h, epochs instead of event packets)
     if (publish && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 5, p.sig_epoch);
-    if ((int)blockIdx.x < nb_border) ego_border_body<CH, R>(p, atlas4, tap_h1, tap_v1, tap_h2, tap_v2, map, skip_term, blockIdx.x, list_count);
-    else ego_miss_body<CH, R>(p, atlas4, tap_h1, tap_v1, tap_h2, tap_v2, layout, map, (int)blockIdx.x - nb_border, (int)gridDim.x - nb_border);
+    __shared__ EgoTap s_row[84][3], s_col[84][3];         // composed taps: one copy for whichever body this workgroup runs
+    if ((int)blockIdx.x < nb_border) ego_border_body<CH, R>(p, atlas4, tap_h1, tap_v1, tap_h2, tap_v2, map, skip_term, blockIdx.x, list_count, s_row, s_col);
+    else ego_miss_body<CH, R>(p, atlas4, tap_h1, tap_v1, tap_h2, tap_v2, layout, map, (int)blockIdx.x - nb_border, (int)gridDim.x - nb_border, s_row, s_col);
 }
 
 // ego_tab3: the squares of every constant-image neighbourhood.  Entry (heading, c, a, l, channel, square) = the pixels of that
