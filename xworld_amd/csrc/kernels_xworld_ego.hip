@@ -11,14 +11,16 @@
 // (cv::resize: 11-bit coefficients, the intermediate image rounded to 8 bits exactly as OpenCV does) of 2 x 2 pixels of
 // the intermediate image, each of which blends 2 x 2 view pixels; a view pixel is found by undoing the quarter-turn view
 // rotation (exact integer map, one border row / column), the cell lookup, and for goals the inverse affine warp with
-// cv::remap's 5-bit sub-pixel bilinear weights.  One workgroup renders one env; the frame is assembled in LDS and
-// leaves as aligned 16-byte stores.  Evaluating all 84^2 pixels that way is instruction-bound (16 view pixels and ~400
-// VALU operations each), so only the pixels that need it are: an output pixel whose 4 x 4 view pixels all lie inside
-// ONE view cell depends on nothing but that cell's image, its position in the frame and the heading, and for blocks,
-// the agent, empty cells and black cells that image is one of a few constants.  xw_ego_build_tab_kernel renders, once
-// per batch, the frame "every cell shows icon i" for each icon and heading with the very same pixel code; the render
-// copies interior pixels from those frames (4 pixels per load, through L2) and evaluates only the pixels on a cell
-// border and the pixels of goal cells (whose images are per env: pose-warped).
+// cv::remap's 5-bit sub-pixel bilinear weights.  Evaluating all 84^2 pixels that way is instruction-bound (16 view pixels
+// and ~400 VALU operations each), so only the pixels that need it are: an output pixel whose 4 x 4 view pixels all lie
+// inside ONE view cell depends on nothing but that cell's image, its position in the frame and the heading, and for
+// blocks, the agent, empty cells and black cells that image is one of a few constants.
+//
+// Two renders share that pixel code (both bit-exact against the oracle and against each other):
+//   - the SPAN PATH (second half of this file; r = 3, 5, 7): cell table -> evaluated pixels -> a gather of 16-byte pieces
+//     from tables of whole squares; what draws the whole batch and the done list whenever the geometry allows;
+//   - ONE WORKGROUP PER ENV (xw_render_ego_kernel, first half; round 1's kernel and the fallback): the frame is assembled in
+//     LDS from table frames "every cell shows icon i" (xw_ego_build_tab_kernel) plus evaluated border pixels and goal cells.
 //
 // OpenCV 3.2 arithmetic restated (third party, cmake/opencv.cmake:5-6; DESIGN.md lists the pieces): the tests compare
 // this kernel bit for bit with a CPU restatement of the same pipeline; pixel parity with the real library is unpinned.
