@@ -301,6 +301,16 @@ int xwb_set_names(xwb_sim *sim, const char *const *goal_names, int32_t n_goal_na
  * Returns the bytes needed in *need; writes when cap suffices.  Needs xwb_set_names.  Synchronises `stream`. */
 int xwb_sentence(xwb_sim *sim, int32_t env, void *stream, char *out, size_t cap, size_t *need);
 
+/* The sentence functions behind xwb_sentence, callable without a batch or a GPU (host only; tests pin them to
+ * xworld_amd/language.py, which is pinned to the reference's CFG): a 3-D task's sentence from its state (stage, event as in
+ * xwb_env_state; name ids into goal_names, 0xffff none; direction 1 front, 2 behind, 3 left, 4 right), and a 2-D-native
+ * task's instruction (task 5 / 7; timeup != 0: its "Time up ." message).  NUL-terminated; *need = bytes needed. */
+int xwb_language_sentence(int32_t task, int32_t stage, int32_t event, const char *const *goal_names, int32_t n_goal_names,
+                          uint32_t name_a, uint32_t name_b, int32_t direction, uint32_t seed, uint32_t gid, uint32_t episode,
+                          char *out, size_t cap, size_t *need);
+int xwb_language_sentence_2d(int32_t task, int32_t timeup, const char *goal_name, const char *color, uint32_t seed, uint32_t gid,
+                             uint32_t episode, uint32_t num_steps, char *out, size_t cap, size_t *need);
+
 /* SimulatorInterface::get_state(reward) of one env, serialised in the reference's StatePacket wire
  * layout (data_packet.h:313-319, data_packet.cpp:143-174, memory_util.h:307-333): keys "reward",
  * "screen" [, "sentence" for xworld].  Returns bytes needed in *need; writes when cap suffices.

@@ -1677,6 +1677,29 @@ int xwb_sentence(xwb_sim *s, int32_t env, void *stream, char *out, size_t cap, s
     return XWB_OK;
 }
 
+static int copy_out(const std::string &str, char *out, size_t cap, size_t *need) {
+    *need = str.size() + 1;
+    if (out && cap >= str.size() + 1) memcpy(out, str.c_str(), str.size() + 1);
+    return XWB_OK;
+}
+
+int xwb_language_sentence(int32_t task, int32_t stage, int32_t event, const char *const *goal_names, int32_t n_goal_names,
+                          uint32_t name_a, uint32_t name_b, int32_t direction, uint32_t seed, uint32_t gid, uint32_t episode,
+                          char *out, size_t cap, size_t *need) {
+    if (!need || (n_goal_names > 0 && !goal_names) || n_goal_names < 0) return fail(XWB_ERR_ARG, "NULL argument");
+    std::vector<std::string> names;
+    for (int i = 0; i < n_goal_names; ++i) { if (!goal_names[i]) return fail(XWB_ERR_ARG, "NULL name"); names.push_back(goal_names[i]); }
+    return copy_out(xwb::lang::sentence(task, stage, event, names, name_a, name_b, direction, seed, gid, episode), out, cap, need);
+}
+
+int xwb_language_sentence_2d(int32_t task, int32_t timeup, const char *goal_name, const char *color, uint32_t seed, uint32_t gid,
+                             uint32_t episode, uint32_t num_steps, char *out, size_t cap, size_t *need) {
+    if (!need) return fail(XWB_ERR_ARG, "NULL argument");
+    if (timeup) return copy_out(xwb::lang::sentence_2d_timeup(task), out, cap, need);
+    if (!goal_name || !color) return fail(XWB_ERR_ARG, "NULL argument");
+    return copy_out(xwb::lang::sentence_2d(task, goal_name, color, seed, gid, episode, num_steps), out, cap, need);
+}
+
 int xwb_get_state_packet(xwb_sim *s, int32_t env, float reward, void *stream, uint8_t *out_host, size_t cap,
                          size_t *need) {
     if (!s || !need) return fail(XWB_ERR_ARG, "NULL argument");

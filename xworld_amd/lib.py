@@ -87,6 +87,10 @@ _SIGS = [
     ("xwb_ego_render_path", C.c_int, [_vp, C.POINTER(C.c_int32)]),
     ("xwb_set_names", C.c_int, [_vp, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int32]),
     ("xwb_sentence", C.c_int, [_vp, C.c_int32, _vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("xwb_language_sentence", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.c_int32, C.c_uint32, C.c_uint32, C.c_int32,
+                                        C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("xwb_language_sentence_2d", C.c_int, [C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                           C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("xwb_minstd_seed_thread", C.c_uint32, [C.c_int32, C.c_int32]),
     ("xwb_minstd_rand_ind", C.c_int32, [C.POINTER(C.c_uint32), C.c_int32]),
     ("xwb_minstd_rand_range", C.c_float, [C.POINTER(C.c_uint32), C.c_float]),
