@@ -618,8 +618,10 @@ __device__ __forceinline__ void ego_wave_append(bool flag, uint32_t a, uint32_t 
 // 64 envs per workgroup: all four wavefronts stage their grids (and the entity types) in LDS, the first one then walks them
 // LIST: the envs of the done list (the frames of new episodes, drawn on the reset's queue) instead of the whole batch
 template <int R, bool LIST>
-__global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uint8_t *map, int skip_term, const int32_t *count_now) {
+__global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uint8_t *map, int skip_term, const int32_t *count_now, int publish_step) {
     extern __shared__ uint4 smem4[];
+    // (xwb_step_autoreset: this kernel running = the step kernel before it is complete; the reset's queue waits for that)
+    if (publish_step && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 1, p.sig_epoch);
     const int D = p.max_dim, cells = D * D, tid = threadIdx.x, lane = tid;
     uint16_t *s_code = reinterpret_cast<uint16_t *>(smem4);                // [64][cells]
     uint8_t *s_type = reinterpret_cast<uint8_t *>(s_code + 64 * cells);    // [64][cells] type of the entity in a cell, 3 = none
@@ -1463,7 +1465,7 @@ hipError_t ego_span_render(const XwParams &p, const EgoTables &t, int mode, hipS
     // mode 4 without events: the hand-overs to the reset's queue are epochs, published by the kernel that FOLLOWS the producer
     const int publish = mode == 4 && !ev_front && p.sig_epoch != 0;
     const size_t cells_lds = 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15);
-    hipLaunchKernelGGL((xw_ego_cells_kernel<R, false>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, skip_front, nullptr);
+    hipLaunchKernelGGL((xw_ego_cells_kernel<R, false>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, skip_front, nullptr, mode == 2 && p.sig_epoch != 0);
     if (ev_cells) { const hipError_t e = hipEventRecord(ev_cells, s); if (e != hipSuccess) return e; }
     const int nb_border = (p.n + EGO_BORDER_EPW - 1) / EGO_BORDER_EPW;
     hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 4096), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, skip_front, nb_border, (const int32_t *)nullptr, publish);
@@ -1538,7 +1540,7 @@ hipError_t ego_span_render_list(const XwParams &p0, const EgoTables &t, hipStrea
     const int32_t *cnt = (const int32_t *)p.done_count;
     const size_t cells_lds = 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15);
     const int n_cap = p.n < 16384 ? p.n : 16384;               // (workgroups beyond the list leave at once)
-    hipLaunchKernelGGL((xw_ego_cells_kernel<R, true>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, 0, cnt);
+    hipLaunchKernelGGL((xw_ego_cells_kernel<R, true>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, 0, cnt, 0);
     const int nb_border = (p.n + EGO_BORDER_EPW - 1) / EGO_BORDER_EPW;
     hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 1024), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, 0, nb_border, cnt, 0);
     const int es = p.obs_f32 ? 4 : 1;

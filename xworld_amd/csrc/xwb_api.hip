@@ -740,7 +740,8 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
             // (full observation: the hand-overs are epochs in device memory, as in xwb_reset_done -- the side queue's first
             // kernel waits for the step kernel's epoch, which the render publishes; a one-wavefront kernel at the end of
             // this call waits for the side queue's)
-            auto_epochs = queue_sync_by_epochs() && !p.visible_radius;
+            // (egocentric: only on the span path, whose cells kernel publishes the step epoch)
+            auto_epochs = queue_sync_by_epochs() && (!p.visible_radius || xw_ego_span(p));
             if (auto_epochs) {
                 HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->d_sync + 4, s->side));
                 if (++s->epoch_reset == 0) s->epoch_reset = 1;
