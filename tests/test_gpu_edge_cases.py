@@ -206,19 +206,26 @@ def test_batch_copy_out_functions():
     sim.close()
 
 
-def test_queue_sync_modes_agree_and_pmc_env_falls_back():
+@pytest.mark.parametrize("extra", ["", ", 'visible_radius': 3"], ids=["full", "ego"])
+def test_queue_sync_modes_agree_and_pmc_env_falls_back(extra):
     """The step loop's two queues hand over through device-side epochs by default and through events when a tool that
-    serialises kernels is in sight (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION): both give the same rollout."""
+    serialises kernels is in sight (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION): both give the same rollout --
+    step + reset_done and step_autoreset, full observation and the egocentric span path (frames hashed every step)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys, os, hashlib; sys.path.insert(0, %r); import torch\n"
             "from xworld_amd.batched import BatchedSimulator\n"
             "conf = os.path.join(%r, 'xworld_amd', 'confs', 'navigation2d.json')\n"
-            "sim = BatchedSimulator('xworld', {'xwd_conf_path': conf, 'task_mode': 'lang_acquisition', 'max_dim': 7, 'color': True}, num_envs=4096, seed=3, policy_seed=4)\n"
+            "sim = BatchedSimulator('xworld', {'xwd_conf_path': conf, 'task_mode': 'lang_acquisition', 'max_dim': 7, 'color': True" + extra + "}, num_envs=4096, seed=3, policy_seed=4)\n"
             "h = hashlib.sha256()\n"
             "for t in range(150):\n"
-            "    sim.step(); h.update(sim.reward.cpu().numpy().tobytes()); h.update(sim.game_over_codes.cpu().numpy().tobytes()); sim.reset_done()\n"
+            "    if t %% 4 == 3:\n"
+            "        sim.step_autoreset(); h.update(sim.obs.cpu().numpy().tobytes())\n"
+            "    else:\n"
+            "        sim.step(); h.update(sim.obs.cpu().numpy().tobytes())\n"
+            "    h.update(sim.reward.cpu().numpy().tobytes()); h.update(sim.game_over_codes.cpu().numpy().tobytes())\n"
+            "    if t %% 4 != 3: sim.reset_done()\n"
             "h.update(sim.obs.cpu().numpy().tobytes()); assert sim.check_errors() == 0; print(h.hexdigest())\n") % (root, root)
     outs = []
     for env in ({"XWB_QUEUE_SYNC": "epochs"}, {"XWB_QUEUE_SYNC": "events"}, {"ROCPROF_COUNTER_COLLECTION": "1"}):
