@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define XWB_ABI_VERSION 2
+#define XWB_ABI_VERSION 3
 
 enum {
     XWB_OK = 0,
@@ -144,10 +144,27 @@ typedef struct xwb_config {
     int32_t  task_schedule2;
     double   task_weights2[8];
     int32_t  task_groups_exclusive;  /* FLAGS_task_groups_exclusive (teacher.cpp:22-24).  task_mode lang_acquisition forces it
-                                      * off exactly as the reference does (simulator_interface.cpp:46-48); with one group it
-                                      * changes nothing; exclusive scheduling of TWO groups (weighted group shuffle, one group
-                                      * per teach(), 3-D idle stages in mid-episode) is not built: xwb_create refuses it */
+                                      * off exactly as the reference does (simulator_interface.cpp:46-48).  Set: Teacher::teach's
+                                      * exclusive branch (teacher.cpp:209-220) -- every teach() first re-sorts the groups by
+                                      * weighted sampling without replacement (nondeterministic_sort_task_groups, :143-163; the
+                                      * order persists from call to call), then runs ONE group's stage: the last busy group of
+                                      * that order, else its first.  An idle XWorld3DNav* group picked in mid-episode runs its
+                                      * map-rearranging idle stage at step time. */
+    double   task_group_weight;      /* the groups' "weight" keys of the conf JSON (teacher.cpp:83-91; 0 when absent), read by */
+    double   task_group_weight2;     /* the exclusive branch's shuffle only */
+    int32_t  queue_sync;             /* XWB_QUEUE_SYNC_*: how the batch's two internal queues hand over inside a step (see
+                                      * xwb_queue_sync_mode) */
 } xwb_config;
+
+/* xwb_config.queue_sync.  AUTO: device-side epochs (no event / barrier packets: 12 us per step on the C4 loop) on every caller
+ * stream that passes a one-time concurrency probe against the batch's internal stream, events otherwise (the probe fails when
+ * the two streams share one hardware queue -- HIP multiplexes streams onto GPU_MAX_HW_QUEUES queues -- or when a tool
+ * serialises kernel execution); the environment variable XWB_QUEUE_SYNC=events|epochs and the presence of a serialising tool
+ * (rocprofv3 counter collection, AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING) override AUTO.  EVENTS / EPOCHS force one mode. */
+enum { XWB_QUEUE_SYNC_AUTO = 0, XWB_QUEUE_SYNC_EVENTS = 1, XWB_QUEUE_SYNC_EPOCHS = 2 };
+/* why xwb_queue_sync_mode reports the mode it reports */
+enum { XWB_SYNC_REASON_PROBE_OK = 0, XWB_SYNC_REASON_CONFIG = 1, XWB_SYNC_REASON_ENV = 2, XWB_SYNC_REASON_TOOL = 3,
+       XWB_SYNC_REASON_PROBE_FAILED = 4, XWB_SYNC_REASON_PROBE_ERROR = 5, XWB_SYNC_REASON_NOT_USED = 6 };
 
 typedef struct xwb_sim xwb_sim;
 
@@ -199,8 +216,22 @@ int xwb_step_autoreset(xwb_sim *sim, const int32_t *actions_dev, int32_t act_rep
  * step's reward, code and observation written exactly as separate launches would; XWorld2D loops on the host. */
 int xwb_step_n(xwb_sim *sim, int32_t n_steps, int32_t act_rep, void *stream);
 
-/* returns the number of envs that flagged an out-of-range action since the last call (synchronises stream) */
+/* returns the number of envs that flagged an out-of-range action since the last call (synchronises stream).
+ * Fails with XWB_ERR_STATE when the batch is poisoned (see xwb_queue_sync_mode). */
 int xwb_check_errors(xwb_sim *sim, void *stream, int32_t *n_bad);
+
+/* How the batch hands work between the caller's `stream` and its internal stream: *mode = XWB_QUEUE_SYNC_EVENTS or
+ * XWB_QUEUE_SYNC_EPOCHS for calls made on `stream` (runs the one-time probe of that stream if it has not run yet: synchronises
+ * it), *reason = XWB_SYNC_REASON_* (NOT_USED: the game has no internal stream).  Safety of the epoch hand-off: (1) the kernel
+ * that publishes an epoch is always enqueued before the kernel that waits for it, so streams that turn out to share a hardware
+ * queue, or kernels serialised in submission order, cannot deadlock; (2) the probe; (3) a device-side watchdog: a wait that is
+ * not released within 4 s POISONS the batch -- the queues drain, and every later verb of the batch (step, reset, getters,
+ * xwb_check_errors) fails with XWB_ERR_STATE; results since the last successful xwb_check_errors are void and the batch can
+ * only be destroyed.  Returns XWB_ERR_STATE itself when the batch is poisoned. */
+int xwb_queue_sync_mode(xwb_sim *sim, void *stream, int32_t *mode, int32_t *reason);
+/* test hook: enqueue on `stream` a wait for an epoch nobody publishes, with a watchdog of budget_us microseconds -- the
+ * batch is poisoned once it expires (tests/test_gpu_queue_sync.py) */
+int xwb_debug_stall_handoff(xwb_sim *sim, void *stream, int64_t budget_us);
 
 /* ---- observation / result buffers (device pointers, valid until xwb_destroy) ---- */
 /* "screen" of get_state(): [num_envs][context][c][h][w]; uint8 for simple_game / xworld (planar B,G,R),
@@ -210,7 +241,7 @@ int xwb_obs_dev(xwb_sim *sim, void **ptr, size_t *bytes_per_env);
  * float[num_envs][2] in caller-owned device memory (NULL = off) -- one buffer to ship per step (sharding.ResultGather). */
 int xwb_bind_results(xwb_sim *sim, float *packed_dev);
 /* The same with a ring of `slots` such buffers, float[slots][num_envs][2]: the k-th step call after the bind writes slot
- * k % slots (one xwb_step_n launch = one call: the slot keeps its last step).  A per-step record of a rollout without a
+ * k % slots (one xwb_step_n call = one slot for every game: each of its steps writes it, the last one stays).  A per-step record of a rollout without a
  * host call or a copy kernel per step -- bench.py's parity gate and the pipelined result exchange read it (SURVEY 8(d):
  * "parity gates reported with every perf number"). */
 int xwb_bind_results_ring(xwb_sim *sim, float *packed_dev, int64_t slots);

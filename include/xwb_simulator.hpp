@@ -164,6 +164,7 @@ class BatchedSimulator {
     // xworld: the strings behind the palette's name ids (goal names by id; per icon its name and colour, "na" = none): with
     // them get_state()'s "sentence" is the teacher's sentence, without them "-"
     void set_names(const std::vector<std::string> &goal_names, const std::vector<std::string> &icon_names, const std::vector<std::string> &icon_colors) {
+        if (icon_names.size() != icon_colors.size()) throw Error("set_names: one colour per icon name");
         std::vector<const char *> g, n, c;
         for (const std::string &x : goal_names) g.push_back(x.c_str());
         for (const std::string &x : icon_names) n.push_back(x.c_str());

@@ -45,7 +45,7 @@ enum { ORC_ALIVE = 0, ORC_MAX_STEP = 1, ORC_DEAD = 2, ORC_SUCCESS = 4, ORC_LOST_
 
 /* ---------------------------------------------------------------- RNG ---- */
 /* libstdc++ minstd_rand0 + distributions as used by simulator_util.cpp:38-73 */
-/* ---- trig.c: cos / sin of the SimpleRace and goal-warp call sites: include/xwb_trig.h (default) or the host's libm ---- */
+/* ---- trig.c: cos / sin of the SimpleRace and goal-warp call sites: the host's libm (default) or include/xwb_trig.h ---- */
 void   orc_set_trig_libm(int on);
 int    orc_get_trig_libm(void);
 double orc_trig_cos(double x);

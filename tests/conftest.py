@@ -18,3 +18,14 @@ def oracle():
     import _oracle
     _oracle.lib()
     return _oracle
+
+
+@pytest.fixture(params=["libm", "xwb_trig"])
+def trig(request, oracle):
+    """cos / sin of the oracle's SimpleRace and goal-warp call sites: the host's libm (the oracle's default: a checker that
+    shares no arithmetic with the HIP kernels) or include/xwb_trig.h (the kernels' own definition).  Tests that take this
+    fixture run against both; everything else runs against libm."""
+    L = oracle.lib()
+    L.orc_set_trig_libm(1 if request.param == "libm" else 0)
+    yield request.param
+    L.orc_set_trig_libm(1)

@@ -166,18 +166,58 @@ def test_ego_frames_with_host_poses(oracle, key, r, color, context):
     sim.close()
 
 
-def test_ego_frames_device_poses(oracle):
-    """The same with poses drawn by the reset kernel: the warp matrix comes from include/xwb_trig.h's cos / sin on the
-    device and in the oracle alike, so the frames are equal byte for byte."""
+def test_ego_frames_device_poses(oracle, trig):
+    """The same with poses drawn by the reset kernel: its warp matrix comes from include/xwb_trig.h's cos / sin, the
+    oracle's from the host's libm (trig = libm: a checker that shares no arithmetic with the kernel) or from the same
+    header (trig = xwb_trig).  Frames are equal byte for byte either way -- the warp narrows the matrix to 1/1024-pixel
+    fixed point --; differing envs / pixels are counted over the whole batch and reported."""
     _torch()
-    n = 512
+    n = 2048
     sim, pal, cfg = _make(oracle, "nav7", n, 3, seed=23, color=True)
     ow = oracle.XWorld(pal, render=True, **cfg)
     obs = sim.obs.cpu().numpy()
+    bad_envs = bad_px = 0
     for e in range(n):
         ow.reset_game(e, 0)
-        assert np.array_equal(obs[e], ow.state_screen()), e
+        d = int((obs[e] != ow.state_screen()).sum())
+        bad_envs += d > 0
+        bad_px += d
     sim.close()
+    assert bad_envs == 0, "trig=%s: %d of %d first frames differ (%d bytes)" % (trig, bad_envs, n, bad_px)
+
+
+def test_ego_rollout_frames_device_poses(oracle, trig):
+    """... and through a rollout with resets: every frame of 160 envs over 100 steps (each reset draws new goal poses on the
+    device), rewards and codes, against the libm oracle and the xwb_trig one."""
+    torch = _torch()
+    n, steps = 160, 100
+    sim, pal, cfg = _make(oracle, "nav7", n, 3, seed=29, policy_seed=6, color=True)
+    envs = [oracle.XWorld(pal, render=True, **cfg) for _ in range(n)]
+    ep = [0] * n
+    for e, w in enumerate(envs):
+        w.reset_game(e, 0)
+    bad_frames = bad_px = resets = 0
+    for t in range(steps):
+        obs = sim.obs.cpu().numpy()
+        for e, w in enumerate(envs):
+            d = int((obs[e] != w.state_screen()).sum())
+            bad_frames += d > 0
+            bad_px += d
+        sim.step()
+        acts = sim.actions.cpu().numpy()
+        rew = sim.reward.cpu().numpy()
+        codes = sim.game_over_codes.cpu().numpy()
+        for e, w in enumerate(envs):
+            assert np.float32(w.take_actions(int(acts[e]))) == rew[e] and w.game_over() == codes[e], (t, e)
+        sim.reset_done()
+        for e, w in enumerate(envs):
+            if codes[e]:
+                ep[e] += 1
+                resets += 1
+                w.reset_game(e, ep[e])
+    sim.close()
+    assert resets > 15
+    assert bad_frames == 0, "trig=%s: %d of %d frames differ (%d bytes)" % (trig, bad_frames, n * steps, bad_px)
 
 
 def test_ego_curriculum_fewer_goals_than_levels_place(oracle):

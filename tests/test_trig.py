@@ -1,4 +1,4 @@
-"""include/xwb_trig.h, the one deterministic sin / cos shared by the HIP kernels and the oracle, against the host's libm --
+"""include/xwb_trig.h, the deterministic sin / cos of the HIP kernels, against the host's libm (the oracle's default) --
 what replacing the reference's libm calls (simple_race_simulator.cpp:227-243,386-430; xitem.cpp:47-60 -> cv::getRotationMatrix2D)
 changes on the arguments the path can produce.  CPU only."""
 import ctypes as C
@@ -63,8 +63,8 @@ def test_simple_race_same_bits_with_libm(oracle):
             assert np.array_equal(a.codes, b.codes) and np.array_equal(a.obs_ck, b.obs_ck), kw
             assert a.stats.resets > 100
     finally:
-        L.orc_set_trig_libm(0)
-    assert L.orc_get_trig_libm() == 0
+        L.orc_set_trig_libm(1)
+    assert L.orc_get_trig_libm() == 1
 
 
 def test_goal_warps_same_pixels_with_libm(oracle):
@@ -97,4 +97,4 @@ def test_goal_warps_same_pixels_with_libm(oracle):
             mdiff += ma != mb
         print("rotation matrices that differ in some last bit: %d of 1500" % mdiff)
     finally:
-        L.orc_set_trig_libm(0)
+        L.orc_set_trig_libm(1)

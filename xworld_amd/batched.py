@@ -54,6 +54,11 @@ class BatchedSimulator:
         cfg.rng_mode = 1 if rng == "minstd" else 0
         cfg.simulator_seed = int(opts.get("simulator_seed", 0))
         cfg.thread_base = int(opts.get("thread_base", 0))
+        # how the batch's two internal queues hand over (include/xwb.h XWB_QUEUE_SYNC_*; not a reference option)
+        qs = opts.get("queue_sync", "auto")
+        if qs not in ("auto", "events", "epochs"):
+            raise RuntimeError("queue_sync must be 'auto', 'events' or 'epochs'")
+        cfg.queue_sync = ("auto", "events", "epochs").index(qs)
         self.palette = None
         self._keep = []
         if name == "simple_game":
@@ -213,6 +218,12 @@ class BatchedSimulator:
         n = C.c_int32()
         lib.check(self.L.xwb_check_errors(self.h, self._stream(stream), C.byref(n)))
         return n.value
+
+    def queue_sync_mode(self, stream=None):
+        """("events" | "epochs", reason) for calls made on `stream` (xwb_queue_sync_mode; probes the stream once)."""
+        m, r = C.c_int32(), C.c_int32()
+        lib.check(self.L.xwb_queue_sync_mode(self.h, self._stream(stream), C.byref(m), C.byref(r)))
+        return ("events" if m.value == lib.XWB_QUEUE_SYNC_EVENTS else "epochs"), lib.SYNC_REASONS[r.value]
 
     def done_count(self, stream=None):
         n = C.c_int32()

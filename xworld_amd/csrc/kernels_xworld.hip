@@ -266,12 +266,15 @@ hipError_t launch_xw_step(const XwParams &p, hipStream_t s) {
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(64) void xw_wait_kernel(const uint32_t *epoch_slot, uint32_t want, uint32_t *timeout_flag) {
-    xw_wait_epoch(epoch_slot, want, timeout_flag);
+__global__ __launch_bounds__(64) void xw_wait_kernel(const uint32_t *epoch_slot, uint32_t want, uint32_t *poison, uint32_t *poison_host,
+                                                      unsigned long long budget) {
+    xw_wait_epoch(epoch_slot, want, poison, poison_host, budget);
 }
 
-hipError_t launch_xw_wait(const uint32_t *epoch_slot, uint32_t want, uint32_t *timeout_flag, hipStream_t s) {
-    hipLaunchKernelGGL(xw_wait_kernel, dim3(1), dim3(64), 0, s, epoch_slot, want, timeout_flag);
+hipError_t launch_xw_wait(const uint32_t *epoch_slot, uint32_t want, uint32_t *poison, uint32_t *poison_host, hipStream_t s,
+                          unsigned long long budget_ticks) {
+    hipLaunchKernelGGL(xw_wait_kernel, dim3(1), dim3(64), 0, s, epoch_slot, want, poison, poison_host,
+                       budget_ticks ? budget_ticks : XW_WATCHDOG_TICKS);
     return hipGetLastError();
 }
 
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
     // the kernels that publish the epoch need wave slots of their own.  render_list() therefore launches at most half the
     // machine's wave slots when a wait is attached (a batch whose envs all finish on one step otherwise parks one spinning
     // workgroup in every slot: seen as a 4 s stall on the 8x8 workload, where many envs time out on the same step).
-    if (p.wait_epoch) xw_wait_epoch(p.sync + 3, p.wait_epoch, p.sync + 4);
+    if (p.wait_epoch) xw_wait_epoch(p.sync + 3, p.wait_epoch, p.sync + 4, p.poison_host);
     for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
         const int e = i == (int)blockIdx.x ? e_first : p.done_list[i];
         __syncthreads();

@@ -68,16 +68,29 @@ __device__ __forceinline__ void xw_publish_epoch(uint32_t *epoch_slot, uint32_t 
 }
 
 // Wait (one lane spins, the workgroup follows through the barrier) until *epoch_slot has reached `want` (wrap-safe).
-// The publisher runs on another queue: this only terminates when the two queues really execute concurrently.  Tools that
-// serialise kernel execution (rocprofv3 --pmc, AMD_SERIALIZE_KERNEL) break that; the host falls back to events when it
-// sees them (xwb_api.hip: queue_sync_by_epochs), and as a last resort the spin gives up after ~4 s of wall clock, raises
-// `timeout_flag` (reported by xwb_check_errors) and lets the queue drain instead of hanging the device.
-__device__ __forceinline__ void xw_wait_epoch(const uint32_t *epoch_slot, uint32_t want, uint32_t *timeout_flag) {
+// Host-side invariant (xwb_api.hip): the kernel that publishes an epoch is ALWAYS enqueued before the kernel that waits for
+// it, so two streams that share one in-order hardware queue (HIP multiplexes streams onto GPU_MAX_HW_QUEUES queues), or a tool
+// that serialises kernels in submission order, run publisher-then-waiter and the loop never spins; only when the queues run
+// concurrently does the waiter poll, and then its publisher is already in flight.  Each (batch, caller stream) pair is also
+// probed once for real concurrency before epochs are used on it (epoch_selftest), events being the fallback.
+// Watchdog: a spin that still has not been released after `budget` ticks of the 100 MHz wall clock (default 4 s) POISONS the
+// batch -- *poison (device) and *poison_host (pinned host memory the library reads without a sync) are raised, every later
+// verb of the batch fails with XWB_ERR_STATE, and every later wait returns at once so the queues drain instead of hanging.
+constexpr unsigned long long XW_WATCHDOG_TICKS = 400000000ull;
+__device__ __forceinline__ void xw_wait_epoch(const uint32_t *epoch_slot, uint32_t want, uint32_t *poison, uint32_t *poison_host,
+                                              unsigned long long budget = XW_WATCHDOG_TICKS) {
     if (threadIdx.x == 0) {
-        const unsigned long long t0 = wall_clock64();                  // 100 MHz
-        while ((int32_t)(__hip_atomic_load(epoch_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-            __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > 400000000ull) { atomicExch(timeout_flag, 1u); break; }
+        if ((int32_t)(__hip_atomic_load(epoch_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0 &&
+            __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            const unsigned long long t0 = wall_clock64();                  // 100 MHz
+            while ((int32_t)(__hip_atomic_load(epoch_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                __builtin_amdgcn_s_sleep(8);
+                if (wall_clock64() - t0 > budget) {
+                    atomicExch(poison, 1u);
+                    if (poison_host) __hip_atomic_store(poison_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }

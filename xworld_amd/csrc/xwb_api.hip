@@ -81,6 +81,15 @@ struct xwb_sim {
     uint32_t *d_minstd = nullptr;          // XWB_RNG_MINSTD: one engine state per env
     uint32_t *d_sync = nullptr;            // device-side epochs of the step / reset kernels (XwParams::sync)
     uint32_t epoch_step = 0, epoch_reset = 0;
+    // queue hand-off mode (include/xwb.h xwb_queue_sync_mode): decided per caller stream by a one-time probe
+    struct StreamProbe { hipStream_t st; bool ok; int reason; };
+    std::vector<StreamProbe> probes;
+    int sync_reason = XWB_SYNC_REASON_NOT_USED;
+    bool step_epochs = false;              // the last step call's hand-overs were epochs (a following reset_done follows suit:
+                                           // its waiters wait for what that step's kernels publish)
+    uint32_t probe_token = 0;
+    uint32_t *h_poison = nullptr;          // pinned host word: a watchdog expired (XwParams::poison_host points at it)
+    bool poisoned = false;
     hipEvent_t ev_step = nullptr, ev_reset = nullptr, ev_term = nullptr, ev_cells = nullptr;
     bool span_epochs = false;              // ... and handed over through epochs (d_sync[5..7]) rather than those events
     bool span_step = false;                // the last step drew its frames on the egocentric span path (ev_cells / ev_step / ev_term are its)
@@ -154,23 +163,83 @@ int dev_alloc(xwb_sim *s, T **p, size_t count, int fill = 0) {
 
 hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
-// The step loop's two queues hand over through epochs in device memory (XwParams::sync): kernels of one queue spin until a
-// kernel of the other has run, which needs the queues to execute concurrently.  Tools that serialise kernel execution make
-// that a deadlock, so events / barrier packets (3-6 us of idle GPU each) are used instead when one is in sight:
-// rocprofv3's counter collection (ROCPROF_COUNTER_COLLECTION / ROCPROF_COUNTERS), AMD_SERIALIZE_KERNEL,
-// HIP_LAUNCH_BLOCKING.  XWB_QUEUE_SYNC=events|epochs overrides.
-bool queue_sync_by_epochs() {
-    static int mode = -1;
-    if (mode < 0) {
+// The step loop's two queues hand over through epochs in device memory (XwParams::sync) instead of event / barrier packets
+// (3-6 us of idle GPU each).  A waiter polls until a kernel of the other queue has run.  Three things keep that safe
+// (include/xwb.h, xwb_queue_sync_mode): publishers are enqueued before their waiters everywhere below; epochs are only used on
+// a caller stream that passed a concurrency probe against s->side (epoch_probe); a watchdog poisons the batch.
+// Overrides of the AUTO mode: XWB_QUEUE_SYNC=events|epochs, and tools that serialise kernel execution (rocprofv3's counter
+// collection: ROCPROF_COUNTER_COLLECTION / ROCPROF_COUNTERS; AMD_SERIALIZE_KERNEL; HIP_LAUNCH_BLOCKING) -> events.
+// returns -1: no override, 0: events, 1: epochs; *reason = XWB_SYNC_REASON_ENV | _TOOL
+int queue_sync_env(int *reason) {
+    static int mode = -2, why = 0;
+    if (mode == -2) {
         auto on = [](const char *name) { const char *v = getenv(name); return v && *v && strcmp(v, "0") != 0; };
-        mode = 1;
+        mode = -1;
         if (on("ROCPROF_COUNTER_COLLECTION") || getenv("ROCPROF_COUNTERS") || on("AMD_SERIALIZE_KERNEL") || on("HIP_LAUNCH_BLOCKING") ||
-            on("CUDA_LAUNCH_BLOCKING"))
-            mode = 0;
-        if (const char *v = getenv("XWB_QUEUE_SYNC")) mode = strcmp(v, "events") == 0 ? 0 : (strcmp(v, "epochs") == 0 ? 1 : mode);
+            on("CUDA_LAUNCH_BLOCKING")) { mode = 0; why = XWB_SYNC_REASON_TOOL; }
+        if (const char *v = getenv("XWB_QUEUE_SYNC")) {
+            if (strcmp(v, "events") == 0) { mode = 0; why = XWB_SYNC_REASON_ENV; }
+            else if (strcmp(v, "epochs") == 0) { mode = 1; why = XWB_SYNC_REASON_ENV; }
+        }
     }
-    return mode == 1;
+    *reason = why;
+    return mode;
 }
+
+// One-time probe of (caller stream, s->side): do kernels of the two really run concurrently?  A waiter with a 2 ms watchdog
+// is enqueued FIRST on one stream, its publisher on the other, in both directions; on streams that share a hardware queue
+// (or under a tool that serialises kernels) the waiter runs alone, expires and raises the probe's own flag (d_sync[2], not
+// the batch's poison word).  Both streams are drained before and after, so work of the caller that is still queued cannot
+// make the probe fail (or be delayed by it) -- the cost is one synchronisation the first time a stream is seen.
+bool epoch_probe(xwb_sim *s, hipStream_t st, int *reason) {
+    auto bad = [&](int why) { (void)hipGetLastError(); *reason = why; return false; };
+    if (hipStreamSynchronize(st) != hipSuccess || hipStreamSynchronize(s->side) != hipSuccess) return bad(XWB_SYNC_REASON_PROBE_ERROR);
+    if (hipMemsetAsync(s->d_sync + 2, 0, sizeof(uint32_t), s->side) != hipSuccess || hipStreamSynchronize(s->side) != hipSuccess)
+        return bad(XWB_SYNC_REASON_PROBE_ERROR);
+    for (int dir = 0; dir < 2; ++dir) {
+        hipStream_t waiter = dir ? st : s->side, publisher = dir ? s->side : st;
+        if (++s->probe_token == 0) s->probe_token = 1;
+        if (launch_xw_wait(s->d_sync + 0, s->probe_token, s->d_sync + 2, nullptr, waiter, 200000ull) != hipSuccess)   // 2 ms
+            return bad(XWB_SYNC_REASON_PROBE_ERROR);
+        if (launch_xw_signal(s->d_sync + 0, s->probe_token, publisher) != hipSuccess) return bad(XWB_SYNC_REASON_PROBE_ERROR);
+        if (hipStreamSynchronize(waiter) != hipSuccess || hipStreamSynchronize(publisher) != hipSuccess) return bad(XWB_SYNC_REASON_PROBE_ERROR);
+    }
+    uint32_t expired = 1;
+    if (hipMemcpy(&expired, s->d_sync + 2, sizeof expired, hipMemcpyDeviceToHost) != hipSuccess) return bad(XWB_SYNC_REASON_PROBE_ERROR);
+    if (expired) {
+        (void)hipMemset(s->d_sync + 2, 0, sizeof(uint32_t));
+        *reason = XWB_SYNC_REASON_PROBE_FAILED;
+        return false;
+    }
+    *reason = XWB_SYNC_REASON_PROBE_OK;
+    return true;
+}
+
+// may calls on stream `st` hand over through epochs?  (xworld batches only: the other games have no internal stream)
+bool use_epochs(xwb_sim *s, hipStream_t st) {
+    if (!s->d_sync || !s->side) { s->sync_reason = XWB_SYNC_REASON_NOT_USED; return false; }
+    if (s->cfg.queue_sync == XWB_QUEUE_SYNC_EVENTS) { s->sync_reason = XWB_SYNC_REASON_CONFIG; return false; }
+    if (s->cfg.queue_sync == XWB_QUEUE_SYNC_EPOCHS) { s->sync_reason = XWB_SYNC_REASON_CONFIG; return true; }
+    int why = 0;
+    const int env = queue_sync_env(&why);
+    if (env >= 0) { s->sync_reason = why; return env == 1; }
+    for (auto &pr : s->probes) if (pr.st == st) { s->sync_reason = pr.reason; return pr.ok; }
+    int reason = 0;
+    const bool ok = epoch_probe(s, st, &reason);
+    if (s->probes.size() >= 16) s->probes.erase(s->probes.begin());
+    s->probes.push_back(xwb_sim::StreamProbe{st, ok, reason});
+    s->sync_reason = reason;
+    return ok;
+}
+
+const char *POISON_MSG = "a device-side queue hand-off was not released within its watchdog (kernels of the batch's two queues did "
+                         "not run concurrently, or the device is wedged): the batch is poisoned -- results since the last "
+                         "successful xwb_check_errors are void, destroy it (XWB_QUEUE_SYNC=events / xwb_config.queue_sync avoid epochs)";
+bool is_poisoned(xwb_sim *s) {
+    if (!s->poisoned && s->h_poison && *(volatile uint32_t *)s->h_poison) s->poisoned = true;
+    return s->poisoned;
+}
+#define XWB_LIVE(s) do { if (is_poisoned(s)) return fail(XWB_ERR_STATE, POISON_MSG); } while (0)
 
 // ---- host restatement of the SimpleRace constructors (float/double conversion points matter) ----
 void race_setup(const xwb_config &c, RaceParams &r) {
@@ -454,6 +523,14 @@ int xw_setup(xwb_sim *s) {
     p.group2d = c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET;
     p.curriculum = curriculum ? c.curriculum : 0.0; p.cur_level = s->d_cur_level; p.cur_counter = s->d_cur_counter; p.cur_usage = s->d_cur_usage;
     p.sync = s->d_sync; p.sig_epoch = 0; p.wait_epoch = 0;
+    {   // the watchdog's host-visible word (read at the top of every verb, no sync)
+        void *hp = nullptr, *dp = nullptr;
+        HIP_TRY(hipHostMalloc(&hp, 64, hipHostMallocMapped));
+        memset(hp, 0, 64);
+        s->h_poison = static_cast<uint32_t *>(hp);
+        HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+        p.poison_host = static_cast<uint32_t *>(dp);
+    }
     p.minstd = s->d_minstd;
     p.sent_names = s->d_sent_names; p.term_grid = s->d_term_grid; p.term_flag = s->d_term_flag;
     p.goal_cells = s->d_goal_cells; p.cand2d = s->d_cand2d; p.icon_colored = s->d_icon_colored;
@@ -648,19 +725,20 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
     hipStream_t rs = beside_render ? s->side : st;
     const bool span_sync = beside_render && s->span_step && xw_ego_span(p);
     // full observation: the two queues hand over through epochs in device memory (XwParams::sync) -- the side queue's
-    // kernel waits for the step kernel's epoch, the list render for the reset kernel's; no event / barrier packets
-    const bool by_epoch = queue_sync_by_epochs() && beside_render && render && !p.visible_radius && mode != MODE_RESET_ALL;
+    // kernel waits for the step kernel's epoch, the list render for the reset kernel's; no event / barrier packets.
+    // The mode is the one the step call chose (s->step_epochs): its kernels are the publishers, already enqueued.
+    const bool by_epoch = s->step_epochs && beside_render && render && !p.visible_radius && mode != MODE_RESET_ALL;
     if (by_epoch) {
-        HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->d_sync + 4, s->side));
+        HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->d_sync + 4, p.poison_host, s->side));
         if (++s->epoch_reset == 0) s->epoch_reset = 1;
     } else if (beside_render) {
         // (span path: the map generator only has to wait for the kernel that reads the grids; the goal images are redrawn
         // once the kernels that evaluate pixels from them are through)
-        if (span_sync && s->span_epochs) HIP_TRY(launch_xw_wait(s->d_sync + 5, s->epoch_step, s->d_sync + 4, s->side));
+        if (span_sync && s->span_epochs) HIP_TRY(launch_xw_wait(s->d_sync + 5, s->epoch_step, s->d_sync + 4, p.poison_host, s->side));
         else HIP_TRY(hipStreamWaitEvent(s->side, span_sync ? s->ev_cells : s->ev_step, 0));
     }
     timer_begin(s, s->t_reset, rs);
-    if (span_sync && s->span_epochs) HIP_TRY(launch_xw_reset(p, mode, rs, nullptr, s->d_sync + 6, s->epoch_step, s->d_sync + 4));
+    if (span_sync && s->span_epochs) HIP_TRY(launch_xw_reset(p, mode, rs, nullptr, s->d_sync + 6, s->epoch_step));
     else HIP_TRY(launch_xw_reset(p, mode, rs, span_sync ? s->ev_step : nullptr));
     timer_end(s, s->t_reset, rs);
     if (by_epoch) {
@@ -675,11 +753,11 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
         p.auto_reset = 3;
         p.ego_list_beside = 1;
         if (span_sync && s->span_epochs) {
-            HIP_TRY(launch_xw_wait(s->d_sync + 7, s->epoch_step, s->d_sync + 4, rs));      // the terminal frames of these envs are out
+            HIP_TRY(launch_xw_wait(s->d_sync + 7, s->epoch_step, s->d_sync + 4, p.poison_host, rs));      // the terminal frames of these envs are out
             HIP_TRY(launch_xw_render(p, 1, rs));
             if (++s->epoch_reset == 0) s->epoch_reset = 1;
             HIP_TRY(launch_xw_signal(s->d_sync + 3, s->epoch_reset, rs));
-            HIP_TRY(launch_xw_wait(s->d_sync + 3, s->epoch_reset, s->d_sync + 4, st));
+            HIP_TRY(launch_xw_wait(s->d_sync + 3, s->epoch_reset, s->d_sync + 4, p.poison_host, st));
             HIP_TRY(launch_xw_clear_done(p, st));
             return XWB_OK;
         }
@@ -723,30 +801,37 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         HIP_TRY(launch_simple_race(p, st));
         timer_end(s, s->t_step, st);
     } else {
+        // hand-over mode of this call (probes `st` the first time it is seen: synchronises it once)
+        const bool epochs = use_epochs(s, st);
+        s->step_epochs = epochs;
         s->count_sel ^= 1;                     // this step appends to the counter the previous one zeroed
         XwParams p = xw_params(s);
         p.actions = actions_dev; p.act_rep = act_rep;
         if (++s->epoch_step == 0) s->epoch_step = 1;
-        p.sig_epoch = s->epoch_step;           // published by the render kernel queued behind the step kernel
+        p.sig_epoch = epochs ? s->epoch_step : 0;   // published by the render kernel queued behind the step kernel
         timer_begin(s, s->t_step, st);
         HIP_TRY(launch_xw_step(p, st));
         timer_end(s, s->t_step, st);
         s->list_valid = true;
         XwParams pr = xw_params(s);
-        bool auto_epochs = false;
+        pr.sig_epoch = 0;
+        const bool span = xw_ego_span(p);
         if (autoreset) {
-            // finished envs: reset + first frame of the new episode on the side stream, beside the render of everyone
-            // else; their terminal frames are not materialised
-            // (full observation: the hand-overs are epochs in device memory, as in xwb_reset_done -- the side queue's first
-            // kernel waits for the step kernel's epoch, which the render publishes; a one-wavefront kernel at the end of
-            // this call waits for the side queue's)
-            // (egocentric: only on the span path, whose cells kernel publishes the step epoch)
-            auto_epochs = queue_sync_by_epochs() && (!p.visible_radius || xw_ego_span(p));
+            // Finished envs: reset + first frame of the new episode on the side stream, beside the render of everyone else;
+            // their terminal frames are not materialised.
+            // Epochs (full observation, and the egocentric span path, whose cells kernel publishes the step epoch): the side
+            // queue's first kernel waits for "step kernel complete", which the FIRST kernel of the render publishes; a
+            // one-wavefront kernel at the end of this call waits for the side queue's.  The render is enqueued BEFORE the
+            // side queue's waiter (publisher first: xw_device.h), and the side queue's signal before the final waiter.
+            const bool auto_epochs = epochs && (!p.visible_radius || span);
+            if (!auto_epochs) { p.sig_epoch = 0; HIP_TRY(hipEventRecord(s->ev_step, st)); }
+            timer_begin(s, s->t_render, st);
+            HIP_TRY(launch_xw_render(p, 2, st));
+            timer_end(s, s->t_render, st);
             if (auto_epochs) {
-                HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->d_sync + 4, s->side));
+                HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->d_sync + 4, p.poison_host, s->side));
                 if (++s->epoch_reset == 0) s->epoch_reset = 1;
             } else {
-                HIP_TRY(hipEventRecord(s->ev_step, st));
                 HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
             }
             pr.auto_reset = 1;
@@ -754,11 +839,16 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
             HIP_TRY(launch_xw_reset(pr, MODE_RESET_DONE, s->side));
             timer_end(s, s->t_reset, s->side);
             HIP_TRY(launch_xw_render(pr, 1, s->side));
-            if (auto_epochs) HIP_TRY(launch_xw_signal(s->d_sync + 3, s->epoch_reset, s->side));      // queued behind the list render
-            else HIP_TRY(hipEventRecord(s->ev_reset, s->side));
+            if (auto_epochs) {
+                HIP_TRY(launch_xw_signal(s->d_sync + 3, s->epoch_reset, s->side));      // queued behind the list render
+                HIP_TRY(launch_xw_wait(s->d_sync + 3, s->epoch_reset, s->d_sync + 4, p.poison_host, st));
+            } else {
+                HIP_TRY(hipEventRecord(s->ev_reset, s->side));
+                HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
+            }
             s->list_valid = false;
         } else {
-            if (!p.visible_radius && !queue_sync_by_epochs()) HIP_TRY(hipEventRecord(s->ev_step, st));
+            if (!p.visible_radius && !epochs) HIP_TRY(hipEventRecord(s->ev_step, st));
             // Finished envs keep a terminal snapshot of their grid (step kernel) from which the big render draws their
             // last frame, so a following xwb_reset_done can regenerate the live state beside that render right away.
             // The egocentric render reads more than the grid (heading, goal images): there the terminal frames are
@@ -766,7 +856,7 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
             // following xwb_reset_done queues behind that list render.
             // On the span path (kernels_xworld_ego.hip) only the front kernels read the env state: ev_step is recorded
             // behind them, the terminal frames leave through a short list gather (ev_term) and the big gather skips them.
-            if (p.visible_radius && !xw_ego_span(p)) {
+            if (p.visible_radius && !span) {
                 HIP_TRY(hipEventRecord(s->ev_step, st));
                 pr.list_flag = 1;
                 pr.ego_list_beside = 1;
@@ -774,21 +864,17 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
                 HIP_TRY(launch_xw_render(pr, 1, s->side));
                 HIP_TRY(hipEventRecord(s->ev_term, s->side));
             }
-        }
-        timer_begin(s, s->t_render, st);
-        if (!autoreset && xw_ego_span(p)) {
-            p.list_flag = 1;
-            s->span_epochs = queue_sync_by_epochs();
-            if (s->span_epochs) HIP_TRY(launch_xw_render(p, 4, st));          // (p.sig_epoch = this step's epoch: d_sync[5..7])
-            else HIP_TRY(launch_xw_render(p, 4, st, s->ev_step, s->ev_term, s->ev_cells));
-        } else {
-            HIP_TRY(launch_xw_render(p, autoreset || p.visible_radius ? 2 : 3, st));
-        }
-        timer_end(s, s->t_render, st);
-        if (!autoreset && p.visible_radius && !xw_ego_span(p)) HIP_TRY(hipStreamWaitEvent(st, s->ev_term, 0));
-        if (autoreset) {
-            if (auto_epochs) HIP_TRY(launch_xw_wait(s->d_sync + 3, s->epoch_reset, s->d_sync + 4, st));
-            else HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
+            timer_begin(s, s->t_render, st);
+            if (span) {
+                p.list_flag = 1;
+                s->span_epochs = epochs;
+                if (epochs) HIP_TRY(launch_xw_render(p, 4, st));          // (p.sig_epoch = this step's epoch: d_sync[5..7])
+                else HIP_TRY(launch_xw_render(p, 4, st, s->ev_step, s->ev_term, s->ev_cells));
+            } else {
+                HIP_TRY(launch_xw_render(p, p.visible_radius ? 2 : 3, st));
+            }
+            timer_end(s, s->t_render, st);
+            if (p.visible_radius && !span) HIP_TRY(hipStreamWaitEvent(st, s->ev_term, 0));
         }
     }
     s->span_step = !autoreset && xw_ego_span(s->xw);
@@ -890,6 +976,7 @@ int xwb_create(const xwb_config *cfg, xwb_sim **out) {
             return bail(fail(XWB_ERR_ARG, "Unrecognized game type"));     // simulator_interface.cpp:82
     }
     if (cfg->rng_mode != XWB_RNG_PHILOX && cfg->rng_mode != XWB_RNG_MINSTD) return bail(fail(XWB_ERR_ARG, "unknown rng_mode"));
+    if (cfg->queue_sync < XWB_QUEUE_SYNC_AUTO || cfg->queue_sync > XWB_QUEUE_SYNC_EPOCHS) return bail(fail(XWB_ERR_ARG, "unknown queue_sync"));
     if (cfg->rng_mode == XWB_RNG_MINSTD) {
         // the reference seeds an engine per thread only when FLAGS_simulator_seed != 0 (simulator_util.cpp:44-52); with 0
         // its engines start from hash(thread id), which nobody can replay
@@ -933,6 +1020,7 @@ int xwb_create(const xwb_config *cfg, xwb_sim **out) {
     rc = xwb_reset(s, nullptr);
     if (rc) return bail(rc);
     HIP_TRY(hipDeviceSynchronize());
+    if (s->d_sync) (void)use_epochs(s, nullptr);      // probe the default stream now; other streams when they are first seen
     *out = s;
     return XWB_OK;
 }
@@ -941,6 +1029,7 @@ int xwb_destroy(xwb_sim *s) {
     if (!s) return XWB_OK;
     XWB_ON_DEVICE(s);
     for (void *p : s->allocs) (void)hipFree(p);
+    if (s->h_poison) (void)hipHostFree(s->h_poison);
     if (s->side) (void)hipStreamDestroy(s->side);
     if (s->ev_step) (void)hipEventDestroy(s->ev_step);
     if (s->ev_reset) (void)hipEventDestroy(s->ev_reset);
@@ -955,6 +1044,7 @@ int xwb_destroy(xwb_sim *s) {
 int xwb_reset(xwb_sim *s, void *stream) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
     XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
     hipStream_t st = as_stream(stream);
     s->autoreset_done = false;
     if (s->cfg.game != XWB_XWORLD2D) return simple_reset(s, MODE_RESET_ALL, nullptr, st);
@@ -965,6 +1055,7 @@ int xwb_reset(xwb_sim *s, void *stream) {
 int xwb_reset_done(xwb_sim *s, void *stream) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
     XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
     hipStream_t st = as_stream(stream);
     if (s->autoreset_done) {
         // xwb_step_autoreset / xwb_step_n already reset every env whose code is set (the codes are kept for the caller
@@ -987,6 +1078,7 @@ int xwb_reset_done(xwb_sim *s, void *stream) {
 int xwb_reset_masked(xwb_sim *s, const uint8_t *mask_dev, void *stream) {
     if (!s || !mask_dev) return fail(XWB_ERR_ARG, "NULL argument");
     XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
     hipStream_t st = as_stream(stream);
     if (s->cfg.game != XWB_XWORLD2D) return simple_reset(s, MODE_RESET_MASK, mask_dev, st);
     XwParams p = xw_params(s);
@@ -1000,6 +1092,7 @@ int xwb_reset_masked(xwb_sim *s, const uint8_t *mask_dev, void *stream) {
 int xwb_reset_env(xwb_sim *s, int32_t env, void *stream) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
     XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
     hipStream_t st = as_stream(stream);
     HIP_TRY(hipMemsetAsync(s->d_mask, 0, (size_t)s->n, st));
@@ -1010,12 +1103,14 @@ int xwb_reset_env(xwb_sim *s, int32_t env, void *stream) {
 int xwb_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, void *stream) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
     XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
     return do_step(s, actions_dev, act_rep, false, as_stream(stream));
 }
 
 int xwb_step_host(xwb_sim *s, const int32_t *actions_host, int32_t act_rep, void *stream) {
     if (!s || !actions_host) return fail(XWB_ERR_ARG, "NULL argument");
     XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
     hipStream_t st = as_stream(stream);
     HIP_TRY(hipMemcpyAsync(s->d_actions_in, actions_host, sizeof(int32_t) * (size_t)s->n, hipMemcpyHostToDevice, st));
     return do_step(s, s->d_actions_in, act_rep, false, st);
@@ -1024,10 +1119,17 @@ int xwb_step_host(xwb_sim *s, const int32_t *actions_host, int32_t act_rep, void
 int xwb_step_n(xwb_sim *s, int32_t n_steps, int32_t act_rep, void *stream) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
     XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
     if (n_steps < 1 || act_rep < 1) return fail(XWB_ERR_ARG, "n_steps and act_rep must be >= 1");
     hipStream_t st = as_stream(stream);
     if (s->cfg.game == XWB_XWORLD2D) {                      // one render per step is the work: nothing to fuse
-        for (int i = 0; i < n_steps; ++i) { int rc = do_step(s, nullptr, act_rep, true, st); if (rc) return rc; }
+        // one call = one slot of a results ring, as for the simple games: every step writes it, the last one stays
+        const int64_t slot = s->packed_pos;
+        for (int i = 0; i < n_steps; ++i) {
+            s->packed_pos = slot;
+            int rc = do_step(s, nullptr, act_rep, true, st);
+            if (rc) return rc;
+        }
         return XWB_OK;
     }
     timer_begin(s, s->t_step, st);
@@ -1052,6 +1154,7 @@ int xwb_step_n(xwb_sim *s, int32_t n_steps, int32_t act_rep, void *stream) {
 int xwb_step_autoreset(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, void *stream) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
     XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
     return do_step(s, actions_dev, act_rep, true, as_stream(stream));
 }
 
@@ -1069,15 +1172,30 @@ int xwb_check_errors(xwb_sim *s, void *stream, int32_t *n_bad) {
     HIP_TRY(hipMemcpyAsync(n_bad, s->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemsetAsync(s->d_err, 0, sizeof(int32_t), st));
     uint32_t timed_out = 0;
-    if (s->d_sync) {
-        HIP_TRY(hipMemcpyAsync(&timed_out, s->d_sync + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemsetAsync(s->d_sync + 4, 0, sizeof(uint32_t), st));
-    }
+    if (s->d_sync) HIP_TRY(hipMemcpyAsync(&timed_out, s->d_sync + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (timed_out)
-        return fail(XWB_ERR_STATE, "a device-side queue hand-off timed out (kernels of the two queues did not run concurrently: a tool "
-                                   "that serialises kernel execution?); results since the last check are unreliable -- run with "
-                                   "XWB_QUEUE_SYNC=events");
+    if (timed_out) s->poisoned = true;                 // sticky: the device word is never cleared
+    XWB_LIVE(s);
+    return XWB_OK;
+}
+
+int xwb_queue_sync_mode(xwb_sim *s, void *stream, int32_t *mode, int32_t *reason) {
+    if (!s || !mode) return fail(XWB_ERR_ARG, "NULL argument");
+    XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
+    const bool e = use_epochs(s, as_stream(stream));
+    *mode = e ? XWB_QUEUE_SYNC_EPOCHS : XWB_QUEUE_SYNC_EVENTS;
+    if (reason) *reason = s->sync_reason;
+    return XWB_OK;
+}
+
+int xwb_debug_stall_handoff(xwb_sim *s, void *stream, int64_t budget_us) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    if (!s->d_sync) return fail(XWB_ERR_STATE, "this game has no queue hand-off");
+    if (budget_us < 1 || budget_us > 10000000) return fail(XWB_ERR_ARG, "budget_us must be in 1..10 000 000");
+    XWB_ON_DEVICE(s);
+    // (slot 0 is the probe's; its tokens count up from 1, so this value is never reached)
+    HIP_TRY(launch_xw_wait(s->d_sync + 0, 0x7fffffffu, s->d_sync + 4, s->xw.poison_host, as_stream(stream), (unsigned long long)budget_us * 100ull));
     return XWB_OK;
 }
 
@@ -1140,6 +1258,7 @@ int xwb_xw_grid_dev(xwb_sim *s, uint16_t **ptr) {
 int xwb_done_count(xwb_sim *s, void *stream, int32_t *n_done) {
     if (!s || !n_done) return fail(XWB_ERR_ARG, "NULL argument");
     XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
     hipStream_t st = as_stream(stream);
     const int32_t *src = s->cfg.game == XWB_XWORLD2D ? s->d_done_count + s->count_sel : s->d_reset_count + s->rc_sel;
     HIP_TRY(hipMemcpyAsync(n_done, src, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1180,6 +1299,7 @@ int xwb_num_envs(const xwb_sim *s, int32_t *n) {
 int xwb_get_env_state(xwb_sim *s, int32_t env, void *stream, xwb_env_state *o) {
     if (!s || !o) return fail(XWB_ERR_ARG, "NULL argument");
     XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
     hipStream_t st = as_stream(stream);
     memset(o, 0, sizeof *o);
@@ -1247,6 +1367,7 @@ namespace {
 int copy_out(xwb_sim *s, void *dst, const void *src, size_t bytes, void *stream) {
     if (!s || !dst) return fail(XWB_ERR_ARG, "NULL argument");
     XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
     hipStream_t st = as_stream(stream);
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st));
     hipPointerAttribute_t attr;
@@ -1259,6 +1380,7 @@ int copy_out(xwb_sim *s, void *dst, const void *src, size_t bytes, void *stream)
 int xwb_get_obs(xwb_sim *s, void *dst, size_t bytes, void *stream) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
     XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
     if (bytes != (size_t)s->n * s->obs_bytes_per_env) return fail(XWB_ERR_ARG, "bytes must be num_envs * bytes_per_env");
     return copy_out(s, dst, s->d_obs, bytes, stream);
 }
@@ -1268,6 +1390,7 @@ int xwb_get_done(xwb_sim *s, uint8_t *dst, void *stream) { return s ? copy_out(s
 int xwb_get_env_obs(xwb_sim *s, int32_t env, void *stream, void *out_host, size_t bytes) {
     if (!s || !out_host) return fail(XWB_ERR_ARG, "NULL argument");
     XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
     if (bytes != s->obs_bytes_per_env) return fail(XWB_ERR_ARG, "bytes must equal bytes_per_env");
     hipStream_t st = as_stream(stream);
@@ -1279,6 +1402,7 @@ int xwb_get_env_obs(xwb_sim *s, int32_t env, void *stream, void *out_host, size_
 int xwb_get_env_grid(xwb_sim *s, int32_t env, void *stream, uint16_t *out_host) {
     if (!s || !out_host) return fail(XWB_ERR_ARG, "NULL argument");
     XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
     if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
     if (env < 0 || env >= s->n) return fail(XWB_ERR_ARG, "env out of range");
     hipStream_t st = as_stream(stream);
@@ -1548,6 +1672,7 @@ int xwb_state_bytes(xwb_sim *s, int32_t include_obs, size_t *bytes) {
 int xwb_save_state(xwb_sim *s, int32_t include_obs, uint8_t *out_host, size_t cap) {
     if (!s || !out_host) return fail(XWB_ERR_ARG, "NULL argument");
     XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
     size_t need = 0;
     xwb_state_bytes(s, include_obs, &need);
     if (cap < need) return fail(XWB_ERR_ARG, "buffer smaller than xwb_state_bytes");
@@ -1572,6 +1697,7 @@ int xwb_save_state(xwb_sim *s, int32_t include_obs, uint8_t *out_host, size_t ca
 int xwb_load_state(xwb_sim *s, const uint8_t *in_host, size_t bytes) {
     if (!s || !in_host) return fail(XWB_ERR_ARG, "NULL argument");
     XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
     if (bytes < sizeof(StateHeader)) return fail(XWB_ERR_ARG, "not a state blob");
     StateHeader h;
     memcpy(&h, in_host, sizeof h);

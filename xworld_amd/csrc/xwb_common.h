@@ -247,18 +247,22 @@ struct XwParams {
     // kernel, sync[4] != 0: a wait gave up (xw_device.h: xw_publish_epoch / xw_wait_epoch).  render_all with sig_epoch != 0 publishes it to sync[1] when it
     // starts (= the step kernel before it in the queue is complete); the list render with wait_epoch != 0 waits for sync[3].
     uint32_t *sync;
+    uint32_t *poison_host;       // pinned host word raised together with sync[4] when a wait's watchdog expires (the host reads
+                                 // it at the top of every verb without a sync: the batch is poisoned from then on)
     uint32_t sig_epoch, wait_epoch;
     uint32_t *minstd;            // nullable: XWB_RNG_MINSTD, one libstdc++ minstd_rand0 state per env: the teacher's task draw
 };
 hipError_t launch_xw_step(const XwParams &p, hipStream_t s);
 // one wavefront that ends once *epoch_slot has reached `want`: orders the work queued behind it after the publisher
-hipError_t launch_xw_wait(const uint32_t *epoch_slot, uint32_t want, uint32_t *timeout_flag, hipStream_t s);
+// (budget_ticks: watchdog in 100 MHz ticks, 0 = the default 4 s; poison / poison_host: xw_device.h xw_wait_epoch)
+hipError_t launch_xw_wait(const uint32_t *epoch_slot, uint32_t want, uint32_t *poison, uint32_t *poison_host, hipStream_t s,
+                          unsigned long long budget_ticks = 0);
 // one thread that publishes `value`: queued behind a kernel, it tells the other queue that kernel is complete
 hipError_t launch_xw_signal(uint32_t *epoch_slot, uint32_t value, hipStream_t s);
 // reset envs: mode RESET_ALL -> every env; otherwise the compacted done_list / done_count
 // before_warp (egocentric): the redraw of the goal images waits for it (kernels still reading the old images)
 hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s, hipEvent_t before_warp = nullptr, const uint32_t *warp_epoch_slot = nullptr,
-                           uint32_t warp_epoch = 0, uint32_t *timeout_flag = nullptr);
+                           uint32_t warp_epoch = 0);
 // compaction of done[] (mode RESET_DONE) or mask (RESET_MASK) into done_list / done_count
 hipError_t launch_xw_compact(const XwParams &p, int mode, hipStream_t s);
 // render: indexed == 0 -> all envs (LDS-resident atlas, persistent workgroups);

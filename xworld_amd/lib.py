@@ -10,11 +10,13 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libxwb.so")
 
-XWB_ABI_VERSION = 2
+XWB_ABI_VERSION = 3
 XWB_SIMPLE_GAME, XWB_SIMPLE_RACE, XWB_XWORLD2D = 0, 1, 2
 XWB_MAP_NAV, XWB_MAP_WALLS = 0, 1
 XWB_TASKMODE_LANG_ACQ, XWB_TASKMODE_ONE_CHANNEL = 0, 1
 ALIVE, MAX_STEP, DEAD, SUCCESS, LOST_LIFE = 0, 1, 2, 4, 8
+XWB_QUEUE_SYNC_AUTO, XWB_QUEUE_SYNC_EVENTS, XWB_QUEUE_SYNC_EPOCHS = 0, 1, 2
+SYNC_REASONS = ["probe_ok", "config", "env", "tool", "probe_failed", "probe_error", "not_used"]
 
 
 class XwbConfig(C.Structure):
@@ -37,6 +39,8 @@ class XwbConfig(C.Structure):
         ("rng_mode", C.c_int32), ("simulator_seed", C.c_int32), ("thread_base", C.c_int32),
         ("n_tasks2", C.c_int32), ("tasks2", C.c_int32 * 8), ("task_schedule2", C.c_int32), ("task_weights2", C.c_double * 8),
         ("task_groups_exclusive", C.c_int32),
+        ("task_group_weight", C.c_double), ("task_group_weight2", C.c_double),
+        ("queue_sync", C.c_int32),
     ]
 
 
@@ -69,6 +73,8 @@ _SIGS = [
     ("xwb_step_n", C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
     ("xwb_step_autoreset", C.c_int, [_vp, _vp, C.c_int32, _vp]),
     ("xwb_check_errors", C.c_int, [_vp, _vp, C.POINTER(C.c_int32)]),
+    ("xwb_queue_sync_mode", C.c_int, [_vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("xwb_debug_stall_handoff", C.c_int, [_vp, _vp, C.c_int64]),
     ("xwb_obs_dev", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     ("xwb_bind_results", C.c_int, [_vp, _vp]),
     ("xwb_bind_results_ring", C.c_int, [_vp, _vp, C.c_int64]),

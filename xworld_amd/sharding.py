@@ -199,22 +199,29 @@ class ScreensGather:
 
     The root renders straight into its slice of the destination (BatchedSimulator.bind_obs), so its own slab is never
     copied.  A context ring (context > 1) shifts frames in place and therefore needs ONE observation buffer: the gather
-    then is waited for before the next step (`depth` = 1)."""
+    then is waited for before the next step (`depth` = 1).
 
-    def __init__(self, sim, counts, rank, dst=0, group=None):
+    The two buffers start zeroed.  With depth 2 every env must be drawn by every step: an env left out of a step
+    (XWB_ACTION_SKIP, whose observation the kernels leave untouched) would show its frame of two steps ago -- callers that
+    skip envs pass depth=1."""
+
+    def __init__(self, sim, counts, rank, dst=0, group=None, depth=None):
         self.sim, self.counts, self.rank, self.dst, self.group = sim, list(counts), rank, dst, group
         self.world = len(counts)
         self.depth = 2 if sim.cfg.context == 1 else 1
+        if depth is not None:
+            assert depth == 1 or (depth == 2 and sim.cfg.context == 1), "depth 2 needs context == 1"
+            self.depth = int(depth)
         shape = tuple(sim.obs.shape[1:])
         dtype, device = sim.obs.dtype, sim.obs.device
         n = counts[rank]
         self.off = sum(counts[:rank])
         if rank == dst:
-            self.full = [torch.empty((sum(counts),) + shape, dtype=dtype, device=device) for _ in range(self.depth)]
+            self.full = [torch.zeros((sum(counts),) + shape, dtype=dtype, device=device) for _ in range(self.depth)]
             self.local = [f[self.off:self.off + n] for f in self.full]
         else:
             self.full = [None] * self.depth
-            self.local = [torch.empty((n,) + shape, dtype=dtype, device=device) for _ in range(self.depth)]
+            self.local = [torch.zeros((n,) + shape, dtype=dtype, device=device) for _ in range(self.depth)]
         self.work = [None] * self.depth
         self.k = self.depth - 1          # buffer pair of the current step
         self.done_k = None               # newest pair whose gather was waited for
