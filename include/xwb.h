@@ -136,9 +136,10 @@ typedef struct xwb_config {
                                   * first env; global env g uses the engine of thread number thread_base + g + 1 */
     /* A second task group of the conf's "task_groups" (listed after the first; the teacher keeps conf order,
      * teacher.cpp:56-98): n_tasks2 == 0 -> none.  One of the two groups holds XWorld3DNav* tasks, the other the 2-D-native
-     * XWorldNav* ones.  They run NON-exclusively -- Teacher::teach's else branch (teacher.cpp:221-225): every teach() runs
+     * XWorldNav* ones.  Run NON-exclusively -- Teacher::teach's else branch (teacher.cpp:221-225) --, every teach() runs
      * each group's stage in conf order, rewards add up, the last group's event ("" included) is what game_over() sees, and
-     * only the first group's task sees the step's collision events (xworld_simulator.cpp:118-122). */
+     * only the first group's task sees the step's collision events (xworld_simulator.cpp:118-122) -- unless
+     * task_groups_exclusive is in force, see below. */
     int32_t  n_tasks2;
     int32_t  tasks2[8];
     int32_t  task_schedule2;
@@ -298,6 +299,9 @@ typedef struct xwb_env_state {
                                   * TARGET G = the picked goal; NEAR G = g1; BETWEEN G1, G2; DIRECTION, AVOID G = the referent */
     /* the second task group's Task FSM (n_tasks2 > 0; else zeros); xw_event / xw_event2 = what each group's task recorded */
     int32_t  xw_task2, xw_stage2, xw_event2, xw_target2, xw_steps_in_task2;
+    /* exclusive scheduling of two groups (else -1): conf index (0 / 1) of the group that heads Teacher::task_groups_ after
+     * the last sort, and of the one group the last teach() ran */
+    int32_t  xw_group_first, xw_group_ran;
 } xwb_env_state;
 int xwb_get_env_state(xwb_sim *sim, int32_t env, void *stream, xwb_env_state *out);
 /* copies env's "screen" (context frames) to host memory; bytes must equal bytes_per_env */

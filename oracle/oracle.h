@@ -165,6 +165,12 @@ typedef struct {
     int tasks2[8];
     int task_schedule2;
     double task_weights2[8];
+    /* FLAGS_task_groups_exclusive (teacher.cpp:22-24; ignored under lang_acquisition, simulator_interface.cpp:46-48):
+     * Teacher::teach's exclusive branch (teacher.cpp:209-220) -- per teach() nondeterministic_sort_task_groups (:143-163)
+     * re-sorts the group list in place by weighted sampling without replacement over group_weight (the conf's "weight" keys,
+     * 0 when absent), then ONE group runs its stage: the last busy one of that order, else the first */
+    int task_groups_exclusive;
+    double group_weight[2];
 } orc_xw_cfg;
 
 typedef struct {
@@ -179,6 +185,8 @@ typedef struct orc_xworld orc_xworld;
 /* Task FSM of task group g (0 or 1) after the last call; ev = the event ITS task recorded in that call */
 void   orc_xw_group_state(const orc_xworld *w, int g, int *kind, int *stage, int *steps_in_task, int *event,
                           int *target2d_x, int *target2d_y);
+/* exclusive scheduling: the conf index of the group that heads Teacher::task_groups_ after the last sort */
+int    orc_xw_group_first(const orc_xworld *w);
 /* icons64: n_icons*64*64*3 BGR bytes (may be NULL when no rendering is asked for) */
 orc_xworld *orc_xw_create(const orc_xw_cfg *cfg, int n_icons, const orc_icon_info *info,
                           const uint8_t *icons64);

@@ -542,12 +542,59 @@ static void group_load(orc_xworld *w, int g) {
 
 static void teacher_run_group(orc_xworld *w, int idle_pick);
 
-/* Teacher::teach, teacher.cpp:207-230, task_groups_exclusive_ == false: every group's stage in conf order.  Rewards add
+static int teacher_exclusive(const orc_xworld *w) {
+    return w->cfg.task_groups_exclusive && w->cfg.task_mode != ORC_TASKMODE_LANG_ACQ;      /* simulator_interface.cpp:46-48 */
+}
+
+/* Teacher::nondeterministic_sort_task_groups, teacher.cpp:143-163: position i takes one of the remaining groups with
+ * probability proportional to its weight -- util::simple_importance_sampling over the accumulated remaining weights, also
+ * for the last position (one weight: index 0, the draw is still made).  Decisions ("xwb-taskgen-v1"): stream 4, block =
+ * num_steps, one unit() per position; under cfg.simulator_seed the env's own minstd engine, as in the reference. */
+static void teacher_sort_groups(orc_xworld *w) {
+    orc_stream gs;
+    orc_stream_init(&gs, w->cfg.seed, w->env_gid, w->episode, 4);
+    gs.ctr[0] = (uint32_t)w->num_steps;
+    for (int i = 0; i < w->n_groups; ++i) {
+        double acc[2], total = 0;
+        for (int j = i; j < w->n_groups; ++j) { total += w->cfg.group_weight[w->grp_order[j]]; acc[j - i] = total; }
+        int idx;
+        if (w->forced) {
+            idx = orc_xw_draw_below(w, w->n_groups - i);
+        } else {
+            float val = orc_stream_unit(&gs) * (float)total;             /* get_rand_range_val(float(acc.back())) */
+            if (w->cfg.simulator_seed) val = orc_minstd_rand_range(&w->reng, (float)total);
+            idx = w->n_groups - i - 1;
+            for (int j = 0; j < w->n_groups - i; ++j) if ((double)val <= acc[j]) { idx = j; break; }
+        }
+        int t = w->grp_order[i]; w->grp_order[i] = w->grp_order[i + idx]; w->grp_order[i + idx] = t;
+    }
+}
+
+/* Teacher::teach, teacher.cpp:207-230.  task_groups_exclusive_ == false: every group's stage in conf order.  Rewards add
  * up in the buffer (add_teacher_reward); Task::py_stage ends with record_event_in_buffer(task.get_event()), so the buffer
- * holds the LAST group's event, "" included; game_events_ is cleared by the first py_stage that reads it. */
+ * holds the LAST group's event, "" included; game_events_ is cleared by the first py_stage that reads it.
+ * task_groups_exclusive_ == true: the groups are re-sorted, then one group runs -- the last one of the sorted list that is
+ * not idle (the reference's loop has no break), else the first. */
 static void teacher_teach(orc_xworld *w, int idle_pick) {
     /* before_teach: clear_teacher_env_buffer */
     w->teacher_reward = 0; w->event = ORC_EV_NONE;
+    if (teacher_exclusive(w)) {
+        teacher_sort_groups(w);
+        if (w->n_groups > 1) {
+            int pick = -1;
+            for (int k = 0; k < w->n_groups; ++k)
+                if (w->grp[w->grp_order[k]].stage != ORC_STAGE_IDLE) pick = w->grp_order[k];   /* TaskGroup::is_idle */
+            if (pick < 0) pick = w->grp_order[0];
+            group_load(w, pick);
+            w->event = ORC_EV_NONE;
+            teacher_run_group(w, idle_pick);
+            const int ev = w->event;
+            group_save(w, pick);
+            group_load(w, 0);                     /* accessors read group 0 */
+            w->event = ev;
+            return;
+        }
+    }
     if (w->n_groups <= 1) {
         group_load(w, 0);                         /* (the working fields already are group 0's: sets the task list) */
         teacher_run_group(w, idle_pick);
@@ -572,11 +619,17 @@ static void teacher_run_group(orc_xworld *w, int idle_pick) {
     switch (w->stage) {
         case ORC_STAGE_IDLE:
             (void)idle_pick;
-            /* an idle stage at step time (only the 2-D-native tasks come back to "idle"): its decisions are the
-             * words of stream 2, block = num_steps ("xwb-taskgen-v1") */
+            /* an idle stage at step time: the 2-D-native tasks come back to "idle" (decisions: the words of stream 2,
+             * block = num_steps); under exclusive scheduling an XWorld3DNav* group can be picked idle in mid-episode: its
+             * (many) decisions are the successive words of a stream of that step's own, id 5 | num_steps << 8
+             * ("xwb-taskgen-v1") */
             if (w->num_steps > 0) {
-                orc_stream_init(&w->rs, w->cfg.seed, w->env_gid, w->episode, 2);
-                w->rs.ctr[0] = (uint32_t)w->num_steps;
+                if (w->act_n_tasks > 0 && w->act_tasks[0] >= ORC_TASK2D_TARGET) {
+                    orc_stream_init(&w->rs, w->cfg.seed, w->env_gid, w->episode, 2);
+                    w->rs.ctr[0] = (uint32_t)w->num_steps;
+                } else {
+                    orc_stream_init(&w->rs, w->cfg.seed, w->env_gid, w->episode, 5u | ((uint32_t)w->num_steps << 8));
+                }
             }
             orc_task_idle(w);
             break;
@@ -797,6 +850,7 @@ static void after_map(orc_xworld *w, int idle_pick) {
     w->num_steps = 0;             /* last_action_success_ is NOT touched by reset_game */
     /* Teacher::reset_after_game_reset + teach(): lazy Task::reset then idle stage */
     w->n_groups = w->cfg.n_tasks2 > 0 ? 2 : 1;
+    if (w->episode == 0) { w->grp_order[0] = 0; w->grp_order[1] = 1; }    /* a new env's teacher: conf order */
     for (int g = w->n_groups - 1; g >= 0; --g) {      /* TaskGroup::reset for every group; group 0's ends up in the working fields */
         w->stage = ORC_STAGE_IDLE;
         w->steps_in_cur_task = 0;
@@ -936,6 +990,7 @@ void orc_xw_group_state(const orc_xworld *w, int g, int *kind, int *stage, int *
     *kind = s->task_kind; *stage = s->stage; *steps_in_task = s->steps_in_cur_task; *event = s->last_event;
     *target2d_x = s->target2d_x; *target2d_y = s->target2d_y;
 }
+int orc_xw_group_first(const orc_xworld *w) { return w->grp_order[0]; }
 int orc_xw_stage(const orc_xworld *w) { return w->stage; }
 int orc_xw_target_name(const orc_xworld *w) { return w->target_name; }
 int orc_xw_task_kind(const orc_xworld *w) { return w->task_kind; }

@@ -22,6 +22,8 @@ struct orc_xworld {
     orc_xw_cfg cfg;
     orc_group_state grp[2];          /* saved FSMs; the working fields below always end a call holding group 0's */
     int n_groups;
+    int grp_order[2];                /* Teacher::task_groups_ as the last sort left it (exclusive scheduling): conf indices.
+                                      * Lives as long as the teacher: across game resets; a new env (episode 0) starts in conf order */
     /* the running group's task list (orc_task_idle) */
     int act_n_tasks, act_schedule;
     const int *act_tasks;

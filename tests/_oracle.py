@@ -46,7 +46,8 @@ class XwCfg(C.Structure):
                 ("curriculum", C.c_double), ("start_level", C.c_int),
                 ("task_schedule", C.c_int), ("task_weights", C.c_double * 8), ("no_wall_shadow", C.c_int),
                 ("simulator_seed", C.c_int), ("thread_base", C.c_int),
-                ("n_tasks2", C.c_int), ("tasks2", C.c_int * 8), ("task_schedule2", C.c_int), ("task_weights2", C.c_double * 8)]
+                ("n_tasks2", C.c_int), ("tasks2", C.c_int * 8), ("task_schedule2", C.c_int), ("task_weights2", C.c_double * 8),
+                ("task_groups_exclusive", C.c_int), ("group_weight", C.c_double * 2)]
 
 
 class Entity(C.Structure):
@@ -149,6 +150,7 @@ def lib():
     sig("orc_xw_load_map_ex", None, vp, C.c_int, C.POINTER(Entity), C.c_int, i32p, C.c_int, C.c_uint32, C.c_uint32)
     sig("orc_xw_task_kind", C.c_int, vp)
     sig("orc_xw_group_state", None, vp, C.c_int, *([C.POINTER(C.c_int)] * 6))
+    sig("orc_xw_group_first", C.c_int, vp)
     sig("orc_xw_between_cell", None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
     sig("orc_xw_set_pose", None, vp, C.c_int, C.c_double, C.c_double, C.c_double)
     sig("orc_xw_get_pose", None, vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
@@ -359,6 +361,9 @@ def xw_cfg(**kw):
     weights = kw.pop("task_weights", None)
     tasks2 = kw.pop("tasks2", None)
     weights2 = kw.pop("task_weights2", None)
+    gw = kw.pop("group_weights", None)                   # the conf's per-group "weight" keys (exclusive scheduling)
+    if gw is not None:
+        c.group_weight[0], c.group_weight[1] = float(gw[0]), float(gw[1])
     if tasks2 is not None:                               # a second task group, after the first in conf order
         c.n_tasks2 = len(tasks2)
         for i, t in enumerate(tasks2):
@@ -489,6 +494,10 @@ class XWorld:
         v = [C.c_int() for _ in range(6)]
         self.L.orc_xw_group_state(self.h, g, *[C.byref(x) for x in v])
         return tuple(x.value for x in v)
+
+    def group_first(self):
+        """exclusive scheduling: conf index of the group that heads the teacher's list after the last sort"""
+        return self.L.orc_xw_group_first(self.h)
 
     def task_kind(self):
         return self.L.orc_xw_task_kind(self.h)

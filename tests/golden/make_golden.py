@@ -42,6 +42,8 @@ Fixtures written:
                  as a one-task group, both task modes, every teach() call of a 70-step episode
   groups.json    two task groups (an XWorld3DNav* and an XWorldNav* task) run non-exclusively in both conf orders: every
                  teach() call of 60-step episodes, per group and summed
+  groups_exclusive.json  the same two groups under EXCLUSIVE scheduling (task_mode one_channel): the per-teach() group sort,
+                 the one group that runs, mid-episode 3-D idle stages with the entity list they leave
   tasks.json     all five tasks of the XWorld3DNav group (Target, Near, Between, Direction, Avoid): the idle stage
                  driven by logged decisions (see DecisionRandom), the map after the teacher's rearrangement,
                  the target cells, and a random-action trace as in teacher.json
@@ -674,6 +676,125 @@ def gen_groups(pal, n_maps, seed0, steps):
     return out
 
 
+# ------------------------------------------- two task groups, EXCLUSIVE scheduling (D13) ----
+def gen_groups_exclusive(pal, n_maps, seed0, steps):
+    """Teacher::teach with TWO task groups and task_groups_exclusive = true (teacher.cpp:207-220; py_simulator's default,
+    in force whenever task_mode is not lang_acquisition): a one-task XWorld3DNav* group and a one-task XWorldNav*
+    (2-D-native) group, both conf orders, several group weights, task_mode one_channel.  The lines of teacher.cpp restated
+    here: per teach() nondeterministic_sort_task_groups (:143-163) re-sorts the group list IN PLACE by weighted sampling
+    without replacement -- one util::simple_importance_sampling draw per position, the last one over a single weight --, then
+    the LAST non-idle group of that order runs its stage, else the first (:209-220; the loop has no break).  The sampling
+    decisions (index into the remaining groups) are drawn here with the same rule (uniform value in [0, total), first
+    accumulated weight >= it) and logged; a group's stage runs as in gen_groups.  A 3-D group that is picked while idle in
+    mid-episode runs its map-rearranging idle stage at step time: the entity list after every such call is recorded."""
+    import importlib
+    sys.path.insert(0, os.path.join(REF, "games", "xworld", "tasks"))
+    pairs = [("XWorld3DNavTarget", "XWorldNavTarget"), ("XWorld3DNavTargetNear", "XWorldNavColorTarget"),
+             ("XWorld3DNavTargetBetween", "XWorldNavTarget"), ("XWorld3DNavTargetDirection", "XWorldNavColorTarget"),
+             ("XWorld3DNavTargetAvoid", "XWorldNavNear")]
+    weights = {"3d_first": [(1.0, 1.0), (0.5, 2.0)], "2d_first": [(1.0, 1.0), (3.0, 1.0)]}    # (first, second) in conf order
+    out = {}
+    rnd = random.Random(2468)
+    FLAGS["task_mode"] = "one_channel"
+    env = XWorldNav(ITEM_PATH)
+    mh, mw = env.get_max_dims()
+    try:
+        for n3, n2 in pairs:
+            m3, m2 = importlib.import_module(n3), importlib.import_module(n2)
+            for order in ("3d_first", "2d_first"):
+                for wts in weights[order]:
+                    runs = []
+                    k = 0
+                    while len(runs) < n_maps and k < 8 * n_maps:
+                        k += 1
+                        random.seed(seed0 + k + 100 * len(out))
+                        env.reset()
+                        env.env_changed()
+                        before = entity_records(env, pal)
+                        h = Harness(env)
+                        env.get_max_dims = lambda _h=mh, _w=mw: (_Py2Int(_h), _Py2Int(_w))
+                        t3, t2 = getattr(m3, n3)(env), getattr(m2, n2)(env)
+                        t2.directions = _ItDict(t2.directions)
+                        fake = DecisionRandom(seed0 * 17 + k + 1000 * len(out))
+                        grnd = random.Random(seed0 * 19 + k + 1000 * len(out))
+                        real3, real2 = m3.random, m2.random
+                        m3.random = m2.random = fake
+                        task = {"3d": t3, "2d": t2}
+                        # Teacher::task_groups_ / task_group_weights_: conf order, then whatever the sorts leave
+                        glist = ["3d", "2d"] if order == "3d_first" else ["2d", "3d"]
+                        gw = list(wts)
+                        stage = {"3d": "idle", "2d": "idle"}
+
+                        def teach():
+                            draws = []
+                            for i in range(len(glist)):                 # nondeterministic_sort_task_groups
+                                acc, tot = [], 0.0
+                                for x in gw[i:]:
+                                    tot += x
+                                    acc.append(tot)
+                                val = grnd.random() * tot
+                                idx = [j for j, a in enumerate(acc) if val <= a][0]
+                                draws.append(idx)
+                                glist[i], glist[i + idx] = glist[i + idx], glist[i]
+                                gw[i], gw[i + idx] = gw[i + idx], gw[i]
+                            busy = None
+                            for fam in glist:                           # no break: the last busy group wins
+                                if stage[fam] != "idle":
+                                    busy = fam
+                            fam = busy if busy is not None else glist[0]
+                            was_idle = stage[fam] == "idle"
+                            if was_idle:
+                                task[fam].reset()
+                            n0 = len(fake.log)
+                            env.update_entities_from_cpp([dict(e) for e in h.ents])
+                            env.update_agent_sentence_from_cpp("")
+                            env.update_agent_action_success_from_cpp(h.success)
+                            ev, h.game_events = h.game_events, ""
+                            env.update_game_event_from_cpp(ev)
+                            ret = getattr(task[fam], stage[fam])()
+                            st, reward = ret[0], float(ret[1])
+                            stage[fam] = st
+                            changed = env.env_changed()
+                            event = task[fam].get_event()
+                            # compact record (GX_FIELDS): the sort's draws, is the 3-D group first afterwards, did the 3-D group
+                            # run, was it idle, its idle stage's decisions, reward, event, stage, both groups' stages, the
+                            # 2-D task's target cell, the entity list when the stage changed the map (else None)
+                            rec = [draws[0], draws[1], int(glist[0] == "3d"), int(fam == "3d"), int(was_idle), list(fake.log[n0:]),
+                                   reward, event, st, stage["3d"], stage["2d"]]
+                            ents_after = None
+                            if changed:                                  # Task::py_stage -> game_->update_environment()
+                                h.ents = [dict(e) for e in env.cpp_get_entities()]
+                                for e in h.ents:
+                                    e["loc"] = tuple(int(v) for v in e["loc"])
+                                h.agent = [e for e in h.ents if e["type"] == "agent"][0]
+                                ents_after = entity_records(env, pal)
+                            tgt = t2.target
+                            rec += [int(tgt[0]) + env.offset_w, int(tgt[1]) + env.offset_h] if tgt[0] >= 0 else [-1, -1]
+                            rec.append(ents_after)
+                            return rec
+                        ok = True
+                        try:
+                            first = teach()
+                            trace = []
+                            for t in range(steps):
+                                a = rnd.randrange(4)
+                                h.act(a)
+                                rec = teach()
+                                trace.append(rec + [a, int(h.agent["loc"][0]), int(h.agent["loc"][1]), int(bool(h.success))])
+                        except AssertionError:                           # "map too crowded?": the reference process would die
+                            ok = False
+                        finally:
+                            m3.random, m2.random = real3, real2
+                            del env.get_max_dims
+                        if ok:
+                            runs.append({"py_seed": seed0 + k + 100 * len(out), "dim": env.get_dims()[0], "max_dim": mh, "weights": list(wts),
+                                         "entities_before": before, "reset_teach": first, "trace": trace})
+                    out["%s+%s/%s/%g:%g" % (n3, n2, order, wts[0], wts[1])] = runs
+    finally:
+        FLAGS["task_mode"] = "lang_acquisition"
+    return out
+
+
 # ------------------------------------------------------------ teacher sentences ----
 def gen_sentences(n_per_task, seed0):
     """The reference's context_free_grammar.CFG (the real module, not the no-op stand-in above) fed with each task's own
@@ -850,6 +971,7 @@ def main():
         "tasks2d.json": lambda: gen_tasks2d({"nav": nav_pal, "walls": walls_pal}, 6, 12000, 70),
         "curriculum.json": lambda: gen_curriculum(nav_pal, 920, 41000, 0.33),
         "groups.json": lambda: gen_groups(nav_pal, 6, 52000, 60),
+        "groups_exclusive.json": lambda: gen_groups_exclusive(nav_pal, 3, 63000, 100),
     }
     only = sys.argv[1:]                      # optional: the fixtures to (re)generate
     out = {name: make() for name, make in makers.items() if not only or name in only}

@@ -1,6 +1,8 @@
 """D13 on the GPU: two task groups run non-exclusively (Teacher::teach, teacher.cpp:207-230; forced by lang_acquisition,
-simulator_interface.cpp:46-48) against the oracle, which tests/test_oracle_groups.py pins to the reference's own Python
-tasks; the reference's confs/walls.json loaded unchanged; task_groups_exclusive honoured or refused, never ignored."""
+simulator_interface.cpp:46-48) and exclusively (teacher.cpp:209-220: the per-teach() group sort, one group per call, idle
+XWorld3DNav* groups rearranging the map in mid-episode) against the oracle, which tests/test_oracle_groups.py and
+tests/test_oracle_groups_exclusive.py pin to the reference's own Python tasks; the reference's confs/walls.json loaded
+unchanged."""
 import os
 import warnings
 
@@ -108,10 +110,20 @@ def test_two_group_conf_and_exclusive_flag():
     assert isinstance(sim.sentence(3), str)
     assert all(sim.sentence(e) == sim.sentence_c(e) for e in range(0, sim.num_envs, 9))      # the first speaking group wins, on both sides of the ABI
     sim.close()
-    # one_channel + exclusive (the Python defaults) with two built groups: refused, not silently run non-exclusively
-    with pytest.raises(XwbError, match="exclusive"):
-        BatchedSimulator("xworld", {"xwd_conf_path": conf}, num_envs=4)
+    # one_channel + exclusive (the Python defaults) with two built groups: Teacher::teach's exclusive branch, group weights
+    # from the conf
+    sim = BatchedSimulator("xworld", {"xwd_conf_path": conf, "max_steps": 50}, num_envs=64)
+    assert sim.cfg.task_groups_exclusive == 1 and (sim.cfg.task_group_weight, sim.cfg.task_group_weight2) == (1.0, 0.5)
+    for _ in range(120):
+        sim.step()
+        sim.reset_done()
+    st = [sim.env_state(e) for e in range(64)]
+    assert {s.xw_group_first for s in st} == {0, 1} and {s.xw_group_ran for s in st} == {0, 1}
+    assert all(sim.sentence(e) == sim.sentence_c(e) for e in range(64))
+    assert sim.check_errors() == 0
+    sim.close()
     sim = BatchedSimulator("xworld", {"xwd_conf_path": conf, "task_groups_exclusive": False}, num_envs=4)   # one_channel, both run
+    assert sim.env_state(0).xw_group_ran == -1
     sim.close()
     # one group: the flag changes nothing
     one = os.path.join(CONF, "navigation2d.json")
@@ -124,3 +136,109 @@ def test_two_group_conf_and_exclusive_flag():
     a.close(); b.close()
     with pytest.raises(XwbError, match="one must hold"):
         BatchedSimulator("xworld", {"xwd_conf_path": one, "task_mode": "lang_acquisition", "tasks": T3[:2], "tasks2": T3[2:]}, num_envs=4)
+
+
+EXCL_CASES = {
+    "3d+2d": (T3, T2, [1, 1], {}),
+    "2d+3d": (T2, T3, [1, 1], {}),
+    "weights": (T3, T2, [0.5, 2], {"task_weights2": [2, 1, 3, 1]}),
+    "zero_weights": (T2, T3, [0, 0], {}),                   # conf without "weight" keys: the sort never swaps
+    "near+color": (T3[1:2], T2[2:3], [1, 3], {}),
+    "walls": (T2, T3[:1] + T3[4:], [1, 1], {"map": "XWorldWalls"}),
+    "ego": (T3, T2, [1, 1], {"visible_radius": 3}),
+    "curriculum": (T2, T3, [2, 1], {"curriculum": 0.1, "max_dim": 8}),
+    "minstd": (T3, T2, [1, 2], {"rng": "minstd", "simulator_seed": 7, "thread_base": 2}),
+}
+
+
+@pytest.mark.parametrize("case", sorted(EXCL_CASES))
+def test_exclusive_groups_reset_and_rollout(oracle, case):
+    """task_groups_exclusive = true (py_simulator's default) in one_channel mode, FLAGS_max_steps ending the games: reset
+    state (map, both groups' FSMs, the group order), then every reward and game-over code of a rollout with resets."""
+    _torch()
+    from xworld_amd.batched import BatchedSimulator
+    first, second, gw, extra = EXCL_CASES[case]
+    n, steps, gid0 = 768, 300, 11
+    walls = extra.get("map") == "XWorldWalls"
+    md = extra.get("max_dim", 7)
+    opts = {"xwd_conf_path": os.path.join(CONF, "navigation2d.json"), "task_mode": "one_channel",
+            "max_dim": md, "tasks": first, "tasks2": second, "task_groups_exclusive": True, "task_group_weights": gw, "max_steps": 45}
+    if not walls:
+        opts["num_blocks"] = 16
+    opts.update(extra)
+    sim = BatchedSimulator("xworld", opts, num_envs=n, seed=33, policy_seed=9, env_gid0=gid0)
+    pal = oracle.Palette(oracle.WALLS_SUBTREES if walls else oracle.NAV_SUBTREES)
+    cfg = dict(map_kind=1 if walls else 0, max_dim=md, dim=md, num_goals=sim.cfg.num_goals, num_blocks=sim.cfg.num_blocks, seed=33,
+               tasks=first, tasks2=second, task_mode=1, task_groups_exclusive=1, group_weights=gw, max_steps=45,
+               visible_radius=extra.get("visible_radius", 0), curriculum=extra.get("curriculum", 0.0),
+               simulator_seed=extra.get("simulator_seed", 0), thread_base=extra.get("thread_base", 0))
+    if "task_weights2" in extra:
+        cfg["task_weights2"] = extra["task_weights2"]
+    ow = oracle.XWorld(pal, render=False, **cfg)
+    firsts = set()
+    for e in range(0, n, 3):
+        ow.reset_game(gid0 + e, 0)
+        st = sim.env_state(e)
+        assert np.array_equal(sim.env_grid(e).astype(np.int32), ow.grid()), e
+        assert (st.xw_agent_x, st.xw_agent_y) == ow.agent_xy(), e
+        assert st.xw_group_first == ow.group_first() == st.xw_group_ran, e
+        firsts.add(st.xw_group_first)
+        k0, s0, _, _, tx0, ty0 = ow.group_state(0)
+        k1, s1, _, _, tx1, ty1 = ow.group_state(1)
+        assert (st.xw_stage, st.xw_stage2) == (s0, s1), e
+        ran = st.xw_group_ran
+        assert (st.xw_task, st.xw_task2)[ran] == (k0, k1)[ran], e
+        for kind, stage, target, tx, ty in ((k0, s0, st.xw_target, tx0, ty0), (k1, s1, st.xw_target2, tx1, ty1)):
+            if kind >= 5 and stage == 1:                    # the 2-D group's target cell
+                assert target == ty * md + tx, (e, kind)
+    if gw[0] > 0 and gw[1] > 0:
+        assert firsts == {0, 1}
+    ref = oracle.xw_rollout(n, oracle.xw_cfg(**cfg), pal, steps, policy_seed=9, env_gid0=gid0)
+    rewards = set()
+    ran3d_idle = 0
+    for t in range(steps):
+        sim.reset_done()
+        sim.step()
+        r = sim.reward.cpu().numpy()
+        bad = np.nonzero(r.view(np.uint32) != ref.rewards[t].view(np.uint32))[0]
+        assert bad.size == 0, (t, bad[:5], r[bad[:5]], ref.rewards[t][bad[:5]])
+        assert np.array_equal(sim.game_over_codes.cpu().numpy(), ref.codes[t]), t
+        rewards.update(np.unique(r).tolist())
+    assert ref.stats.resets > 2 * n and len(rewards) >= 4
+    assert sim.check_errors() == 0
+    sim.close()
+
+
+@pytest.mark.parametrize("ego", [0, 3], ids=["full", "ego"])
+def test_exclusive_groups_frames_follow_mid_episode_rearrangement(oracle, ego):
+    """Frames of an exclusive two-group rollout against the oracle's renderer: the map a mid-episode idle stage leaves is
+    what the next frame shows (also the terminal frame when the same step ends the game), through step + reset_done and
+    through step_autoreset."""
+    _torch()
+    from xworld_amd.batched import BatchedSimulator
+    n, steps = 96, 130
+    opts = {"xwd_conf_path": os.path.join(CONF, "navigation2d.json"), "task_mode": "one_channel", "max_dim": 7, "num_blocks": 16,
+            "tasks": T2[:1], "tasks2": T3[1:4], "task_groups_exclusive": True, "task_group_weights": [1, 1], "max_steps": 40,
+            "color": True, "visible_radius": ego}
+    pal = oracle.Palette(oracle.NAV_SUBTREES)
+    cfg = dict(map_kind=0, max_dim=7, dim=7, num_goals=4, num_blocks=16, seed=5, tasks=T2[:1], tasks2=T3[1:4], task_mode=1,
+               task_groups_exclusive=1, group_weights=[1, 1], max_steps=40, color=1, visible_radius=ego)
+    ref = oracle.xw_rollout(n, oracle.xw_cfg(**cfg), pal, steps, policy_seed=2, render=True)
+    a = BatchedSimulator("xworld", opts, num_envs=n, seed=5, policy_seed=2)
+    b = BatchedSimulator("xworld", opts, num_envs=n, seed=5, policy_seed=2)
+    moved = 0
+    prev_agent = None
+    for t in range(steps):
+        a.reset_done()
+        obs = a.obs.cpu().numpy().reshape(n, -1)
+        assert np.array_equal(oracle.obs_checksum_np(obs), ref.obs_ck[t]), t          # the frame the policy sees at step t
+        assert np.array_equal(b.obs.cpu().numpy().reshape(n, -1), obs), t            # step_autoreset shows the same frames
+        a.step()
+        b.step_autoreset()
+        assert np.array_equal(a.reward.cpu().numpy().view(np.uint32), ref.rewards[t].view(np.uint32)), t
+        assert np.array_equal(b.reward.cpu().numpy().view(np.uint32), ref.rewards[t].view(np.uint32)), t
+    # a 3-D idle stage in mid-episode did happen (the 2-D task times out after 7 * 7 / 2 steps, then the sort may pick the 3-D group)
+    st = [a.env_state(e) for e in range(n)]
+    assert any(s.xw_stage2 != 0 and s.xw_group_ran == 1 for s in st)
+    a.close()
+    b.close()

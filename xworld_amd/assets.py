@@ -101,6 +101,13 @@ def conf_groups(conf, group=None):
     return out
 
 
+def conf_group_weights(conf, names):
+    """The "weight" keys of the named task groups (teacher.cpp:83-91: 0 when a group has none): what the exclusive
+    scheduler's weighted group sort reads (teacher.cpp:143-163)."""
+    groups = conf.get("task_groups") or {}
+    return [float(groups.get(n, {}).get("weight", 0)) for n in names]
+
+
 def conf_tasks(conf, group=None):
     """Task ids of one task group of the conf, in the order the JSON lists them (`group` names it when the conf
     has several: confs/walls.json also lists the language group XWorldRec, which is out of scope).

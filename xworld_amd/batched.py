@@ -131,6 +131,14 @@ class BatchedSimulator:
             # FLAGS_task_groups_exclusive (py_simulator.cpp:132, default true); lang_acquisition turns it off as the
             # reference does (simulator_interface.cpp:46-48)
             cfg.task_groups_exclusive = int(bool(opts.get("task_groups_exclusive", True))) if mode != "lang_acquisition" else 0
+            # the groups' "weight" keys (teacher.cpp:83-91), read by the exclusive scheduler's group sort only
+            gw = opts.get("task_group_weights")
+            if gw is None:
+                gw = assets.conf_group_weights(conf, [g[0] for g in groups]) if opts.get("tasks") is None else [0.0] * len(groups)
+            if len(gw) != len(groups):
+                raise RuntimeError("task_group_weights needs one weight per task group")
+            cfg.task_group_weight = float(gw[0])
+            cfg.task_group_weight2 = float(gw[1]) if len(gw) > 1 else 0.0
             self.tasks = list(groups[0][1])
             self.task_groups = [(g[0], list(g[1])) for g in groups]
             cfg.visible_radius = int(opts.get("visible_radius", 0))         # py_simulator.cpp:133
@@ -379,8 +387,10 @@ class BatchedSimulator:
         task groups the first one (conf order) that speaks wins: Task::teacher_speak only records into an empty buffer
         (teaching_task.cpp:118-127)."""
         st = self.env_state(env, stream)
+        if st.xw_group_ran == 1:                    # exclusive scheduling: only the group the last teach() ran can have spoken
+            return self._group_sentence(env, stream, st, st.xw_task2, st.xw_stage2, st.xw_event2, st.xw_target2, st.xw_steps_in_task2)
         out = self._group_sentence(env, stream, st, st.xw_task, st.xw_stage, st.xw_event, st.xw_target, st.xw_steps_in_task)
-        if not out and self.cfg.n_tasks2 > 0:
+        if not out and self.cfg.n_tasks2 > 0 and st.xw_group_ran < 0:
             out = self._group_sentence(env, stream, st, st.xw_task2, st.xw_stage2, st.xw_event2, st.xw_target2, st.xw_steps_in_task2)
         return out
 

@@ -50,7 +50,8 @@ struct StepCtx {
 // reward it adds to the teacher buffer and the event it leaves there (every py_stage overwrites it).
 template <int G>
 __device__ __forceinline__ void teach_group(const XwParams &p, const StepCtx &c, const uint8_t *s_icon_type, int ts, int tsteps_in,
-                                            double &rew, int &event, int &ts_out, int &tsteps_out) {
+                                            double &rew, int &event, int &ts_out, int &tsteps_out, bool &defer_idle) {
+    defer_idle = false;
     const int e = c.e, D = c.D, ax = c.ax, ay = c.ay, steps = c.steps, hit = c.hit, hit_cell = c.hit_cell;
     const int ddx = c.ddx, ddy = c.ddy, vx = c.vx, vy = c.vy, ld_level = c.level;
     const bool success = c.success;
@@ -89,6 +90,11 @@ __device__ __forceinline__ void teach_group(const XwParams &p, const StepCtx &c,
             }
             // `agent.loc in goal_locs` (-1.0) cannot hold: XMap::move_item never enters an occupied cell
         }
+    } else if (stage == STAGE_IDLE) {
+        // an idle XWorld3DNav* group picked in mid-episode (exclusive scheduling only: at reset the group's idle stage has
+        // always run).  TaskGroup::run_stage draws a task and runs its idle stage, which rearranges the map: reward 0, no
+        // event -- the stage itself runs in xw_idle3d_kernel, right behind this kernel, over the envs listed here.
+        defer_idle = true;
     } else if (stage == STAGE_NAV) {
         rew = -0.01;                                // time_penalty
         tsteps += 1;
@@ -136,7 +142,8 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     int32_t *count_now = p.done_count;
     if (e == 0) *p.done_count_next = 0;        // double-buffered done counter: zero the next step's
-    bool is_done = false;
+    bool is_done = false, idle3d = false;
+    if (e == 0 && p.idle_count_next) *p.idle_count_next = 0;
     int ld_axy = 0, ld_steps = 0, ld_ts = 0, ld_tsteps = 0, ld_dir = 1, ld_level = 0, ld_ts2 = 0, ld_tsteps2 = 0;
     if (e < p.n) {
         ld_axy = p.agent_xy[e]; ld_steps = p.num_steps[e]; ld_ts = p.task_state[e]; ld_tsteps = p.task_steps[e];
@@ -202,29 +209,61 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
                     }
                 }
             }
-            // Teacher::teach (teacher.cpp:207-230), groups run non-exclusively in conf order: each group's Task stage adds its
-            // reward to the teacher buffer and overwrites the buffer's event ("" included); only the first py_stage of a
-            // teach() sees this step's collisions (XWorldSimulator::get_events_of_game clears them, xworld_simulator.cpp:
-            // 118-122).  One group is the usual case.
             StepCtx cx{e, D, ax, ay, steps, hit, hit_cell, ddx, ddy, vx, vy, success, ld_level};
             double rew = 0.0;
             int event = EV_NONE;
-            {
+            if (p.exclusive && p.n_tasks2 > 0) {
+                // Teacher::teach, exclusive branch (teacher.cpp:209-220): re-sort the groups, then run ONE: the last busy
+                // group of the sorted list (the reference's loop has no break), else its first.  A busy 3-D group stays busy
+                // until the game resets (its "terminal" stage returns "terminal"), a 2-D one until it is back in "idle".
+                const int go = p.grp_order[e];
+                const int first = xw_sort_groups(p, e, p.episode[e], (uint32_t)steps, go & 1), second = first ^ 1;
+                const bool busy0 = task_stage(ld_ts) != STAGE_IDLE, busy1 = task_stage(ld_ts2) != STAGE_IDLE;
+                const bool busy_first = first ? busy1 : busy0, busy_second = first ? busy0 : busy1;
+                const int pick = busy_second ? second : (busy_first ? first : first);
                 int ts_new, tsteps_new;
                 double r0;
-                teach_group<0>(p, cx, s_icon_type, ld_ts, ld_tsteps, r0, event, ts_new, tsteps_new);
-                rew = 0.0 + r0;                             // add_teacher_reward on a cleared buffer
-                p.task_state[e] = ts_new;
-                p.task_steps[e] = tsteps_new;
-            }
-            if (p.n_tasks2 > 0) {
-                cx.hit = 0;                                 // game_events_ was consumed by the first group's py_stage
-                int ts_new, tsteps_new;
-                double r1;
-                teach_group<1>(p, cx, s_icon_type, ld_ts2, ld_tsteps2, r1, event, ts_new, tsteps_new);
-                rew += r1;
-                p.task_state2[e] = ts_new;
-                p.task_steps2[e] = tsteps_new;
+                bool defer;
+                if (pick == 0) {
+                    teach_group<0>(p, cx, s_icon_type, ld_ts, ld_tsteps, r0, event, ts_new, tsteps_new, defer);
+                    p.task_state[e] = ts_new;
+                    p.task_steps[e] = tsteps_new;
+                } else {
+                    teach_group<1>(p, cx, s_icon_type, ld_ts2, ld_tsteps2, r0, event, ts_new, tsteps_new, defer);
+                    p.task_state2[e] = ts_new;
+                    p.task_steps2[e] = tsteps_new;
+                }
+                rew = 0.0 + r0;
+                idle3d = defer;
+                p.grp_order[e] = (uint8_t)(first | (pick << 1));
+            } else {
+                // Teacher::teach (teacher.cpp:207-230), groups run non-exclusively in conf order: each group's Task stage adds
+                // its reward to the teacher buffer and overwrites the buffer's event ("" included); only the first py_stage
+                // of a teach() sees this step's collisions (XWorldSimulator::get_events_of_game clears them,
+                // xworld_simulator.cpp:118-122).  One group is the usual case.
+                bool defer;
+                if (p.exclusive && p.minstd) {      // one group: the sort still draws once from the reference's engine
+                    uint32_t x = p.minstd[e];
+                    (void)xwb_minstd_rand_range_state(&x, (float)p.group_weight[0]);
+                    p.minstd[e] = x;
+                }
+                {
+                    int ts_new, tsteps_new;
+                    double r0;
+                    teach_group<0>(p, cx, s_icon_type, ld_ts, ld_tsteps, r0, event, ts_new, tsteps_new, defer);
+                    rew = 0.0 + r0;                             // add_teacher_reward on a cleared buffer
+                    p.task_state[e] = ts_new;
+                    p.task_steps[e] = tsteps_new;
+                }
+                if (p.n_tasks2 > 0) {
+                    cx.hit = 0;                                 // game_events_ was consumed by the first group's py_stage
+                    int ts_new, tsteps_new;
+                    double r1;
+                    teach_group<1>(p, cx, s_icon_type, ld_ts2, ld_tsteps2, r1, event, ts_new, tsteps_new, defer);
+                    rew += r1;
+                    p.task_state2[e] = ts_new;
+                    p.task_steps2[e] = tsteps_new;
+                }
             }
             float r = 0.0f;                                 // SimulatorInterface::take_actions
             r += 0.0f;                                      // XWorldSimulator::take_action returns 0
@@ -240,6 +279,7 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
         }
     }
     wave_append(is_done, e, p.done_list, count_now);
+    if (p.idle_list) wave_append(idle3d, e, p.idle_list, p.idle_count);
     // "this step finished the env": stays put until the next step, whatever a reset_done does to the done codes meanwhile
     if (e < p.n) p.term_flag[e] = is_done ? 1 : 0;
     if (!p.visible_radius) {

@@ -221,6 +221,285 @@ __device__ __forceinline__ Mask<NW> xw_maze(Stream &s, int D, const LaneLds &L) 
     return mz;
 }
 
+// The idle stage of an XWorld3DNav* task on one env's board (decision order "xwb-taskgen-v1"): shared by the reset
+// kernel (the episode's first teach()) and by xw_idle3d_kernel (exclusive group scheduling: an idle XWorld3DNav* group picked
+// in mid-episode, teacher.cpp:209-220).  The board is what the caller holds in registers / its LDS columns: cells are
+// indices of the actual D x D dims, L.gcell / L.gname / L.gicon the goal slots in entity order.
+template <int NW>
+struct Idle3d {                                            // (references to the caller's registers: nothing is copied)
+    const int D, MD, off, ng, agent_icon;
+    const Mask<NW> &valid, &col0, &colN;
+    Mask<NW> &occupied;                                    // in / out: blocks and goals
+    int &agent_cell;                                       // in / out
+    uint32_t &target_bits;                                 // out: goal slot i belongs to self.target
+    int &sent_a, &sent_b;                                  // out: names bound into the teacher's grammar (G / G1, G2)
+    int &between;                                          // out: NavTargetBetween's middle cell (actual-dim index)
+};
+
+// REORDER: a 2-D-native group runs beside this one -- a later idle stage enumerates the goals in env.entities order
+template <int NW, bool REORDER>
+__device__ __forceinline__ void xw_idle_stage_3d(const XwParams &p, int e, Stream &s, const LaneLds &L, uint16_t *g, const Idle3d<NW> &c,
+                                                 int kind, int &tf) {
+    const int D = c.D, MD = c.MD, off = c.off, ng = c.ng, agent_icon = c.agent_icon;
+    const Mask<NW> &valid = c.valid, &col0 = c.col0, &colN = c.colN;
+    Mask<NW> &occupied = c.occupied;
+    int &agent_cell = c.agent_cell, &sent_a = c.sent_a, &sent_b = c.sent_b, &between = c.between;
+    uint32_t &target_bits = c.target_bits;
+    auto put = [&](int cell, int icon) { g[(cell / D + off) * MD + (cell % D + off)] = (uint16_t)(icon + 1); };
+    if (kind == TASK_TARGET || kind == TASK_AVOID) {
+        // goals reachable from the agent with blocks and the other goals as obstacles: flood the empty cells from
+        // the agent by whole-board shifts; a goal is reachable iff one of its 4-neighbours is flooded
+        const Mask<NW> free_cells = valid.andnot(occupied);          // agent cell included: it is the seed
+        Mask<NW> reach;
+        reach.clear();
+        reach.set(agent_cell);
+        for (int it = 0; it < D * D; ++it) {
+            const Mask<NW> grown = reach | (neighbours<NW>(reach, D, col0, colN, valid) & free_cells);
+            if (grown.equals(reach)) break;
+            reach = grown;
+        }
+        int nc = 0;
+        uint32_t cand_bits = 0;
+        for (int i = 0; i < ng; ++i) {
+            Mask<NW> gm;
+            gm.clear();
+            gm.set(L.gcell[L.at(i)]);
+            if ((neighbours<NW>(gm, D, col0, colN, valid) & reach).any()) { cand_bits |= 1u << i; nc++; }
+        }
+        if (nc > 0) {                                                // else: assert targets, "map too crowded?"
+            int k = (int)s.below((uint32_t)nc);                      // sel_goal = random.choice(targets)
+            int pick = 0;
+            for (int i = 0; i < ng; ++i)
+                if ((cand_bits >> i) & 1u) { if (k == 0) { pick = i; break; } k--; }
+            const int selname = L.gname[L.at(pick)];
+            if (kind == TASK_TARGET) {
+                tf = selname;
+                sent_a = selname;
+                for (int i = 0; i < ng; ++i) if (L.gname[L.at(i)] == selname) target_bits |= 1u << i;
+            } else {
+                int nr = 0;
+                for (int i = 0; i < ng; ++i) if (L.gname[L.at(i)] != selname) nr++;
+                if (nr > 0) {                                        // else: assert referents
+                    int r = (int)s.below((uint32_t)nr);              // referent = random.choice(referents)
+                    int refname = 0;
+                    for (int i = 0; i < ng; ++i)
+                        if (L.gname[L.at(i)] != selname) { if (r == 0) { refname = L.gname[L.at(i)]; break; } r--; }
+                    for (int i = 0; i < ng; ++i) if (L.gname[L.at(i)] != refname) target_bits |= 1u << i;
+                    sent_a = refname;
+                }
+            }
+        }
+    } else if (ng >= 2) {
+        // ---- Near / Between / Direction: delete the agent and two goals, put the goals on a tile, re-place the agent
+        Mask<NW> A = valid.andnot(occupied);                         // available_grids after _delete_entity(agent)
+        const int d0 = (int)s.below((uint32_t)ng);                   // random.shuffle(goals); g1, g2 = goals[:2]
+        const int d1 = (int)s.below((uint32_t)(ng - 1));
+        const int g1 = d0, g2 = d1 < d0 ? d1 : d1 + 1;
+        const int c1o = L.gcell[L.at(g1)], c2o = L.gcell[L.at(g2)];
+        A.set(c1o); A.set(c2o);
+        auto from_right = [&](const Mask<NW> &m) { return m.andnot(col0).shr(1); };   // bit c = m[c+1], x < D-1
+        const Mask<NW> Nl = A.andnot(colN).shl(1) & valid, Nr = from_right(A), Nu = A.shl(D) & valid, Nd = A.shr(D);
+        Mask<NW> M[6];
+        int nm = 0;
+        if (kind == TASK_NEAR) {                                     // _get_p_tiles
+            const Mask<NW> C1 = Nl | Nr | Nu | Nd;
+            const Mask<NW> C2 = (Nl & Nr) | (Nl & Nu) | (Nl & Nd) | (Nr & Nu) | (Nr & Nd) | (Nu & Nd);
+            const Mask<NW> Hb = A & Nr, Vb = A & Nd, Db = A & from_right(A.shr(D));
+            M[0] = Hb & from_right(C2); M[1] = Hb & C2;
+            M[2] = Vb & C2.shr(D);      M[3] = Vb & C2;
+            M[4] = Db & from_right(C1.shr(D)); M[5] = Db & C1;
+            nm = 6;
+        } else if (kind == TASK_BETWEEN) {                           // _get_t_tiles
+            M[0] = A & Nl & Nr & (Nu | Nd);
+            M[1] = A & Nu & Nd & (Nl | Nr);
+            nm = 2;
+        } else {                                                     // _get_l_tiles
+            const Mask<NW> Tv = A & Nd & A.shr(2 * D);
+            const Mask<NW> Th = A & Nr & from_right(Nr);
+            M[0] = Tv; M[1] = Tv; M[2] = Th; M[3] = Th;
+            nm = 4;
+        }
+        int nt = 0;
+        for (int m = 0; m < 6; ++m) if (m < nm)
+#pragma unroll
+            for (int wi = 0; wi < NW; ++wi) nt += __popcll(M[m].w[wi]);
+        bool ok = nt > 0;                                            // assert tiles, "map too crowded?"
+        int l1 = 0, l2 = 0, al = 0, direction = 0, tgt = g1, ref = g2;
+        if (ok) {
+            int t0 = (int)s.below((uint32_t)nt);                     // random.shuffle(tiles); tiles[0]
+            if (nt >= 2) (void)s.below((uint32_t)(nt - 1));
+            // tiles are listed cell-major, the nm kinds in order inside a cell: find the cell, then the kind
+            int tc = 0, tm = 0;
+            {
+                int lo = 0, hi = D * D;                              // smallest c with prefix(c + 1) > t0
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    int pre = 0;
+                    for (int m = 0; m < 6; ++m) if (m < nm)
+#pragma unroll
+                        for (int wi = 0; wi < NW; ++wi) {
+                            const int b = mid + 1 - wi * 64;
+                            const uint64_t lowmask = b <= 0 ? 0ull : (b >= 64 ? ~0ull : ((1ull << b) - 1ull));
+                            pre += __popcll(M[m].w[wi] & lowmask);
+                        }
+                    if (pre > t0) hi = mid; else lo = mid + 1;
+                }
+                tc = lo;
+                int pre = 0;
+                for (int m = 0; m < 6; ++m) if (m < nm)
+#pragma unroll
+                    for (int wi = 0; wi < NW; ++wi) {
+                        const int b = tc - wi * 64;
+                        const uint64_t lowmask = b <= 0 ? 0ull : (b >= 64 ? ~0ull : ((1ull << b) - 1ull));
+                        pre += __popcll(M[m].w[wi] & lowmask);
+                    }
+                int r = t0 - pre;
+                for (int m = 0; m < 6; ++m) if (m < nm && M[m].test(tc)) { if (r == 0) { tm = m; break; } r--; }
+            }
+            if (kind == TASK_NEAR) {
+                const int other = tm < 2 ? tc + 1 : (tm < 4 ? tc + D : tc + D + 1);
+                l1 = (tm & 1) ? other : tc; l2 = (tm & 1) ? tc : other;
+            } else if (kind == TASK_BETWEEN) {
+                l1 = tm == 0 ? tc - 1 : tc - D; l2 = tm == 0 ? tc + 1 : tc + D;
+            } else {
+                const int st = tm < 2 ? D : 1;
+                l1 = (tm & 1) ? tc + st : tc; l2 = (tm & 1) ? tc + 2 * st : tc + st;
+            }
+            occupied.reset(c1o); occupied.reset(c2o);
+            occupied.set(l1); occupied.set(l2);                      // _set_entity_inst(g1), (g2)
+            A.reset(l1); A.reset(l2);
+            int seed = l2;
+            bool inclusive = false;
+            if (kind == TASK_BETWEEN) {
+                seed = (l1 + l2) / 2;                                // _middle_loc: same row or same column
+            } else if (kind == TASK_DIRECTION) {
+                Mask<NW> one;
+                one.clear(); one.set(l1);
+                Mask<NW> Ne = neighbours<NW>(one, D, col0, colN, valid) & A;   // empty 4-neighbours of g1 ...
+                if (!Ne.any()) { one.clear(); one.set(l2); Ne = neighbours<NW>(one, D, col0, colN, valid) & A; tgt = g2; ref = g1; }
+                int ne = 0;
+#pragma unroll
+                for (int wi = 0; wi < NW; ++wi) ne += __popcll(Ne.w[wi]);
+                if (ne == 0) ok = false;                             // assert empty_grids
+                else {
+                    const int ec = Ne.select((int)s.below((uint32_t)ne));    // random.choice(empty_grids), row-major
+                    const int tl = tgt == g1 ? l1 : l2, rl = ref == g1 ? l1 : l2;
+                    // __compute_triple_direction(target, referent, e): view = e -> target, v2 = target -> referent
+                    const int v1x = tl % D - ec % D, v1y = tl / D - ec / D;
+                    const int v2x = rl % D - tl % D, v2y = rl / D - tl / D;
+                    const int c = v1x * v2x + v1y * v2y, sn = v1y * v2x - v1x * v2y;
+                    direction = c > 0 ? DIR_FRONT : (c < 0 ? DIR_BEHIND : (sn > 0 ? DIR_RIGHT : DIR_LEFT));
+                    seed = ec; inclusive = true;                     // _propagate_agent([e], inclusive=True)
+                }
+            }
+            if (ok) {
+                // _propagate_agent: flood fill from the seed over cells that hold neither blocks nor goals
+                const Mask<NW> open = valid.andnot(occupied);
+                Mask<NW> fl;
+                fl.clear(); fl.set(seed);
+                for (int it = 0; it < D * D; ++it) {
+                    const Mask<NW> grown = fl | (neighbours<NW>(fl, D, col0, colN, valid) & open);
+                    if (grown.equals(fl)) break;
+                    fl = grown;
+                }
+                int na = inclusive ? 0 : -1;                         // the seed itself only counts when inclusive
+#pragma unroll
+                for (int wi = 0; wi < NW; ++wi) na += __popcll(fl.w[wi]);
+                if (na <= 0) ok = false;                             // assert new_a
+                else {
+                    int ka = (int)s.below((uint32_t)na);             // agent.loc, _ = random.choice(new_a)
+                    al = seed;
+                    if (!(inclusive && ka == 0)) {
+                        // new_a is in BFS discovery order (moves left, right, up, down): replay the BFS up to entry ka
+                        const int want = inclusive ? ka - 1 : ka;
+                        Mask<NW> seen;
+                        seen.clear(); seen.set(seed);
+                        int head = 0, tail = 0, count = 0;
+                        L.blk[L.at(tail++)] = (uint8_t)seed;
+                        bool found = false;
+                        while (head < tail && !found) {
+                            const int c = L.blk[L.at(head++)];
+                            const int cx = c % D, cy = c / D;
+                            for (int m = 0; m < 4 && !found; ++m) {
+                                const int nx = cx + (m == 0 ? -1 : (m == 1 ? 1 : 0)), ny = cy + (m == 2 ? -1 : (m == 3 ? 1 : 0));
+                                if (nx < 0 || ny < 0 || nx >= D || ny >= D) continue;
+                                const int nc2 = ny * D + nx;
+                                if (seen.test(nc2) || occupied.test(nc2)) continue;
+                                seen.set(nc2);
+                                L.blk[L.at(tail++)] = (uint8_t)nc2;
+                                if (count == want) { al = nc2; found = true; }
+                                count++;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (ok) {
+            // the env changed: XWorld::reset(false).  Clear the three old cells, then write the new ones.
+            auto clear_cell = [&](int c) { g[(c / D + off) * MD + (c % D + off)] = 0; };
+            clear_cell(c1o); clear_cell(c2o); clear_cell(agent_cell);
+            L.gcell[L.at(g1)] = (uint8_t)l1; L.gcell[L.at(g2)] = (uint8_t)l2;
+            put(al, agent_icon);
+            agent_cell = al;
+            sent_a = L.gname[L.at(kind == TASK_DIRECTION ? ref : g1)];
+            if (kind == TASK_BETWEEN) sent_b = L.gname[L.at(g2)];
+            if (REORDER) {
+                // (only where a later idle stage enumerates the goals: a batch with a 2-D-native group beside this one)
+                // env.entities: g1 and g2 were deleted and set again, so they now follow the other goals, in that order
+                // (xworld_env.py _delete_entity / _set_entity_inst).  A later idle stage that enumerates the goals -- the
+                // 2-D-native group's random.choice(targets) -- sees that order, so the goal slots take it too; the
+                // egocentric poses travel with their goals.
+                const uint8_t c1 = L.gcell[L.at(g1)], c2 = L.gcell[L.at(g2)];
+                const uint16_t i1 = L.gicon[L.at(g1)], i2 = L.gicon[L.at(g2)], n1 = L.gname[L.at(g1)], n2 = L.gname[L.at(g2)];
+                double *gw = p.visible_radius ? p.goal_warp + (size_t)e * XW_MAX_GOALS * 6 : nullptr;
+                double w1[6], w2[6];
+                if (gw) for (int q = 0; q < 6; ++q) { w1[q] = gw[g1 * 6 + q]; w2[q] = gw[g2 * 6 + q]; }
+                int k = 0;
+                for (int i = 0; i < ng; ++i) {
+                    if (i == g1 || i == g2) continue;
+                    if (k != i) {
+                        L.gcell[L.at(k)] = L.gcell[L.at(i)]; L.gicon[L.at(k)] = L.gicon[L.at(i)]; L.gname[L.at(k)] = L.gname[L.at(i)];
+                        if (gw) for (int q = 0; q < 6; ++q) gw[k * 6 + q] = gw[i * 6 + q];
+                    }
+                    ++k;
+                }
+                L.gcell[L.at(k)] = c1; L.gicon[L.at(k)] = i1; L.gname[L.at(k)] = n1;
+                L.gcell[L.at(k + 1)] = c2; L.gicon[L.at(k + 1)] = i2; L.gname[L.at(k + 1)] = n2;
+                if (gw) for (int q = 0; q < 6; ++q) { gw[k * 6 + q] = w1[q]; gw[(k + 1) * 6 + q] = w2[q]; }
+            }
+            if (kind == TASK_NEAR) {
+                // _get_surrounding_goals(refer=g1.loc): dist < 1.5 + 1e-3 = the 8-neighbourhood, goals AT g1.loc skipped
+                for (int i = 0; i < ng; ++i) {
+                    const int c = L.gcell[L.at(i)];
+                    const int ddx = c % D - l1 % D, ddy = c / D - l1 / D;
+                    if (c != l1 && ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1) target_bits |= 1u << i;
+                }
+            } else if (kind == TASK_BETWEEN) {
+                between = (l1 + l2) / 2;
+            } else {
+                // navigation_reward: a reached goal g wins iff direction(g, referent) seen along the agent's constant
+                // yaw 1.5707963 (heading +y) equals `direction` and g is within 1.0 + 1e-3 of the referent
+                // (the step kernel evaluates the same test with the heading at that time -- it changes in egocentric
+                // mode; the bits below are the answer for the heading at reset)
+                const int rl = ref == g1 ? l1 : l2;
+                const int hd = p.visible_radius ? p.agent_dir[e] : 1;
+                const int hx = hd == 0 ? 1 : (hd == 2 ? -1 : 0), hy = hd == 1 ? 1 : (hd == 3 ? -1 : 0);
+                for (int i = 0; i < ng; ++i) {
+                    const int c = L.gcell[L.at(i)];
+                    const int v2x = rl % D - c % D, v2y = rl / D - c / D;
+                    if (v2x * v2x + v2y * v2y != 1) continue;         // dist == 0 -> False; dist > 1.001 -> far
+                    const int cs = hx * v2x + hy * v2y, sn = hy * v2x - hx * v2y;
+                    const int dir = cs > 0 ? DIR_FRONT : (cs < 0 ? DIR_BEHIND : (sn > 0 ? DIR_RIGHT : DIR_LEFT));
+                    if (dir == direction) target_bits |= 1u << i;
+                }
+                tf = ((rl / D + off) * MD + (rl % D + off)) | (direction << 8);
+            }
+        }
+    }
+        if (kind == TASK_BETWEEN && between >= 0) tf = (between / D + off) * MD + (between % D + off);
+}
+
 // GM (task groups, compile time so that the usual one-group batch carries none of the other paths): 0 = one XWorld3DNav*
 // group, 1 = one 2-D-native group, 2 = two groups
 template <int NW, int KIND, int GM>
@@ -444,273 +723,47 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
         }
     };
     auto idle_stage_3d = [&](int kind, int &tf) {
-    if (kind == TASK_TARGET || kind == TASK_AVOID) {
-        // goals reachable from the agent with blocks and the other goals as obstacles: flood the empty cells from
-        // the agent by whole-board shifts; a goal is reachable iff one of its 4-neighbours is flooded
-        const Mask<NW> free_cells = valid.andnot(occupied);          // agent cell included: it is the seed
-        Mask<NW> reach;
-        reach.clear();
-        reach.set(agent_cell);
-        for (int it = 0; it < D * D; ++it) {
-            const Mask<NW> grown = reach | (neighbours<NW>(reach, D, col0, colN, valid) & free_cells);
-            if (grown.equals(reach)) break;
-            reach = grown;
-        }
-        int nc = 0;
-        uint32_t cand_bits = 0;
-        for (int i = 0; i < ng; ++i) {
-            Mask<NW> gm;
-            gm.clear();
-            gm.set(L.gcell[L.at(i)]);
-            if ((neighbours<NW>(gm, D, col0, colN, valid) & reach).any()) { cand_bits |= 1u << i; nc++; }
-        }
-        if (nc > 0) {                                                // else: assert targets, "map too crowded?"
-            int k = (int)s.below((uint32_t)nc);                      // sel_goal = random.choice(targets)
-            int pick = 0;
-            for (int i = 0; i < ng; ++i)
-                if ((cand_bits >> i) & 1u) { if (k == 0) { pick = i; break; } k--; }
-            const int selname = L.gname[L.at(pick)];
-            if (kind == TASK_TARGET) {
-                tf = selname;
-                sent_a = selname;
-                for (int i = 0; i < ng; ++i) if (L.gname[L.at(i)] == selname) target_bits |= 1u << i;
-            } else {
-                int nr = 0;
-                for (int i = 0; i < ng; ++i) if (L.gname[L.at(i)] != selname) nr++;
-                if (nr > 0) {                                        // else: assert referents
-                    int r = (int)s.below((uint32_t)nr);              // referent = random.choice(referents)
-                    int refname = 0;
-                    for (int i = 0; i < ng; ++i)
-                        if (L.gname[L.at(i)] != selname) { if (r == 0) { refname = L.gname[L.at(i)]; break; } r--; }
-                    for (int i = 0; i < ng; ++i) if (L.gname[L.at(i)] != refname) target_bits |= 1u << i;
-                    sent_a = refname;
-                }
-            }
-        }
-    } else if (ng >= 2) {
-        // ---- Near / Between / Direction: delete the agent and two goals, put the goals on a tile, re-place the agent
-        Mask<NW> A = valid.andnot(occupied);                         // available_grids after _delete_entity(agent)
-        const int d0 = (int)s.below((uint32_t)ng);                   // random.shuffle(goals); g1, g2 = goals[:2]
-        const int d1 = (int)s.below((uint32_t)(ng - 1));
-        const int g1 = d0, g2 = d1 < d0 ? d1 : d1 + 1;
-        const int c1o = L.gcell[L.at(g1)], c2o = L.gcell[L.at(g2)];
-        A.set(c1o); A.set(c2o);
-        auto from_right = [&](const Mask<NW> &m) { return m.andnot(col0).shr(1); };   // bit c = m[c+1], x < D-1
-        const Mask<NW> Nl = A.andnot(colN).shl(1) & valid, Nr = from_right(A), Nu = A.shl(D) & valid, Nd = A.shr(D);
-        Mask<NW> M[6];
-        int nm = 0;
-        if (kind == TASK_NEAR) {                                     // _get_p_tiles
-            const Mask<NW> C1 = Nl | Nr | Nu | Nd;
-            const Mask<NW> C2 = (Nl & Nr) | (Nl & Nu) | (Nl & Nd) | (Nr & Nu) | (Nr & Nd) | (Nu & Nd);
-            const Mask<NW> Hb = A & Nr, Vb = A & Nd, Db = A & from_right(A.shr(D));
-            M[0] = Hb & from_right(C2); M[1] = Hb & C2;
-            M[2] = Vb & C2.shr(D);      M[3] = Vb & C2;
-            M[4] = Db & from_right(C1.shr(D)); M[5] = Db & C1;
-            nm = 6;
-        } else if (kind == TASK_BETWEEN) {                           // _get_t_tiles
-            M[0] = A & Nl & Nr & (Nu | Nd);
-            M[1] = A & Nu & Nd & (Nl | Nr);
-            nm = 2;
-        } else {                                                     // _get_l_tiles
-            const Mask<NW> Tv = A & Nd & A.shr(2 * D);
-            const Mask<NW> Th = A & Nr & from_right(Nr);
-            M[0] = Tv; M[1] = Tv; M[2] = Th; M[3] = Th;
-            nm = 4;
-        }
-        int nt = 0;
-        for (int m = 0; m < 6; ++m) if (m < nm)
-#pragma unroll
-            for (int wi = 0; wi < NW; ++wi) nt += __popcll(M[m].w[wi]);
-        bool ok = nt > 0;                                            // assert tiles, "map too crowded?"
-        int l1 = 0, l2 = 0, al = 0, direction = 0, tgt = g1, ref = g2;
-        if (ok) {
-            int t0 = (int)s.below((uint32_t)nt);                     // random.shuffle(tiles); tiles[0]
-            if (nt >= 2) (void)s.below((uint32_t)(nt - 1));
-            // tiles are listed cell-major, the nm kinds in order inside a cell: find the cell, then the kind
-            int tc = 0, tm = 0;
-            {
-                int lo = 0, hi = D * D;                              // smallest c with prefix(c + 1) > t0
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    int pre = 0;
-                    for (int m = 0; m < 6; ++m) if (m < nm)
-#pragma unroll
-                        for (int wi = 0; wi < NW; ++wi) {
-                            const int b = mid + 1 - wi * 64;
-                            const uint64_t lowmask = b <= 0 ? 0ull : (b >= 64 ? ~0ull : ((1ull << b) - 1ull));
-                            pre += __popcll(M[m].w[wi] & lowmask);
-                        }
-                    if (pre > t0) hi = mid; else lo = mid + 1;
-                }
-                tc = lo;
-                int pre = 0;
-                for (int m = 0; m < 6; ++m) if (m < nm)
-#pragma unroll
-                    for (int wi = 0; wi < NW; ++wi) {
-                        const int b = tc - wi * 64;
-                        const uint64_t lowmask = b <= 0 ? 0ull : (b >= 64 ? ~0ull : ((1ull << b) - 1ull));
-                        pre += __popcll(M[m].w[wi] & lowmask);
-                    }
-                int r = t0 - pre;
-                for (int m = 0; m < 6; ++m) if (m < nm && M[m].test(tc)) { if (r == 0) { tm = m; break; } r--; }
-            }
-            if (kind == TASK_NEAR) {
-                const int other = tm < 2 ? tc + 1 : (tm < 4 ? tc + D : tc + D + 1);
-                l1 = (tm & 1) ? other : tc; l2 = (tm & 1) ? tc : other;
-            } else if (kind == TASK_BETWEEN) {
-                l1 = tm == 0 ? tc - 1 : tc - D; l2 = tm == 0 ? tc + 1 : tc + D;
-            } else {
-                const int st = tm < 2 ? D : 1;
-                l1 = (tm & 1) ? tc + st : tc; l2 = (tm & 1) ? tc + 2 * st : tc + st;
-            }
-            occupied.reset(c1o); occupied.reset(c2o);
-            occupied.set(l1); occupied.set(l2);                      // _set_entity_inst(g1), (g2)
-            A.reset(l1); A.reset(l2);
-            int seed = l2;
-            bool inclusive = false;
-            if (kind == TASK_BETWEEN) {
-                seed = (l1 + l2) / 2;                                // _middle_loc: same row or same column
-            } else if (kind == TASK_DIRECTION) {
-                Mask<NW> one;
-                one.clear(); one.set(l1);
-                Mask<NW> Ne = neighbours<NW>(one, D, col0, colN, valid) & A;   // empty 4-neighbours of g1 ...
-                if (!Ne.any()) { one.clear(); one.set(l2); Ne = neighbours<NW>(one, D, col0, colN, valid) & A; tgt = g2; ref = g1; }
-                int ne = 0;
-#pragma unroll
-                for (int wi = 0; wi < NW; ++wi) ne += __popcll(Ne.w[wi]);
-                if (ne == 0) ok = false;                             // assert empty_grids
-                else {
-                    const int ec = Ne.select((int)s.below((uint32_t)ne));    // random.choice(empty_grids), row-major
-                    const int tl = tgt == g1 ? l1 : l2, rl = ref == g1 ? l1 : l2;
-                    // __compute_triple_direction(target, referent, e): view = e -> target, v2 = target -> referent
-                    const int v1x = tl % D - ec % D, v1y = tl / D - ec / D;
-                    const int v2x = rl % D - tl % D, v2y = rl / D - tl / D;
-                    const int c = v1x * v2x + v1y * v2y, sn = v1y * v2x - v1x * v2y;
-                    direction = c > 0 ? DIR_FRONT : (c < 0 ? DIR_BEHIND : (sn > 0 ? DIR_RIGHT : DIR_LEFT));
-                    seed = ec; inclusive = true;                     // _propagate_agent([e], inclusive=True)
-                }
-            }
-            if (ok) {
-                // _propagate_agent: flood fill from the seed over cells that hold neither blocks nor goals
-                const Mask<NW> open = valid.andnot(occupied);
-                Mask<NW> fl;
-                fl.clear(); fl.set(seed);
-                for (int it = 0; it < D * D; ++it) {
-                    const Mask<NW> grown = fl | (neighbours<NW>(fl, D, col0, colN, valid) & open);
-                    if (grown.equals(fl)) break;
-                    fl = grown;
-                }
-                int na = inclusive ? 0 : -1;                         // the seed itself only counts when inclusive
-#pragma unroll
-                for (int wi = 0; wi < NW; ++wi) na += __popcll(fl.w[wi]);
-                if (na <= 0) ok = false;                             // assert new_a
-                else {
-                    int ka = (int)s.below((uint32_t)na);             // agent.loc, _ = random.choice(new_a)
-                    al = seed;
-                    if (!(inclusive && ka == 0)) {
-                        // new_a is in BFS discovery order (moves left, right, up, down): replay the BFS up to entry ka
-                        const int want = inclusive ? ka - 1 : ka;
-                        Mask<NW> seen;
-                        seen.clear(); seen.set(seed);
-                        int head = 0, tail = 0, count = 0;
-                        L.blk[L.at(tail++)] = (uint8_t)seed;
-                        bool found = false;
-                        while (head < tail && !found) {
-                            const int c = L.blk[L.at(head++)];
-                            const int cx = c % D, cy = c / D;
-                            for (int m = 0; m < 4 && !found; ++m) {
-                                const int nx = cx + (m == 0 ? -1 : (m == 1 ? 1 : 0)), ny = cy + (m == 2 ? -1 : (m == 3 ? 1 : 0));
-                                if (nx < 0 || ny < 0 || nx >= D || ny >= D) continue;
-                                const int nc2 = ny * D + nx;
-                                if (seen.test(nc2) || occupied.test(nc2)) continue;
-                                seen.set(nc2);
-                                L.blk[L.at(tail++)] = (uint8_t)nc2;
-                                if (count == want) { al = nc2; found = true; }
-                                count++;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (ok) {
-            // the env changed: XWorld::reset(false).  Clear the three old cells, then write the new ones.
-            auto clear_cell = [&](int c) { g[(c / D + off) * MD + (c % D + off)] = 0; };
-            clear_cell(c1o); clear_cell(c2o); clear_cell(agent_cell);
-            L.gcell[L.at(g1)] = (uint8_t)l1; L.gcell[L.at(g2)] = (uint8_t)l2;
-            put(al, agent_icon);
-            agent_cell = al;
-            sent_a = L.gname[L.at(kind == TASK_DIRECTION ? ref : g1)];
-            if (kind == TASK_BETWEEN) sent_b = L.gname[L.at(g2)];
-            if (GM == 2) {
-                // (only where a later idle stage enumerates the goals: a batch with a 2-D-native group beside this one)
-                // env.entities: g1 and g2 were deleted and set again, so they now follow the other goals, in that order
-                // (xworld_env.py _delete_entity / _set_entity_inst).  A later idle stage that enumerates the goals -- the
-                // 2-D-native group's random.choice(targets) -- sees that order, so the goal slots take it too; the
-                // egocentric poses travel with their goals.
-                const uint8_t c1 = L.gcell[L.at(g1)], c2 = L.gcell[L.at(g2)];
-                const uint16_t i1 = L.gicon[L.at(g1)], i2 = L.gicon[L.at(g2)], n1 = L.gname[L.at(g1)], n2 = L.gname[L.at(g2)];
-                double *gw = p.visible_radius ? p.goal_warp + (size_t)e * XW_MAX_GOALS * 6 : nullptr;
-                double w1[6], w2[6];
-                if (gw) for (int q = 0; q < 6; ++q) { w1[q] = gw[g1 * 6 + q]; w2[q] = gw[g2 * 6 + q]; }
-                int k = 0;
-                for (int i = 0; i < ng; ++i) {
-                    if (i == g1 || i == g2) continue;
-                    if (k != i) {
-                        L.gcell[L.at(k)] = L.gcell[L.at(i)]; L.gicon[L.at(k)] = L.gicon[L.at(i)]; L.gname[L.at(k)] = L.gname[L.at(i)];
-                        if (gw) for (int q = 0; q < 6; ++q) gw[k * 6 + q] = gw[i * 6 + q];
-                    }
-                    ++k;
-                }
-                L.gcell[L.at(k)] = c1; L.gicon[L.at(k)] = i1; L.gname[L.at(k)] = n1;
-                L.gcell[L.at(k + 1)] = c2; L.gicon[L.at(k + 1)] = i2; L.gname[L.at(k + 1)] = n2;
-                if (gw) for (int q = 0; q < 6; ++q) { gw[k * 6 + q] = w1[q]; gw[(k + 1) * 6 + q] = w2[q]; }
-            }
-            if (kind == TASK_NEAR) {
-                // _get_surrounding_goals(refer=g1.loc): dist < 1.5 + 1e-3 = the 8-neighbourhood, goals AT g1.loc skipped
-                for (int i = 0; i < ng; ++i) {
-                    const int c = L.gcell[L.at(i)];
-                    const int ddx = c % D - l1 % D, ddy = c / D - l1 / D;
-                    if (c != l1 && ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1) target_bits |= 1u << i;
-                }
-            } else if (kind == TASK_BETWEEN) {
-                between = (l1 + l2) / 2;
-            } else {
-                // navigation_reward: a reached goal g wins iff direction(g, referent) seen along the agent's constant
-                // yaw 1.5707963 (heading +y) equals `direction` and g is within 1.0 + 1e-3 of the referent
-                // (the step kernel evaluates the same test with the heading at that time -- it changes in egocentric
-                // mode; the bits below are the answer for the heading at reset)
-                const int rl = ref == g1 ? l1 : l2;
-                const int hd = p.visible_radius ? p.agent_dir[e] : 1;
-                const int hx = hd == 0 ? 1 : (hd == 2 ? -1 : 0), hy = hd == 1 ? 1 : (hd == 3 ? -1 : 0);
-                for (int i = 0; i < ng; ++i) {
-                    const int c = L.gcell[L.at(i)];
-                    const int v2x = rl % D - c % D, v2y = rl / D - c / D;
-                    if (v2x * v2x + v2y * v2y != 1) continue;         // dist == 0 -> False; dist > 1.001 -> far
-                    const int cs = hx * v2x + hy * v2y, sn = hy * v2x - hx * v2y;
-                    const int dir = cs > 0 ? DIR_FRONT : (cs < 0 ? DIR_BEHIND : (sn > 0 ? DIR_RIGHT : DIR_LEFT));
-                    if (dir == direction) target_bits |= 1u << i;
-                }
-                tf = ((rl / D + off) * MD + (rl % D + off)) | (direction << 8);
-            }
-        }
-    }
-        if (kind == TASK_BETWEEN && between >= 0) tf = (between / D + off) * MD + (between % D + off);
+        const Idle3d<NW> c{D, MD, off, ng, agent_icon, valid, col0, colN, occupied, agent_cell, target_bits, sent_a, sent_b, between};
+        xw_idle_stage_3d<NW, GM == 2>(p, e, s, L, g, c, kind, tf);
     };
     int kindv[2] = {TASK_TARGET, TASK_TARGET}, tfv[2] = {-1, -1}, st0v[2] = {STAGE_NAV, STAGE_NAV};
     const bool first_2d = GM == 1 || (GM == 2 && p.group2d);
-    {
-        const int tsel = sample_task<0>(p, s, e);
-        kindv[0] = p.n_tasks > 0 ? task_at<0>(p, tsel) : TASK_TARGET;
-        if (GM != 0 && first_2d) idle_stage_2d(kindv[0], true, tfv[0], st0v[0]);
-        if (GM != 1 && !first_2d) idle_stage_3d(kindv[0], tfv[0]);
-    }
-    if (GM == 2) {
-        const int tsel = sample_task<1>(p, s, e);
-        kindv[1] = task_at<1>(p, tsel);
-        if (!first_2d) idle_stage_2d(kindv[1], true, tfv[1], st0v[1]);
-        else idle_stage_3d(kindv[1], tfv[1]);
-        if (first_2d) { int tf_unused, st_unused; idle_stage_2d(kindv[0], false, tf_unused, st_unused); }
+    if (GM == 2 && p.exclusive) {
+        // Teacher::teach's exclusive branch at reset (teacher.cpp:209-220 after reset_after_game_reset): the groups are
+        // re-sorted, nobody is busy, so the group that now heads the list runs its idle stage -- the other one stays idle
+        // until a later teach() picks it (an XWorld3DNav* group then rearranges the map in mid-episode: xw_idle3d_kernel).
+        const int pick = xw_sort_groups(p, e, ep, 0u, p.grp_order[e] & 1), other = pick ^ 1;
+        const bool pick_2d = pick == 0 ? first_2d : !first_2d;
+        const int tsel = pick ? sample_task<1>(p, s, e) : sample_task<0>(p, s, e);
+        kindv[pick] = pick ? task_at<1>(p, tsel) : task_at<0>(p, tsel);
+        kindv[other] = TASK_TARGET; tfv[other] = -1; st0v[other] = STAGE_IDLE;       // TaskGroup::reset: no busy task
+        if (pick_2d) {
+            idle_stage_2d(kindv[pick], true, tfv[pick], st0v[pick]);
+        } else {
+            idle_stage_3d(kindv[pick], tfv[pick]);
+            int tf_unused, st_unused;
+            idle_stage_2d(TASK2D_TARGET, false, tf_unused, st_unused);            // the 2-D group's candidate tables, from the final map
+        }
+        p.grp_order[e] = (uint8_t)(pick | (pick << 1));
+    } else {
+        if (p.exclusive && GM != 2 && p.minstd) {         // one group: the sort still draws once from the reference's engine
+            uint32_t x = p.minstd[e];
+            (void)xwb_minstd_rand_range_state(&x, (float)p.group_weight[0]);
+            p.minstd[e] = x;
+        }
+        {
+            const int tsel = sample_task<0>(p, s, e);
+            kindv[0] = p.n_tasks > 0 ? task_at<0>(p, tsel) : TASK_TARGET;
+            if (GM != 0 && first_2d) idle_stage_2d(kindv[0], true, tfv[0], st0v[0]);
+            if (GM != 1 && !first_2d) idle_stage_3d(kindv[0], tfv[0]);
+        }
+        if (GM == 2) {
+            const int tsel = sample_task<1>(p, s, e);
+            kindv[1] = task_at<1>(p, tsel);
+            if (!first_2d) idle_stage_2d(kindv[1], true, tfv[1], st0v[1]);
+            else idle_stage_3d(kindv[1], tfv[1]);
+            if (first_2d) { int tf_unused, st_unused; idle_stage_2d(kindv[0], false, tf_unused, st_unused); }
+        }
     }
     const int kind = kindv[0];
     RP_T(3);
@@ -796,6 +849,99 @@ __global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int 
     // one-thread kernel queued behind this one.  Publishing it from here -- a release fence per writing wavefront, the last
     // one through stores the epoch -- saves that kernel's 5 us but the L2 write-backs cost the render running beside it 6 %:
     // 0.122 -> 0.127 ms per step on C4.)
+}
+
+// ---- exclusive scheduling of two task groups: an idle XWorld3DNav* group picked in mid-episode (teacher.cpp:209-220) ----
+// TaskGroup::run_stage (teaching_task.cpp:204-222) for the envs the step kernel listed: draw a task, run its idle stage on the
+// env's CURRENT map -- the board is rebuilt from the grid row, the goal slots from goal_cells (entity order) --, write the
+// rearranged map back.  Decisions: the successive words of stream 5 | num_steps << 8 of the episode ("xwb-taskgen-v1").
+// One env per wavefront (lane 0): the list holds a handful of envs per step at most.
+template <int NW>
+__device__ void xw_idle3d_env(const XwParams &p, const LaneLds &L, int e) {
+    const int MD = p.max_dim, D = p.curriculum != 0 ? 3 + p.cur_level[e] : p.dim, off = (MD - D) / 2;
+    const int G3 = p.group2d ? 1 : 0;                      // conf index of the XWorld3DNav* group
+    uint16_t *g = p.grid + (size_t)e * MD * MD;
+    Mask<NW> valid, col0, colN, occupied;
+    valid.clear(); col0.clear(); colN.clear(); occupied.clear();
+    for (int y = 0; y < D; ++y) { col0.set(y * D); colN.set(y * D + D - 1); }
+    for (int c = 0; c < D * D; ++c) valid.set(c);
+    const int axy = p.agent_xy[e];
+    int agent_cell = ((axy >> 16) - off) * D + ((axy & 0xffff) - off);
+    const int agent_icon = (int)(g[(axy >> 16) * MD + (axy & 0xffff)] & CELL_ICON_MASK) - 1;
+    for (int c = 0; c < D * D; ++c)
+        if (c != agent_cell && (g[(c / D + off) * MD + (c % D + off)] & CELL_ICON_MASK)) occupied.set(c);
+    uint8_t *gc = p.goal_cells + (size_t)e * XW_MAX_GOALS;
+    int ng = 0;
+    for (int i = 0; i < XW_MAX_GOALS; ++i) {
+        const int mc = gc[i];
+        if (mc == 0xff) break;
+        const int icon = (int)(g[mc] & CELL_ICON_MASK) - 1;
+        L.gcell[L.at(i)] = (uint8_t)((mc / MD - off) * D + (mc % MD - off));
+        L.gicon[L.at(i)] = (uint16_t)icon;
+        L.gname[L.at(i)] = (uint16_t)p.icon_name[icon];
+        ng++;
+    }
+    Stream s;
+    s.init(p.seed, p.env_gid0 + (uint32_t)e, p.episode[e], 5u | ((uint32_t)p.num_steps[e] << 8));
+    const int tsel = G3 ? sample_task<1>(p, s, e) : sample_task<0>(p, s, e);
+    const int kind = G3 ? task_at<1>(p, tsel) : task_at<0>(p, tsel);
+    uint32_t target_bits = 0;
+    int sent_a = 0xffff, sent_b = 0xffff, between = -1, tf = -1;
+    const Idle3d<NW> c{D, MD, off, ng, agent_icon, valid, col0, colN, occupied, agent_cell, target_bits, sent_a, sent_b, between};
+    xw_idle_stage_3d<NW, true>(p, e, s, L, g, c, kind, tf);
+    for (int i = 0; i < ng; ++i) {
+        const int cell = L.gcell[L.at(i)];
+        g[(cell / D + off) * MD + (cell % D + off)] = (uint16_t)((L.gicon[L.at(i)] + 1) | (((target_bits >> i) & 1u) ? 0x8000u : 0u));
+        gc[i] = (uint8_t)((cell / D + off) * MD + (cell % D + off));
+    }
+    p.agent_xy[e] = (agent_cell % D + off) | ((agent_cell / D + off) << 16);
+    (G3 ? p.task_state2 : p.task_state)[e] = pack_task(tf, STAGE_NAV, EV_NONE, kind);
+    (G3 ? p.task_steps2 : p.task_steps)[e] = 0;
+    p.sent_names[e] = (uint32_t)sent_a | ((uint32_t)sent_b << 16);
+    // the step that picked the group may also have ended the game (FLAGS_max_steps): its terminal frame shows the new map
+    if (!p.visible_radius && p.term_flag[e]) {
+        uint16_t *t = p.term_grid + (size_t)e * MD * MD;
+        for (int k = 0; k < MD * MD; ++k) t[k] = g[k];
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64) void xw_idle3d_kernel(XwParams p, const int32_t *count_now) {
+    extern __shared__ uint32_t lds32[];
+    const int total = *count_now;
+    if ((int)blockIdx.x >= total) return;
+    LaneLds L;
+    L.lane = threadIdx.x;
+    L.stack = lds32;                                                        // (unused: the maze generator's)
+    L.gname = reinterpret_cast<uint16_t *>(lds32);
+    L.ov_idx = L.gname + XW_MAX_GOALS * 64;
+    L.ov_val = L.ov_idx + XW_MAX_GOALS * 64;
+    L.gicon = L.ov_idx;
+    L.gcell = reinterpret_cast<uint8_t *>(L.ov_val + XW_MAX_GOALS * 64);
+    L.blk = L.gcell + XW_MAX_GOALS * 64;
+    for (int i = blockIdx.x; i < total; i += gridDim.x)
+        if (threadIdx.x == 0) xw_idle3d_env<NW>(p, L, p.idle_list[i]);
+}
+
+hipError_t launch_xw_idle3d(const XwParams &p, hipStream_t s) {
+    const int lds_dim = p.curriculum != 0 ? p.max_dim : p.dim;
+    const int cells = lds_dim * lds_dim;
+    const size_t lds = 3 * XW_MAX_GOALS * 64 * 2 + XW_MAX_GOALS * 64 + (size_t)cells * 64;
+    dim3 grid(p.n < 256 ? p.n : 256);
+    const int32_t *cnt = p.idle_count;
+    if (cells <= 64) hipLaunchKernelGGL((xw_idle3d_kernel<1>), grid, dim3(64), lds, s, p, cnt);
+    else if (cells <= 128) hipLaunchKernelGGL((xw_idle3d_kernel<2>), grid, dim3(64), lds, s, p, cnt);
+    else hipLaunchKernelGGL((xw_idle3d_kernel<4>), grid, dim3(64), lds, s, p, cnt);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    // egocentric: the goal slots of those envs were re-ordered (poses travel with their goals): their images are redrawn
+    // slot by slot, which also drops the envs' cached goal cells
+    if (p.visible_radius) {
+        XwParams q = p;
+        q.done_list = p.idle_list; q.done_count = p.idle_count;
+        return launch_xw_warp_goals(q, true, s);
+    }
+    return hipSuccess;
 }
 
 template <int NW>

@@ -131,6 +131,30 @@ __device__ inline int sample_task(const XwParams &p, S &s, int e) {
     return n - 1;
 }
 
+// Teacher::nondeterministic_sort_task_groups (teacher.cpp:143-163) for two groups: position 0 takes one of the two with
+// probability proportional to its weight -- util::simple_importance_sampling: a float uniform in [0, float(w_a + w_b)), the
+// first accumulated weight >= it --, position 1 draws over the one weight that is left (index 0 whatever the value: only
+// the reference's engine notices).  `first` = conf index of the group heading the list before the call; returns the one
+// heading it afterwards.  Decisions ("xwb-taskgen-v1"): stream 4, block = num_steps of the teach() call (0 at reset),
+// word 0; XWB_RNG_MINSTD: two draws of the env's own engine, as in the reference.
+__device__ inline int xw_sort_groups(const XwParams &p, int e, uint32_t episode, uint32_t steps, int first) {
+    const double wa = first ? p.group_weight[1] : p.group_weight[0], wb = first ? p.group_weight[0] : p.group_weight[1];
+    const double total = wa + wb;
+    const uint4 o = philox4x32_10(steps, episode, 4u, 0u, p.seed, p.env_gid0 + (uint32_t)e);
+    float val = (float)(o.x >> 8) * (1.0f / 16777216.0f) * (float)total;
+    int idx;
+    if (p.minstd) {
+        uint32_t x = p.minstd[e];
+        val = xwb_minstd_rand_range_state(&x, (float)total);
+        idx = (double)val <= wa ? 0 : 1;
+        (void)xwb_minstd_rand_range_state(&x, (float)(idx ? wa : wb));
+        p.minstd[e] = x;
+    } else {
+        idx = (double)val <= wa ? 0 : 1;
+    }
+    return idx ? first ^ 1 : first;
+}
+
 // ---- curriculum (FLAGS_curriculum != 0) ----
 // XWorld(3D)Task.__record_result (xworld3d_task.py:129-133, xworld_task.py:87-91): success_seq.append(res), the oldest of
 // more than performance_window_size = 200 dropped.  One window: len, sum, head, pad, 200 bits.

@@ -112,6 +112,8 @@ struct xwb_sim {
     // xworld
     uint16_t *d_grid = nullptr;
     int32_t *d_task_steps2 = nullptr, *d_task_state2 = nullptr;
+    uint8_t *d_grp_order = nullptr;        // exclusive group scheduling (XwParams::grp_order)
+    int32_t *d_idle_list = nullptr, *d_idle_count = nullptr;
     int32_t *d_agent = nullptr, *d_task_steps = nullptr, *d_task_state = nullptr, *d_done_list = nullptr,
             *d_done_count = nullptr;
     uint8_t *d_fresh = nullptr, *d_icon_type = nullptr, *d_icon_colored = nullptr, *d_goal_cells = nullptr;
@@ -363,11 +365,8 @@ int xw_setup(xwb_sim *s) {
         if (c.task_schedule2 == XWB_SCHEDULE_WEIGHTED)
             for (int i = 0; i < c.n_tasks2; ++i)
                 if (!(c.task_weights2[i] > 0)) return fail(XWB_ERR_ARG, "A task must have a positive weight");
-        // simulator_interface.cpp:46-48: lang_acquisition runs the groups non-exclusively whatever the flag says
-        if (c.task_groups_exclusive && c.task_mode != XWB_TASKMODE_LANG_ACQ)
-            return fail(XWB_ERR_ARG, "xworld: exclusive scheduling of two task groups is not built (teacher.cpp:209-220 would run "
-                                     "3-D idle stages in mid-episode); use task_groups_exclusive = 0 or task_mode lang_acquisition");
     }
+    if (!(c.task_group_weight >= 0) || !(c.task_group_weight2 >= 0)) return fail(XWB_ERR_ARG, "xworld: task group weights must be >= 0");
     const int n = s->n, cells = c.max_dim * c.max_dim, ch = c.color ? 3 : 1;
     const bool group2d_cfg = (c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET) || (c.n_tasks2 > 0 && c.tasks2[0] >= XWB_TASK2D_TARGET);
     // goal_cells holds one byte per goal slot with 0xff = "no goal": cell 255 only exists on a 16x16 map
@@ -431,6 +430,13 @@ int xw_setup(xwb_sim *s) {
     if (c.n_tasks2 > 0) {
         if ((rc = dev_alloc(s, &s->d_task_state2, n))) return rc;
         if ((rc = dev_alloc(s, &s->d_task_steps2, n))) return rc;
+    }
+    // simulator_interface.cpp:46-48: lang_acquisition runs the groups non-exclusively whatever the flag says
+    const bool exclusive = c.task_groups_exclusive && c.task_mode != XWB_TASKMODE_LANG_ACQ;
+    if (exclusive && c.n_tasks2 > 0) {
+        if ((rc = dev_alloc(s, &s->d_grp_order, n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_idle_list, n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_idle_count, 2))) return rc;
     }
     if ((rc = dev_alloc(s, &s->d_done_list, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_done_count, 2))) return rc;
@@ -544,6 +550,9 @@ int xw_setup(xwb_sim *s) {
     for (int i = 0; i < 8; ++i) p.tasks2[i] = i < c.n_tasks2 ? c.tasks2[i] : 0;
     for (int i = 0; i < 8; ++i) p.task_acc2[i] = (i ? p.task_acc2[i - 1] : 0.0) + (i < c.n_tasks2 && p.task_weighted2 ? c.task_weights2[i] : 0.0);
     p.task_state2 = s->d_task_state2; p.task_steps2 = s->d_task_steps2;
+    p.exclusive = exclusive ? 1 : 0;
+    p.group_weight[0] = c.task_group_weight; p.group_weight[1] = c.task_group_weight2;
+    p.grp_order = s->d_grp_order; p.idle_list = s->d_idle_list; p.idle_count = s->d_idle_count; p.idle_count_next = nullptr;
     for (int i = 0; i < 8; ++i) p.task_acc[i] = (i ? p.task_acc[i - 1] : 0.0) + (i < c.n_tasks && p.task_weighted ? c.task_weights[i] : 0.0);
     p.policy_seed = c.policy_seed; p.env_gid0 = c.env_gid0; p.policy_step = 0; p.seed = c.seed;
     p.icon_type = s->d_icon_type; p.icon_name = s->d_icon_name;
@@ -708,6 +717,7 @@ XwParams xw_params(xwb_sim *s) {
     p.list_flag = 2;
     p.done_count = s->d_done_count + s->count_sel;
     p.done_count_next = s->d_done_count + (1 - s->count_sel);
+    if (s->d_idle_count) { p.idle_count = s->d_idle_count + s->count_sel; p.idle_count_next = s->d_idle_count + (1 - s->count_sel); }
     return p;
 }
 
@@ -811,6 +821,8 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         p.sig_epoch = epochs ? s->epoch_step : 0;   // published by the render kernel queued behind the step kernel
         timer_begin(s, s->t_step, st);
         HIP_TRY(launch_xw_step(p, st));
+        // exclusive scheduling of two groups: idle XWorld3DNav* groups the step picked run their idle stage now
+        if (p.idle_list) HIP_TRY(launch_xw_idle3d(p, st));
         timer_end(s, s->t_step, st);
         s->list_valid = true;
         XwParams pr = xw_params(s);
@@ -1359,6 +1371,12 @@ int xwb_get_env_state(xwb_sim *s, int32_t env, void *stream, xwb_env_state *o) {
         uint32_t sn = 0xffffffffu;
         HIP_TRY(hipMemcpy(&sn, s->d_sent_names + env, 4, hipMemcpyDeviceToHost));
         o->xw_sentence_names = sn;
+        o->xw_group_first = o->xw_group_ran = -1;
+        if (s->d_grp_order) {
+            uint8_t go = 0;
+            HIP_TRY(hipMemcpy(&go, s->d_grp_order + env, 1, hipMemcpyDeviceToHost));
+            o->xw_group_first = go & 1; o->xw_group_ran = (go >> 1) & 1;
+        }
     }
     return XWB_OK;
 }
@@ -1629,7 +1647,7 @@ std::vector<StateArray> state_arrays(xwb_sim *s, bool include_obs) {
     if (s->cfg.game == XWB_XWORLD2D) {
         const size_t cells = (size_t)s->cfg.max_dim * s->cfg.max_dim;
         add(s->d_grid, n * cells * 2); add(s->d_agent, n * 4); add(s->d_task_steps, n * 4); add(s->d_task_state, n * 4);
-        add(s->d_task_steps2, n * 4); add(s->d_task_state2, n * 4);
+        add(s->d_task_steps2, n * 4); add(s->d_task_state2, n * 4); add(s->d_grp_order, n);
         add(s->d_done_list, n * 4); add(s->d_done_count, 8); add(s->d_fresh, n);
         add(s->d_goal_cells, n * XW_MAX_GOALS); add(s->d_cand2d, n * 4); add(s->d_agent_dir, n); add(s->d_sent_names, n * 4);
         add(s->d_goal_warp, n * XW_MAX_GOALS * 6 * sizeof(double));     // goal images are re-warped from these on load
@@ -1655,6 +1673,7 @@ uint64_t config_hash(const xwb_config &c) {            // everything that shapes
     mix(&c.seed, 4); mix(&c.policy_seed, 4); mix(&c.env_gid0, 4);
     mix(&c.rng_mode, 4); mix(&c.simulator_seed, 4); mix(&c.thread_base, 4);
     mix(&c.n_tasks2, 4); mix(c.tasks2, sizeof c.tasks2); mix(&c.task_schedule2, 4); mix(c.task_weights2, sizeof c.task_weights2);
+    mix(&c.task_groups_exclusive, 4); mix(&c.task_group_weight, 8); mix(&c.task_group_weight2, 8);
     mix(&c.curriculum, 8); mix(&c.start_level, 4); mix(&c.task_schedule, 4); mix(c.task_weights, sizeof c.task_weights); mix(&c.no_wall_shadow, 4);
     return h;
 }
@@ -1763,10 +1782,12 @@ static int env_sentence(xwb_sim *s, int32_t env, void *stream, std::string *out)
     xwb_env_state st;
     int rc = xwb_get_env_state(s, env, stream, &st);
     if (rc) return rc;
+    if (st.xw_group_ran == 1)      // exclusive scheduling: only the group the last teach() ran can have spoken
+        return group_sentence(s, env, stream, st, st.xw_task2, st.xw_stage2, st.xw_event2, st.xw_target2, st.xw_steps_in_task2, out);
     rc = group_sentence(s, env, stream, st, st.xw_task, st.xw_stage, st.xw_event, st.xw_target, st.xw_steps_in_task, out);
-    if (rc) return rc;
-    // two task groups: the first one (conf order) that speaks wins -- Task::teacher_speak only records into an empty
-    // buffer (teaching_task.cpp:118-127)
+    if (rc || st.xw_group_ran == 0) return rc;
+    // two task groups run side by side: the first one (conf order) that speaks wins -- Task::teacher_speak only records into
+    // an empty buffer (teaching_task.cpp:118-127)
     if (out->empty() && s->cfg.n_tasks2 > 0)
         rc = group_sentence(s, env, stream, st, st.xw_task2, st.xw_stage2, st.xw_event2, st.xw_target2, st.xw_steps_in_task2, out);
     return rc;

@@ -160,6 +160,16 @@ struct XwParams {
     int n_tasks2, tasks2[8], task_weighted2, group2d_2;
     double task_acc2[8];
     int32_t *task_state2, *task_steps2;   // [n] the second group's Task FSM (same encoding as task_state / task_steps)
+    // Teacher::teach's exclusive branch (teacher.cpp:209-220; FLAGS_task_groups_exclusive outside lang_acquisition): every
+    // teach() re-sorts the groups by weighted sampling without replacement (nondeterministic_sort_task_groups, :143-163),
+    // then ONE group runs: the last busy one of that order, else its first.
+    int exclusive;
+    double group_weight[2];      // the conf's per-group "weight" keys, conf order
+    uint8_t *grp_order;          // [n] bit 0: conf index of the group that heads Teacher::task_groups_ (the sort is in place
+                                 // and the list lives as long as the teacher: across resets); bit 1: the group the last teach() ran
+    int32_t *idle_list;          // two groups, exclusive: envs whose IDLE XWorld3DNav* group this step picked -- its
+    int32_t *idle_count;         // map-rearranging idle stage runs right behind the step kernel (xw_idle3d_kernel);
+    int32_t *idle_count_next;    // counters double-buffered like done_count
     int list_flag;               // list render: 2 = first frame of a new episode (init_screen: older context frames zeroed,
                                  // fresh / done flags cleared); 1 = the terminal frame of a finished env (ring shift only)
     int group2d;                 // the group holds the 2-D-native tasks (rule D14b): idle stages also run at step time
@@ -253,6 +263,8 @@ struct XwParams {
     uint32_t *minstd;            // nullable: XWB_RNG_MINSTD, one libstdc++ minstd_rand0 state per env: the teacher's task draw
 };
 hipError_t launch_xw_step(const XwParams &p, hipStream_t s);
+// exclusive scheduling of two groups: the idle stages of the XWorld3DNav* group that the step kernel deferred (idle_list)
+hipError_t launch_xw_idle3d(const XwParams &p, hipStream_t s);
 // one wavefront that ends once *epoch_slot has reached `want`: orders the work queued behind it after the publisher
 // (budget_ticks: watchdog in 100 MHz ticks, 0 = the default 4 s; poison / poison_host: xw_device.h xw_wait_epoch)
 hipError_t launch_xw_wait(const uint32_t *epoch_slot, uint32_t want, uint32_t *poison, uint32_t *poison_host, hipStream_t s,

@@ -55,6 +55,7 @@ class XwbEnvState(C.Structure):
         ("episode", C.c_uint32), ("xw_task", C.c_int32), ("xw_target", C.c_int32), ("xw_agent_dir", C.c_int32), ("xw_level", C.c_int32), ("xw_check_counter", C.c_int32), ("xw_sentence_names", C.c_uint32),
         ("xw_task2", C.c_int32), ("xw_stage2", C.c_int32), ("xw_event2", C.c_int32), ("xw_target2", C.c_int32),
         ("xw_steps_in_task2", C.c_int32),
+        ("xw_group_first", C.c_int32), ("xw_group_ran", C.c_int32),
     ]
 
 
