@@ -94,18 +94,24 @@ def algorithmic_bytes(workload, sim):
 
 
 def measured_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE in separate runs, gfx950 corrections applied by tools/summarize_prof.py); None if not profiled."""
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs, gfx950 corrections applied by tools/summarize_prof.py); None if not profiled.
+    The number is a STORED measurement, not something this run measured: the line says which file, which commit and which
+    source fingerprint it comes from, and `traffic_stale` when the sources this run executes are not those."""
     best = None
     for d in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         f = os.path.join(ROOT, "profiles", d, "traffic_%s.json" % workload)
         if os.path.exists(f):
             best = f
     if not best:
-        return None, None
+        return None, {"traffic_source": None}
     with open(best) as fh:
         t = json.load(fh)
-    return t["traffic_bytes_per_launch"], os.path.relpath(best, ROOT)
+    from xworld_amd import build
+    now = build.source_fingerprint()
+    return t["traffic_bytes_per_launch"], {"traffic_source": os.path.relpath(best, ROOT), "traffic_commit": t.get("commit", "unknown"),
+                                           "traffic_source_sha16": t.get("source_sha16"), "source_sha16": now,
+                                           "traffic_stale": t.get("source_sha16") != now}
 
 
 def _oracle():
@@ -144,7 +150,7 @@ def parity_gate(workload, rec, calls, slots, fused, gid0, seed, slab, calls_befo
         row = got[k % slots]
         mism += int(np.count_nonzero(row[:, 0].view(np.uint32) != ref.rewards[t].view(np.uint32)))
         mism += int(np.count_nonzero(row[:, 1].astype(np.uint8) != ref.codes[t]))
-    return {"checked_env_steps": (calls - first) * slab, "mismatches": mism, "envs": slab,
+    return {"checked_env_steps": (calls - first) * slab, "mismatches": mism, "envs": slab, "scope": "a slab of envs, every recorded step: reward bits + game_over code (not the frames, not the whole batch)",
             "step_calls": [calls_before + first, calls_before + calls], "against": "oracle/liboracle.so rollout from reset, reward bits + game_over code"}
 
 
@@ -206,7 +212,8 @@ def main():
     ap.add_argument("--no-screens-gather", action="store_true", help="N > 1: skip the screens-gather-inclusive regions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--parity-envs", type=int, default=256)
+    ap.add_argument("--parity-envs", type=int, default=4096, help="envs whose whole per-step record is checked against the oracle "
+                    "(a slab of the batch, not all of it: `parity.envs` of `config.envs_per_gpu`)")
     ap.add_argument("--autoreset", action="store_true", help="use the fused step+reset+single-render call")
     ap.add_argument("--fused", type=int, default=1, help="simple games only: steps per launch (xwb_step_n); --steps must be "
                     "a multiple; every step still writes its reward / code / observation")
@@ -370,7 +377,7 @@ def main():
         value = total_envs * args.steps / dt_med
         # algorithmic bytes of one launch = per-step bytes x the steps that launch runs
         achieved = n_local * per_launch * fused / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
-        traffic, traffic_src = measured_traffic(args.workload) if n_local == WORKLOADS[args.workload][2] else (None, None)
+        traffic, traffic_info = measured_traffic(args.workload) if n_local == WORKLOADS[args.workload][2] else (None, {"traffic_source": None})
         line = {
             "metric": "env-steps/sec (batched random policy)",
             "value": value,
@@ -397,13 +404,13 @@ def main():
                         "untimed_before": {"warmup_steps": args.warmup, "spin_steps": spin_calls * fused,
                                            "spin_seconds_target": args.spin_seconds, "probe_steps": probe_calls * fused}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kernel_name,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
                          "kernel_avg_us": kern_us, "kernel_launches": kern_n,
                          "algorithmic_bytes_per_launch": n_local * per_launch * fused,
                          "algorithmic_bytes_per_env_step": per_step,
                          "step_loop_GBps": total_envs * per_step * args.steps / dt_med / 1e9,
-                         "step_loop_frac": total_envs * per_step * args.steps / dt_med / 1e9 / HBM_PEAK_GBS / world},
+                         "step_loop_frac": total_envs * per_step * args.steps / dt_med / 1e9 / HBM_PEAK_GBS / world,
+                         **traffic_info},
             "timed_with_events_ms_per_step": statistics.median(ev_regions) / args.steps * 1e3,
             "rccl": sharding.backend_info(),
         }

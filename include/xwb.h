@@ -368,6 +368,18 @@ int xwb_load_state(xwb_sim *sim, const uint8_t *in_host, size_t bytes);
  * "<pid>|task:<task class>,event:<event>,height:<actual h>,width:<actual w>"; the other games: "". */
 int xwb_get_extra_info(xwb_sim *sim, int32_t env, void *stream, char *out, size_t cap);
 
+/* SimulatorInterface::teacher_report_task_performance (simulator_interface.cpp:149-153 -> Teacher::report_task_performance,
+ * teacher.cpp:175-200): what every task object's obtain_performance() returns -- num_successes, num_failures, success_steps
+ * (xworld3d_task.py:135-142, 383-384) -- summed over the batch's envs since xwb_create, per task class (index = XWB_TASK_*).
+ * success_steps: the XWorld3DNav* tasks add steps_in_cur_task on every success; the 2-D-native tasks keep none (their
+ * obtain_performance returns a 2-tuple: the reference's report would abort on them).  time_ups = the failures that were
+ * time-ups; *resets (nullable) = games reset.  Counted on the device by the step / reset kernels; the call synchronises. */
+typedef struct xwb_task_performance { int64_t successes, failures, success_steps, time_ups; } xwb_task_performance;
+int xwb_get_task_performance(xwb_sim *sim, void *stream, xwb_task_performance out[9], int64_t *resets);
+/* the same as the text the reference logs: per task class that occurred "=== <task class> ===" and
+ * "=== <S>(S)/<F>(F) -> <success rate>@<steps per success>" (-1 when no success).  *need = bytes needed incl. NUL. */
+int xwb_task_performance_report(xwb_sim *sim, void *stream, char *out, size_t cap, size_t *need);
+
 /* GameSimulator::decode_game_over_code, simulator.cpp:125-144 ("alive" | "max_step|dead|...") */
 int xwb_decode_game_over_code(int32_t code, char *out, size_t cap);
 

@@ -254,7 +254,9 @@ class SlotClient {
                 m.clear();
                 m.append("get_extra_info"); m.append(info);
             } else if (cmd == "report_perf") {
-                // teacher_report_task_performance(): nothing to report; the request body goes back unchanged
+                // teacher_report_task_performance() (simulator_interface.cpp:372-373): the table is logged on this side, as in
+                // the reference; the request body goes back unchanged
+                game_.teacher_report_task_performance();
             } else if (cmd == "stop") {
                 break;
             }

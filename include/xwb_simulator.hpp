@@ -20,6 +20,7 @@
 #include <map>
 #include <memory>
 #include <stdexcept>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -228,6 +229,21 @@ class SimulatorInterface {
         char buf[256];
         check(xwb_get_extra_info(batch_->handle(), env_, nullptr, buf, sizeof buf));
         info = buf;
+    }
+    // simulator_interface.cpp:149-153 -> Teacher::report_task_performance (teacher.cpp:175-200): the reference logs the table
+    // (LOG(INFO)); here it goes to stderr, and task_performance_report() hands the same text back.  The numbers are the
+    // batch's (every env slot), not this slot's alone.  No-op for games without a teacher.
+    virtual std::string task_performance_report() {
+        size_t need = 0;
+        if (xwb_task_performance_report(batch_->handle(), nullptr, nullptr, 0, &need) != XWB_OK) return std::string();
+        std::string text(need, '\0');
+        check(xwb_task_performance_report(batch_->handle(), nullptr, &text[0], text.size(), &need));
+        text.resize(need ? need - 1 : 0);
+        return text;
+    }
+    virtual void teacher_report_task_performance() {
+        const std::string text = task_performance_report();
+        if (!text.empty()) fputs(text.c_str(), stderr);
     }
     virtual bool last_action_success() { return batch_->env_state(env_).last_action_success != 0; }
     virtual std::string last_action() {

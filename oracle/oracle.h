@@ -289,7 +289,13 @@ int     orc_decode_game_over_code(int code, char *out, int cap);
 typedef struct {
     double   reward_sum;
     uint64_t resets;
+    /* xworld: what Teacher::report_task_performance sums up (teacher.cpp:175-200, teaching_task.h:22-36), over every env of the
+     * rollout: per task class (ORC_TASK_*) successes, failures, success_steps (XWorld3DTask._record_success adds
+     * steps_in_cur_task; the 2-D-native tasks keep none), and the failures that were time-ups */
+    int64_t  task_perf[9][4];
 } orc_rollout_stats;
+/* the same tallies of one orc_xworld since it was created */
+void orc_xw_get_performance(const orc_xworld *w, int64_t out[9][4]);
 /* optional per-step outputs, layout [steps][n_envs] (pass NULL to skip):
  *   rewards  float   return value of take_actions
  *   codes    uint8   game_over() after the step

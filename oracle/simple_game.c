@@ -157,7 +157,8 @@ void orc_sg_get_state_screen(const orc_simple_game *g, uint8_t *out) {
 uint64_t orc_sg_rollout(int n_envs, int array_size, int context, int steps, uint32_t policy_seed,
                         uint32_t env_gid0, orc_rollout_stats *st, const orc_rollout_out *out) {
     uint64_t n_steps = 0;
-    orc_rollout_stats s = {0.0, 0};
+    orc_rollout_stats s;
+    memset(&s, 0, sizeof s);
     size_t osz = (size_t)array_size * (size_t)(context < 1 ? 1 : context);
     uint8_t *obs = (uint8_t *)malloc(osz);
     for (int e = 0; e < n_envs; ++e) {

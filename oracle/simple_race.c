@@ -378,7 +378,8 @@ static void race_reset_stream(orc_simple_race *g, uint32_t seed, uint32_t gid, u
 uint64_t orc_race_rollout(int n_envs, const orc_race_cfg *cfg, uint32_t seed, int steps, uint32_t policy_seed,
                           uint32_t env_gid0, orc_rollout_stats *st, const orc_rollout_out *out) {
     uint64_t n_steps = 0;
-    orc_rollout_stats s = {0.0, 0};
+    orc_rollout_stats s;
+    memset(&s, 0, sizeof s);
     size_t osz = sizeof(float) * 4 * (size_t)(cfg->context < 1 ? 1 : cfg->context);
     float *obs = (float *)malloc(osz);
     for (int e = 0; e < n_envs; ++e) {

@@ -274,6 +274,10 @@ static void set_dims(orc_xworld *w, int h, int wd) {
  * (xworld3d_task.py:129-133, xworld_task.py:87-91); _record_env_usage hands the list to the env */
 void orc_xw_record_result(orc_xworld *w, int kind, int result) {
     if (kind < 0 || kind >= 9) abort();
+    /* _record_success / _record_failure (xworld3d_task.py:135-142, xworld_task.py:93-99): the counters
+     * Task::obtain_performance reads; only the XWorld3D tasks add steps_in_cur_task */
+    w->perf[kind][result ? 0 : 1] += 1;
+    if (result && kind < ORC_TASK2D_TARGET) w->perf[kind][2] += w->steps_in_cur_task;
     if (w->use_len[kind] < 200) {
         w->use_bits[kind][(w->use_head[kind] + w->use_len[kind]) % 200] = (uint8_t)result;
         w->use_len[kind]++;
@@ -483,6 +487,7 @@ static void task_navigation_reward(orc_xworld *w) {
     if (w->steps_in_cur_task >= w->actual_h * w->actual_w * w->cfg.max_steps_factor) {
         w->event = ORC_EV_TIMEUP;
         orc_xw_record_result(w, w->task_kind, 0);   /* _time_reward: _record_failure */
+        w->perf[w->task_kind][3] += 1;
         time_out = 1;
     }
     int next_stage = ORC_STAGE_NAV;
@@ -990,6 +995,7 @@ void orc_xw_group_state(const orc_xworld *w, int g, int *kind, int *stage, int *
     *kind = s->task_kind; *stage = s->stage; *steps_in_task = s->steps_in_cur_task; *event = s->last_event;
     *target2d_x = s->target2d_x; *target2d_y = s->target2d_y;
 }
+void orc_xw_get_performance(const orc_xworld *w, int64_t out[9][4]) { memcpy(out, w->perf, sizeof w->perf); }
 int orc_xw_group_first(const orc_xworld *w) { return w->grp_order[0]; }
 int orc_xw_stage(const orc_xworld *w) { return w->stage; }
 int orc_xw_target_name(const orc_xworld *w) { return w->target_name; }
@@ -1030,7 +1036,8 @@ uint64_t orc_xw_rollout(int n_envs, const orc_xw_cfg *cfg, int n_icons, const or
                         const uint8_t *icons64, int steps, uint32_t policy_seed,
                         uint32_t env_gid0, int render, orc_rollout_stats *st, const orc_rollout_out *out) {
     uint64_t n_steps = 0;
-    orc_rollout_stats s = {0.0, 0};
+    orc_rollout_stats s;
+    memset(&s, 0, sizeof s);
     orc_xworld *w = orc_xw_create(cfg, n_icons, info, render ? icons64 : NULL);
     size_t sz = screen_size(w) * (size_t)w->cfg.context;
     uint8_t *obs = (uint8_t *)malloc(sz ? sz : 1);
@@ -1060,6 +1067,7 @@ uint64_t orc_xw_rollout(int n_envs, const orc_xw_cfg *cfg, int n_icons, const or
             n_steps++;
         }
     }
+    memcpy(s.task_perf, w->perf, sizeof s.task_perf);
     free(obs);
     orc_xw_destroy(w);
     if (st) *st = s;

@@ -68,6 +68,7 @@ struct orc_xworld {
     const int *forced; int n_forced, forced_at;   /* golden replay: decisions instead of stream draws */
     /* curriculum: XWorldEnv.current_level / curriculum_check_counter (xworld_env.py:73-77); per task class the
      * success_seq window of the last 200 results (xworld3d_task.py:129-146) -- current_usage holds a class once it recorded */
+    int64_t perf[9][4];              /* XWorld(3D)Task.num_successes / num_failures / success_steps (+ time-ups), per task class */
     int cur_level, cur_counter;
     int use_len[9], use_sum[9], use_head[9];
     uint8_t use_bits[9][200];

@@ -353,6 +353,7 @@ void orc_task2d_navigation_reward(orc_xworld *w) {
         w->steps_in_cur_task >= w->height * w->width / 2) {             /* get_max_dims(); Python-2 int division */
         w->steps_in_cur_task = 0;
         orc_xw_record_result(w, w->task_kind, 0);                        /* _record_failure */
+        w->perf[w->task_kind][3] += 1;                                   /* (a time-up) */
         next_stage = ORC_STAGE_IDLE;                                     /* "S -> timeup" */
     } else if (a->x == w->target2d_x && a->y == w->target2d_y) {
         w->steps_in_cur_task = 0;

@@ -64,7 +64,7 @@ class PacketField(C.Structure):
 
 
 class RolloutStats(C.Structure):
-    _fields_ = [("reward_sum", C.c_double), ("resets", C.c_uint64)]
+    _fields_ = [("reward_sum", C.c_double), ("resets", C.c_uint64), ("task_perf", (C.c_int64 * 4) * 9)]
 
 
 class RolloutOut(C.Structure):

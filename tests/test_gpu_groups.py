@@ -204,7 +204,7 @@ def test_exclusive_groups_reset_and_rollout(oracle, case):
         assert bad.size == 0, (t, bad[:5], r[bad[:5]], ref.rewards[t][bad[:5]])
         assert np.array_equal(sim.game_over_codes.cpu().numpy(), ref.codes[t]), t
         rewards.update(np.unique(r).tolist())
-    assert ref.stats.resets > 2 * n and len(rewards) >= 4
+    assert ref.stats.resets > 2 * n and len(rewards) >= (4 if gw[0] > 0 and gw[1] > 0 else 3)
     assert sim.check_errors() == 0
     sim.close()
 

@@ -420,3 +420,53 @@ def test_weighted_schedule(oracle):
         assert np.array_equal(sim.reward.cpu().numpy().view(np.uint32), ref.rewards[t].view(np.uint32)), t
         assert np.array_equal(sim.game_over_codes.cpu().numpy(), ref.codes[t]), t
     sim.close()
+
+
+def test_teacher_performance_counters(oracle):
+    """Teacher::report_task_performance (teacher.cpp:175-200): successes / failures / success_steps per task class, counted on
+    the device over a 10 000-step soak with resets, against the oracle's tallies of the same rollout; the report text; the
+    counters travel with a checkpoint."""
+    _torch()
+    from xworld_amd.batched import BatchedSimulator
+    n, steps = 1024, 10000
+    conf = os.path.join(CONF, "navigation2d.json")
+    sim = BatchedSimulator("xworld", {"xwd_conf_path": conf, "task_mode": "lang_acquisition", "max_dim": 7, "num_blocks": 16},
+                           num_envs=n, seed=77, policy_seed=12)
+    pal = oracle.Palette(oracle.NAV_SUBTREES)
+    cfg = dict(map_kind=0, max_dim=7, dim=7, num_goals=4, num_blocks=16, seed=77, tasks=[0, 1, 2, 3, 4])
+    ref = oracle.xw_rollout(n, oracle.xw_cfg(**cfg), pal, steps, policy_seed=12)
+    blob = None
+    for t in range(steps):
+        sim.reset_done()
+        sim.step()
+        if t == 4000:
+            blob, at4000 = sim.save_state(), sim.task_performance()
+    # the example loop resets at the top of an iteration: the games that ended on the last step are still to be reset
+    got, resets = sim.task_performance()
+    want = {}
+    from xworld_amd.lib import TASK_CLASSES
+    for k in range(9):
+        row = tuple(int(x) for x in ref.stats.task_perf[k])
+        if row[0] + row[1]:
+            want[TASK_CLASSES[k]] = row
+    assert got == want, (got, want)
+    assert len(got) == 5 and all(v[0] > 100 and v[1] > 100 and v[2] > v[0] for v in got.values())
+    assert resets == n + ref.stats.resets                       # the first reset of every env + the example loop's
+    text = sim.task_performance_report()
+    lines = text.splitlines()
+    assert lines[0] == "=== XWorld3DNavTarget ===" and len(lines) == 10
+    s, f, ss, _ = got["XWorld3DNavTarget"]
+    assert lines[1] == "=== %d(S)/%d(F) -> %g@%g" % (s, f, s / (s + f), ss / s)
+    sim.load_state(blob)
+    assert sim.task_performance() == at4000
+    sim.close()
+    # one_channel, the 2-D-native group: failures are time-ups, no success_steps
+    sim = BatchedSimulator("xworld", {"xwd_conf_path": os.path.join(CONF, "walls.json"), "task_mode": "one_channel", "max_steps": 200},
+                           num_envs=256, seed=3)
+    for t in range(400):
+        sim.reset_done()
+        sim.step()
+    got, _ = sim.task_performance()
+    assert set(got) <= {"XWorldNavTarget", "XWorldNavColorTarget"} and got
+    assert all(v[0] == 0 and v[1] == v[3] > 0 and v[2] == 0 for v in got.values()), got
+    sim.close()

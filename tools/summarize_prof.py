@@ -9,6 +9,12 @@ import sys
 FILL_BYTES = 693633024          # tools/hbm_write_ceiling.py buffer
 
 
+def _fingerprint():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from xworld_amd import build
+    return build.source_fingerprint()
+
+
 def counter_by_kernel(out, tag, counter):
     agg = {}
     for f in glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True):
@@ -69,7 +75,9 @@ def main(out, bench_args):
             f = per_kernel[k].get("FETCH_SIZE", 0.0)
         traffic = {"workload": workload, "kernel": k[:200], "write_bytes_per_launch": w, "fetch_bytes_per_launch_raw": f,
                    "fetch_bytes_per_launch_corrected": 2 * f, "traffic_bytes_per_launch": w + 2 * f,
-                   "calibration": cal, "source": os.path.basename(out)}
+                   "calibration": cal, "source": os.path.basename(out),
+                   # which code this describes: bench.py compares source_sha16 with the sources it runs and flags a stale quote
+                   "commit": os.environ.get("GIT_HEAD", "unknown"), "source_sha16": _fingerprint()}
         with open(os.path.join(out, "traffic.json"), "w") as fh:
             json.dump(traffic, fh, indent=1)
         print("== traffic ==")

@@ -423,6 +423,24 @@ class BatchedSimulator:
                                  (target >> 8) & 7 if task == 3 and target >= 0 else 0,
                                  self.cfg.seed, self.cfg.env_gid0 + int(env), st.episode)
 
+    def task_performance(self, stream=None):
+        """Teacher::report_task_performance's numbers for the whole batch since it was created: ({task class: (successes,
+        failures, success_steps, time_ups)} for the classes that occurred, games reset)."""
+        arr = (lib.XwbTaskPerformance * 9)()
+        resets = C.c_int64()
+        lib.check(self.L.xwb_get_task_performance(self.h, self._stream(stream), arr, C.byref(resets)))
+        out = {lib.TASK_CLASSES[k]: (p.successes, p.failures, p.success_steps, p.time_ups)
+               for k, p in enumerate(arr) if p.successes + p.failures}
+        return out, resets.value
+
+    def task_performance_report(self, stream=None):
+        """the text SimulatorInterface::teacher_report_task_performance logs (teacher.cpp:175-200)"""
+        need = C.c_size_t()
+        lib.check(self.L.xwb_task_performance_report(self.h, self._stream(stream), None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value)
+        lib.check(self.L.xwb_task_performance_report(self.h, self._stream(stream), buf, need.value, C.byref(need)))
+        return buf.value.decode()
+
     def save_state(self, include_obs=True):
         """The batch's whole dynamic state as one numpy uint8 blob (checkpoint); load_state() resumes bit for bit."""
         n = C.c_size_t()

@@ -32,6 +32,21 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_fingerprint():
+    """sha256[:16] over the sources libxwb.so is built from (csrc/*.hip, csrc/*.h, include/*.h): stamps profiles and bench
+    lines so that a stored measurement says which code it describes (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    files = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] +
+                   [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith((".h", ".hpp"))])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
     cc = hipcc()
     objs = []

@@ -60,7 +60,8 @@ __device__ __forceinline__ void teach_group(const XwParams &p, const StepCtx &c,
     int stage = task_stage(ts);
     int tsteps = tsteps_in;
     event = EV_NONE;
-    int record = -1;                                // curriculum: the result this step adds to the task's window
+    int record = -1;                                // the result this step adds to the task's window / counters
+    bool timeup = false;
     rew = 0.0;
     if (group2d) {
         // rule D14b (games/xworld/tasks/xworld_task.py:184-223): the group draws a task whenever its busy
@@ -81,6 +82,7 @@ __device__ __forceinline__ void teach_group(const XwParams &p, const StepCtx &c,
             if (p.task_mode == 1 && tsteps >= D * D / 2) {           // one_channel: h*w / 2 (max dims)
                 tsteps = 0;
                 record = 0;                         // _record_failure
+                timeup = true;
                 stage = STAGE_IDLE;                 // "S -> timeup"
             } else if (ay * D + ax == target) {     // agent.loc == self.target
                 tsteps = 0;
@@ -102,6 +104,7 @@ __device__ __forceinline__ void teach_group(const XwParams &p, const StepCtx &c,
         if (tsteps >= dim * dim * p.max_steps_factor) {
             event = EV_TIMEUP;
             record = 0;
+            timeup = true;
             stage = STAGE_TERMINAL;
         } else if (hit != 0 && ddx == vx && ddy == vy && s_icon_type[(hit & CELL_ICON_MASK) - 1] == 0) {
             // _reach_object: id in collisions and |theta| < pi/4, i.e. the goal was bumped into along the
@@ -129,6 +132,14 @@ __device__ __forceinline__ void teach_group(const XwParams &p, const StepCtx &c,
         }
     }
     if (record >= 0 && p.curriculum != 0) usage_push(p.cur_usage + ((size_t)e * 9 + kind) * XW_USAGE_BYTES, record);
+    if (record >= 0) {
+        // XWorld(3D)Task._record_success / _record_failure (xworld3d_task.py:135-142, xworld_task.py:93-99): the tallies
+        // Task::obtain_performance hands to Teacher::report_task_performance; only the XWorld3D tasks keep success_steps
+        unsigned long long *c = p.perf + kind * 4;
+        atomicAdd(c + (record ? 0 : 1), 1ull);
+        if (record && !group2d) atomicAdd(c + 2, (unsigned long long)tsteps);
+        if (timeup) atomicAdd(c + 3, 1ull);
+    }
     ts_out = pack_task(target, stage, event, kind);
     tsteps_out = tsteps;
 }

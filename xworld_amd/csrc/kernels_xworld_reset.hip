@@ -785,6 +785,7 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
     p.task_steps[e] = 0;
     p.num_steps[e] = 0;
     p.fresh[e] = 2;                                       // render: init_screen (zero the older context frames)
+    atomicAdd(p.perf + 36, 1ull);                         // games reset
     if (!keep_done) p.done[e] = (uint8_t)done_code(p, 0, EV_NONE);
     RP_T(4);
 }

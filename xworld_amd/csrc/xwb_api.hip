@@ -114,6 +114,7 @@ struct xwb_sim {
     int32_t *d_task_steps2 = nullptr, *d_task_state2 = nullptr;
     uint8_t *d_grp_order = nullptr;        // exclusive group scheduling (XwParams::grp_order)
     int32_t *d_idle_list = nullptr, *d_idle_count = nullptr;
+    unsigned long long *d_perf = nullptr;  // XwParams::perf
     int32_t *d_agent = nullptr, *d_task_steps = nullptr, *d_task_state = nullptr, *d_done_list = nullptr,
             *d_done_count = nullptr;
     uint8_t *d_fresh = nullptr, *d_icon_type = nullptr, *d_icon_colored = nullptr, *d_goal_cells = nullptr;
@@ -438,6 +439,7 @@ int xw_setup(xwb_sim *s) {
         if ((rc = dev_alloc(s, &s->d_idle_list, n))) return rc;
         if ((rc = dev_alloc(s, &s->d_idle_count, 2))) return rc;
     }
+    if ((rc = dev_alloc(s, &s->d_perf, 40))) return rc;
     if ((rc = dev_alloc(s, &s->d_done_list, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_done_count, 2))) return rc;
     if ((rc = dev_alloc(s, &s->d_fresh, n))) return rc;
@@ -550,6 +552,7 @@ int xw_setup(xwb_sim *s) {
     for (int i = 0; i < 8; ++i) p.tasks2[i] = i < c.n_tasks2 ? c.tasks2[i] : 0;
     for (int i = 0; i < 8; ++i) p.task_acc2[i] = (i ? p.task_acc2[i - 1] : 0.0) + (i < c.n_tasks2 && p.task_weighted2 ? c.task_weights2[i] : 0.0);
     p.task_state2 = s->d_task_state2; p.task_steps2 = s->d_task_steps2;
+    p.perf = s->d_perf;
     p.exclusive = exclusive ? 1 : 0;
     p.group_weight[0] = c.task_group_weight; p.group_weight[1] = c.task_group_weight2;
     p.grp_order = s->d_grp_order; p.idle_list = s->d_idle_list; p.idle_count = s->d_idle_count; p.idle_count_next = nullptr;
@@ -1648,7 +1651,7 @@ std::vector<StateArray> state_arrays(xwb_sim *s, bool include_obs) {
         const size_t cells = (size_t)s->cfg.max_dim * s->cfg.max_dim;
         add(s->d_grid, n * cells * 2); add(s->d_agent, n * 4); add(s->d_task_steps, n * 4); add(s->d_task_state, n * 4);
         add(s->d_task_steps2, n * 4); add(s->d_task_state2, n * 4); add(s->d_grp_order, n);
-        add(s->d_done_list, n * 4); add(s->d_done_count, 8); add(s->d_fresh, n);
+        add(s->d_done_list, n * 4); add(s->d_done_count, 8); add(s->d_fresh, n); add(s->d_perf, 40 * 8);
         add(s->d_goal_cells, n * XW_MAX_GOALS); add(s->d_cand2d, n * 4); add(s->d_agent_dir, n); add(s->d_sent_names, n * 4);
         add(s->d_goal_warp, n * XW_MAX_GOALS * 6 * sizeof(double));     // goal images are re-warped from these on load
         add(s->d_cur_level, n); add(s->d_cur_counter, n * 4); add(s->d_cur_usage, n * 9 * XW_USAGE_BYTES);
@@ -1886,6 +1889,55 @@ int xwb_get_state_packet(xwb_sim *s, int32_t env, float reward, void *stream, ui
         w.str("sentence");
         f = 8; w.put(&f, 1); w.str(sent.c_str());
     }
+    return XWB_OK;
+}
+
+static const char *const TASK_CLASS[9] = {"XWorld3DNavTarget", "XWorld3DNavTargetNear", "XWorld3DNavTargetBetween", "XWorld3DNavTargetDirection",
+                                          "XWorld3DNavTargetAvoid", "XWorldNavTarget", "XWorldNavNear", "XWorldNavColorTarget", "XWorldNavBetween"};
+
+int xwb_get_task_performance(xwb_sim *s, void *stream, xwb_task_performance out[9], int64_t *resets) {
+    if (!s || !out) return fail(XWB_ERR_ARG, "NULL argument");
+    if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not a teaching environment");
+    XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
+    unsigned long long h[40];
+    hipStream_t st = as_stream(stream);
+    HIP_TRY(hipMemcpyAsync(h, s->d_perf, sizeof h, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int k = 0; k < 9; ++k) {
+        out[k].successes = (int64_t)h[k * 4]; out[k].failures = (int64_t)h[k * 4 + 1];
+        out[k].success_steps = (int64_t)h[k * 4 + 2]; out[k].time_ups = (int64_t)h[k * 4 + 3];
+    }
+    if (resets) *resets = (int64_t)h[36];
+    return XWB_OK;
+}
+
+int xwb_task_performance_report(xwb_sim *s, void *stream, char *out, size_t cap, size_t *need) {
+    if (!s || !need) return fail(XWB_ERR_ARG, "NULL argument");
+    xwb_task_performance perf[9];
+    const int rc = xwb_get_task_performance(s, stream, perf, nullptr);
+    if (rc) return rc;
+    // Teacher::report_task_performance, teacher.cpp:175-200 (an unordered_map there: the order of the blocks is unspecified;
+    // here: task id).  Tasks of the batch's groups only; a task that did not occur prints its name line alone.
+    std::string text;
+    auto add_group = [&](const int32_t *tasks, int n) {
+        for (int i = 0; i < n; ++i) {
+            const int k = tasks[i];
+            if (k < 0 || k >= 9) continue;
+            text += std::string("=== ") + TASK_CLASS[k] + " ===\n";
+            const long long succ = perf[k].successes, failed = perf[k].failures;
+            if (succ + failed == 0) continue;                        // "skip task that did not occur"
+            const double per = succ > 0 ? (double)perf[k].success_steps / (double)succ : -1.0;
+            char line[160];
+            snprintf(line, sizeof line, "=== %lld(S)/%lld(F) -> %g@%g\n", succ, failed, (double)succ / (double)(succ + failed), per);
+            text += line;
+        }
+    };
+    static const int32_t only_target[1] = {XWB_TASK_TARGET};
+    if (s->cfg.n_tasks > 0) add_group(s->cfg.tasks, s->cfg.n_tasks); else add_group(only_target, 1);
+    add_group(s->cfg.tasks2, s->cfg.n_tasks2);
+    *need = text.size() + 1;
+    if (out && cap >= text.size() + 1) memcpy(out, text.c_str(), text.size() + 1);
     return XWB_OK;
 }
 

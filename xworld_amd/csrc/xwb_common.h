@@ -252,6 +252,10 @@ struct XwParams {
     int32_t *done_count;         // counter the current step / compaction appends to
     int32_t *done_count_next;    // the other one of the pair; zeroed by the step kernel
     int32_t *err_count;
+    // what Teacher::report_task_performance adds up (teacher.cpp:175-200; teaching_task.h:22-36 BenchmarkRes), for the whole
+    // batch since it was created: perf[task class][0..3] = successes, failures, success_steps, time-ups (a subset of the
+    // failures); perf[36] = games reset.  Bumped with atomics by the few lanes that record a result (~0.3 % of a step's envs).
+    unsigned long long *perf;
     // device-side hand-off between the two queues of the step loop, instead of event / barrier packets (each costs the
     // loop ~3-6 us of idle GPU): sync[1] = epoch of the last completed step kernel, sync[3] = of the last completed reset
     // kernel, sync[4] != 0: a wait gave up (xw_device.h: xw_publish_epoch / xw_wait_epoch).  render_all with sig_epoch != 0 publishes it to sync[1] when it

@@ -59,6 +59,13 @@ class XwbEnvState(C.Structure):
     ]
 
 
+class XwbTaskPerformance(C.Structure):
+    _fields_ = [("successes", C.c_int64), ("failures", C.c_int64), ("success_steps", C.c_int64), ("time_ups", C.c_int64)]
+
+
+TASK_CLASSES = ["XWorld3DNavTarget", "XWorld3DNavTargetNear", "XWorld3DNavTargetBetween", "XWorld3DNavTargetDirection",
+                "XWorld3DNavTargetAvoid", "XWorldNavTarget", "XWorldNavNear", "XWorldNavColorTarget", "XWorldNavBetween"]
+
 # every symbol include/xwb.h declares: (name, restype, argtypes)
 _vp = C.c_void_p
 _SIGS = [
@@ -120,6 +127,8 @@ _SIGS = [
     ("xwb_xw_load_map_task", C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     ("xwb_race_set_car", C.c_int, [_vp, C.c_int32, C.c_float, C.c_float, C.c_float]),
     ("xwb_get_state_packet", C.c_int, [_vp, C.c_int32, C.c_float, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("xwb_get_task_performance", C.c_int, [_vp, _vp, C.POINTER(XwbTaskPerformance), C.POINTER(C.c_int64)]),
+    ("xwb_task_performance_report", C.c_int, [_vp, _vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("xwb_decode_game_over_code", C.c_int, [C.c_int32, C.c_char_p, C.c_size_t]),
     ("xwb_xw_get_tile_table", C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("xwb_profile_begin", C.c_int, [_vp]),
