@@ -19,13 +19,18 @@
 
 namespace xwb {
 
-// Envs reset by this launch, counted into *counter with ONE atomic per wavefront per LAUNCH.  (One per wavefront per step
-// was 90 % of a fused SimpleRace launch: under a random policy nearly every wavefront holds an env that ends at any
-// given step, so a thousand wavefronts hit one address every step and L2 serialises same-address atomics.)
-__device__ __forceinline__ void count_resets(int32_t *counter, int n_reset) {
+// Envs reset by this launch: each workgroup stores its own count (xwb_done_count adds them up) -- no atomics.  (One atomic
+// per wavefront per step on a shared counter was 90 % of a fused SimpleRace launch, and one per wavefront per launch still
+// made the reset_done pass of the example loop a 13 us kernel: under a random policy nearly every wavefront holds an env
+// that ends at any given step, and L2 serialises same-address atomics.)  Every thread of the workgroup must call it.
+__device__ __forceinline__ void store_reset_count(int32_t *partial, int n_reset) {
+    __shared__ int s_cnt[4];
+    if (!partial) return;                                   // (kernel argument: uniform)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n_reset += __shfl_down(n_reset, off);
-    if ((threadIdx.x & 63) == 0 && n_reset) atomicAdd(counter, n_reset);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = n_reset;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
 // ============================================================ SimpleGame ====
@@ -89,7 +94,7 @@ __device__ __forceinline__ void sg_body(const SgParams &p, uint32_t policy_step,
     bool fresh = false;
     if (e < p.n) {
         bool do_reset = false;
-        if (FAST || p.mode == MODE_STEP) {
+        {                                                   // (the reset modes have a kernel of their own: sg_reset_kernel)
             int a = (FAST || !p.actions) ? policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, policy_step, 2) : p.actions[e];
             p.actions_out[e] = a;
             if (a == ACTION_SKIP) {
@@ -113,18 +118,11 @@ __device__ __forceinline__ void sg_body(const SgParams &p, uint32_t policy_step,
                 obs_pos = pos;
                 if (p.auto_reset && code != ALIVE) do_reset = true;
             }
-        } else {
-            do_reset = p.mode == MODE_RESET_ALL || (p.mode == MODE_RESET_DONE && p.done[e] != 0) ||
-                       (p.mode == MODE_RESET_MASK && p.mask[e] != 0);
         }
         if (do_reset) {
-            // SimpleGameEngine::reset_game cpp:31-38 ; GameSimulator::reset_game
+            // SimpleGameEngine::reset_game cpp:31-38 ; GameSimulator::reset_game (the terminal code stays for the caller)
             pos = A / 2; flags = 0; steps = 0;
             episode += 1;
-            if (!FAST && p.mode != MODE_STEP) {
-                // game_over() right after reset (over at once for array_size <= 2)
-                p.done[e] = (uint8_t)(sg_over(pos, A) ? SUCCESS : ALIVE);   // num_steps_ == 0 < max_steps
-            }
             obs_pos = pos; fresh = true;
         }
         n_reset += do_reset ? 1 : 0;
@@ -166,20 +164,62 @@ __global__ __launch_bounds__(256) void sg_kernel(SgParams p) {
     uint32_t flags = 0, episode = 0;
     bool dirty = false;
     int n_reset = 0;
-    if (e == 0 && p.reset_count_next) *p.reset_count_next = 0;
     if (e < p.n) { pos = p.pos[e]; flags = p.flags[e]; steps = p.num_steps[e]; episode = p.episode[e]; }
     for (int it = 0; it < p.n_steps; ++it) {
         sg_body<G, FAST>(p, p.policy_step + (uint32_t)it, pos, flags, steps, episode, dirty, n_reset);   // (p stays in kernel-argument memory: never written)
         __syncthreads();                                   // the shared staging of this step is dead
     }
     if (e < p.n && dirty) { p.pos[e] = pos; p.flags[e] = (uint8_t)flags; p.num_steps[e] = steps; p.episode[e] = episode; }
-    count_resets(p.reset_count, n_reset);
+    store_reset_count(p.reset_partial, n_reset);
+}
+
+// reset_game for the envs a mode selects (all / game over / mask), as its own kernel: a reset needs nothing of an env's old
+// state but its episode counter, so the lanes load `done` (or the mask) and `episode` in ONE round trip, and lanes that
+// do not reset touch nothing else -- the generic kernel in a reset mode loaded and wrote back the whole state of every
+// env (the reset_done pass of the example loop then cost more than the step it follows).
+template <int G>
+__global__ __launch_bounds__(256) void sg_reset_kernel(SgParams p) {
+    using chunk_t = typename ChunkT<G>::type;
+    __shared__ uint8_t s_reset[256];
+    const int tid = threadIdx.x;
+    const int e = blockIdx.x * 256 + tid;
+    const int A = p.array_size;
+    bool do_reset = false;
+    uint32_t episode = 0;
+    if (e < p.n) {
+        episode = p.episode[e];
+        do_reset = p.mode == MODE_RESET_ALL || (p.mode == MODE_RESET_DONE ? p.done[e] != 0 : p.mask[e] != 0);
+    }
+    s_reset[tid] = do_reset ? 1 : 0;
+    if (!__syncthreads_or(do_reset)) {                       // nobody in this workgroup: nothing to write
+        if (tid == 0 && p.reset_partial) p.reset_partial[blockIdx.x] = 0;
+        return;
+    }
+    const int pos = A / 2;                                   // SimpleGameEngine::reset_game cpp:31-38 ; GameSimulator::reset_game
+    if (do_reset) {
+        p.pos[e] = pos; p.flags[e] = 0; p.num_steps[e] = 0; p.episode[e] = episode + 1;
+        p.done[e] = (uint8_t)(sg_over(pos, A) ? SUCCESS : ALIVE);     // over at once for array_size <= 2; num_steps_ == 0 < max_steps
+    }
+    // init_screen (simulator.cpp:110-113): zeros, then the first frame last
+    const int cpf = A / G, ctx = p.context;
+    const int base_env = blockIdx.x * 256;
+    const int n_here = min(256, p.n - base_env);
+    for (int i = tid; i < n_here * cpf; i += 256) {
+        const int le = i / cpf, j = i - le * cpf;
+        if (!s_reset[le]) continue;
+        chunk_t *frame0 = reinterpret_cast<chunk_t *>(p.obs + ((size_t)(base_env + le) * ctx) * A) + j;
+        for (int f = 0; f + 1 < ctx; ++f) frame0[(size_t)f * cpf] = zero_chunk<G>();
+        frame0[(size_t)(ctx - 1) * cpf] = sg_onehot_chunk<G>(pos - j * G);
+    }
+    store_reset_count(p.reset_partial, do_reset ? 1 : 0);
 }
 
 hipError_t launch_simple_game(const SgParams &p, hipStream_t s) {
     dim3 grid((p.n + 255) / 256), block(256);
     const bool fast = p.mode == MODE_STEP && !p.actions && p.context == 1;
-#define SG_LAUNCH(GV) do { if (fast) hipLaunchKernelGGL((sg_kernel<GV, true>), grid, block, 0, s, p); else hipLaunchKernelGGL((sg_kernel<GV, false>), grid, block, 0, s, p); } while (0)
+#define SG_LAUNCH(GV) do { if (p.mode != MODE_STEP) hipLaunchKernelGGL((sg_reset_kernel<GV>), grid, block, 0, s, p); \
+                           else if (fast) hipLaunchKernelGGL((sg_kernel<GV, true>), grid, block, 0, s, p); \
+                           else hipLaunchKernelGGL((sg_kernel<GV, false>), grid, block, 0, s, p); } while (0)
     if (p.array_size % 16 == 0) SG_LAUNCH(16);
     else if (p.array_size % 4 == 0) SG_LAUNCH(4);
     else SG_LAUNCH(1);
@@ -308,7 +348,7 @@ template <bool FAST>        // see sg_body
 __device__ __forceinline__ void race_body(const RaceParams &p, uint32_t policy_step, int e, RaceLane &L) {
     RaceCar &c = L.c;
     bool do_reset = false, touched = false;
-    if (FAST || p.mode == MODE_STEP) {
+    {                                                       // (the reset modes have a kernel of their own: race_reset_kernel)
         int a = (FAST || !p.actions) ? policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, policy_step, p.n_legal) : p.actions[e];
         p.actions_out[e] = a;
         if (a == ACTION_SKIP) {
@@ -362,17 +402,12 @@ __device__ __forceinline__ void race_body(const RaceParams &p, uint32_t policy_s
             touched = true;
             if (p.auto_reset && code != ALIVE) do_reset = true;
         }
-    } else {
-        do_reset = p.mode == MODE_RESET_ALL || (p.mode == MODE_RESET_DONE && p.done[e] != 0) ||
-                   (p.mode == MODE_RESET_MASK && p.mask[e] != 0);
     }
     if (do_reset) {
         L.episode += 1;
         race_reset(p, c, p.env_gid0 + (uint32_t)e, L.episode, (!FAST && p.minstd) ? p.minstd + e : nullptr);
         L.trig = false;
         L.steps = 0;
-        if (!FAST && p.mode != MODE_STEP)
-            p.done[e] = (uint8_t)(race_oob(p, c.x, c.y) ? DEAD : ALIVE);
         touched = true;
     }
     L.n_reset += do_reset ? 1 : 0;
@@ -396,19 +431,49 @@ __global__ __launch_bounds__(256) void race_kernel(RaceParams p) {
     const bool live = e < p.n;
     RaceLane L;
     L.trig = false; L.dirty = false; L.ca = L.sa = 0; L.n_reset = 0;
-    if (e == 0 && p.reset_count_next) *p.reset_count_next = 0;
     L.c.x = L.c.y = L.c.angle = 0; L.steps = 0; L.episode = 0;
     if (live) { L.c.x = p.x[e]; L.c.y = p.y[e]; L.c.angle = p.angle[e]; L.steps = p.num_steps[e]; L.episode = p.episode[e]; }
     for (int it = 0; it < p.n_steps; ++it) {               // n_steps > 1: xwb_step_n, see sg_kernel
         if (live) race_body<FAST>(p, p.policy_step + (uint32_t)it, e, L);
     }
     if (live && L.dirty) { p.x[e] = L.c.x; p.y[e] = L.c.y; p.angle[e] = L.c.angle; p.num_steps[e] = L.steps; p.episode[e] = L.episode; }
-    count_resets(p.reset_count, L.n_reset);
+    store_reset_count(p.reset_partial, L.n_reset);
+}
+
+// reset_game for the envs a mode selects, as its own kernel (see sg_reset_kernel): `done` / mask and `episode` in one round
+// trip; lanes that do not reset leave at once, the others write the new car, counters, code and first frame.
+__global__ __launch_bounds__(256) void race_reset_kernel(RaceParams p) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    bool do_reset = false;
+    uint32_t episode = 0;
+    if (e < p.n) {
+        episode = p.episode[e];
+        do_reset = p.mode == MODE_RESET_ALL || (p.mode == MODE_RESET_DONE ? p.done[e] != 0 : p.mask[e] != 0);
+    }
+    if (!__syncthreads_or(do_reset)) {                       // nobody in this workgroup
+        if (threadIdx.x == 0 && p.reset_partial) p.reset_partial[blockIdx.x] = 0;
+        return;
+    }
+    if (do_reset) {
+        RaceCar c;
+        episode += 1;
+        race_reset(p, c, p.env_gid0 + (uint32_t)e, episode, p.minstd ? p.minstd + e : nullptr);
+        p.x[e] = c.x; p.y[e] = c.y; p.angle[e] = c.angle; p.num_steps[e] = 0; p.episode[e] = episode;
+        p.done[e] = (uint8_t)(race_oob(p, c.x, c.y) ? DEAD : ALIVE);        // game_over() right after the reset
+        double sa, ca;
+        xwb_sincos((double)c.angle, &sa, &ca);
+        // init_screen: [env][context][4] floats; older frames zero, the first frame last
+        float4 *frames = reinterpret_cast<float4 *>(p.obs) + (size_t)e * p.context;
+        for (int f = 0; f + 1 < p.context; ++f) frames[f] = make_float4(0, 0, 0, 0);
+        frames[p.context - 1] = race_screen(p, c, ca, sa);
+    }
+    store_reset_count(p.reset_partial, do_reset ? 1 : 0);
 }
 
 hipError_t launch_simple_race(const RaceParams &p, hipStream_t s) {
     dim3 grid((p.n + 255) / 256), block(256);
-    if (p.mode == MODE_STEP && !p.actions && p.context == 1 && !p.minstd) hipLaunchKernelGGL(race_kernel<true>, grid, block, 0, s, p);
+    if (p.mode != MODE_STEP) hipLaunchKernelGGL(race_reset_kernel, grid, block, 0, s, p);
+    else if (!p.actions && p.context == 1 && !p.minstd) hipLaunchKernelGGL(race_kernel<true>, grid, block, 0, s, p);
     else hipLaunchKernelGGL(race_kernel<false>, grid, block, 0, s, p);
     return hipGetLastError();
 }

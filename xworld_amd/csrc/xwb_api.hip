@@ -72,7 +72,6 @@ struct xwb_sim {
     int num_actions = 0;
     uint32_t policy_step = 0;
     bool list_valid = false;
-    int rc_sel = 0;                        // simple games: the reset counter of the pair the last counting launch used
     bool autoreset_done = false;           // the last step call already reset the envs whose codes are still set
     int count_sel = 0;
     bool profiling = false;
@@ -96,7 +95,7 @@ struct xwb_sim {
     // common device buffers
     int32_t *d_actions_in = nullptr;       // staging for xwb_step_host
     uint8_t *d_mask = nullptr;             // staging for xwb_reset_env
-    int32_t *d_actions = nullptr, *d_num_steps = nullptr, *d_err = nullptr, *d_reset_count = nullptr;
+    int32_t *d_actions = nullptr, *d_num_steps = nullptr, *d_err = nullptr, *d_reset_partial = nullptr;   // (SgParams::reset_partial)
     uint32_t *d_episode = nullptr;
     float *d_reward = nullptr;
     uint8_t *d_done = nullptr, *d_success = nullptr;
@@ -665,7 +664,7 @@ SgParams sg_params(xwb_sim *s) {
     p.reward = s->d_reward; p.done = s->d_done; p.obs = static_cast<uint8_t *>(s->d_obs);
     p.packed = packed_slot(s);
     p.n_steps = 1;
-    p.err_count = s->d_err; p.reset_count = s->d_reset_count + s->rc_sel; p.reset_count_next = nullptr;
+    p.err_count = s->d_err; p.reset_partial = nullptr;
     return p;
 }
 
@@ -680,19 +679,14 @@ RaceParams race_params(xwb_sim *s) {
     p.reward = s->d_reward; p.done = s->d_done; p.obs = static_cast<float *>(s->d_obs);
     p.packed = packed_slot(s);
     p.n_steps = 1;
-    p.err_count = s->d_err; p.reset_count = s->d_reset_count + s->rc_sel; p.reset_count_next = nullptr;
+    p.err_count = s->d_err; p.reset_partial = nullptr;
     p.minstd = s->d_minstd;
     return p;
 }
 
-// A launch that counts the envs it resets takes the other counter of the pair, which the previous counting launch zeroed,
-// and zeroes that one's for the next (no memset per call in the queue).
+// a launch that may reset envs writes its per-workgroup counts (xwb_done_count reports the last such launch)
 template <typename P>
-void take_reset_counter(xwb_sim *s, P &p) {
-    s->rc_sel ^= 1;
-    p.reset_count = s->d_reset_count + s->rc_sel;
-    p.reset_count_next = s->d_reset_count + (s->rc_sel ^ 1);
-}
+void take_reset_counter(xwb_sim *s, P &p) { p.reset_partial = s->d_reset_partial; }
 
 // reset for the simple games: one launch, mode selects the envs
 int simple_reset(xwb_sim *s, int mode, const uint8_t *mask, hipStream_t st) {
@@ -1008,7 +1002,7 @@ int xwb_create(const xwb_config *cfg, xwb_sim **out) {
     if ((rc = dev_alloc(s, &s->d_mask, n))) return bail(rc);
     if ((rc = dev_alloc(s, &s->d_num_steps, n))) return bail(rc);
     if ((rc = dev_alloc(s, &s->d_err, 1))) return bail(rc);
-    if ((rc = dev_alloc(s, &s->d_reset_count, 2))) return bail(rc);
+    if ((rc = dev_alloc(s, &s->d_reset_partial, (size_t)(n + 255) / 256))) return bail(rc);
     if ((rc = dev_alloc(s, &s->d_episode, n, 0xff))) return bail(rc);      // first reset -> episode 0
     if ((rc = dev_alloc(s, &s->d_reward, n))) return bail(rc);
     if ((rc = dev_alloc(s, &s->d_done, n))) return bail(rc);
@@ -1275,8 +1269,16 @@ int xwb_done_count(xwb_sim *s, void *stream, int32_t *n_done) {
     XWB_ON_DEVICE(s);
     XWB_LIVE(s);
     hipStream_t st = as_stream(stream);
-    const int32_t *src = s->cfg.game == XWB_XWORLD2D ? s->d_done_count + s->count_sel : s->d_reset_count + s->rc_sel;
-    HIP_TRY(hipMemcpyAsync(n_done, src, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (s->cfg.game != XWB_XWORLD2D) {                     // per-workgroup counts of the last launch that reset envs
+        std::vector<int32_t> part((size_t)(s->n + 255) / 256);
+        HIP_TRY(hipMemcpyAsync(part.data(), s->d_reset_partial, part.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        int64_t total = 0;
+        for (int32_t v : part) total += v;
+        *n_done = (int32_t)total;
+        return XWB_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(n_done, s->d_done_count + s->count_sel, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return XWB_OK;
 }
@@ -1643,7 +1645,7 @@ std::vector<StateArray> state_arrays(xwb_sim *s, bool include_obs) {
     std::vector<StateArray> a;
     auto add = [&](void *p, size_t bytes) { if (p) a.push_back(StateArray{p, bytes}); };
     add(s->d_actions, n * 4); add(s->d_num_steps, n * 4); add(s->d_episode, n * 4); add(s->d_reward, n * 4);
-    add(s->d_done, n); add(s->d_success, n); add(s->d_err, 4); add(s->d_reset_count, 8);
+    add(s->d_done, n); add(s->d_success, n); add(s->d_err, 4); add(s->d_reset_partial, ((n + 255) / 256) * 4);
     add(s->d_pos, n * 4); add(s->d_flags, n);
     add(s->d_x, n * 4); add(s->d_y, n * 4); add(s->d_angle, n * 4);
     add(s->d_minstd, n * 4);
@@ -1703,7 +1705,7 @@ int xwb_save_state(xwb_sim *s, int32_t include_obs, uint8_t *out_host, size_t ca
     StateHeader h{};
     memcpy(h.magic, "XWBSTATE", 8);
     h.version = 2; h.game = (uint32_t)s->cfg.game; h.num_envs = (uint32_t)s->n; h.include_obs = include_obs ? 1u : 0u;
-    h.n_arrays = (uint32_t)arrays.size(); h.policy_step = s->policy_step; h.count_sel = (uint32_t)s->count_sel | ((uint32_t)s->rc_sel << 1);
+    h.n_arrays = (uint32_t)arrays.size(); h.policy_step = s->policy_step; h.count_sel = (uint32_t)s->count_sel;
     h.list_valid = (s->list_valid ? 1u : 0u) | (s->autoreset_done ? 2u : 0u); h.obs_bytes_per_env = s->obs_bytes_per_env; h.cfg_hash = config_hash(s->cfg);
     uint8_t *w = out_host;
     memcpy(w, &h, sizeof h); w += sizeof h;
@@ -1739,7 +1741,7 @@ int xwb_load_state(xwb_sim *s, const uint8_t *in_host, size_t bytes) {
         HIP_TRY(hipMemcpy(a.ptr, r, a.bytes, hipMemcpyHostToDevice));
         r += b;
     }
-    s->policy_step = h.policy_step; s->count_sel = (int)(h.count_sel & 1u); s->rc_sel = (int)((h.count_sel >> 1) & 1u); s->list_valid = (h.list_valid & 1u) != 0; s->autoreset_done = (h.list_valid & 2u) != 0;
+    s->policy_step = h.policy_step; s->count_sel = (int)(h.count_sel & 1u); s->list_valid = (h.list_valid & 1u) != 0; s->autoreset_done = (h.list_valid & 2u) != 0;
     if (s->cfg.game == XWB_XWORLD2D) {
         XwParams p = xw_params(s);
         if (p.visible_radius) HIP_TRY(launch_xw_warp_goals(p, false, nullptr));

@@ -104,8 +104,10 @@ struct SgParams {
     uint8_t *done;
     uint8_t *obs;               // [n][context][array_size]
     int32_t *err_count;
-    int32_t *reset_count;       // envs reset by this launch are added here (one of a pair)
-    int32_t *reset_count_next;  // nullable: the pair's other counter, zeroed by this launch for the next counting one
+    int32_t *reset_partial;     // nullable (launches that reset nothing): [workgroups] envs this launch reset, per workgroup --
+                                // plain stores, summed by xwb_done_count (one atomic per wavefront on a shared counter made
+                                // the reset_done pass 13 us: L2 serialises same-address atomics, and under a random policy
+                                // nearly every wavefront holds an env that just finished)
 };
 hipError_t launch_simple_game(const SgParams &p, hipStream_t s);
 
@@ -132,8 +134,7 @@ struct RaceParams {
     uint8_t *done;
     float *obs;                 // [n][context][4]
     int32_t *err_count;
-    int32_t *reset_count;       // see SgParams
-    int32_t *reset_count_next;
+    int32_t *reset_partial;     // see SgParams
     uint32_t *minstd;           // nullable: XWB_RNG_MINSTD, one libstdc++ minstd_rand0 state per env (include/xwb_minstd.h)
 };
 hipError_t launch_simple_race(const RaceParams &p, hipStream_t s);
