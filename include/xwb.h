@@ -394,6 +394,43 @@ int xwb_profile_begin(xwb_sim *sim);
 int xwb_profile_end(xwb_sim *sim, void *stream, const char *kernel, double *avg_us, int64_t *launches);
 int xwb_profile_stop(xwb_sim *sim);
 
+/* ---- multi-GPU: one xwb_sim per GPU holds a shard of the batch (contiguous global env ids, xwb_config.env_gid0); the per-step
+ * exchange is RCCL over xGMI, issued by the library itself so that C / C++ holders of a xwb_sim shard like the Python layer
+ * does.  Replaces the reference's scale-out point: one OS process per environment behind SimulatorServer's TCP socket
+ * (examples/demo_interface.cpp:67-95, simulator_interface.cpp:170-313).  RCCL is resolved at run time (the librccl.so.1
+ * already loaded in the process, else the system's): libxwb.so has no link-time RCCL dependency. ----
+ * xwb_comm = an RCCL communicator plus a stream of its own, on which the screens travel beside the caller's kernels. */
+typedef struct xwb_comm xwb_comm;
+#define XWB_COMM_ID_BYTES 128
+int xwb_comm_version(int32_t *version);                                  /* ncclGetVersion of the RCCL in use */
+int xwb_comm_unique_id(uint8_t out[XWB_COMM_ID_BYTES]);                  /* ncclGetUniqueId: rank 0 makes it, everyone gets a copy */
+/* ncclCommInitRank on `device` (collective: every rank of the world calls it) */
+int xwb_comm_init_rank(const uint8_t id[XWB_COMM_ID_BYTES], int32_t world, int32_t rank, int32_t device, xwb_comm **out);
+/* wrap a communicator (ncclComm_t) the caller created with the RCCL of this process; it is not destroyed with the object */
+int xwb_comm_adopt(void *nccl_comm, int32_t device, xwb_comm **out);
+int xwb_comm_destroy(xwb_comm *comm);
+int xwb_comm_info(const xwb_comm *comm, int32_t *world, int32_t *rank);
+/* ncclGroupStart / ncclGroupEnd: lets several shards that live on ONE rank (two batches on one device, a loopback
+ * communicator) post their halves of an exchange as one group */
+int xwb_comm_group_start(xwb_comm *comm);
+int xwb_comm_group_end(xwb_comm *comm);
+/* A gather's layout: n_shards shards in global-env-id order, shard i = counts[i] envs held by communicator rank
+ * peers[i] (peers == NULL: rank i, the usual one shard per rank); `shard` = the caller's own.
+ * xwb_gather_results: every shard's packed (reward, game_over code) rows -- what xwb_bind_results receives, float[count][2] --
+ * into float[sum(counts)][2] on every holder: one ncclAllGather (equal shards) or grouped ncclSend / ncclRecv, on `stream`. */
+int xwb_gather_results(xwb_comm *comm, const float *packed_dev, float *all_dev, const int32_t *counts, const int32_t *peers,
+                       int32_t n_shards, int32_t shard, void *stream);
+/* The screens of every shard as ONE contiguous tensor on the root shard's GPU: dst_dev (root only; else NULL) =
+ * [sum(counts)][bytes_per_env].  _begin orders the transfer behind the work already queued on `stream` (the step's render)
+ * and issues it on the communicator's own stream -- the root posts one ncclRecv per remote shard into that shard's slice
+ * (its own slab is copied unless xwb_bind_obs already points the batch at its slice), the others one ncclSend --, so it
+ * runs beside whatever `stream` does next; _end makes `stream` wait for it.  With two observation buffers per batch
+ * (xwb_bind_obs) the transfer of step t overlaps the kernels of step t + 1.  Each remote GPU reaches the root over ONE
+ * xGMI link (~153.6 GB/s): a C4 shard (693.6 MB) needs >= 4.5 ms against 0.115 ms of compute (DESIGN.md "multi-GPU"). */
+int xwb_gather_screens_begin(xwb_sim *sim, xwb_comm *comm, void *dst_dev, const int32_t *counts, const int32_t *peers,
+                             int32_t n_shards, int32_t shard, int32_t root_shard, void *stream);
+int xwb_gather_screens_end(xwb_comm *comm, void *stream);
+
 /* ---- the reference's thread-local RNG on the host (include/xwb_minstd.h): what XWB_RNG_MINSTD runs per env on the device ----
  * xwb_minstd_seed_thread: the engine state of the nth simulator thread under FLAGS_simulator_seed (simulator_util.cpp:44-52);
  * xwb_minstd_rand_ind / rand_range: util::get_rand_ind / get_rand_range_val on a caller-held state. */

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libxwb.so")
-SOURCES = ["kernels_simple.hip", "kernels_xworld.hip", "kernels_xworld_reset.hip", "kernels_xworld_ego.hip", "xwb_api.hip"]
+SOURCES = ["kernels_simple.hip", "kernels_xworld.hip", "kernels_xworld_reset.hip", "kernels_xworld_ego.hip", "xwb_api.hip", "xwb_comm.hip"]
 HEADERS = [os.path.join(CSRC, "xwb_common.h"), os.path.join(CSRC, "xw_device.h"), os.path.join(CSRC, "xwb_language.h"), os.path.join(os.path.dirname(HERE), "include", "xwb.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
@@ -60,7 +60,7 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
     if force or _stale(LIB, objs):
-        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

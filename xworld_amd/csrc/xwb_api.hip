@@ -903,6 +903,9 @@ struct Writer {
 
 }  // namespace
 
+// (xwb_comm.hip reports its errors through the same per-thread message)
+extern "C" __attribute__((visibility("hidden"))) int xwb_internal_fail(int code, const char *msg) { return fail(code, msg); }
+
 // =============================================================== C ABI =====
 extern "C" {
 

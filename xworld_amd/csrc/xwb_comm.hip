@@ -1,0 +1,294 @@
+// xwb_comm.hip -- the multi-GPU exchange of libxwb.so: RCCL directly, below any Python (include/xwb.h, "multi-GPU").
+//
+// The reference scales out with one OS process per environment behind a TCP server (examples/demo_interface.cpp:67-95,
+// simulator_interface.cpp:170-313: every process ships its StatePacket to the trainer).  Here one xwb_sim per GPU holds a
+// shard of the batch (contiguous global env ids, xwb_config.env_gid0) and the per-step exchange is one RCCL operation per
+// shard over xGMI: an all-gather of (reward, game_over) -- 8 bytes per env --, and the north star's "one contiguous
+// observation tensor": every remote shard's frames sent straight into its slice of the root's tensor (ncclSend / ncclRecv
+// inside one group: each remote GPU has ONE direct xGMI link to the root, so this is link-bound by construction and is
+// issued on the communicator's own stream, beside the next step's kernels).
+//
+// RCCL is resolved at run time (dlopen of the librccl.so.1 already in the process -- PyTorch ships its own -- else the
+// system's): libxwb.so itself has no RCCL dependency, and a communicator the caller created with that same RCCL can be
+// adopted as it is.
+#include "../../include/xwb.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" __attribute__((visibility("hidden"))) int xwb_internal_fail(int code, const char *msg);     // xwb_api.hip: sets xwb_last_error on this thread
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+Rccl *rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return &r;
+    tried = true;
+    // the RCCL this process already runs (a communicator handed to xwb_comm_adopt belongs to it), else the system's
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : names) if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char *n : names) if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!r.handle) { r.error = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return &r; }
+    bool ok = true;
+    auto sym = [&](const char *name) { void *p = dlsym(r.handle, name); if (!p) { ok = false; r.error = std::string("RCCL lacks ") + name; } return p; };
+#define XWB_RCCL_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(sym(name))
+    XWB_RCCL_SYM(GetVersion, "ncclGetVersion"); XWB_RCCL_SYM(GetUniqueId, "ncclGetUniqueId"); XWB_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+    XWB_RCCL_SYM(CommDestroy, "ncclCommDestroy"); XWB_RCCL_SYM(CommCount, "ncclCommCount"); XWB_RCCL_SYM(CommUserRank, "ncclCommUserRank");
+    XWB_RCCL_SYM(GroupStart, "ncclGroupStart"); XWB_RCCL_SYM(GroupEnd, "ncclGroupEnd"); XWB_RCCL_SYM(Send, "ncclSend"); XWB_RCCL_SYM(Recv, "ncclRecv");
+    XWB_RCCL_SYM(AllGather, "ncclAllGather"); XWB_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef XWB_RCCL_SYM
+    if (!ok) r.handle = nullptr;
+    return &r;
+}
+
+int fail(int code, const std::string &msg) { return xwb_internal_fail(code, msg.c_str()); }
+
+#define RCCL_TRY(expr)                                                                                     \
+    do {                                                                                                   \
+        ncclResult_t _e = (expr);                                                                          \
+        if (_e != ncclSuccess) return fail(XWB_ERR_HIP, std::string(#expr) + ": " + R->GetErrorString(_e)); \
+    } while (0)
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess) return fail(XWB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
+};
+
+}  // namespace
+
+struct xwb_comm {
+    ncclComm_t comm = nullptr;
+    bool owned = false;                    // created by xwb_comm_init_rank (destroyed with the object)
+    int world = 1, rank = 0, device = 0;
+    hipStream_t stream = nullptr;          // the exchange runs here, beside the caller's stream
+    hipEvent_t ready = nullptr, done = nullptr;
+    int in_flight = 0;                     // begins since the last end (several shards may share one communicator)
+};
+
+extern "C" {
+
+int xwb_comm_version(int32_t *version) {
+    if (!version) return fail(XWB_ERR_ARG, "NULL argument");
+    Rccl *R = rccl();
+    if (!R->handle) return fail(XWB_ERR_STATE, R->error);
+    int v = 0;
+    RCCL_TRY(R->GetVersion(&v));
+    *version = v;
+    return XWB_OK;
+}
+
+int xwb_comm_unique_id(uint8_t out[XWB_COMM_ID_BYTES]) {
+    if (!out) return fail(XWB_ERR_ARG, "NULL argument");
+    Rccl *R = rccl();
+    if (!R->handle) return fail(XWB_ERR_STATE, R->error);
+    static_assert(sizeof(ncclUniqueId) == XWB_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    RCCL_TRY(R->GetUniqueId(&id));
+    memcpy(out, &id, sizeof id);
+    return XWB_OK;
+}
+
+static int finish_comm(xwb_comm *c) {
+    DeviceGuard g(c->device);
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    return XWB_OK;
+}
+
+int xwb_comm_init_rank(const uint8_t id_bytes[XWB_COMM_ID_BYTES], int32_t world, int32_t rank, int32_t device, xwb_comm **out) {
+    if (!id_bytes || !out) return fail(XWB_ERR_ARG, "NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(XWB_ERR_ARG, "need 0 <= rank < world");
+    Rccl *R = rccl();
+    if (!R->handle) return fail(XWB_ERR_STATE, R->error);
+    DeviceGuard g(device);
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof id);
+    xwb_comm *c = new xwb_comm();
+    c->world = world; c->rank = rank; c->device = device; c->owned = true;
+    ncclResult_t e = R->CommInitRank(&c->comm, world, id, rank);
+    if (e != ncclSuccess) { delete c; return fail(XWB_ERR_HIP, std::string("ncclCommInitRank: ") + R->GetErrorString(e)); }
+    const int rc = finish_comm(c);
+    if (rc) { xwb_comm_destroy(c); return rc; }
+    *out = c;
+    return XWB_OK;
+}
+
+int xwb_comm_adopt(void *nccl_comm, int32_t device, xwb_comm **out) {
+    if (!nccl_comm || !out) return fail(XWB_ERR_ARG, "NULL argument");
+    Rccl *R = rccl();
+    if (!R->handle) return fail(XWB_ERR_STATE, R->error);
+    xwb_comm *c = new xwb_comm();
+    c->comm = static_cast<ncclComm_t>(nccl_comm); c->device = device; c->owned = false;
+    ncclResult_t e = R->CommCount(c->comm, &c->world);
+    if (e == ncclSuccess) e = R->CommUserRank(c->comm, &c->rank);
+    if (e != ncclSuccess) { delete c; return fail(XWB_ERR_HIP, std::string("ncclCommCount / ncclCommUserRank: ") + R->GetErrorString(e)); }
+    const int rc = finish_comm(c);
+    if (rc) { xwb_comm_destroy(c); return rc; }
+    *out = c;
+    return XWB_OK;
+}
+
+int xwb_comm_destroy(xwb_comm *c) {
+    if (!c) return XWB_OK;
+    Rccl *R = rccl();
+    DeviceGuard g(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->owned && c->comm && R->handle) (void)R->CommDestroy(c->comm);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    if (c->done) (void)hipEventDestroy(c->done);
+    delete c;
+    return XWB_OK;
+}
+
+int xwb_comm_info(const xwb_comm *c, int32_t *world, int32_t *rank) {
+    if (!c) return fail(XWB_ERR_ARG, "NULL argument");
+    if (world) *world = c->world;
+    if (rank) *rank = c->rank;
+    return XWB_OK;
+}
+
+int xwb_comm_group_start(xwb_comm *c) {
+    if (!c) return fail(XWB_ERR_ARG, "NULL argument");
+    Rccl *R = rccl();
+    RCCL_TRY(R->GroupStart());
+    return XWB_OK;
+}
+
+int xwb_comm_group_end(xwb_comm *c) {
+    if (!c) return fail(XWB_ERR_ARG, "NULL argument");
+    Rccl *R = rccl();
+    RCCL_TRY(R->GroupEnd());
+    return XWB_OK;
+}
+
+// The layout of a gather: shard i holds counts[i] envs and lives on communicator rank peers[i] (NULL: rank i).
+static int check_layout(const xwb_comm *c, const int32_t *counts, const int32_t *peers, int32_t n_shards, int32_t shard) {
+    if (!c || !counts) return fail(XWB_ERR_ARG, "NULL argument");
+    if (n_shards < 1 || shard < 0 || shard >= n_shards) return fail(XWB_ERR_ARG, "need 0 <= shard < n_shards");
+    for (int i = 0; i < n_shards; ++i) {
+        if (counts[i] < 0) return fail(XWB_ERR_ARG, "negative shard size");
+        const int p = peers ? peers[i] : i;
+        if (p < 0 || p >= c->world) return fail(XWB_ERR_ARG, "a shard's peer is not a rank of the communicator");
+    }
+    return XWB_OK;
+}
+
+int xwb_gather_results(xwb_comm *c, const float *packed_dev, float *all_dev, const int32_t *counts, const int32_t *peers,
+                       int32_t n_shards, int32_t shard, void *stream) {
+    int rc = check_layout(c, counts, peers, n_shards, shard);
+    if (rc) return rc;
+    if (!packed_dev || !all_dev) return fail(XWB_ERR_ARG, "NULL argument");
+    Rccl *R = rccl();
+    DeviceGuard g(c->device);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    bool equal = !peers && n_shards == c->world;
+    for (int i = 1; i < n_shards; ++i) equal = equal && counts[i] == counts[0];
+    if (equal) {                                        // the plainest collective there is: 8 bytes per env
+        RCCL_TRY(R->AllGather(packed_dev, all_dev, (size_t)counts[0] * 2, ncclFloat32, c->comm, st));
+        return XWB_OK;
+    }
+    // ragged shards / several shards per rank: every holder sends its rows to every other holder's rank, one group
+    std::vector<size_t> off(n_shards + 1, 0);
+    for (int i = 0; i < n_shards; ++i) off[i + 1] = off[i] + (size_t)counts[i];
+    const int me = peers ? peers[shard] : shard;
+    HIP_TRY(hipMemcpyAsync(all_dev + off[shard] * 2, packed_dev, (size_t)counts[shard] * 8, hipMemcpyDeviceToDevice, st));
+    RCCL_TRY(R->GroupStart());
+    for (int i = 0; i < n_shards; ++i) {
+        const int p = peers ? peers[i] : i;
+        if (i == shard || p == me || counts[i] == 0) continue;
+        ncclResult_t e = R->Recv(all_dev + off[i] * 2, (size_t)counts[i] * 2, ncclFloat32, p, c->comm, st);
+        if (e == ncclSuccess && counts[shard] > 0) e = R->Send(packed_dev, (size_t)counts[shard] * 2, ncclFloat32, p, c->comm, st);
+        if (e != ncclSuccess) { (void)R->GroupEnd(); return fail(XWB_ERR_HIP, std::string("ncclSend / ncclRecv: ") + R->GetErrorString(e)); }
+    }
+    RCCL_TRY(R->GroupEnd());
+    return XWB_OK;
+}
+
+int xwb_gather_screens_begin(xwb_sim *sim, xwb_comm *c, void *dst_dev, const int32_t *counts, const int32_t *peers, int32_t n_shards,
+                             int32_t shard, int32_t root_shard, void *stream) {
+    int rc = check_layout(c, counts, peers, n_shards, shard);
+    if (rc) return rc;
+    if (!sim) return fail(XWB_ERR_ARG, "NULL argument");
+    if (root_shard < 0 || root_shard >= n_shards) return fail(XWB_ERR_ARG, "root_shard out of range");
+    void *obs = nullptr;
+    size_t bpe = 0;
+    int32_t n = 0;
+    if ((rc = xwb_obs_dev(sim, &obs, &bpe)) || (rc = xwb_num_envs(sim, &n))) return rc;
+    if (n != counts[shard]) return fail(XWB_ERR_ARG, "counts[shard] is not this batch's num_envs");
+    if (shard == root_shard && !dst_dev) return fail(XWB_ERR_ARG, "the root needs the destination tensor");
+    Rccl *R = rccl();
+    DeviceGuard g(c->device);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // the frames are complete in `stream` order; the transfer runs on the communicator's stream from there on
+    HIP_TRY(hipEventRecord(c->ready, st));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ready, 0));
+    std::vector<size_t> off(n_shards + 1, 0);
+    for (int i = 0; i < n_shards; ++i) off[i + 1] = off[i] + (size_t)counts[i] * bpe;
+    const int root_peer = peers ? peers[root_shard] : root_shard, me = peers ? peers[shard] : shard;
+    uint8_t *dst = static_cast<uint8_t *>(dst_dev);
+    if (shard == root_shard) {
+        if (dst + off[shard] != obs)                  // (bound into its slice with xwb_bind_obs: nothing to copy)
+            HIP_TRY(hipMemcpyAsync(dst + off[shard], obs, (size_t)n * bpe, hipMemcpyDeviceToDevice, c->stream));
+        RCCL_TRY(R->GroupStart());
+        for (int i = 0; i < n_shards; ++i) {
+            if (i == root_shard || counts[i] == 0) continue;
+            const int p = peers ? peers[i] : i;
+            ncclResult_t e = R->Recv(dst + off[i], (size_t)counts[i] * bpe, ncclUint8, p, c->comm, c->stream);
+            if (e != ncclSuccess) { (void)R->GroupEnd(); return fail(XWB_ERR_HIP, std::string("ncclRecv: ") + R->GetErrorString(e)); }
+        }
+        RCCL_TRY(R->GroupEnd());
+    } else if (n > 0) {
+        (void)me;
+        RCCL_TRY(R->Send(obs, (size_t)n * bpe, ncclUint8, root_peer, c->comm, c->stream));
+    }
+    c->in_flight += 1;          // (the completion event is recorded by xwb_gather_screens_end: inside a caller's group the
+    return XWB_OK;              //  operations above are only enqueued when the outermost group ends)
+}
+
+int xwb_gather_screens_end(xwb_comm *c, void *stream) {
+    if (!c) return fail(XWB_ERR_ARG, "NULL argument");
+    if (!c->in_flight) return XWB_OK;
+    DeviceGuard g(c->device);
+    HIP_TRY(hipEventRecord(c->done, c->stream));
+    HIP_TRY(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), c->done, 0));
+    c->in_flight = 0;
+    return XWB_OK;
+}
+
+}  // extern "C"

@@ -134,6 +134,17 @@ _SIGS = [
     ("xwb_profile_begin", C.c_int, [_vp]),
     ("xwb_profile_end", C.c_int, [_vp, _vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("xwb_profile_stop", C.c_int, [_vp]),
+    ("xwb_comm_version", C.c_int, [C.POINTER(C.c_int32)]),
+    ("xwb_comm_unique_id", C.c_int, [_vp]),
+    ("xwb_comm_init_rank", C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    ("xwb_comm_adopt", C.c_int, [_vp, C.c_int32, C.POINTER(_vp)]),
+    ("xwb_comm_destroy", C.c_int, [_vp]),
+    ("xwb_comm_info", C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("xwb_comm_group_start", C.c_int, [_vp]),
+    ("xwb_comm_group_end", C.c_int, [_vp]),
+    ("xwb_gather_results", C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32, _vp]),
+    ("xwb_gather_screens_begin", C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, _vp]),
+    ("xwb_gather_screens_end", C.c_int, [_vp, _vp]),
     ("xwb_last_error", C.c_char_p, []),
     ("xwb_version", C.c_char_p, []),
 ]

@@ -84,7 +84,35 @@ def _p2p_gather(local, out_root, counts, rank, dst, group):
                for r in range(world) if r != dst and counts[r] > 0]
     else:
         ops = [dist.P2POp(dist.isend, local, dst, group=group)] if counts[rank] > 0 else []
-    return _Ordered(dist.batch_isend_irecv(ops) if ops else [])
+    global _P2P_BROKEN
+    if not _P2P_BROKEN:
+        try:
+            return _Ordered(dist.batch_isend_irecv(ops) if ops else [])
+        except Exception as e:                              # pragma: no cover  (never seen; first contact with a new node)
+            # every rank runs the same code on the same backend: a refusal is expected to hit all of them alike
+            import warnings
+            warnings.warn("batched point-to-point failed (%s): screens travel by all_gather from now on" % e)
+            _P2P_BROKEN = True
+    return _allgather_fallback(local, out_root, counts, rank, dst, group)
+
+
+_P2P_BROKEN = False
+
+
+def _allgather_fallback(local, out_root, counts, rank, dst, group):
+    """Plan B for a backend that refuses batched send / recv: all_gather of equal (padded) slabs; only `dst` keeps them."""
+    world = len(counts)
+    m = max(counts)
+    pad = local if counts[rank] == m else torch.cat([local, local.new_zeros((m - counts[rank],) + tuple(local.shape[1:]))])
+    tmp = local.new_empty((world * m,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(tmp, pad.contiguous(), group=group)
+    if rank == dst:
+        off = 0
+        for r in range(world):
+            if r != dst and counts[r] > 0:
+                out_root[off:off + counts[r]].copy_(tmp[r * m:r * m + counts[r]])
+            off += counts[r]
+    return _Ordered([])
 
 
 class _Ordered:
@@ -259,3 +287,112 @@ class ScreensGather:
                 self.work[k] = None
         self.done_k = self.k
         return self.full[self.k] if self.rank == self.dst else None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The same two exchanges issued by libxwb.so itself (include/xwb.h "multi-GPU": xwb_comm_*, xwb_gather_*): RCCL directly,
+# below Python, so that C / C++ holders of a xwb_sim shard the same way.  torch.distributed is only used to hand the
+# communicator's unique id from rank 0 to the others.
+class LibComm:
+    """An RCCL communicator made through the library (ncclGetUniqueId on rank 0 -> broadcast -> ncclCommInitRank)."""
+
+    def __init__(self, rank, world, device, group=None):
+        import ctypes as C
+        from . import lib
+        self.L = lib.load()
+        self.rank, self.world, self.device = rank, world, device
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            lib.check(self.L.xwb_comm_unique_id(ident))
+        if world > 1:
+            on_gpu = dist.get_backend(group) == "nccl"
+            t = torch.tensor(list(ident), dtype=torch.uint8, device="cuda:%d" % device if on_gpu else "cpu")
+            dist.broadcast(t, 0, group=group)
+            ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+        h = C.c_void_p()
+        lib.check(self.L.xwb_comm_init_rank(ident, world, rank, device, C.byref(h)))
+        self.h = h
+        v = C.c_int32()
+        lib.check(self.L.xwb_comm_version(C.byref(v)))
+        self.version = v.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.xwb_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LibScreensGather:
+    """ScreensGather through xwb_gather_screens_begin / _end: same protocol (bind_next / start / latest / drain), same
+    double buffering; the transfers run on the communicator's own stream inside the library."""
+
+    def __init__(self, sim, comm, counts, rank, dst=0, depth=None):
+        import ctypes as C
+        from . import lib
+        self.C, self.lib = C, lib
+        self.sim, self.comm, self.counts, self.rank, self.dst = sim, comm, list(counts), rank, dst
+        self.depth = 2 if sim.cfg.context == 1 else 1
+        if depth is not None:
+            self.depth = int(depth)
+        shape = tuple(sim.obs.shape[1:])
+        dtype, device = sim.obs.dtype, sim.obs.device
+        n = counts[rank]
+        self.off = sum(counts[:rank])
+        if rank == dst:
+            self.full = [torch.zeros((sum(counts),) + shape, dtype=dtype, device=device) for _ in range(self.depth)]
+            self.local = [f[self.off:self.off + n] for f in self.full]
+        else:
+            self.full = [None] * self.depth
+            self.local = [torch.zeros((n,) + shape, dtype=dtype, device=device) for _ in range(self.depth)]
+        self.c_counts = (C.c_int32 * len(counts))(*counts)
+        self.busy = [False] * self.depth
+        self.k = self.depth - 1
+        self.done_k = None
+
+    def _end(self, k):
+        # (one communicator stream: ending the newest transfer also orders the older ones)
+        if self.busy[k]:
+            self.lib.check(self.comm.L.xwb_gather_screens_end(self.comm.h, None))
+            self.busy = [False] * self.depth
+            self.done_k = k
+
+    def bind_next(self):
+        self.k = (self.k + 1) % self.depth
+        self._end(self.k)
+        self.sim.bind_obs(self.local[self.k])
+
+    def start(self):
+        C = self.C
+        dst = self.full[self.k]
+        self.lib.check(self.comm.L.xwb_gather_screens_begin(self.sim.h, self.comm.h, C.c_void_p(dst.data_ptr()) if dst is not None else None,
+                                                            self.c_counts, None, len(self.counts), self.rank, self.dst, None))
+        self.busy[self.k] = True
+        if self.depth == 1:
+            self._end(self.k)
+
+    def latest(self):
+        k = self.k if self.depth == 1 else (self.k + 1) % self.depth
+        self._end(k)
+        return self.full[k] if (self.rank == self.dst and self.done_k is not None) else None
+
+    def drain(self):
+        for k in range(self.depth):
+            self._end(k)
+        self.done_k = self.k
+        return self.full[self.k] if self.rank == self.dst else None
+
+
+def lib_gather_results(comm, packed, out, counts, rank):
+    """xwb_gather_results: every shard's [n, 2] (reward, code) rows into out [total, 2] on every rank, on the current stream."""
+    import ctypes as C
+    from . import lib
+    c_counts = (C.c_int32 * len(counts))(*counts)
+    lib.check(comm.L.xwb_gather_results(comm.h, C.c_void_p(packed.data_ptr()), C.c_void_p(out.data_ptr()), c_counts, None,
+                                        len(counts), rank, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out
