@@ -199,6 +199,84 @@ def cpu_baseline(workload, seed, seconds_target=8.0):
                       "in %.1f s; one thread alone: %d env-steps in %.1f s" % (done, workload, cores, wall, n * steps, dt)}
 
 
+def c5_block(args, world, rank, local_rank, dev, K):
+    """BASELINE.json config C5 -- XWorld2D 11x11, 32 768 envs per GPU (262 144 over 8), "sharded 8 x MI355X with RCCL gather
+    of screens" -- as a sub-object of the N > 1 line: the same loop as the main measurement on the xworld11 workload, once
+    with the screens left device-resident (value) and once with every shard's screens gathered into one tensor on rank 0
+    (double-buffered), beside the xGMI link ceiling.  Fewer regions than the main line (3): it is a second measurement."""
+    import torch
+    import torch.distributed as dist
+    from xworld_amd import sharding
+    n_local = args.envs_per_gpu or WORKLOADS["xworld11"][2]
+    sim = make_sim("xworld11", n_local, local_rank, rank * n_local, args.seed)
+    counts = [n_local] * world
+    results = sharding.ResultGather(counts, rank, dev)
+    packed = torch.zeros((2, n_local, 2), dtype=torch.float32, device=dev)
+    sim.bind_results_ring(packed)
+    state = {"screens": None, "calls": 0}
+
+    def one_step():
+        if state["screens"] is not None:
+            state["screens"].bind_next()
+        state["calls"] += 1
+        sim.step()
+        results.finish()
+        results.start(packed=packed[(state["calls"] - 1) % 2])
+        sim.reset_done()
+        if state["screens"] is not None:
+            state["screens"].start()
+
+    def fence():
+        results.finish()
+        if state["screens"] is not None:
+            state["screens"].drain()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def region():
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            one_step()
+        fence()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    for _ in range(max(10, args.warmup)):
+        one_step()
+    t_end = time.perf_counter() + args.spin_seconds
+    while True:                                          # (every rank spins the same number of steps: the count is agreed on)
+        for _ in range(50):
+            one_step()
+        flag = torch.tensor([1 if time.perf_counter() < t_end else 0], device=dev)
+        dist.broadcast(flag, 0)
+        if not int(flag.item()):
+            break
+    dev_regions = [region() for _ in range(3)]
+    state["screens"] = sharding.ScreensGather(sim, counts, rank)
+    for _ in range(4):
+        one_step()
+    sg_regions = [region() for _ in range(3)]
+    fence()
+    state["screens"] = None
+    errs = sim.check_errors()
+    shard_bytes = n_local * sim.obs_bytes_per_env
+    link_s = shard_bytes / (XGMI_LINK_GBS * 1e9)
+    d_med, s_med = statistics.median(dev_regions), statistics.median(sg_regions)
+    out = {"workload": "xworld11", "config": "BASELINE C5: 11x11, 132x132x3 u8, %d envs per GPU, %d in all" % (n_local, n_local * world),
+           "value": n_local * world * K / d_med, "unit": "env-steps/s", "ms_per_step": d_med / K * 1e3,
+           "exchange": "all_gather(reward,done) per step, screens device-resident", "regions": 3, "steps_per_region": K,
+           "action_errors": errs,
+           "screens_gather": {"value": n_local * world * K / s_med, "ms_per_step": s_med / K * 1e3,
+                              "bytes_into_root_per_step": shard_bytes * (world - 1), "link_bound_ms_per_step": link_s * 1e3,
+                              "link_bound_ceiling": n_local * world / link_s, "link_GBps_assumed": XGMI_LINK_GBS,
+                              "achieved_GBps_per_link": shard_bytes / (s_med / K) / 1e9}}
+    sim.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,6 +295,9 @@ def main():
     ap.add_argument("--autoreset", action="store_true", help="use the fused step+reset+single-render call")
     ap.add_argument("--fused", type=int, default=1, help="simple games only: steps per launch (xwb_step_n); --steps must be "
                     "a multiple; every step still writes its reward / code / observation")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "lib"], help="N > 1 screens gather: torch.distributed "
+                    "point-to-point (default) or libxwb.so's own RCCL calls (xwb_gather_screens_begin / _end; backend nccl only)")
+    ap.add_argument("--c5", action="store_true", help="N > 1: add the BASELINE C5 block (xworld11); on by itself at N = 8")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo with every rank "
                     "on the visible GPUs modulo their count only exercises the N > 1 code path on a smaller box)")
     args = ap.parse_args()
@@ -354,7 +435,12 @@ def main():
     # ---- N > 1: the same loop with the screens of every shard gathered into one tensor on rank 0 ----
     sg_line = None
     if with_screens:
-        screens = sharding.ScreensGather(sim, counts, rank)
+        lib_comm = None
+        if args.exchange == "lib":
+            lib_comm = sharding.LibComm(rank, world, local_rank)
+            screens = sharding.LibScreensGather(sim, lib_comm, counts, rank)
+        else:
+            screens = sharding.ScreensGather(sim, counts, rank)
         for _ in range(2 * K):
             one_step()
         sg_regions = [timed_region() for _ in range(R)]
@@ -367,10 +453,19 @@ def main():
                    "link_bound_ms_per_step": link_s * 1e3, "link_bound_ceiling": n_local * world / link_s,
                    "link_GBps_assumed": XGMI_LINK_GBS, "achieved_GBps_per_link": shard_bytes / (sg_med / args.steps) / 1e9,
                    "overlap": "double-buffered: transfer of step t beside the kernels of step t+1" if screens.depth == 2 else "none (context ring)",
+                   "issued_by": "libxwb.so (xwb_gather_screens_begin/_end: ncclSend / ncclRecv on the communicator's stream)" if lib_comm else
+                                "torch.distributed batch_isend_irecv",
                    "regions_ms_per_step": {"min": min(sg_regions) / args.steps * 1e3, "max": max(sg_regions) / args.steps * 1e3}}
         screens = None                                   # (the batch keeps the buffer it is bound to alive)
     errs = sim.check_errors()
     assert errs == 0
+    # ---- N > 1: BASELINE C5 (xworld11, 8 x 32 768 envs, RCCL gather of screens) as a block of the same line ----
+    c5 = None
+    if world > 1 and (args.c5 or world == 8) and args.workload != "xworld11":
+        try:
+            c5 = c5_block(args, world, rank, local_rank, dev, K)
+        except Exception as e:                           # the main line must not die with its second measurement
+            c5 = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         total_envs = n_local * world
@@ -416,6 +511,11 @@ def main():
         }
         if sg_line is not None:
             line["screens_gather"] = sg_line
+        if c5 is not None:
+            line["c5"] = c5
+        if world > 1:
+            line["multi_gpu_note"] = ("value / screens_gather / c5 are this run's measurements; DESIGN.md carries no 8-GPU number of "
+                                      "its own until a SCALE record exists")
         if not args.no_parity:
             # the checker leg: nothing above this line touched the oracle
             line["parity"] = parity_gate(args.workload, rec[0], calls[0], slots, fused, 0, args.seed,

@@ -48,6 +48,7 @@ def test_two_shards_on_a_loopback_communicator(game, opts):
     allres = torch.full((total, 2), -9.0, device="cuda")
     for s, p in zip(shards, packed):
         s.bind_results(p)
+    prev_pending = None
     for t in range(40):
         k = t & 1
         shards[0].bind_obs(full[k][:counts[0]])
@@ -58,23 +59,29 @@ def test_two_shards_on_a_loopback_communicator(game, opts):
         # results: each shard hands its rows over (shards on one rank only copy: nothing crosses RCCL)
         for i, s in enumerate(shards):
             lib.check(L.xwb_gather_results(comm.h, C.c_void_p(packed[i].data_ptr()), C.c_void_p(allres.data_ptr()), c_counts, peers, 2, i, None))
-        # screens: root posts the receive, the other shard the send, one group
+        torch.cuda.synchronize()
+        assert torch.equal(allres[:, 0], whole.reward) and torch.equal(allres[:, 1], whole.game_over_codes.float()), t
+        for s in shards + [whole]:
+            s.reset_done()
+        # screens (the frames the next policy step sees): root posts the receive, the other shard the send, one group; the
+        # transfer runs on the communicator's stream, beside the next iteration's step (which renders into the other buffers)
         lib.check(L.xwb_comm_group_start(comm.h))
         lib.check(L.xwb_gather_screens_begin(shards[0].h, comm.h, C.c_void_p(full[k].data_ptr()), c_counts, peers, 2, 0, 0, None))
         lib.check(L.xwb_gather_screens_begin(shards[1].h, comm.h, None, c_counts, peers, 2, 1, 0, None))
         lib.check(L.xwb_comm_group_end(comm.h))
-        for s in shards + [whole]:
-            s.reset_done()                                    # runs beside the transfer (the frames on their way are the step's)
-        lib.check(L.xwb_gather_screens_end(comm.h, None))
-        torch.cuda.synchronize()
-        assert torch.equal(allres[:, 0], whole.reward) and torch.equal(allres[:, 1], whole.game_over_codes.float()), t
-        # the gathered tensor holds the frames of the STEP (terminal frames included); reset_done has since redrawn the reset
-        # envs of the root's own slice in place (it is bound into the destination), the other shard's slab is the step's
-        done = allres[:, 1] != 0
-        ref = whole.obs
-        alive = ~done
-        assert torch.equal(full[k][alive], ref[alive]), t
-        assert torch.equal(full[k][:counts[0]], ref[:counts[0]]), t
+        want = whole.obs.clone()
+        if t % 3 == 2:                                        # sometimes waited for at once, usually one step later
+            lib.check(L.xwb_gather_screens_end(comm.h, None))
+            torch.cuda.synchronize()
+            assert torch.equal(full[k], want), t
+            pending = None
+        else:
+            pending = (k, want)
+        if prev_pending is not None:                          # the transfer begun one iteration ago: its buffers come up next
+            lib.check(L.xwb_gather_screens_end(comm.h, None))
+            torch.cuda.synchronize()
+            assert torch.equal(full[prev_pending[0]], prev_pending[1]), t
+        prev_pending = pending
     # one shard per rank, equal shards: the all-gather path of a world of one
     one = (C.c_int32 * 1)(counts[0])
     out = torch.zeros((counts[0], 2), device="cuda")

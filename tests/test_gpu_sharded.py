@@ -113,7 +113,7 @@ def test_sharded_equals_unsharded(world, total, game, steps):
     assert sorted(res) == [(r, "ok") for r in range(world)], res
 
 
-@pytest.mark.parametrize("workload,extra", [("xworld7", []), ("simple_game", []), ("xworld7", ["--autoreset"])])
+@pytest.mark.parametrize("workload,extra", [("xworld7", []), ("simple_game", []), ("xworld7", ["--autoreset"]), ("xworld7", ["--c5"])])
 def test_bench_two_ranks_on_one_gpu(workload, extra):
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run), on one GPU over gloo: the line carries the
     device-resident value, the screens-gather figures, what the exchange ran on, and a clean parity gate."""
@@ -133,3 +133,10 @@ def test_bench_two_ranks_on_one_gpu(workload, extra):
     assert line["regions"]["repetitions"] == 3 and len(line["regions"]["ms_per_step_all"]) == 3
     assert line["parity"]["mismatches"] == 0 and line["parity"]["checked_env_steps"] > 0
     assert "cpu_baseline" not in line                     # rank 0 at N = 1 only
+    if "--c5" in extra:                                   # BASELINE C5 (xworld11) as a block of the same line
+        c5 = line["c5"]
+        assert "error" not in c5, c5
+        assert c5["workload"] == "xworld11" and c5["value"] > 0 and c5["action_errors"] == 0
+        assert c5["screens_gather"]["value"] > 0 and c5["screens_gather"]["link_bound_ceiling"] > 0
+    else:
+        assert "c5" not in line
