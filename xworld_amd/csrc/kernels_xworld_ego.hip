@@ -762,10 +762,13 @@ __global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uin
             const bool rowb = (w >> 29 & 1u) != 0, colb = (w >> 30 & 1u) != 0, goal = (w & 0x8000u) != 0;
             const bool row_dirty = rowb && ((wa | w) & 0x8000u), col_dirty = colb && ((wl | w) & 0x8000u);
             const uint32_t c = (w >> 16) & 0xffu, ca = rowb && !row_dirty ? (wa >> 16) & 0xffu : c, cl = colb && !col_dirty ? (wl >> 16) & 0xffu : c;
+            const uint32_t key = (((uint32_t)dir * nc + c) * nc + ca) * nc + cl;
             const uint32_t off = goal ? (((w & 0xfu) * (r * r) + ((w >> 4) & 0x3fu)) * 4 + dir) * entry16
-                                      : ((((uint32_t)dir * nc + c) * nc + ca) * nc + cl) * ch_n * (Q::PBP / 16) + f * (Q::CBP / 16);
+                                      : key * ch_n * (Q::PBP / 16) + f * (Q::CBP / 16);
+            // bits 30-31: the table entry is one flat colour (1: 255, 2: 0) -- the gather reads the shared constant line instead
+            const uint32_t flat = goal ? 0u : (uint32_t)p.ego_flat[key * (r * r) + f];
             src_e[f] = off | (goal ? 1u << 23 : 0u) | (row_dirty ? 1u << 24 : 0u) | (col_dirty ? 1u << 25 : 0u) | (rowb && colb ? 1u << 26 : 0u) |
-                       (term ? 1u << 27 : 0u) | ((uint32_t)fresh & 3u) << 28;
+                       (term ? 1u << 27 : 0u) | ((uint32_t)fresh & 3u) << 28 | flat << 30;
         }
     }
     // the cache bits of the goal cells, fetched together, then one list append per view cell across the wavefront
@@ -1033,6 +1036,7 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
     constexpr int cpf = (int)FB / BPC;
     constexpr int NL = 2 * (R - 1);
     static_assert(GB % 16 == 0 && U % 4 == 0, "aligned pieces");
+    static_assert(4 * Q::UP <= 128, "a unit fits the constant line");
     __shared__ uint4 s_out4[(GB + SB + GB) / 16];
     __shared__ uint32_t s_env[NE];                                          // a cell word of each env: its flags
     __shared__ const uint8_t *s_usrc[NU];
@@ -1057,8 +1061,11 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
             uint32_t w = p.ego_cellsrc[((size_t)e0 + le) * RR + fy * R + fx];
             if (skip_term && (w >> 27 & 1u)) w = 0;
             const bool cached = (w >> 23 & 1u) != 0;
+            const uint32_t flat = w >> 30;
             const uint8_t *base = cached ? p.ego_cache + ((size_t)e0 + le) * env_cache : p.ego_tab3;
-            s_usrc[ut] = base + (size_t)(w & 0x7fffffu) * 16 + ch * (cached ? (unsigned)Q::CBP : (unsigned)Q::PBP) + py0 * Q::UP;
+            const uint8_t *from = base + (size_t)(w & 0x7fffffu) * 16 + ch * (cached ? (unsigned)Q::CBP : (unsigned)Q::PBP) + py0 * Q::UP;
+            // a flat square: every unit of it is the same 4 * UP bytes -- one line shared by the whole batch (L1-resident)
+            s_usrc[ut] = flat ? p.ego_constline + (flat - 1u) * 128u : from;
             // what this lane places itself: bit 0 the first row (evaluated for this env), bit 1 the first dword of every row
             // (an evaluated border column), bit 2 the first dword of the first row (the crossing)
             const bool f_row = (w >> 24 & 1u) && py0 == 0, f_col = (w >> 25 & 1u) != 0, f_x = (w >> 26 & 1u) && py0 == 0 && !f_col;

@@ -135,7 +135,7 @@ struct xwb_sim {
     uint32_t *d_ego_cellinfo = nullptr;    // span path of the egocentric render (XwParams::ego_span)
     uint2 *d_ego_miss = nullptr;
     int32_t *d_ego_miss_count = nullptr;
-    uint8_t *d_ego_border = nullptr, *d_ego_cls = nullptr, *d_ego_tab3 = nullptr;
+    uint8_t *d_ego_border = nullptr, *d_ego_cls = nullptr, *d_ego_tab3 = nullptr, *d_ego_flat = nullptr, *d_ego_constline = nullptr;
     uint16_t *d_ego_cls_icon = nullptr;
     double *d_goal_warp = nullptr;
     int16_t *d_icon_name = nullptr, *d_name_first = nullptr, *d_name_variants = nullptr;
@@ -628,6 +628,30 @@ int xw_setup(xwb_sim *s) {
         HIP_TRY(launch_xw_ego_build_tab(p, nullptr));
         if (p.ego_cellinfo) HIP_TRY(launch_xw_ego_build_squares(p, nullptr));
         HIP_TRY(hipStreamSynchronize(nullptr));
+        if (p.ego_cellinfo) {
+            // which squares of the table are one flat colour (empty cells: 255; outside the map / shadow: 0): found by looking
+            // at the table itself, so the shortcut the gather takes for them (XwParams::ego_flat) cannot change a byte
+            const int r = c.visible_radius, U = 84 / r, UP = 4 * ((U / 4 + 3) & ~3), RR = r * r, nc = p.ego_ncls;
+            const size_t CBP = (size_t)U * UP, PBP = (size_t)RR * CBP, keys = (size_t)4 * nc * nc * nc;
+            std::vector<uint8_t> tab(xw_ego_square_tab_bytes(p)), flat(keys * RR, 0);
+            HIP_TRY(hipMemcpy(tab.data(), s->d_ego_tab3, tab.size(), hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < keys; ++k)
+                for (int f = 0; f < RR; ++f) {
+                    const uint8_t v0 = tab[k * p.channels * PBP + (size_t)f * CBP];
+                    bool same = v0 == 0 || v0 == 255;
+                    for (int chn = 0; chn < p.channels && same; ++chn)
+                        for (int y = 0; y < U && same; ++y) {
+                            const uint8_t *row = tab.data() + (k * p.channels + chn) * PBP + (size_t)f * CBP + (size_t)y * UP;
+                            for (int x = 0; x < U; ++x) if (row[x] != v0) { same = false; break; }
+                        }
+                    flat[k * RR + f] = same && !getenv("XWB_EGO_NO_FLAT") ? (v0 == 255 ? 1 : 2) : 0;      // (A/B hook)
+                }
+            if ((rc = dev_alloc(s, &s->d_ego_flat, flat.size()))) return rc;
+            HIP_TRY(hipMemcpy(s->d_ego_flat, flat.data(), flat.size(), hipMemcpyHostToDevice));
+            if ((rc = dev_alloc(s, &s->d_ego_constline, 256))) return rc;
+            HIP_TRY(hipMemset(s->d_ego_constline, 0xff, 128));
+            p.ego_flat = s->d_ego_flat; p.ego_constline = s->d_ego_constline;
+        }
     }
     return XWB_OK;
 }

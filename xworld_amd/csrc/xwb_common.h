@@ -230,6 +230,11 @@ struct XwParams {
     const uint16_t *ego_cls_icon;
     int ego_ncls;
     const uint8_t *ego_tab3;     // [heading][class c][class a][class l][channel][square] squares (kernels_xworld_ego.hip, EgoSq)
+    const uint8_t *ego_flat;     // [heading][c][a][l][square]: that entry of ego_tab3 is one flat colour: 1 = 255 (empty cells), 2 = 0 (outside
+                                 //     the map, shadow); found by scanning the table once.  The gather reads such squares from ONE shared
+                                 //     128-byte line (ego_constline: 128 x 0xff, 128 x 0x00), which stays in every CU's L1 -- two thirds of a
+                                 //     frame's squares, whose table lines otherwise each miss to L2 (the gather was bound by L1 miss handling)
+    const uint8_t *ego_constline;
     uint32_t *ego_cellsrc;       // [n][r * r] per square: where the gather finds its pixels (xw_ego_cells_kernel has the bit layout)
     uint2 *ego_miss;             // goal cells the cache does not hold yet: (env, view cell | slot << 8 | heading << 16)
     int32_t *ego_miss_count;
