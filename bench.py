@@ -292,6 +292,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--parity-envs", type=int, default=4096, help="envs whose whole per-step record is checked against the oracle "
                     "(a slab of the batch, not all of it: `parity.envs` of `config.envs_per_gpu`)")
+    ap.add_argument("--frame-envs", type=int, default=64, help="envs whose frames are checked against the oracle's renderer ...")
+    ap.add_argument("--frame-steps", type=int, default=24, help="... over this many steps from reset (untimed, before the warm-up)")
     ap.add_argument("--autoreset", action="store_true", help="use the fused step+reset+single-render call")
     ap.add_argument("--fused", type=int, default=1, help="simple games only: steps per launch (xwb_step_n); --steps must be "
                     "a multiple; every step still writes its reward / code / observation")
@@ -384,6 +386,24 @@ def main():
     probe = torch.zeros((2, n_local, 2), dtype=torch.float32, device=dev)
     sim.bind_results_ring(probe)
     rec[0] = probe
+    # ---- frame gate (untimed, before anything else runs): the frame every policy step sees, for a slab of rank 0's envs over
+    # the first steps, against the oracle's own renderer (position-weighted checksums, oracle/oracle.h orc_obs_checksum) ----
+    frames = None
+    if not args.no_parity and fused == 1 and not (is_xworld and sim.obs_is_float):      # (float32 frames: the oracle renders uint8)
+        import numpy as np
+        fe, fs = min(args.frame_envs, n_local), args.frame_steps
+        got = []
+        for _ in range(fs):
+            fence()
+            got.append(sim.obs[:fe].contiguous().view(torch.uint8).reshape(fe, -1).cpu().numpy() if rank == 0 else None)
+            one_step()
+        fence()
+        if rank == 0:
+            ref = oracle_rollout(args.workload, fe, fs, 0, args.seed, render=True)
+            O = _oracle()
+            bad = sum(int(np.count_nonzero(O.obs_checksum_np(got[t]) != ref.obs_ck[t])) for t in range(fs))
+            frames = {"checked_frames": fe * fs, "mismatches": bad, "envs": fe, "steps": fs,
+                      "against": "oracle/liboracle.so renderer (64 px canvas + cv::resize restatement), checksum of every byte of the frame"}
     for _ in range(3):
         one_step()
     fence()
@@ -520,6 +540,8 @@ def main():
             # the checker leg: nothing above this line touched the oracle
             line["parity"] = parity_gate(args.workload, rec[0], calls[0], slots, fused, 0, args.seed,
                                          min(args.parity_envs, n_local), probe_calls)
+            if frames is not None:
+                line["parity"]["frames"] = frames
         if not args.no_cpu_baseline and world == 1:          # rank 0, N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.workload, args.seed)
         print(json.dumps(line))

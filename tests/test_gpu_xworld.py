@@ -177,19 +177,58 @@ def test_tile_table_every_icon(oracle, color):
     sim.close()
 
 
+class _OracleSample:
+    """A scattered sample of a full-size batch's envs run by the oracle in lock step (its own 64 px canvas + cv::resize
+    restatement, no tile table): the full-size frames are compared with ORACLE PIXELS, not only through the
+    obs == tile_table[grid] property."""
+
+    def __init__(self, oracle, pal, cfg, ids, gid0=0):
+        self.ids = list(ids)
+        self.gid0 = gid0
+        self.envs = [oracle.XWorld(pal, render=True, **cfg) for _ in self.ids]
+        self.ep = [0] * len(self.ids)
+        for w, e in zip(self.envs, self.ids):
+            w.reset_game(gid0 + e, 0)
+
+    def check_frames(self, sim, where):
+        import torch
+        obs = sim.obs[torch.tensor(self.ids, device="cuda")].cpu().numpy()
+        for k, w in enumerate(self.envs):
+            exp = w.state_screen()
+            assert np.array_equal(obs[k], exp), (where, self.ids[k], int((obs[k] != exp).sum()))
+
+    def reset_done(self):
+        for k, w in enumerate(self.envs):
+            if w.game_over():
+                self.ep[k] += 1
+                w.reset_game(self.gid0 + self.ids[k], self.ep[k])
+
+    def step(self, sim):
+        acts = sim.actions.cpu().numpy()
+        rew = sim.reward.cpu().numpy()
+        for k, w in enumerate(self.envs):
+            assert np.float32(w.take_actions(int(acts[self.ids[k]]))) == rew[self.ids[k]], self.ids[k]
+
+
 def test_full_size_c4(oracle):
-    """BASELINE config C4: 32 768 envs, 7x7, 84x84x3.  Rewards / codes vs the oracle batch driver;
-    screens through the size-independent property obs == tile_table[grid] (table checked above)."""
+    """BASELINE config C4: 32 768 envs, 7x7, 84x84x3.  Rewards / codes of every env vs the oracle batch driver; screens of
+    every env through the size-independent property obs == tile_table[grid] (table checked above), and of a scattered
+    sample of 320 envs against the oracle's own pixels at every step (terminal frames and first frames included)."""
     torch = _torch()
     n, steps = 32768, 24
     sim, pal, cfg = _make(oracle, "nav7", n, seed=5, policy_seed=6, color=True)
     ref = oracle.xw_rollout(n, oracle.xw_cfg(**cfg), pal, steps, policy_seed=6)
+    sample = _OracleSample(oracle, pal, cfg, list(range(7, n, 103))[:320])
     table = torch.from_numpy(sim.tile_table()).cuda()
     full = torch.cat([torch.full_like(table[:1], 255), table])          # index 0 = empty cell
     D = 7
     for t in range(steps):
         sim.reset_done()
+        sample.reset_done()
+        sample.check_frames(sim, ("after reset_done", t))
         sim.step()
+        sample.step(sim)
+        sample.check_frames(sim, ("after step", t))
         assert np.array_equal(sim.reward.cpu().numpy().view(np.uint32), ref.rewards[t].view(np.uint32)), t
         assert np.array_equal(sim.game_over_codes.cpu().numpy(), ref.codes[t]), t
         if t % 8 == 0 or t == steps - 1:
@@ -215,11 +254,15 @@ def test_full_size_c5_shard(oracle):
     pal = oracle.Palette(oracle.NAV_SUBTREES)
     cfg = dict(map_kind=0, max_dim=D, dim=D, num_goals=4, num_blocks=30, color=1, seed=0xC0FFEE, tasks=[0, 1, 2, 3, 4])
     ref = oracle.xw_rollout(n, oracle.xw_cfg(**cfg), pal, steps, policy_seed=0x5EED, env_gid0=gid0)
+    sample = _OracleSample(oracle, pal, cfg, list(range(3, n, 257))[:96], gid0)      # oracle pixels for a scattered sample
     table = torch.from_numpy(sim.tile_table()).cuda()
     full = torch.cat([torch.full_like(table[:1], 255), table])          # index 0 = empty cell
     for t in range(steps):
         sim.reset_done()
+        sample.reset_done()
         sim.step()
+        sample.step(sim)
+        sample.check_frames(sim, ("after step", t))
         assert np.array_equal(sim.reward.cpu().numpy().view(np.uint32), ref.rewards[t].view(np.uint32)), t
         assert np.array_equal(sim.game_over_codes.cpu().numpy(), ref.codes[t]), t
         if t % 5 == 0 or t == steps - 1:
