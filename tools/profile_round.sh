@@ -1,0 +1,17 @@
+#!/bin/bash
+# On the GPU box (via gpurun): the round's evidence for profiles/ -- per workload a plain bench line, the rocprofv3 kernel-trace
+# summary of the same command and the calibrated HBM traffic of its dominant kernel (tools/profile_gpu.sh).
+# Usage: GIT_HEAD=$(git rev-parse HEAD) tools/profile_round.sh <round tag> <workload>...   -> gpurun_out/profiles_<tag>/
+set -u
+TAG=${1:-r3}; shift
+OUT=$PWD/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+for W in "$@"; do
+  python bench.py --workload $W > $OUT/bench_$W.json 2> $OUT/bench_$W.err || true
+  bash tools/profile_gpu.sh $W --workload $W > /dev/null 2>&1
+  cp gpurun_out/prof_$W/summary.txt $OUT/${W}_rocprof_summary.txt 2>/dev/null
+  cp gpurun_out/prof_$W/traffic.json $OUT/traffic_$W.json 2>/dev/null
+  tail -c 300 $OUT/bench_$W.json | head -c 300; echo
+done
+python bench.py --workload xworld7 --autoreset --no-cpu-baseline > $OUT/bench_xworld7_autoreset.json 2>/dev/null || true
+ls -la $OUT
