@@ -152,7 +152,12 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
     __shared__ uint8_t s_icon_type[4096];                  // xw_setup: n_icons <= 4000
     const int e = blockIdx.x * 256 + threadIdx.x;
     int32_t *count_now = p.done_count;
-    if (e == 0) *p.done_count_next = 0;        // double-buffered done counter: zero the next step's
+    if (e == 0) {
+        // (pre-generated episodes: the regeneration of the previous step's list may still be reading that list and its count --
+        // the counter zeroed here is the one it read, two steps back in the rotation)
+        if (p.swap_shadow) xw_wait_epoch_lane(p.sync + 8, p.regen_wait, p.sync + 4, p.poison_host);
+        *p.done_count_next = 0;                // double-buffered done counter: zero the next step's
+    }
     bool is_done = false, idle3d = false;
     if (e == 0 && p.idle_count_next) *p.idle_count_next = 0;
     int ld_axy = 0, ld_steps = 0, ld_ts = 0, ld_tsteps = 0, ld_dir = 1, ld_level = 0, ld_ts2 = 0, ld_tsteps2 = 0;
@@ -289,11 +294,48 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
             is_done = code != ALIVE;
         }
     }
+    if (p.swap_shadow) {
+        // xwb_step_autoreset with pre-generated episodes: a finished env starts its next episode here -- its shadow state (the
+        // reset kernel's output for episode + 1, made beside an earlier render) is copied over the live state; reward and code
+        // keep the terminal transition's values, the render that follows draws the new episode's first frame.  The list
+        // (appended below) is what the side queue regenerates next; it and the shadows of envs that finish again are only
+        // touched once the previous regeneration is through.
+        const unsigned long long m = __ballot(is_done);
+        if (m) {
+            const int lane = threadIdx.x & 63, cells = p.max_dim * p.max_dim;
+            if (lane == __ffsll((long long)m) - 1) xw_wait_epoch_lane(p.sync + 8, p.regen_wait, p.sync + 4, p.poison_host);
+            __builtin_amdgcn_wave_barrier();
+            if (is_done) {
+                p.agent_xy[e] = p.sh_agent_xy[e];
+                p.task_state[e] = p.sh_task_state[e];
+                p.task_steps[e] = 0;
+                if (p.n_tasks2 > 0) { p.task_state2[e] = p.sh_task_state2[e]; p.task_steps2[e] = 0; }
+                p.sent_names[e] = p.sh_sent_names[e];
+                p.cand2d[e] = p.sh_cand2d[e];
+                reinterpret_cast<uint4 *>(p.goal_cells)[e] = reinterpret_cast<const uint4 *>(p.sh_goal_cells)[e];
+                p.num_steps[e] = 0;
+                p.episode[e] = p.episode[e] + 1;
+                p.fresh[e] = 2;                         // init_screen: the older context frames start black
+                p.sh_valid[e] = 0;
+                atomicAdd(p.perf + 36, 1ull);           // games reset
+            }
+            __threadfence();                            // the agent's move was stored by one lane; the copy below overwrites it
+            unsigned long long mm = m;
+            while (mm) {
+                const int j = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                const int ej = __shfl(e, j);
+                const uint16_t *src = p.sh_grid + (size_t)ej * cells;
+                uint16_t *g = p.grid + (size_t)ej * cells;
+                for (int c = lane; c < cells; c += 64) g[c] = src[c];
+            }
+        }
+    }
     wave_append(is_done, e, p.done_list, count_now);
     if (p.idle_list) wave_append(idle3d, e, p.idle_list, p.idle_count);
     // "this step finished the env": stays put until the next step, whatever a reset_done does to the done codes meanwhile
     if (e < p.n) p.term_flag[e] = is_done ? 1 : 0;
-    if (!p.visible_radius) {
+    if (!p.visible_radius && !p.swap_shadow) {
         // terminal snapshot: the frame of a finished env is rendered from this copy, which lets xwb_reset_done rebuild
         // the live grid on the side stream while the big render is still running.  The wavefront copies the grids of
         // its finished envs together (consecutive lanes = consecutive cells).

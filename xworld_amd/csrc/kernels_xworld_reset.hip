@@ -516,7 +516,7 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
     const int MD = p.max_dim, D = level_dim, off = (MD - D) / 2;
     RP_T0();
     const uint32_t ep = p.episode[e] + 1;
-    p.episode[e] = ep;
+    if (!p.shadow) p.episode[e] = ep;                     // (shadow: the episode after the live one, which keeps its counter)
     Stream s;
     s.init(p.seed, p.env_gid0 + (uint32_t)e, ep, 0);
     s.pre = (Stream::lds_block_ptr)pre_draws; s.npre = n_pre_draws;
@@ -780,12 +780,17 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
 
     p.agent_xy[e] = (agent_cell % D + off) | ((agent_cell / D + off) << 16);
     p.task_state[e] = pack_task(tfv[0], st0v[0], EV_NONE, kind);
-    if (GM == 2) { p.task_state2[e] = pack_task(tfv[1], st0v[1], EV_NONE, kindv[1]); p.task_steps2[e] = 0; }
+    if (GM == 2) { p.task_state2[e] = pack_task(tfv[1], st0v[1], EV_NONE, kindv[1]); if (!p.shadow) p.task_steps2[e] = 0; }
     p.sent_names[e] = (uint32_t)sent_a | ((uint32_t)sent_b << 16);
+    if (p.shadow) {                                       // a pre-generated episode: the step kernel starts it (xw_step_kernel)
+        p.sh_valid[e] = 1;
+        return;
+    }
     p.task_steps[e] = 0;
     p.num_steps[e] = 0;
     p.fresh[e] = 2;                                       // render: init_screen (zero the older context frames)
     atomicAdd(p.perf + 36, 1ull);                         // games reset
+    if (p.sh_valid) p.sh_valid[e] = 0;                    // whatever was pre-generated for this env is a past episode now
     if (!keep_done) p.done[e] = (uint8_t)done_code(p, 0, EV_NONE);
     RP_T(4);
 }

@@ -97,6 +97,23 @@ __device__ __forceinline__ void xw_wait_epoch(const uint32_t *epoch_slot, uint32
     __syncthreads();
 }
 
+// the same wait for ONE lane inside a running kernel (no barrier): the other lanes of its wavefront wait with it
+__device__ __forceinline__ void xw_wait_epoch_lane(const uint32_t *epoch_slot, uint32_t want, uint32_t *poison, uint32_t *poison_host) {
+    if ((int32_t)(__hip_atomic_load(epoch_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0 &&
+        __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        const unsigned long long t0 = wall_clock64();
+        while ((int32_t)(__hip_atomic_load(epoch_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > XW_WATCHDOG_TICKS) {
+                atomicExch(poison, 1u);
+                if (poison_host) __hip_atomic_store(poison_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+
 __device__ __forceinline__ int done_code(const XwParams &p, int num_steps, int event) {
     // AgentSpecificSimulator::game_over = GameSimulator::game_over | XWorldSimulator::game_over
     int code = (p.max_steps > 0 && num_steps >= p.max_steps) ? MAX_STEP : ALIVE;

@@ -114,6 +114,13 @@ struct xwb_sim {
     uint8_t *d_grp_order = nullptr;        // exclusive group scheduling (XwParams::grp_order)
     int32_t *d_idle_list = nullptr, *d_idle_count = nullptr;
     unsigned long long *d_perf = nullptr;  // XwParams::perf
+    // pre-generated next episodes (XwParams::shadow / swap_shadow): xwb_step_autoreset's fast path
+    bool pregen = false, shadow_ok = false, regen_pending = false, regen_by_epoch = false;
+    uint32_t epoch_regen = 0;
+    uint8_t *d_sh_valid = nullptr, *d_sh_goal_cells = nullptr;
+    uint16_t *d_sh_grid = nullptr;
+    int32_t *d_sh_agent = nullptr, *d_sh_task_state = nullptr, *d_sh_task_state2 = nullptr;
+    uint32_t *d_sh_sent_names = nullptr, *d_sh_cand2d = nullptr;
     int32_t *d_agent = nullptr, *d_task_steps = nullptr, *d_task_state = nullptr, *d_done_list = nullptr,
             *d_done_count = nullptr;
     uint8_t *d_fresh = nullptr, *d_icon_type = nullptr, *d_icon_colored = nullptr, *d_goal_cells = nullptr;
@@ -326,6 +333,8 @@ void build_tile_table(const uint8_t *icons64, int n_icons, int channels, uint8_t
 
 namespace {
 
+bool curriculum_cfg(const xwb_config &c) { return c.curriculum != 0 && c.map_kind == XWB_MAP_NAV; }
+
 int xw_setup(xwb_sim *s) {
     const xwb_config &c = s->cfg;
     if (c.max_dim < 1 || c.max_dim > XW_MAX_DIM || c.dim < 1 || c.dim > c.max_dim)
@@ -439,6 +448,21 @@ int xw_setup(xwb_sim *s) {
         if ((rc = dev_alloc(s, &s->d_idle_count, 2))) return rc;
     }
     if ((rc = dev_alloc(s, &s->d_perf, 40))) return rc;
+    // Pre-generated next episodes: possible where an env's next episode is a pure function of (seed, global id, episode + 1)
+    // and the render reads nothing but the grid -- full observation, no curriculum (the level depends on the results so far),
+    // no per-env reference engine (its state depends on the draws so far), no exclusive group order carried across resets.
+    s->pregen = c.visible_radius == 0 && !curriculum_cfg(c) && c.rng_mode != XWB_RNG_MINSTD && !(exclusive && c.n_tasks2 > 0) &&
+                !getenv("XWB_NO_PREGEN");
+    if (s->pregen) {
+        if ((rc = dev_alloc(s, &s->d_sh_valid, n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_sh_grid, (size_t)n * cells))) return rc;
+        if ((rc = dev_alloc(s, &s->d_sh_agent, n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_sh_task_state, n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_sh_task_state2, n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_sh_sent_names, n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_sh_cand2d, n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_sh_goal_cells, (size_t)n * XW_MAX_GOALS))) return rc;
+    }
     if ((rc = dev_alloc(s, &s->d_done_list, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_done_count, 2))) return rc;
     if ((rc = dev_alloc(s, &s->d_fresh, n))) return rc;
@@ -456,7 +480,7 @@ int xw_setup(xwb_sim *s) {
         if ((rc = dev_alloc(s, &s->d_cur_counter, n))) return rc;
         if ((rc = dev_alloc(s, &s->d_cur_usage, (size_t)n * 9 * XW_USAGE_BYTES))) return rc;
     }
-    if ((rc = dev_alloc(s, &s->d_sync, 8))) return rc;
+    if ((rc = dev_alloc(s, &s->d_sync, 16))) return rc;
     if ((rc = dev_alloc(s, &s->d_term_grid, (size_t)n * cells))) return rc;
     if ((rc = dev_alloc(s, &s->d_term_flag, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_agent_dir, n, 1))) return rc;                 // heading "down": yaw 1.5707963
@@ -552,6 +576,9 @@ int xw_setup(xwb_sim *s) {
     for (int i = 0; i < 8; ++i) p.task_acc2[i] = (i ? p.task_acc2[i - 1] : 0.0) + (i < c.n_tasks2 && p.task_weighted2 ? c.task_weights2[i] : 0.0);
     p.task_state2 = s->d_task_state2; p.task_steps2 = s->d_task_steps2;
     p.perf = s->d_perf;
+    p.shadow = 0; p.swap_shadow = 0; p.regen_wait = 0; p.sh_valid = s->d_sh_valid;
+    p.sh_grid = s->d_sh_grid; p.sh_agent_xy = s->d_sh_agent; p.sh_task_state = s->d_sh_task_state; p.sh_task_state2 = s->d_sh_task_state2;
+    p.sh_sent_names = s->d_sh_sent_names; p.sh_cand2d = s->d_sh_cand2d; p.sh_goal_cells = s->d_sh_goal_cells;
     p.exclusive = exclusive ? 1 : 0;
     p.group_weight[0] = c.task_group_weight; p.group_weight[1] = c.task_group_weight2;
     p.grp_order = s->d_grp_order; p.idle_list = s->d_idle_list; p.idle_count = s->d_idle_count; p.idle_count_next = nullptr;
@@ -742,12 +769,33 @@ XwParams xw_params(xwb_sim *s) {
     return p;
 }
 
+// the reset kernel's parameters for a pre-generation pass: episode[e] + 1 of the listed envs into the shadow arrays
+XwParams shadow_params(xwb_sim *s) {
+    XwParams q = xw_params(s);
+    q.shadow = 1; q.auto_reset = 1; q.sig_epoch = 0; q.wait_epoch = 0; q.packed = nullptr;
+    q.grid = s->d_sh_grid; q.agent_xy = s->d_sh_agent; q.task_state = s->d_sh_task_state; q.task_state2 = s->d_sh_task_state2;
+    q.sent_names = s->d_sh_sent_names; q.cand2d = s->d_sh_cand2d; q.goal_cells = s->d_sh_goal_cells;
+    return q;
+}
+
+// A regeneration pass of xwb_step_autoreset may still be reading the done list and the episode counters on the side queue:
+// every other verb that touches them orders `st` behind it first (the next xwb_step_autoreset waits inside its step kernel).
+int join_regen(xwb_sim *s, hipStream_t st) {
+    if (!s->regen_pending) return XWB_OK;
+    if (s->regen_by_epoch) HIP_TRY(launch_xw_wait(s->d_sync + 8, s->epoch_regen, s->d_sync + 4, s->xw.poison_host, st));
+    else HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
+    s->regen_pending = false;
+    return XWB_OK;
+}
+
 // xworld: reset the compacted list (or all), then re-render those envs.
 // `beside_render`: the list comes from the step kernel that was just launched on `st` followed by render_all;
 // the (latency-bound, two-wavefront) reset kernel then runs on the side stream as soon as the step kernel is
 // done, i.e. *beside* render_all.  render_all may read grid rows of finished envs while they are being
 // regenerated; those envs' frames are rewritten in full by render(list) below, which waits for both.
 int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t st, bool beside_render = false) {
+    { const int rcj = join_regen(s, st); if (rcj) return rcj; }
+    s->shadow_ok = false;                  // the episodes these envs start now are the ones their shadows held
     XwParams p = xw_params(s);
     // 0: the reset kernel clears the done codes; 1: they are kept (step_autoreset); 2: the reset runs on the side stream
     // beside work already queued on `st` that may still read this step's codes -> the list render, which is ordered
@@ -835,9 +883,26 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         // hand-over mode of this call (probes `st` the first time it is seen: synchronises it once)
         const bool epochs = use_epochs(s, st);
         s->step_epochs = epochs;
+        // xwb_step_autoreset with pre-generated episodes (XwParams::swap_shadow): the step kernel starts the next episode of
+        // the envs it finishes, ONE render draws every env, the side queue regenerates the consumed shadows beside it
+        const bool pregen = autoreset && s->pregen;
+        if (pregen) {
+            if (!s->shadow_ok) {               // first use, or another verb reset envs since: make every env's next episode
+                { const int rcj = join_regen(s, st); if (rcj) return rcj; }
+                HIP_TRY(launch_xw_reset(shadow_params(s), MODE_RESET_ALL, st));
+                s->shadow_ok = true;
+            } else if (s->regen_pending && !s->regen_by_epoch) {
+                HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));      // (events: the step kernel cannot wait for itself)
+                s->regen_pending = false;
+            }
+        } else {
+            const int rcj = join_regen(s, st);
+            if (rcj) return rcj;
+        }
         s->count_sel ^= 1;                     // this step appends to the counter the previous one zeroed
         XwParams p = xw_params(s);
         p.actions = actions_dev; p.act_rep = act_rep;
+        if (pregen) { p.swap_shadow = 1; p.regen_wait = s->regen_pending ? s->epoch_regen : 0; }
         if (++s->epoch_step == 0) s->epoch_step = 1;
         p.sig_epoch = epochs ? s->epoch_step : 0;   // published by the render kernel queued behind the step kernel
         timer_begin(s, s->t_step, st);
@@ -849,7 +914,26 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         XwParams pr = xw_params(s);
         pr.sig_epoch = 0;
         const bool span = xw_ego_span(p);
-        if (autoreset) {
+        if (pregen) {
+            if (!epochs) { p.sig_epoch = 0; HIP_TRY(hipEventRecord(s->ev_step, st)); }
+            timer_begin(s, s->t_render, st);
+            HIP_TRY(launch_xw_render(p, 0, st));                     // every env from its live grid; publishes the step epoch
+            timer_end(s, s->t_render, st);
+            XwParams q = shadow_params(s);
+            if (epochs) HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->d_sync + 4, p.poison_host, s->side));
+            else HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
+            timer_begin(s, s->t_reset, s->side);
+            HIP_TRY(launch_xw_reset(q, MODE_RESET_DONE, s->side));
+            timer_end(s, s->t_reset, s->side);
+            if (epochs) {
+                if (++s->epoch_regen == 0) s->epoch_regen = 1;
+                HIP_TRY(launch_xw_signal(s->d_sync + 8, s->epoch_regen, s->side));
+            } else {
+                HIP_TRY(hipEventRecord(s->ev_reset, s->side));
+            }
+            s->regen_pending = true; s->regen_by_epoch = epochs;
+            s->list_valid = false;
+        } else if (autoreset) {
             // Finished envs: reset + first frame of the new episode on the side stream, beside the render of everyone else;
             // their terminal frames are not materialised.
             // Epochs (full observation, and the egocentric span path, whose cells kernel publishes the step epoch): the side
@@ -1102,6 +1186,7 @@ int xwb_reset_done(xwb_sim *s, void *stream) {
     }
     if (s->cfg.game != XWB_XWORLD2D) return simple_reset(s, MODE_RESET_DONE, nullptr, st);
     if (!s->list_valid) {                      // no step since the last reset: rebuild the list from done[]
+        { const int rcj = join_regen(s, st); if (rcj) return rcj; }
         XwParams p = xw_params(s);
         HIP_TRY(hipMemsetAsync(p.done_count, 0, sizeof(int32_t), st));
         HIP_TRY(launch_xw_compact(p, MODE_RESET_DONE, st));
@@ -1117,6 +1202,7 @@ int xwb_reset_masked(xwb_sim *s, const uint8_t *mask_dev, void *stream) {
     XWB_LIVE(s);
     hipStream_t st = as_stream(stream);
     if (s->cfg.game != XWB_XWORLD2D) return simple_reset(s, MODE_RESET_MASK, mask_dev, st);
+    { const int rcj = join_regen(s, st); if (rcj) return rcj; }
     XwParams p = xw_params(s);
     p.mask = mask_dev;
     HIP_TRY(hipMemsetAsync(p.done_count, 0, sizeof(int32_t), st));
@@ -1476,6 +1562,7 @@ int xwb_xw_load_map_task(xwb_sim *s, int32_t env, const uint16_t *grid_host, int
     const int D = s->cfg.max_dim;
     if (agent_x < 0 || agent_y < 0 || agent_x >= D || agent_y >= D) return fail(XWB_ERR_ARG, "agent outside the map");
     HIP_TRY(hipDeviceSynchronize());
+    s->shadow_ok = false; s->regen_pending = false;
     const size_t cells = (size_t)D * D;
     int32_t axy = agent_x | (agent_y << 16);
     const bool is2d = task >= XWB_TASK2D_TARGET;
@@ -1768,6 +1855,7 @@ int xwb_load_state(xwb_sim *s, const uint8_t *in_host, size_t bytes) {
         HIP_TRY(hipMemcpy(a.ptr, r, a.bytes, hipMemcpyHostToDevice));
         r += b;
     }
+    s->shadow_ok = false; s->regen_pending = false;
     s->policy_step = h.policy_step; s->count_sel = (int)(h.count_sel & 1u); s->list_valid = (h.list_valid & 1u) != 0; s->autoreset_done = (h.list_valid & 2u) != 0;
     if (s->cfg.game == XWB_XWORLD2D) {
         XwParams p = xw_params(s);

@@ -262,6 +262,20 @@ struct XwParams {
     // batch since it was created: perf[task class][0..3] = successes, failures, success_steps, time-ups (a subset of the
     // failures); perf[36] = games reset.  Bumped with atomics by the few lanes that record a result (~0.3 % of a step's envs).
     unsigned long long *perf;
+    // Pre-generated next episodes (xwb_step_autoreset, full observation, no curriculum / minstd / exclusive scheduling: the next
+    // episode of an env is then a pure function of (seed, global env id, episode + 1)): the reset kernel run with `shadow` set
+    // writes episode[e] + 1 of the listed envs into the sh_* arrays (the host swaps them in for grid, agent_xy, ...; live
+    // counters and flags are left alone) and raises sh_valid[e]; the step kernel with `swap_shadow` set starts a finished env's
+    // next episode itself by copying its shadow over the live state -- the reset and its first-frame render leave the
+    // critical path, the step's one render draws every env.  Regeneration runs on the side queue beside that render; a wave
+    // that holds a finished env first waits (device-side) for the previous step's regeneration: sync[8] >= regen_wait.
+    int shadow, swap_shadow;
+    uint32_t regen_wait;
+    uint8_t *sh_valid;
+    uint16_t *sh_grid;
+    int32_t *sh_agent_xy, *sh_task_state, *sh_task_state2;
+    uint32_t *sh_sent_names, *sh_cand2d;
+    uint8_t *sh_goal_cells;
     // device-side hand-off between the two queues of the step loop, instead of event / barrier packets (each costs the
     // loop ~3-6 us of idle GPU): sync[1] = epoch of the last completed step kernel, sync[3] = of the last completed reset
     // kernel, sync[4] != 0: a wait gave up (xw_device.h: xw_publish_epoch / xw_wait_epoch).  render_all with sig_epoch != 0 publishes it to sync[1] when it
