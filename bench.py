@@ -336,6 +336,7 @@ def main():
     with_screens = world > 1 and not args.no_screens_gather
     screens = None                                   # ScreensGather while the screens regions run
 
+    loop = {"autoreset": args.autoreset}             # which call sequence one_step() issues
     calls = [0]                                      # step calls so far == the record slot counter
     rec = [None]
 
@@ -354,7 +355,7 @@ def main():
         if fused > 1:                                    # `fused` steps in one launch (built-in policy, auto-reset)
             sim.step_n(fused)
             return
-        if args.autoreset:
+        if loop["autoreset"]:
             sim.step_autoreset()
             exchange_results()
         else:
@@ -414,7 +415,7 @@ def main():
     est = (time.perf_counter() - t0) / 10
     spin_calls = bcast_int(min(200000, math.ceil(max(0.0, args.spin_seconds) / max(est, 1e-7))))
     screens_regions = R if with_screens else 0
-    total_calls = 13 + W + spin_calls + 2 * R * K + screens_regions * K + (2 * K if with_screens else 0)
+    total_calls = 13 + W + spin_calls + 2 * R * K + screens_regions * K + (2 * K if with_screens else 0) + 4 * K
     slots = int(max(2, min(total_calls, REC_BYTES_CAP // (n_local * 8))))
     rec[0] = torch.zeros((slots, n_local, 2), dtype=torch.float32, device=dev)
     # the probe's 13 calls happened with another ring: restart the slot counter with the library's (bind resets it)
@@ -451,6 +452,22 @@ def main():
     kern = "render" if is_xworld else "step"
     kern_us, kern_n = sim.profile_end(kern)
     sim.profile_stop()
+
+    # ---- a second, shorter measurement in the same run: the fused call xwb_step_autoreset (the reference example loop's
+    # `if game_over: reset_game()` inside the step: a finished env's observation is the first frame of its next episode,
+    # its terminal frame is not materialised -- NOT the loop `value` is quoted on) ----
+    ar_line = None
+    if is_xworld and fused == 1 and not args.autoreset:
+        loop["autoreset"] = True
+        for _ in range(K):
+            one_step()
+        ar_regions = [timed_region() for _ in range(3)]
+        loop["autoreset"] = False
+        ar_med = statistics.median(ar_regions)
+        ar_line = {"loop": "step_autoreset (terminal frames of finished envs not materialised)", "regions": 3,
+                   "ms_per_step": ar_med / args.steps * 1e3, "value": n_local * world * args.steps / ar_med, "unit": "env-steps/s",
+                   "step_loop_frac": n_local * per_step * args.steps / ar_med / 1e9 / HBM_PEAK_GBS}
+        one_step()                                       # back in the default loop before anything else is measured
 
     # ---- N > 1: the same loop with the screens of every shard gathered into one tensor on rank 0 ----
     sg_line = None
@@ -529,6 +546,8 @@ def main():
             "timed_with_events_ms_per_step": statistics.median(ev_regions) / args.steps * 1e3,
             "rccl": sharding.backend_info(),
         }
+        if ar_line is not None:
+            line["step_autoreset"] = ar_line
         if sg_line is not None:
             line["screens_gather"] = sg_line
         if c5 is not None:

@@ -16,7 +16,7 @@ T2 = ["XWorldNavTarget", "XWorldNavNear", "XWorldNavColorTarget", "XWorldNavBetw
 CASES = {
     "c4": ({"xwd_conf_path": os.path.join(CONF, "navigation2d.json"), "task_mode": "lang_acquisition", "max_dim": 7, "num_blocks": 16, "color": True}, 4096),
     "ctx3_gray": ({"xwd_conf_path": os.path.join(CONF, "navigation2d.json"), "task_mode": "lang_acquisition", "max_dim": 7, "context": 3}, 1024),
-    "two_groups": ({"xwd_conf_path": os.path.join(CONF, "navigation2d.json"), "task_mode": "lang_acquisition", "max_dim": 8, "tasks": T3, "tasks2": T2}, 1024),
+    "two_groups": ({"xwd_conf_path": os.path.join(CONF, "navigation2d.json"), "task_mode": "lang_acquisition", "max_dim": 8, "tasks": T3, "tasks2": T2, "max_steps": 40}, 1024),
     "walls_2d": ({"xwd_conf_path": os.path.join(CONF, "walls.json"), "map": "XWorldWalls", "task_mode": "one_channel", "max_steps": 37}, 1024),
     "nav11_f32": ({"xwd_conf_path": os.path.join(CONF, "navigation2d.json"), "task_mode": "lang_acquisition", "max_dim": 11, "num_blocks": 30,
                    "color": True, "obs_format": "float32", "max_steps": 50}, 512),
