@@ -166,3 +166,23 @@ def test_reference_rng_known_answers_through_libxwb(oracle):
                 a, b = L.xwb_minstd_rand_range(C.byref(st), u), OL.orc_minstd_rand_range(C.byref(g), u)
                 assert a == b and 0 <= a <= u
             assert st.value == g.x
+
+
+def test_rccl_is_resolved_at_run_time_and_argument_errors():
+    """xwb_comm_* / xwb_gather_*: libxwb.so has no link-time RCCL dependency (the exchange resolves the librccl.so.1 of the
+    process when it is first used); bad arguments are refused before anything reaches RCCL or the device."""
+    from xworld_amd import lib
+    L = lib.load()
+    out = subprocess.check_output(["readelf", "-d", lib.LIB_PATH]).decode()
+    assert "rccl" not in out.lower()
+    v = C.c_int32()
+    assert L.xwb_comm_version(C.byref(v)) == 0 and v.value >= 20000, L.xwb_last_error()
+    assert L.xwb_comm_version(None) != 0
+    assert L.xwb_comm_unique_id(None) != 0
+    h = C.c_void_p()
+    ident = (C.c_uint8 * 128)()
+    assert L.xwb_comm_init_rank(ident, 2, 2, 0, C.byref(h)) != 0 and b"rank" in L.xwb_last_error()
+    assert L.xwb_comm_adopt(None, 0, C.byref(h)) != 0
+    assert L.xwb_gather_results(None, None, None, None, None, 1, 0, None) != 0
+    assert L.xwb_gather_screens_end(None, None) != 0
+    assert L.xwb_comm_destroy(None) == 0
