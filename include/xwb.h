@@ -210,7 +210,10 @@ int xwb_step_host(xwb_sim *sim, const int32_t *actions_host, int32_t act_rep, vo
 
 /* xwb_step followed by xwb_reset_done in one call, with a single render of the final state
  * (the observation of a finished env is the first frame of its next episode; reward / game_over
- * keep the values of the terminal transition). */
+ * keep the values of the terminal transition).  XWorld2D under full observation (no curriculum, no XWB_RNG_MINSTD, no
+ * exclusive scheduling of two groups): every env's NEXT episode is kept pre-generated, the step kernel itself starts it for
+ * the envs it finishes and one render draws the whole batch -- same results, byte for byte, as xwb_step + xwb_reset_done;
+ * the pre-generated episodes are rebuilt (once, whole batch) when another verb started episodes in between. */
 int xwb_step_autoreset(xwb_sim *sim, const int32_t *actions_dev, int32_t act_rep, void *stream);
 /* n_steps consecutive xwb_step_autoreset calls under the built-in random policy (actions drawn on the device).  For
  * SimpleGame / SimpleRace they run inside ONE launch -- a step there moves a few MB and is launch-bound -- with every
