@@ -596,6 +596,11 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
 // envs per workgroup of the border-line evaluation (8: 49 us for the evaluation kernel on the C4-sized batch -- four rounds
 // of workgroups that mostly wait for their staging loads; 32: one round)
 constexpr int EGO_BORDER_EPW = 32;
+// threads per workgroup of the gather kernels (A/B hook: -DEGO_BS=...).  Round 3: 256 threads x 4 chunks = 16 KB spans, four waves
+// per barrier: r = 3 colour 0.236 -> 0.228 ms per step, +2 .. 6 % on every geometry tried; 128 (round 2) and 512 lose
+#ifndef EGO_BS
+#define EGO_BS 256
+#endif
 
 // a square's pixels in the span path's sources (ego_tab3, the goal-cell cache): [channel][U rows][UP bytes], rows padded to whole
 // 16-byte pieces
@@ -991,7 +996,7 @@ __global__ __launch_bounds__(256) void xw_ego_build_squares_kernel(XwParams p, c
 
 template <int CH, int R, int ES, int PER_>
 struct EgoSpanGeom {
-    static constexpr int BS = 128, PER = PER_, SPAN = BS * PER;
+    static constexpr int BS = EGO_BS, PER = PER_, SPAN = BS * PER;
     static constexpr int U = 84 / R, O = R * U;
     static constexpr unsigned FB = CH * O * O;
     static constexpr int BPC = 16 / ES;                                     // frame bytes behind one 16-byte chunk
@@ -1023,7 +1028,7 @@ struct EgoSpanGeom {
 template <int CH, int R, bool CTX1, int ES, int PER>
 __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, unsigned cr, int nc, int skip_term, int flag_all) {
     typedef EgoSq<R> Q;
-    constexpr int BS = 128, SPAN = BS * PER;
+    constexpr int BS = EGO_BS, SPAN = BS * PER;
     constexpr int U = Q::U, UD = Q::UD, O = R * U, RR = R * R;
     constexpr unsigned PB = O * O, FB = CH * PB;                            // bytes per plane, per frame
     constexpr int BPC = 16 / ES;                                            // frame bytes behind one 16-byte chunk
@@ -1176,7 +1181,7 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
 }
 
 template <int CH, int R, bool CTX1, int ES, int PER>
-__global__ __launch_bounds__(128) void xw_ego_gather_kernel(XwParams p, int skip_term, int publish) {
+__global__ __launch_bounds__(EGO_BS) void xw_ego_gather_kernel(XwParams p, int skip_term, int publish) {
     typedef EgoSpanGeom<CH, R, ES, PER> G;
     if (publish && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 7, p.sig_epoch);      // the listed frames are out
     // (chunk indices fit 32 bits: the launcher checks)
@@ -1188,7 +1193,7 @@ __global__ __launch_bounds__(128) void xw_ego_gather_kernel(XwParams p, int skip
 
 // the frames of the listed envs, from what the front kernels left of them (terminal frames: p.list_flag = 1)
 template <int CH, int R, bool CTX1, int ES>
-__global__ __launch_bounds__(128) void xw_ego_gather_list_kernel(XwParams p, const int32_t *count_now, int publish) {
+__global__ __launch_bounds__(EGO_BS) void xw_ego_gather_list_kernel(XwParams p, const int32_t *count_now, int publish) {
     typedef EgoSpanGeom<CH, R, ES, 2> G;
     if (publish && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 6, p.sig_epoch);      // the evaluation kernel is through
     const int cnt = *count_now, part = blockIdx.x % G::SPE;
@@ -1488,13 +1493,13 @@ hipError_t ego_span_render(const XwParams &p, const EgoTables &t, int mode, hipS
     static const int per = getenv("XWB_EGO_PER") ? atoi(getenv("XWB_EGO_PER")) : 4;
     static const int pad_env = getenv("XWB_EGO_PAD") ? atoi(getenv("XWB_EGO_PAD")) : -1;
 #define EGO_PAD(ESV, PERV) (pad_env >= 0 ? pad_env : (163840 / 13 - EgoSpanGeom<CH, R, ESV, PERV>::LDS > 0 ? 163840 / 13 - EgoSpanGeom<CH, R, ESV, PERV>::LDS : 0))
-#define EGO_GATHER_BIG(CTXV, ESV, PERV) hipLaunchKernelGGL((xw_ego_gather_kernel<CH, R, CTXV, ESV, PERV>), dim3((unsigned)((n_chunks + 128 * PERV - 1) / (128 * PERV))), dim3(128), EGO_PAD(ESV, PERV), s, p, skip_gather, publish)
+#define EGO_GATHER_BIG(CTXV, ESV, PERV) hipLaunchKernelGGL((xw_ego_gather_kernel<CH, R, CTXV, ESV, PERV>), dim3((unsigned)((n_chunks + EGO_BS * PERV - 1) / (EGO_BS * PERV))), dim3(EGO_BS), EGO_PAD(ESV, PERV), s, p, skip_gather, publish)
 #define EGO_GATHER(CTXV, ESV) do { \
         if (mode == 4) { \
-            hipLaunchKernelGGL((xw_ego_gather_list_kernel<CH, R, CTXV, ESV>), dim3(list_blocks * EgoSpanGeom<CH, R, ESV, 2>::SPE), dim3(128), 0, s, p, cnt, publish); \
+            hipLaunchKernelGGL((xw_ego_gather_list_kernel<CH, R, CTXV, ESV>), dim3(list_blocks * EgoSpanGeom<CH, R, ESV, 2>::SPE), dim3(EGO_BS), 0, s, p, cnt, publish); \
             if (ev_list) { const hipError_t e = hipEventRecord(ev_list, s); if (e != hipSuccess) return e; } \
         } \
-        if (per == 2) EGO_GATHER_BIG(CTXV, ESV, 2); else EGO_GATHER_BIG(CTXV, ESV, 4); \
+        if (per == 2) EGO_GATHER_BIG(CTXV, ESV, 2); else if (per == 8) EGO_GATHER_BIG(CTXV, ESV, 8); else EGO_GATHER_BIG(CTXV, ESV, 4); \
     } while (0)
     if (p.context == 1) { if (es == 4) EGO_GATHER(true, 4); else EGO_GATHER(true, 1); }
     else { if (es == 4) EGO_GATHER(false, 4); else EGO_GATHER(false, 1); }
@@ -1552,7 +1557,7 @@ hipError_t ego_span_render_list(const XwParams &p0, const EgoTables &t, hipStrea
     hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 1024), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, 0, nb_border, cnt, 0);
     const int es = p.obs_f32 ? 4 : 1;
     const unsigned list_blocks = (unsigned)(n_cap < 2048 ? n_cap : 2048);
-#define EGO_LIST(CTXV, ESV) hipLaunchKernelGGL((xw_ego_gather_list_kernel<CH, R, CTXV, ESV>), dim3(list_blocks * EgoSpanGeom<CH, R, ESV, 2>::SPE), dim3(128), 0, s, p, cnt, 0)
+#define EGO_LIST(CTXV, ESV) hipLaunchKernelGGL((xw_ego_gather_list_kernel<CH, R, CTXV, ESV>), dim3(list_blocks * EgoSpanGeom<CH, R, ESV, 2>::SPE), dim3(EGO_BS), 0, s, p, cnt, 0)
     if (p.context == 1) { if (es == 4) EGO_LIST(true, 4); else EGO_LIST(true, 1); }
     else { if (es == 4) EGO_LIST(false, 4); else EGO_LIST(false, 1); }
 #undef EGO_LIST
