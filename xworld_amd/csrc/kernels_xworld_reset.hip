@@ -882,6 +882,7 @@ __device__ void xw_idle3d_env(const XwParams &p, const LaneLds &L, int e) {
         const int mc = gc[i];
         if (mc == 0xff) break;
         const int icon = (int)(g[mc] & CELL_ICON_MASK) - 1;
+        if (icon < 0) break;                               // (cannot happen: the table lists cells that hold goals)
         L.gcell[L.at(i)] = (uint8_t)((mc / MD - off) * D + (mc % MD - off));
         L.gicon[L.at(i)] = (uint16_t)icon;
         L.gname[L.at(i)] = (uint16_t)p.icon_name[icon];
