@@ -142,3 +142,32 @@ def test_pregen_rollout_against_the_oracle(oracle):
         assert np.array_equal(sim.reward.cpu().numpy().view(np.uint32), full.rewards[t].view(np.uint32)), t
         assert np.array_equal(sim.game_over_codes.cpu().numpy(), full.codes[t]), t
     sim.close()
+
+
+@pytest.mark.parametrize("case", ["c4", "ctx3_gray", "walls_2d"])
+def test_lazy_default_loop_equals_classic(case):
+    """xwb_step + xwb_reset_done with pre-generated episodes (no terminal snapshot in the step, the list render installs the
+    shadows) against the classic path (XWB_NO_LAZY: snapshot, reset on the side queue beside the render): the frames after the
+    step (terminal frames included), after reset_done, rewards, codes, counters, grids -- byte for byte."""
+    torch = _torch()
+    from xworld_amd.batched import BatchedSimulator
+    code = ("import sys, hashlib; sys.path.insert(0, %r); import torch\n"
+            "from xworld_amd.batched import BatchedSimulator\n"
+            "sim = BatchedSimulator('xworld', %r, num_envs=%d, seed=11, policy_seed=5)\n"
+            "h = hashlib.sha256()\n"
+            "for t in range(150):\n"
+            "    sim.step()\n"
+            "    for x in (sim.obs, sim.reward, sim.game_over_codes, sim.grid, sim.num_steps, sim.episode): h.update(x.cpu().numpy().tobytes())\n"
+            "    sim.reset_done()\n"
+            "    for x in (sim.obs, sim.game_over_codes, sim.grid, sim.num_steps, sim.episode): h.update(x.cpu().numpy().tobytes())\n"
+            "assert sim.check_errors() == 0; print('HASH', h.hexdigest(), sim.task_performance())\n") % (ROOT, CASES[case][0], CASES[case][1])
+    import subprocess, sys
+    outs = []
+    for env in ({}, {"XWB_NO_LAZY": "1"}, {"XWB_NO_PREGEN": "1"}, {"XWB_QUEUE_SYNC": "events"}, {"GPU_MAX_HW_QUEUES": "1", "XWB_QUEUE_SYNC": "epochs"}):
+        e = dict(os.environ)
+        e.pop("XWB_QUEUE_SYNC", None)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][-1])
+    assert len(set(outs)) == 1, outs

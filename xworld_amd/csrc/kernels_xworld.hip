@@ -294,7 +294,15 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
             is_done = code != ALIVE;
         }
     }
-    if (p.swap_shadow) {
+    if (p.swap_shadow == 2) {
+        // a plain step whose reset_done will install pre-generated episodes (list_swap): nothing to install here, but the list
+        // appended below may still be read by the previous step's regeneration
+        if (__ballot(is_done)) {
+            if ((threadIdx.x & 63) == 0) xw_wait_epoch_lane(p.sync + 8, p.regen_wait, p.sync + 4, p.poison_host);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (p.swap_shadow == 1) {
         // xwb_step_autoreset with pre-generated episodes: a finished env starts its next episode here -- its shadow state (the
         // reset kernel's output for episode + 1, made beside an earlier render) is copied over the live state; reward and code
         // keep the terminal transition's values, the render that follows draws the new episode's first frame.  The list
@@ -305,18 +313,20 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
             const int lane = threadIdx.x & 63, cells = p.max_dim * p.max_dim;
             if (lane == __ffsll((long long)m) - 1) xw_wait_epoch_lane(p.sync + 8, p.regen_wait, p.sync + 4, p.poison_host);
             __builtin_amdgcn_wave_barrier();
+            const uint32_t ep_old = is_done ? p.episode[e] : 0u;
+            const int slot = (int)((ep_old + 1u) & 1u);                                  // the shadow slot that holds episode + 1
+            const size_t es = (size_t)slot * (size_t)p.n + (size_t)e;
             if (is_done) {
-                p.agent_xy[e] = p.sh_agent_xy[e];
-                p.task_state[e] = p.sh_task_state[e];
+                p.agent_xy[e] = p.sh_agent_xy[es];
+                p.task_state[e] = p.sh_task_state[es];
                 p.task_steps[e] = 0;
-                if (p.n_tasks2 > 0) { p.task_state2[e] = p.sh_task_state2[e]; p.task_steps2[e] = 0; }
-                p.sent_names[e] = p.sh_sent_names[e];
-                p.cand2d[e] = p.sh_cand2d[e];
-                reinterpret_cast<uint4 *>(p.goal_cells)[e] = reinterpret_cast<const uint4 *>(p.sh_goal_cells)[e];
+                if (p.n_tasks2 > 0) { p.task_state2[e] = p.sh_task_state2[es]; p.task_steps2[e] = 0; }
+                p.sent_names[e] = p.sh_sent_names[es];
+                p.cand2d[e] = p.sh_cand2d[es];
+                reinterpret_cast<uint4 *>(p.goal_cells)[e] = reinterpret_cast<const uint4 *>(p.sh_goal_cells)[es];
                 p.num_steps[e] = 0;
-                p.episode[e] = p.episode[e] + 1;
+                p.episode[e] = ep_old + 1u;
                 p.fresh[e] = 2;                         // init_screen: the older context frames start black
-                p.sh_valid[e] = 0;
                 atomicAdd(p.perf + 36, 1ull);           // games reset
             }
             __threadfence();                            // the agent's move was stored by one lane; the copy below overwrites it
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
                 const int j = __ffsll((long long)mm) - 1;
                 mm &= mm - 1;
                 const int ej = __shfl(e, j);
-                const uint16_t *src = p.sh_grid + (size_t)ej * cells;
+                const uint16_t *src = p.sh_grid + ((size_t)__shfl(slot, j) * (size_t)p.n + (size_t)ej) * cells;
                 uint16_t *g = p.grid + (size_t)ej * cells;
                 for (int c = lane; c < cells; c += 64) g[c] = src[c];
             }
@@ -554,12 +564,37 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
     // the kernels that publish the epoch need wave slots of their own.  render_list() therefore launches at most half the
     // machine's wave slots when a wait is attached (a batch whose envs all finish on one step otherwise parks one spinning
     // workgroup in every slot: seen as a 4 s stall on the 8x8 workload, where many envs time out on the same step).
-    if (p.wait_epoch) xw_wait_epoch(p.sync + 3, p.wait_epoch, p.sync + 4, p.poison_host);
+    if (p.wait_epoch) xw_wait_epoch(p.sync + p.wait_slot, p.wait_epoch, p.sync + 4, p.poison_host);
     for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
         const int e = i == (int)blockIdx.x ? e_first : p.done_list[i];
         __syncthreads();
-        for (int k = threadIdx.x; k < cells; k += 256) s_grid[k] = p.grid[(size_t)e * cells + k] & CELL_ICON_MASK;
-        __syncthreads();
+        if (p.list_swap) {
+            // xwb_reset_done with pre-generated episodes: install the env's next episode (what the reset kernel made for it
+            // beside an earlier render) -- the grid through this workgroup, the scalars through its first thread -- and draw it
+            const uint32_t ep_old = p.episode[e];
+            const size_t es = (size_t)((ep_old + 1u) & 1u) * (size_t)p.n + (size_t)e;
+            for (int k = threadIdx.x; k < cells; k += 256) {
+                const uint16_t code = p.sh_grid[es * cells + k];
+                p.grid[(size_t)e * cells + k] = code;
+                s_grid[k] = code & CELL_ICON_MASK;
+            }
+            __syncthreads();                              // (every thread has read the episode counter)
+            if (threadIdx.x == 0) {
+                p.agent_xy[e] = p.sh_agent_xy[es];
+                p.task_state[e] = p.sh_task_state[es];
+                p.task_steps[e] = 0;
+                if (p.n_tasks2 > 0) { p.task_state2[e] = p.sh_task_state2[es]; p.task_steps2[e] = 0; }
+                p.sent_names[e] = p.sh_sent_names[es];
+                p.cand2d[e] = p.sh_cand2d[es];
+                reinterpret_cast<uint4 *>(p.goal_cells)[e] = reinterpret_cast<const uint4 *>(p.sh_goal_cells)[es];
+                p.num_steps[e] = 0;
+                p.episode[e] = ep_old + 1u;
+                atomicAdd(p.perf + 36, 1ull);             // games reset
+            }
+        } else {
+            for (int k = threadIdx.x; k < cells; k += 256) s_grid[k] = p.grid[(size_t)e * cells + k] & CELL_ICON_MASK;
+            __syncthreads();
+        }
         uint4 *frame0 = reinterpret_cast<uint4 *>(p.obs) + (size_t)e * ctx * cpf;
         for (int cc = threadIdx.x; cc < cpf; cc += 256) {
             const uint4 v = xw_expand_chunk<DIM_T, CH, ES>(p.atlas, s_grid, cc, D);

@@ -504,7 +504,7 @@ __device__ __forceinline__ void xw_idle_stage_3d(const XwParams &p, int e, Strea
 // group, 1 = one 2-D-native group, 2 = two groups
 template <int NW, int KIND, int GM>
 __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneLds &L, int e, bool keep_done,
-                             const uint4 *pre_draws, uint32_t n_pre_draws) {
+                             const uint4 *pre_draws, uint32_t n_pre_draws, int mode_all) {
     int level_dim = p.dim, level_goals = p.num_goals, level_blocks = p.num_blocks;
     if (KIND == 0 && p.curriculum != 0) {
         // XWorldNav._configure: level -> dims, goals, blocks (XWorldNav.py:27-34)
@@ -515,8 +515,13 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
     }
     const int MD = p.max_dim, D = level_dim, off = (MD - D) / 2;
     RP_T0();
-    const uint32_t ep = p.episode[e] + 1;
-    if (!p.shadow) p.episode[e] = ep;                     // (shadow: the episode after the live one, which keeps its counter)
+    // shadow (a pre-generated episode): the one after the newest this env already holds -- sh_ep counts them, so the number
+    // does not depend on whether the live counter has been bumped yet by whoever installs the previous one; written into
+    // shadow slot (episode & 1) of the swapped-in arrays (index ew), the live counters and flags are left alone
+    const uint32_t ep = (p.shadow && mode_all == 0 ? p.sh_ep[e] : p.episode[e]) + 1;
+    if (!p.shadow) p.episode[e] = ep;
+    else p.sh_ep[e] = ep;
+    const size_t ew = p.shadow ? (size_t)(ep & 1u) * (size_t)p.n + (size_t)e : (size_t)e;
     Stream s;
     s.init(p.seed, p.env_gid0 + (uint32_t)e, ep, 0);
     s.pre = (Stream::lds_block_ptr)pre_draws; s.npre = n_pre_draws;
@@ -530,7 +535,7 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
     // grid row: brick padding outside the actual dims, empty inside; entity cells are overwritten below
     // (same lane, program order).  cpp_get_entities shifts by the padding offset, __padding_walls adds bricks.
     const uint16_t brick = (uint16_t)(T.icon(1, 0, 0) + 1);      // self.items["block"]["brick"][0]
-    uint16_t *g = p.grid + (size_t)e * MD * MD;
+    uint16_t *g = p.grid + ew * MD * MD;
     for (int y = 0; y < MD; ++y)
         for (int x = 0; x < MD; ++x) {
             const int lx = x - off, ly = y - off;
@@ -711,12 +716,12 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
             const int c = L.gcell[L.at(i)];
             if (r2.test(c)) cand |= (1u << i) | (p.icon_colored[L.gicon[L.at(i)]] ? (1u << (16 + i)) : 0u);
         }
-        uint8_t *gc = p.goal_cells + (size_t)e * XW_MAX_GOALS;
+        uint8_t *gc = p.goal_cells + ew * XW_MAX_GOALS;
         for (int i = 0; i < XW_MAX_GOALS; ++i) {
             const int c = i < ng ? L.gcell[L.at(i)] : 0;
             gc[i] = i < ng ? (uint8_t)((c / D + off) * MD + (c % D + off)) : (uint8_t)0xff;
         }
-        p.cand2d[e] = cand;
+        p.cand2d[ew] = cand;
         if (draw) {
             int tsteps0;
             idle_2d(kind, cand, gc, [&](uint32_t n) { return s.below(n); }, tf, st0, tsteps0);
@@ -771,26 +776,22 @@ __device__ void xw_reset_env(const XwParams &p, const IconTables &T, const LaneL
     for (int i = 0; i < ng; ++i)
         put_code(L.gcell[L.at(i)], (uint16_t)((L.gicon[L.at(i)] + 1) | (((target_bits >> i) & 1u) ? 0x8000u : 0u)));
     if (GM == 0) {                                        // goal slot -> cell (the egocentric render finds a goal's pose by it)
-        uint8_t *gc = p.goal_cells + (size_t)e * XW_MAX_GOALS;
+        uint8_t *gc = p.goal_cells + ew * XW_MAX_GOALS;
         for (int i = 0; i < XW_MAX_GOALS; ++i) {
             const int c = i < ng ? L.gcell[L.at(i)] : 0;
             gc[i] = i < ng ? (uint8_t)((c / D + off) * MD + (c % D + off)) : (uint8_t)0xff;
         }
     }
 
-    p.agent_xy[e] = (agent_cell % D + off) | ((agent_cell / D + off) << 16);
-    p.task_state[e] = pack_task(tfv[0], st0v[0], EV_NONE, kind);
-    if (GM == 2) { p.task_state2[e] = pack_task(tfv[1], st0v[1], EV_NONE, kindv[1]); if (!p.shadow) p.task_steps2[e] = 0; }
-    p.sent_names[e] = (uint32_t)sent_a | ((uint32_t)sent_b << 16);
-    if (p.shadow) {                                       // a pre-generated episode: the step kernel starts it (xw_step_kernel)
-        p.sh_valid[e] = 1;
-        return;
-    }
+    p.agent_xy[ew] = (agent_cell % D + off) | ((agent_cell / D + off) << 16);
+    p.task_state[ew] = pack_task(tfv[0], st0v[0], EV_NONE, kind);
+    if (GM == 2) { p.task_state2[ew] = pack_task(tfv[1], st0v[1], EV_NONE, kindv[1]); if (!p.shadow) p.task_steps2[e] = 0; }
+    p.sent_names[ew] = (uint32_t)sent_a | ((uint32_t)sent_b << 16);
+    if (p.shadow) return;                                 // a pre-generated episode: installed later (xw_step_kernel / the list render)
     p.task_steps[e] = 0;
     p.num_steps[e] = 0;
     p.fresh[e] = 2;                                       // render: init_screen (zero the older context frames)
     atomicAdd(p.perf + 36, 1ull);                         // games reset
-    if (p.sh_valid) p.sh_valid[e] = 0;                    // whatever was pre-generated for this env is a past episode now
     if (!keep_done) p.done[e] = (uint8_t)done_code(p, 0, EV_NONE);
     RP_T(4);
 }
@@ -841,13 +842,13 @@ __global__ __launch_bounds__(64) void xw_reset_kernel(XwParams p, int mode, int 
             const bool mine = (solo ? threadIdx.x == 0 : (int)threadIdx.x < per_wave) && i < total;
             const int e = i < total ? (mode == MODE_RESET_ALL ? i : p.done_list[i]) : 0;
             if (solo) {
-                const uint32_t ep = p.episode[e] + 1;                       // (lane 0 bumps it below; read before that)
+                const uint32_t ep = (p.shadow && mode != MODE_RESET_ALL ? p.sh_ep[e] : p.episode[e]) + 1;   // (lane 0 bumps it below; read before that)
                 __builtin_amdgcn_wave_barrier();
                 s_pre[threadIdx.x] = philox4x32_10(threadIdx.x, ep, 0u, 0u, p.seed, p.env_gid0 + (uint32_t)e);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
             }
-            if (mine) xw_reset_env<NW, KIND, GM>(p, T, L, e, keep_done != 0, solo ? s_pre : nullptr, solo ? 64u : 0u);
+            if (mine) xw_reset_env<NW, KIND, GM>(p, T, L, e, keep_done != 0, solo ? s_pre : nullptr, solo ? 64u : 0u, mode == MODE_RESET_ALL);
             if (solo) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         }
     }

@@ -116,8 +116,11 @@ struct xwb_sim {
     unsigned long long *d_perf = nullptr;  // XwParams::perf
     // pre-generated next episodes (XwParams::shadow / swap_shadow): xwb_step_autoreset's fast path
     bool pregen = false, shadow_ok = false, regen_pending = false, regen_by_epoch = false;
+    bool step_lazy = false;                // the last plain step kept no terminal snapshot: its reset_done installs shadows
+    int shadow_breaks = 0;                 // times another verb made the shadows stale (the lazy default path gives up after a few)
     uint32_t epoch_regen = 0;
-    uint8_t *d_sh_valid = nullptr, *d_sh_goal_cells = nullptr;
+    uint32_t *d_sh_ep = nullptr;
+    uint8_t *d_sh_goal_cells = nullptr;
     uint16_t *d_sh_grid = nullptr;
     int32_t *d_sh_agent = nullptr, *d_sh_task_state = nullptr, *d_sh_task_state2 = nullptr;
     uint32_t *d_sh_sent_names = nullptr, *d_sh_cand2d = nullptr;
@@ -454,14 +457,14 @@ int xw_setup(xwb_sim *s) {
     s->pregen = c.visible_radius == 0 && !curriculum_cfg(c) && c.rng_mode != XWB_RNG_MINSTD && !(exclusive && c.n_tasks2 > 0) &&
                 !getenv("XWB_NO_PREGEN");
     if (s->pregen) {
-        if ((rc = dev_alloc(s, &s->d_sh_valid, n))) return rc;
-        if ((rc = dev_alloc(s, &s->d_sh_grid, (size_t)n * cells))) return rc;
-        if ((rc = dev_alloc(s, &s->d_sh_agent, n))) return rc;
-        if ((rc = dev_alloc(s, &s->d_sh_task_state, n))) return rc;
-        if ((rc = dev_alloc(s, &s->d_sh_task_state2, n))) return rc;
-        if ((rc = dev_alloc(s, &s->d_sh_sent_names, n))) return rc;
-        if ((rc = dev_alloc(s, &s->d_sh_cand2d, n))) return rc;
-        if ((rc = dev_alloc(s, &s->d_sh_goal_cells, (size_t)n * XW_MAX_GOALS))) return rc;
+        if ((rc = dev_alloc(s, &s->d_sh_ep, n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_sh_grid, (size_t)2 * n * cells))) return rc;           // two slots per env
+        if ((rc = dev_alloc(s, &s->d_sh_agent, (size_t)2 * n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_sh_task_state, (size_t)2 * n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_sh_task_state2, (size_t)2 * n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_sh_sent_names, (size_t)2 * n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_sh_cand2d, (size_t)2 * n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_sh_goal_cells, (size_t)2 * n * XW_MAX_GOALS))) return rc;
     }
     if ((rc = dev_alloc(s, &s->d_done_list, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_done_count, 2))) return rc;
@@ -576,7 +579,7 @@ int xw_setup(xwb_sim *s) {
     for (int i = 0; i < 8; ++i) p.task_acc2[i] = (i ? p.task_acc2[i - 1] : 0.0) + (i < c.n_tasks2 && p.task_weighted2 ? c.task_weights2[i] : 0.0);
     p.task_state2 = s->d_task_state2; p.task_steps2 = s->d_task_steps2;
     p.perf = s->d_perf;
-    p.shadow = 0; p.swap_shadow = 0; p.regen_wait = 0; p.sh_valid = s->d_sh_valid;
+    p.shadow = 0; p.swap_shadow = 0; p.list_swap = 0; p.regen_wait = 0; p.wait_slot = 3; p.sh_ep = s->d_sh_ep;
     p.sh_grid = s->d_sh_grid; p.sh_agent_xy = s->d_sh_agent; p.sh_task_state = s->d_sh_task_state; p.sh_task_state2 = s->d_sh_task_state2;
     p.sh_sent_names = s->d_sh_sent_names; p.sh_cand2d = s->d_sh_cand2d; p.sh_goal_cells = s->d_sh_goal_cells;
     p.exclusive = exclusive ? 1 : 0;
@@ -795,6 +798,7 @@ int join_regen(xwb_sim *s, hipStream_t st) {
 // regenerated; those envs' frames are rewritten in full by render(list) below, which waits for both.
 int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t st, bool beside_render = false) {
     { const int rcj = join_regen(s, st); if (rcj) return rcj; }
+    if (s->shadow_ok) s->shadow_breaks += 1;
     s->shadow_ok = false;                  // the episodes these envs start now are the ones their shadows held
     XwParams p = xw_params(s);
     // 0: the reset kernel clears the done codes; 1: they are kept (step_autoreset); 2: the reset runs on the side stream
@@ -886,7 +890,12 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         // xwb_step_autoreset with pre-generated episodes (XwParams::swap_shadow): the step kernel starts the next episode of
         // the envs it finishes, ONE render draws every env, the side queue regenerates the consumed shadows beside it
         const bool pregen = autoreset && s->pregen;
-        if (pregen) {
+        // ... and a plain step whose xwb_reset_done installs them (XwParams::list_swap): no terminal snapshot, the render reads
+        // the live grid.  Only while the caller's verbs leave the shadows alone (a loop of masked / single resets would pay a
+        // whole-batch regeneration per call: after a few such breaks the batch stays on the classic path).
+        static const bool no_lazy = getenv("XWB_NO_LAZY") != nullptr;
+        const bool lazy = !autoreset && s->pregen && s->shadow_breaks < 3 && !no_lazy;
+        if (pregen || lazy) {
             if (!s->shadow_ok) {               // first use, or another verb reset envs since: make every env's next episode
                 { const int rcj = join_regen(s, st); if (rcj) return rcj; }
                 HIP_TRY(launch_xw_reset(shadow_params(s), MODE_RESET_ALL, st));
@@ -899,10 +908,11 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
             const int rcj = join_regen(s, st);
             if (rcj) return rcj;
         }
+        s->step_lazy = lazy;
         s->count_sel ^= 1;                     // this step appends to the counter the previous one zeroed
         XwParams p = xw_params(s);
         p.actions = actions_dev; p.act_rep = act_rep;
-        if (pregen) { p.swap_shadow = 1; p.regen_wait = s->regen_pending ? s->epoch_regen : 0; }
+        if (pregen || lazy) { p.swap_shadow = pregen ? 1 : 2; p.regen_wait = s->regen_pending ? s->epoch_regen : 0; }
         if (++s->epoch_step == 0) s->epoch_step = 1;
         p.sig_epoch = epochs ? s->epoch_step : 0;   // published by the render kernel queued behind the step kernel
         timer_begin(s, s->t_step, st);
@@ -988,7 +998,7 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
                 if (epochs) HIP_TRY(launch_xw_render(p, 4, st));          // (p.sig_epoch = this step's epoch: d_sync[5..7])
                 else HIP_TRY(launch_xw_render(p, 4, st, s->ev_step, s->ev_term, s->ev_cells));
             } else {
-                HIP_TRY(launch_xw_render(p, p.visible_radius ? 2 : 3, st));
+                HIP_TRY(launch_xw_render(p, p.visible_radius ? 2 : (lazy ? 0 : 3), st));     // (lazy: nothing rewrites the live grid beside it)
             }
             timer_end(s, s->t_render, st);
             if (p.visible_radius && !span) HIP_TRY(hipStreamWaitEvent(st, s->ev_term, 0));
@@ -1191,7 +1201,35 @@ int xwb_reset_done(xwb_sim *s, void *stream) {
         HIP_TRY(hipMemsetAsync(p.done_count, 0, sizeof(int32_t), st));
         HIP_TRY(launch_xw_compact(p, MODE_RESET_DONE, st));
     }
-    const bool beside = s->list_valid;
+    if (s->list_valid && s->step_lazy && s->shadow_ok) {
+        // the step kept no terminal snapshot and every env's next episode is pre-generated: the list render installs the
+        // shadows of the finished envs and draws their first frames (st); the side queue regenerates what was consumed, for
+        // nobody in particular -- the next holder of the done list waits for it device-side
+        s->list_valid = false;
+        XwParams p = xw_params(s);
+        p.auto_reset = 2; p.list_swap = 1;
+        const bool by_epoch = s->step_epochs;
+        if (s->regen_pending && !s->regen_by_epoch) { HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0)); s->regen_pending = false; }
+        p.wait_slot = 8;
+        p.wait_epoch = s->regen_pending ? s->epoch_regen : 0;
+        HIP_TRY(launch_xw_render(p, 1, st));
+        XwParams q = shadow_params(s);
+        if (by_epoch) HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->d_sync + 4, p.poison_host, s->side));
+        else HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
+        timer_begin(s, s->t_reset, s->side);
+        HIP_TRY(launch_xw_reset(q, MODE_RESET_DONE, s->side));
+        timer_end(s, s->t_reset, s->side);
+        if (by_epoch) {
+            if (++s->epoch_regen == 0) s->epoch_regen = 1;
+            HIP_TRY(launch_xw_signal(s->d_sync + 8, s->epoch_regen, s->side));
+        } else {
+            HIP_TRY(hipEventRecord(s->ev_reset, s->side));
+        }
+        s->regen_pending = true; s->regen_by_epoch = by_epoch;
+        return XWB_OK;
+    }
+    // (a lazy step's render reads the live grid: the classic reset may not rewrite it beside that render)
+    const bool beside = s->list_valid && !s->step_lazy;
     s->list_valid = false;
     return xw_reset_list(s, MODE_RESET_DONE, false, true, st, beside);
 }
@@ -1855,7 +1893,7 @@ int xwb_load_state(xwb_sim *s, const uint8_t *in_host, size_t bytes) {
         HIP_TRY(hipMemcpy(a.ptr, r, a.bytes, hipMemcpyHostToDevice));
         r += b;
     }
-    s->shadow_ok = false; s->regen_pending = false;
+    s->shadow_ok = false; s->regen_pending = false; s->step_lazy = false;
     s->policy_step = h.policy_step; s->count_sel = (int)(h.count_sel & 1u); s->list_valid = (h.list_valid & 1u) != 0; s->autoreset_done = (h.list_valid & 2u) != 0;
     if (s->cfg.game == XWB_XWORLD2D) {
         XwParams p = xw_params(s);

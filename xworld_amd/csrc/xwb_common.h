@@ -262,16 +262,21 @@ struct XwParams {
     // batch since it was created: perf[task class][0..3] = successes, failures, success_steps, time-ups (a subset of the
     // failures); perf[36] = games reset.  Bumped with atomics by the few lanes that record a result (~0.3 % of a step's envs).
     unsigned long long *perf;
-    // Pre-generated next episodes (xwb_step_autoreset, full observation, no curriculum / minstd / exclusive scheduling: the next
-    // episode of an env is then a pure function of (seed, global env id, episode + 1)): the reset kernel run with `shadow` set
-    // writes episode[e] + 1 of the listed envs into the sh_* arrays (the host swaps them in for grid, agent_xy, ...; live
-    // counters and flags are left alone) and raises sh_valid[e]; the step kernel with `swap_shadow` set starts a finished env's
-    // next episode itself by copying its shadow over the live state -- the reset and its first-frame render leave the
-    // critical path, the step's one render draws every env.  Regeneration runs on the side queue beside that render; a wave
-    // that holds a finished env first waits (device-side) for the previous step's regeneration: sync[8] >= regen_wait.
-    int shadow, swap_shadow;
+    // Pre-generated next episodes (full observation, no curriculum / minstd / exclusive scheduling: the next episode of an env is
+    // then a pure function of (seed, global env id, episode + 1)).  The reset kernel run with `shadow` set writes the episode
+    // after the newest one env e already holds (sh_ep[e] counts them) into slot (episode & 1) of the sh_* arrays ([2][n]; the
+    // host swaps them in for grid, agent_xy, ...; live counters and flags are left alone).  Who installs a shadow:
+    //   swap_shadow = 1 (xwb_step_autoreset)  the step kernel, for the envs it finishes: the reset and its first-frame render
+    //                  leave the critical path, the step's one render draws every env;
+    //   list_swap (xwb_reset_done after a step run with swap_shadow = 2)  the list render, right before it draws the first
+    //                  frame: the step then keeps no terminal snapshot (its render reads the live grid, which nothing
+    //                  rewrites beside it) -- 3 us off the step kernel, 2 off the render on C4.
+    // Regeneration runs on the side queue beside the render, two slots per env so that it never writes what an installer may
+    // still read; whoever touches the done list next (the step kernel's wavefronts that hold a finished env, the thread that
+    // zeroes the rotating counter, the installing list render) first waits, device-side, for it: sync[8] >= regen_wait.
+    int shadow, swap_shadow, list_swap;
     uint32_t regen_wait;
-    uint8_t *sh_valid;
+    uint32_t *sh_ep;
     uint16_t *sh_grid;
     int32_t *sh_agent_xy, *sh_task_state, *sh_task_state2;
     uint32_t *sh_sent_names, *sh_cand2d;
@@ -284,6 +289,7 @@ struct XwParams {
     uint32_t *poison_host;       // pinned host word raised together with sync[4] when a wait's watchdog expires (the host reads
                                  // it at the top of every verb without a sync: the batch is poisoned from then on)
     uint32_t sig_epoch, wait_epoch;
+    int wait_slot;               // the list render's wait: sync[wait_slot] >= wait_epoch (3: the reset kernel's epoch, 8: the regeneration's)
     uint32_t *minstd;            // nullable: XWB_RNG_MINSTD, one libstdc++ minstd_rand0 state per env: the teacher's task draw
 };
 hipError_t launch_xw_step(const XwParams &p, hipStream_t s);
