@@ -478,8 +478,10 @@ __global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
         const size_t gi = (size_t)e0 * cells + i;
         // (TERM: the flag, the live cell and the snapshot's cell are fetched together and selected -- flag-then-cell was two
         // dependent round trips at the head of every workgroup; worth ~1 us of the 101 on C4)
-        uint16_t code = p.grid[gi];
-        if (TERM) { const uint16_t snap = p.term_grid[gi]; code = p.term_flag[e0 + i / cells] ? snap : code; }
+        // (uint8 frames; float32 frames -- four times the bytes per workgroup -- measured better with the dependent form)
+        uint16_t code;
+        if (TERM && ES == 1) { const uint16_t live = p.grid[gi], snap = p.term_grid[gi]; code = p.term_flag[e0 + i / cells] ? snap : live; }
+        else code = (TERM && p.term_flag[e0 + i / cells] ? p.term_grid : p.grid)[gi];
         s_code[i] = code & CELL_ICON_MASK;
     }
     if (SKIP_DONE) for (int i = tid; i <= e1 - e0; i += BS) s_done[i] = p.done[e0 + i];

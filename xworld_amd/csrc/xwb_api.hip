@@ -894,7 +894,8 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         // the live grid.  Only while the caller's verbs leave the shadows alone (a loop of masked / single resets would pay a
         // whole-batch regeneration per call: after a few such breaks the batch stays on the classic path).
         static const bool no_lazy = getenv("XWB_NO_LAZY") != nullptr;
-        const bool lazy = !autoreset && s->pregen && s->shadow_breaks < 3 && !no_lazy;
+        // (float32 frames: the render variant without the snapshot select measured 3 % slower there -- left on the classic path)
+        const bool lazy = !autoreset && s->pregen && s->shadow_breaks < 3 && !no_lazy && s->cfg.obs_format == XWB_OBS_U8;
         if (pregen || lazy) {
             if (!s->shadow_ok) {               // first use, or another verb reset envs since: make every env's next episode
                 { const int rcj = join_regen(s, st); if (rcj) return rcj; }
