@@ -170,3 +170,60 @@ def test_lazy_default_loop_equals_classic(case):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][-1])
     assert len(set(outs)) == 1, outs
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_verb_sequences_equal_the_classic_paths(seed):
+    """A seeded random walk over the verbs (step, step_autoreset, step_n, reset_done, masked / single-env / whole-batch resets,
+    explicit actions with skipped envs, a checkpoint round trip) on a batch with pre-generated episodes and on one without
+    (XWB_NO_PREGEN): identical frames, counters, grids and results after every verb -- the host-side state machine (stale
+    shadows, pending regeneration, lazy / classic hand-back after three breaks) has no observable effect."""
+    torch = _torch()
+    from xworld_amd.batched import BatchedSimulator
+    opts, _ = CASES["c4"]
+    opts = dict(opts, max_steps=23)
+    n = 1024
+    a = BatchedSimulator("xworld", opts, num_envs=n, seed=seed, policy_seed=seed + 7)
+    os.environ["XWB_NO_PREGEN"] = "1"
+    try:
+        c = BatchedSimulator("xworld", dict(opts), num_envs=n, seed=seed, policy_seed=seed + 7)
+    finally:
+        del os.environ["XWB_NO_PREGEN"]
+    rng = np.random.default_rng(seed)
+    mask = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    verbs = ["step", "step", "step", "reset_done", "reset_done", "autoreset", "autoreset", "step_n", "masked", "env", "reset", "actions", "ckpt"]
+    weights = np.array([6, 6, 6, 8, 8, 8, 8, 2, 1, 1, 0.3, 2, 0.5])
+    for t in range(400):
+        v = verbs[rng.choice(len(verbs), p=weights / weights.sum())]
+        if v == "masked":
+            mask.zero_()
+            mask[torch.from_numpy(rng.choice(n, 20, replace=False)).cuda()] = 1
+        e = int(rng.integers(n))
+        acts = torch.from_numpy(rng.integers(-1, 4, n).astype(np.int32)).cuda()      # -1: the env sits this call out
+        blob = None
+        for s in (a, c):
+            if v == "step":
+                s.step()
+            elif v == "reset_done":
+                s.reset_done()
+            elif v == "autoreset":
+                s.step_autoreset()
+            elif v == "step_n":
+                s.step_n(3)
+            elif v == "masked":
+                s.reset_masked(mask)
+            elif v == "env":
+                s.reset_env(e)
+            elif v == "reset":
+                s.reset()
+            elif v == "actions":
+                s.step(acts)
+            else:
+                blob = s.save_state()
+                s.step(); s.step_autoreset()
+                s.load_state(blob)
+        _same(torch, a, c, (t, v))
+        assert torch.equal(a.reward, c.reward) and torch.equal(a.game_over_codes, c.game_over_codes), (t, v)
+    assert a.task_performance() == c.task_performance()
+    assert a.check_errors() == 0 and c.check_errors() == 0
+    a.close(); c.close()
