@@ -27,6 +27,9 @@ def _run(sim, steps, autoreset):
             sim.reset_done()
             sim.step()
         out.append((sim.reward.clone(), sim.game_over_codes.clone(), sim.obs.clone(), sim.num_steps.clone()))
+        # num_steps is a state array: xwb_reset_done may start the next episode of a finished env on its internal queue before
+        # reads queued on this stream have run (include/xwb.h; outputs are ordered -- tests/test_gpu_stream_order.py)
+        torch.cuda.synchronize()
     return out
 
 

@@ -390,17 +390,6 @@ hipError_t launch_xw_signal(uint32_t *epoch_slot, uint32_t value, hipStream_t s)
     return hipGetLastError();
 }
 
-// the done codes of the listed envs, cleared on the caller's stream (after whatever it still has queued that reads them)
-__global__ __launch_bounds__(256) void xw_clear_done_kernel(XwParams p, const int32_t *count_now) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < *count_now) p.done[p.done_list[i]] = 0;
-}
-
-hipError_t launch_xw_clear_done(const XwParams &p, hipStream_t s) {
-    hipLaunchKernelGGL(xw_clear_done_kernel, dim3((p.n + 255) / 256), dim3(256), 0, s, p, (const int32_t *)p.done_count);
-    return hipGetLastError();
-}
-
 // ---------------------------------------------------------------- compact --
 __global__ __launch_bounds__(256) void xw_compact_kernel(XwParams p, int mode, int32_t *count_now) {
     const int e = blockIdx.x * 256 + threadIdx.x;

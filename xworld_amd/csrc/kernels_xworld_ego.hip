@@ -1543,8 +1543,10 @@ namespace {
 // the frames of the done list's envs on the span path (new episodes: on the reset's queue, beside the whole-batch gather): the
 // same three stages over the list, with their own source words and goal-cell list (XwParams::ego_cellsrc_list, ...) -- the
 // whole-batch gather may still be reading the batch's
+// `parts`: 1 = the two front kernels (they write the list's own source words, the goal-cell cache and the border rows: nothing
+// the caller reads), 2 = the gather (the frames), 3 = both
 template <int CH, int R>
-hipError_t ego_span_render_list(const XwParams &p0, const EgoTables &t, hipStream_t s) {
+hipError_t ego_span_render_list(const XwParams &p0, const EgoTables &t, hipStream_t s, int parts) {
     XwParams p = p0;
     p.ego_cellsrc = p0.ego_cellsrc_list; p.ego_miss = p0.ego_miss_list; p.ego_miss_count = p0.ego_miss_count_list;
     const uint32_t *a4 = reinterpret_cast<const uint32_t *>(p.atlas64);
@@ -1552,9 +1554,12 @@ hipError_t ego_span_render_list(const XwParams &p0, const EgoTables &t, hipStrea
     const int32_t *cnt = (const int32_t *)p.done_count;
     const size_t cells_lds = 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15);
     const int n_cap = p.n < 16384 ? p.n : 16384;               // (workgroups beyond the list leave at once)
-    hipLaunchKernelGGL((xw_ego_cells_kernel<R, true>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, 0, cnt, 0);
-    const int nb_border = (p.n + EGO_BORDER_EPW - 1) / EGO_BORDER_EPW;
-    hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 1024), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, 0, nb_border, cnt, 0);
+    if (parts & 1) {
+        hipLaunchKernelGGL((xw_ego_cells_kernel<R, true>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, 0, cnt, 0);
+        const int nb_border = (p.n + EGO_BORDER_EPW - 1) / EGO_BORDER_EPW;
+        hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 1024), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, 0, nb_border, cnt, 0);
+    }
+    if (!(parts & 2)) return hipGetLastError();
     const int es = p.obs_f32 ? 4 : 1;
     const unsigned list_blocks = (unsigned)(n_cap < 2048 ? n_cap : 2048);
 #define EGO_LIST(CTXV, ESV) hipLaunchKernelGGL((xw_ego_gather_list_kernel<CH, R, CTXV, ESV>), dim3(list_blocks * EgoSpanGeom<CH, R, ESV, 2>::SPE), dim3(EGO_BS), 0, s, p, cnt, 0)
@@ -1569,16 +1574,18 @@ hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s, h
     const EgoTables t = ego_tables_of(p);
     const int r = p.visible_radius, O = p.out_dim, O4 = (O + 3) & ~3, D = p.max_dim;
     const int CH = p.channels;
-    if (indexed != 1 && xw_ego_span(p)) {
+    if (indexed != 1 && indexed < 5 && xw_ego_span(p)) {
         const int m = indexed;
         if (CH == 3) return r == 3 ? ego_span_render<3, 3>(p, t, m, s, ev_front, ev_list, ev_cells) : (r == 5 ? ego_span_render<3, 5>(p, t, m, s, ev_front, ev_list, ev_cells) : ego_span_render<3, 7>(p, t, m, s, ev_front, ev_list, ev_cells));
         return r == 3 ? ego_span_render<1, 3>(p, t, m, s, ev_front, ev_list, ev_cells) : (r == 5 ? ego_span_render<1, 5>(p, t, m, s, ev_front, ev_list, ev_cells) : ego_span_render<1, 7>(p, t, m, s, ev_front, ev_list, ev_cells));
     }
-    if (indexed == 1 && xw_ego_span(p) && p.ego_cellsrc_list) {
-        if (CH == 3) return r == 3 ? ego_span_render_list<3, 3>(p, t, s) : (r == 5 ? ego_span_render_list<3, 5>(p, t, s) : ego_span_render_list<3, 7>(p, t, s));
-        return r == 3 ? ego_span_render_list<1, 3>(p, t, s) : (r == 5 ? ego_span_render_list<1, 5>(p, t, s) : ego_span_render_list<1, 7>(p, t, s));
+    // (5 / 6: the front kernels / the gather of the list render alone -- xwb_reset_done runs them on two queues)
+    if ((indexed == 1 || indexed == 5 || indexed == 6) && xw_ego_span(p) && p.ego_cellsrc_list) {
+        const int parts = indexed == 5 ? 1 : (indexed == 6 ? 2 : 3);
+        if (CH == 3) return r == 3 ? ego_span_render_list<3, 3>(p, t, s, parts) : (r == 5 ? ego_span_render_list<3, 5>(p, t, s, parts) : ego_span_render_list<3, 7>(p, t, s, parts));
+        return r == 3 ? ego_span_render_list<1, 3>(p, t, s, parts) : (r == 5 ? ego_span_render_list<1, 5>(p, t, s, parts) : ego_span_render_list<1, 7>(p, t, s, parts));
     }
-    if (indexed == 4) return hipErrorInvalidValue;             // (only the span path draws a step's terminal frames itself)
+    if (indexed >= 4) return hipErrorInvalidValue;             // (only the span path draws a step's terminal frames itself)
     const bool fast = p.ego_fast != 0;
     const size_t lds = ego_frame_bytes(p) + (size_t)r * r * sizeof(EgoCell) + (fast ? (size_t)ego_layout_words(O4, r) * 8 : 0) +
                        (size_t)p.n_icons * 4 + (size_t)((p.n_icons + 3) & ~3) + (size_t)((D * D + 3) & ~3) +

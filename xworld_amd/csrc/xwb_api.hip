@@ -832,25 +832,24 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
         HIP_TRY(launch_xw_render(p, 1, st));
         return XWB_OK;
     }
-    if (beside_render && render && p.visible_radius && mode != MODE_RESET_ALL) {
-        // egocentric: the first frames of the new episodes are drawn on the side stream too, beside the big render (which
-        // skips these envs); only the done codes are cleared on the caller's stream, behind whatever still reads them
-        p.auto_reset = 3;
-        p.ego_list_beside = 1;
-        if (span_sync && s->span_epochs) {
-            HIP_TRY(launch_xw_wait(s->d_sync + 7, s->epoch_step, s->d_sync + 4, p.poison_host, rs));      // the terminal frames of these envs are out
-            HIP_TRY(launch_xw_render(p, 1, rs));
+    if (span_sync && render && mode != MODE_RESET_ALL) {
+        // egocentric span path: the map generator and the front kernels of the new episodes' first frames run on the side
+        // queue, beside the big gather (they write nothing the caller reads; the term gather that shares their buffers is
+        // through first).  Only the short gather that stores those frames runs on the CALLER's stream: it overwrites the
+        // terminal frames, which work queued there before this call may still read (xwb.h xwb_reset_done).
+        // (auto_reset == 2: that gather clears the codes.)
+        if (s->span_epochs) HIP_TRY(launch_xw_wait(s->d_sync + 7, s->epoch_step, s->d_sync + 4, p.poison_host, rs));
+        else HIP_TRY(hipStreamWaitEvent(rs, s->ev_term, 0));
+        HIP_TRY(launch_xw_render(p, 5, rs));
+        if (s->span_epochs) {
             if (++s->epoch_reset == 0) s->epoch_reset = 1;
             HIP_TRY(launch_xw_signal(s->d_sync + 3, s->epoch_reset, rs));
             HIP_TRY(launch_xw_wait(s->d_sync + 3, s->epoch_reset, s->d_sync + 4, p.poison_host, st));
-            HIP_TRY(launch_xw_clear_done(p, st));
-            return XWB_OK;
+        } else {
+            HIP_TRY(hipEventRecord(s->ev_reset, s->side));
+            HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
         }
-        if (xw_ego_span(p)) HIP_TRY(hipStreamWaitEvent(rs, s->ev_term, 0));   // the terminal frames of these envs are out
-        HIP_TRY(launch_xw_render(p, 1, rs));
-        HIP_TRY(hipEventRecord(s->ev_reset, s->side));
-        HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
-        HIP_TRY(launch_xw_clear_done(p, st));
+        HIP_TRY(launch_xw_render(p, 6, st));
         return XWB_OK;
     }
     if (beside_render) {

@@ -315,7 +315,6 @@ hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s, hipEv
 // egocentric: indexed 4 = a step's frames on the span path (kernels_xworld_ego.hip), see ego_span_render
 hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s, hipEvent_t ev_front = nullptr, hipEvent_t ev_list = nullptr, hipEvent_t ev_cells = nullptr);
 bool xw_ego_span(const XwParams &p);
-hipError_t launch_xw_clear_done(const XwParams &p, hipStream_t s);
 hipError_t launch_xw_warp_goals(const XwParams &p, bool list, hipStream_t s);
 struct EgoTap;
 hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int *fast_out, int *cell_edge_out, int *span_out);
