@@ -184,11 +184,12 @@ int xwb_reset(xwb_sim *sim, void *stream);
 /* The reference example loop's `if game_over() != alive: reset_game()` (examples/test_xworld.cpp:41-45,
  * python/examples/test_simple_game.py:19-21) applied to every env whose game_over code is non-zero:
  * wavefront-ballot compaction of the done mask, reset of the compacted list, re-render of those envs.
- * Stream ordering: reward and game_over codes of the preceding step stay readable by work queued on `stream`
- * before this call (the codes are cleared on `stream`); for XWorld2D the map generation itself runs on an internal
- * stream beside that step's render, so the other state arrays of the finished envs (grid, agent cell, num_steps) may
- * already hold the new episode: read them after the step through xwb_get_env_state (synchronises) or before calling
- * this function with `stream` synchronised. */
+ * Stream ordering: reward, game_over codes and the observation frames of the preceding step (the terminal frames of the
+ * finished envs included) stay readable by work queued on `stream` before this call: the codes are cleared and the first
+ * frames of the new episodes are stored on `stream` (tests/test_gpu_stream_order.py).  For XWorld2D the map generation
+ * itself runs on an internal stream beside that step's render, so the STATE arrays of the finished envs (grid, agent cell,
+ * num_steps: the xwb_*_dev views) may already hold the new episode: read them after the step through xwb_get_env_state
+ * (synchronises) or before calling this function with `stream` synchronised. */
 int xwb_reset_done(xwb_sim *sim, void *stream);
 
 /* same, for an explicit device mask (mask_dev[e] != 0 -> reset env e) */

@@ -65,3 +65,79 @@ def test_outputs_stay_readable_on_the_callers_stream(case, autoreset):
             for k, (u, v) in enumerate(zip(x, y)):
                 assert torch.equal(u, v), (case, rep, t, ("reward", "codes", "frames", "first_frames")[k],
                                            int((u != v).reshape(u.shape[0], -1).any(1).sum()))
+
+
+T3 = ["XWorld3DNavTarget", "XWorld3DNavTargetNear", "XWorld3DNavTargetBetween", "XWorld3DNavTargetDirection", "XWorld3DNavTargetAvoid"]
+T2 = ["XWorldNavTarget", "XWorldNavNear", "XWorldNavColorTarget", "XWorldNavBetween"]
+WALK = dict(CASES)
+WALK.update({
+    "xworld_ctx3": ("xworld", dict(NAV, context=3)),
+    "xworld_ego_ctx2": ("xworld", dict(NAV, color=True, visible_radius=3, context=2)),
+    "xworld_curriculum": ("xworld", dict(NAV, max_dim=8, color=True, curriculum=0.2)),
+    "xworld_two_groups": ("xworld", dict(NAV, max_dim=8, tasks=T3, tasks2=T2, max_steps=20)),
+    "xworld_exclusive": ("xworld", dict(NAV, max_dim=8, tasks=T3, tasks2=T2, max_steps=20, task_mode="one_channel", task_groups_exclusive=True)),
+})
+
+
+def _walk(game, opts, synced, seed, calls=120, n=1024):
+    """a seeded random walk over the verbs; after every verb the outputs are read (cloned) on the caller's stream"""
+    import numpy as np
+    import torch
+    from xworld_amd.batched import BatchedSimulator
+    rng = np.random.default_rng(seed)
+    sim = BatchedSimulator(game, opts, num_envs=n, seed=seed, policy_seed=seed + 3)
+    acts = torch.from_numpy(rng.integers(-1 if game == "xworld" else 0, sim.num_actions, (calls, n)).astype(np.int32)).cuda()
+    masks = torch.from_numpy((rng.random((calls, n)) < 0.02).astype(np.uint8)).cuda()
+    a = torch.randn(2048, 2048, device="cuda")
+    o = torch.empty_like(a)
+    verbs = ["step", "reset_done", "autoreset", "step_n", "masked", "env", "reset", "actions"]
+    weights = np.array([10, 10, 6, 2, 1.5, 1.5, 0.4, 3])
+    out = []
+    torch.cuda.synchronize()
+    for t in range(calls):
+        v = verbs[rng.choice(len(verbs), p=weights / weights.sum())]
+        k = int(rng.integers(0, 7))
+        e = int(rng.integers(n))
+        if not synced:
+            for _ in range(k):
+                torch.mm(a, a, out=o)
+        if v == "step":
+            sim.step()
+        elif v == "reset_done":
+            sim.reset_done()
+        elif v == "autoreset":
+            sim.step_autoreset()
+        elif v == "step_n":
+            sim.step_n(3)
+        elif v == "masked":
+            sim.reset_masked(masks[t])
+        elif v == "env":
+            sim.reset_env(e)
+        elif v == "reset":
+            sim.reset()
+        else:
+            sim.step(acts[t])
+        if not synced:
+            for _ in range(6 - k):
+                torch.mm(a, a, out=o)
+        out.append((v, sim.reward.clone(), sim.game_over_codes.clone(), sim.obs.clone()))
+        if synced:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    assert sim.check_errors() == 0
+    sim.close()
+    return out
+
+
+@pytest.mark.parametrize("case", list(WALK))
+def test_random_verb_walk_with_the_device_behind_the_host(case):
+    import torch
+    assert torch.cuda.is_available()
+    game, opts = WALK[case]
+    for seed in (1, 2):
+        ref = _walk(game, opts, True, seed)
+        got = _walk(game, opts, False, seed)
+        for t, (x, y) in enumerate(zip(ref, got)):
+            for k in (1, 2, 3):
+                assert torch.equal(x[k], y[k]), (case, seed, t, x[0], ("reward", "codes", "frames")[k - 1],
+                                                 int((x[k] != y[k]).reshape(x[k].shape[0], -1).any(1).sum()))
