@@ -141,3 +141,43 @@ def test_random_verb_walk_with_the_device_behind_the_host(case):
             for k in (1, 2, 3):
                 assert torch.equal(x[k], y[k]), (case, seed, t, x[0], ("reward", "codes", "frames")[k - 1],
                                                  int((x[k] != y[k]).reshape(x[k].shape[0], -1).any(1).sum()))
+
+
+def test_two_batches_interleaved_on_one_stream():
+    """Two batches of one process share the caller's stream (each has its own internal queue and epoch words): interleaved
+    verbs with the device behind the host give each the frames it produces alone."""
+    import torch
+    from xworld_amd.batched import BatchedSimulator
+    cases = [WALK["xworld_full"], WALK["xworld_ego"], WALK["xworld_f32"]]
+
+    def run(which, synced):
+        sims = [BatchedSimulator(g, o, num_envs=1024, seed=21 + i, policy_seed=5) for i, (g, o) in enumerate(cases) if i in which]
+        a = torch.randn(2048, 2048, device="cuda")
+        o = torch.empty_like(a)
+        out = [[] for _ in sims]
+        for t in range(30):
+            for i, s in enumerate(sims):
+                if not synced:
+                    for _ in range(3):
+                        torch.mm(a, a, out=o)
+                if t % 5 == 4:
+                    s.step_autoreset()
+                else:
+                    s.step()
+                out[i].append((s.reward.clone(), s.game_over_codes.clone(), s.obs.clone()))
+            for i, s in enumerate(sims):
+                s.reset_done()
+                out[i].append((s.obs.clone(),))
+            if synced:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        for s in sims:
+            assert s.check_errors() == 0
+            s.close()
+        return out
+
+    alone = [run({i}, True)[0] for i in range(len(cases))]
+    together = run(set(range(len(cases))), False)
+    for i in range(len(cases)):
+        for t, (x, y) in enumerate(zip(alone[i], together[i])):
+            assert all(torch.equal(u, v) for u, v in zip(x, y)), (i, t)
