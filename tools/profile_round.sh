@@ -7,10 +7,12 @@ TAG=${1:-r3}; shift
 OUT=$PWD/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 for W in "$@"; do
-  python bench.py --workload $W > $OUT/bench_$W.json 2> $OUT/bench_$W.err || true
+  # counters first: the bench line quotes profiles/<tag>/traffic_<workload>.json, which then is this HEAD's (traffic_stale false)
   bash tools/profile_gpu.sh $W --workload $W > /dev/null 2>&1
   cp gpurun_out/prof_$W/summary.txt $OUT/${W}_rocprof_summary.txt 2>/dev/null
   cp gpurun_out/prof_$W/traffic.json $OUT/traffic_$W.json 2>/dev/null
+  mkdir -p profiles/$TAG && cp gpurun_out/prof_$W/traffic.json profiles/$TAG/traffic_$W.json 2>/dev/null
+  python bench.py --workload $W > $OUT/bench_$W.json 2> $OUT/bench_$W.err || true
   tail -c 300 $OUT/bench_$W.json | head -c 300; echo
 done
 python bench.py --workload xworld7 --autoreset --no-cpu-baseline > $OUT/bench_xworld7_autoreset.json 2>/dev/null || true
