@@ -622,17 +622,16 @@ __device__ __forceinline__ void ego_wave_append(bool flag, uint32_t a, uint32_t 
 
 // 64 envs per workgroup: all four wavefronts stage their grids (and the entity types) in LDS, the first one then walks them
 // LIST: the envs of the done list (the frames of new episodes, drawn on the reset's queue) instead of the whole batch
-template <int R, bool LIST>
-__global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uint8_t *map, int skip_term, const int32_t *count_now, int publish_step) {
-    extern __shared__ uint4 smem4[];
-    // (xwb_step_autoreset: this kernel running = the step kernel before it is complete; the reset's queue waits for that)
-    if (publish_step && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 1, p.sig_epoch);
+// ALL_MISS (list of freshly reset envs whose goal images are being redrawn beside this: xw_ego_list_front_kernel): every goal
+// cell in view goes on the miss list, the cache bits are not looked at
+template <int R, bool LIST, bool ALL_MISS>
+__device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t *map, int skip_term, const int32_t *count_now, int bid, uint4 *smem4) {
     const int D = p.max_dim, cells = D * D, tid = threadIdx.x, lane = tid;
     uint16_t *s_code = reinterpret_cast<uint16_t *>(smem4);                // [64][cells]
     uint8_t *s_type = reinterpret_cast<uint8_t *>(s_code + 64 * cells);    // [64][cells] type of the entity in a cell, 3 = none
     __shared__ uint4 s_gc[64];                                             // the envs' goal slot -> cell tables
     __shared__ uint32_t s_sq[64][R * R];                                   // the cell words, frame order
-    const int e_base = blockIdx.x * 64, total = LIST ? *count_now : p.n;
+    const int e_base = bid * 64, total = LIST ? *count_now : p.n;
     if (e_base >= total) return;
     const int n_here = total - e_base < 64 ? total - e_base : 64;
     uint8_t *s_itype = s_type + 64 * cells;                                // [n_icons]
@@ -782,7 +781,7 @@ __global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uin
     for (int k = 0; k < r * r; ++k) {
         const bool goal = ((k < 32 ? goal_mask_lo >> k : goal_mask_hi >> (k - 32)) & 1u) != 0;
         const int bit = (gslot[k] * r * r + k) * 4 + dir;
-        vbit[k] = goal ? (valid_e[bit >> 5] >> (bit & 31)) & 1u : 1u;
+        vbit[k] = goal ? (ALL_MISS ? 0u : (valid_e[bit >> 5] >> (bit & 31)) & 1u) : 1u;
     }
     // one atomic for the wavefront's whole lot (one per view cell was up to r * r dependent round trips)
     unsigned long long mk[r * r];
@@ -798,6 +797,14 @@ __global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uin
         if (vbit[k] == 0) p.ego_miss[base + __popcll(mk[k] & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)e, (uint32_t)(k | gslot[k] << 8 | dir << 16));
         base += __popcll(mk[k]);
     }
+}
+
+template <int R, bool LIST>
+__global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uint8_t *map, int skip_term, const int32_t *count_now, int publish_step) {
+    extern __shared__ uint4 smem4[];
+    // (xwb_step_autoreset: this kernel running = the step kernel before it is complete; the reset's queue waits for that)
+    if (publish_step && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 1, p.sig_epoch);
+    ego_cells_body<R, LIST, false>(p, map, skip_term, count_now, (int)blockIdx.x, smem4);
 }
 
 // (cache entries hold the whole square of the frame the cell occupies, in EgoSq's layout; its border row / column, if it has
@@ -1214,11 +1221,11 @@ __global__ __launch_bounds__(EGO_BS) void xw_ego_gather_list_kernel(XwParams p, 
 // Four workgroups per goal, four pixels per lane with all sixteen icon reads in flight together: beside a machine-filling
 // render this kernel is as slow as its chain of dependent reads (16 pixels one after the other: 108 us measured).
 template <bool LIST>
-__global__ __launch_bounds__(256) void xw_warp_goals_kernel(XwParams p, const uint32_t *atlas4, const int32_t *count_now) {
+__device__ __forceinline__ void warp_goals_body(const XwParams &p, const uint32_t *atlas4, const int32_t *count_now, int bid, int nblocks) {
     constexpr int PARTS = 4, PPL = 4096 / PARTS / 256;
     const int G = p.num_goals, D = p.max_dim;
     const int n_items = (LIST ? *count_now : p.n) * G * PARTS;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    for (int item = bid; item < n_items; item += nblocks) {
         const int part = item % PARTS, ig = item / PARTS, ei = ig / G, slot = ig - ei * G;
         const int e = LIST ? p.done_list[ei] : ei;
         const int cell = p.goal_cells[(size_t)e * XW_MAX_GOALS + slot];
@@ -1271,6 +1278,23 @@ __global__ __launch_bounds__(256) void xw_warp_goals_kernel(XwParams p, const ui
             out[part * (4096 / PARTS) + j * 256 + threadIdx.x] = res;
         }
     }
+}
+
+template <bool LIST>
+__global__ __launch_bounds__(256) void xw_warp_goals_kernel(XwParams p, const uint32_t *atlas4, const int32_t *count_now) {
+    warp_goals_body<LIST>(p, atlas4, count_now, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// xwb_reset_done on the span path: the first two things the new episodes' first frames need -- the goal images of the reset envs
+// (read by the evaluation kernel that follows) and their cell tables (which only need the new grids) -- in ONE launch, side by
+// side: as two kernels in the reset's queue they ran one after the other, each as slow as its chain of dependent reads beside
+// the whole-batch gather (33 + 37 us), and made that queue longer than the gather it runs beside.  Blocks [0, nb_cells): cell
+// tables of the listed envs (p: the list's own source words / goal-cell list); the rest: goal images.
+template <int R>
+__global__ __launch_bounds__(256) void xw_ego_list_front_kernel(XwParams p, const uint8_t *map, const uint32_t *atlas4, const int32_t *count_now, int nb_cells) {
+    extern __shared__ uint4 smem4[];
+    if ((int)blockIdx.x < nb_cells) ego_cells_body<R, true, true>(p, map, 0, count_now, (int)blockIdx.x, smem4);
+    else warp_goals_body<true>(p, atlas4, count_now, (int)blockIdx.x - nb_cells, (int)gridDim.x - nb_cells);
 }
 
 hipError_t launch_xw_warp_goals(const XwParams &p, bool list, hipStream_t s) {
@@ -1555,7 +1579,9 @@ hipError_t ego_span_render_list(const XwParams &p0, const EgoTables &t, hipStrea
     const size_t cells_lds = 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15);
     const int n_cap = p.n < 16384 ? p.n : 16384;               // (workgroups beyond the list leave at once)
     if (parts & 1) {
-        hipLaunchKernelGGL((xw_ego_cells_kernel<R, true>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, 0, cnt, 0);
+        // (parts & 4: the goal images of these envs are still to be redrawn -- launch_xw_reset with defer_warp -- in the same launch)
+        if (parts & 4) hipLaunchKernelGGL((xw_ego_list_front_kernel<R>), dim3((p.n + 63) / 64 + 4096), dim3(256), cells_lds, s, p, t.map, a4, cnt, (p.n + 63) / 64);
+        else hipLaunchKernelGGL((xw_ego_cells_kernel<R, true>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, 0, cnt, 0);
         const int nb_border = (p.n + EGO_BORDER_EPW - 1) / EGO_BORDER_EPW;
         hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 1024), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, 0, nb_border, cnt, 0);
     }
@@ -1579,9 +1605,10 @@ hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s, h
         if (CH == 3) return r == 3 ? ego_span_render<3, 3>(p, t, m, s, ev_front, ev_list, ev_cells) : (r == 5 ? ego_span_render<3, 5>(p, t, m, s, ev_front, ev_list, ev_cells) : ego_span_render<3, 7>(p, t, m, s, ev_front, ev_list, ev_cells));
         return r == 3 ? ego_span_render<1, 3>(p, t, m, s, ev_front, ev_list, ev_cells) : (r == 5 ? ego_span_render<1, 5>(p, t, m, s, ev_front, ev_list, ev_cells) : ego_span_render<1, 7>(p, t, m, s, ev_front, ev_list, ev_cells));
     }
-    // (5 / 6: the front kernels / the gather of the list render alone -- xwb_reset_done runs them on two queues)
-    if ((indexed == 1 || indexed == 5 || indexed == 6) && xw_ego_span(p) && p.ego_cellsrc_list) {
-        const int parts = indexed == 5 ? 1 : (indexed == 6 ? 2 : 3);
+    // (5 / 6: the front kernels / the gather of the list render alone -- xwb_reset_done runs them on two queues; 7: as 5, with
+    // the goal images of the listed envs redrawn in the same launch as their cell tables)
+    if ((indexed == 1 || indexed == 5 || indexed == 6 || indexed == 7) && xw_ego_span(p) && p.ego_cellsrc_list) {
+        const int parts = indexed == 5 ? 1 : (indexed == 6 ? 2 : (indexed == 7 ? 5 : 3));
         if (CH == 3) return r == 3 ? ego_span_render_list<3, 3>(p, t, s, parts) : (r == 5 ? ego_span_render_list<3, 5>(p, t, s, parts) : ego_span_render_list<3, 7>(p, t, s, parts));
         return r == 3 ? ego_span_render_list<1, 3>(p, t, s, parts) : (r == 5 ? ego_span_render_list<1, 5>(p, t, s, parts) : ego_span_render_list<1, 7>(p, t, s, parts));
     }

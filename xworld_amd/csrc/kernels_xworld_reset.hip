@@ -962,7 +962,8 @@ static void launch_reset_nw(const XwParams &p, int mode, dim3 grid, size_t lds, 
 #undef XW_RESET_LAUNCH
 }
 
-hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s, hipEvent_t before_warp, const uint32_t *warp_epoch_slot, uint32_t warp_epoch) {
+hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s, hipEvent_t before_warp, const uint32_t *warp_epoch_slot, uint32_t warp_epoch,
+                           int defer_warp) {
     // n / 64 wavefronts in every mode (at least 256 for small batches): the whole batch = 64 envs per wavefront, a short
     // list = one env per wavefront, and the kernel fills the lanes in between as the list grows.  Whole C4 batch
     // finishing together every 8th step (tools/mass_reset.py): 0.183 ms per step with this grid, 0.323 with 2048
@@ -981,7 +982,8 @@ hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s, hipEvent_
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
     // egocentric: the goals of the reset envs got new poses; render their warped images once
-    if (p.visible_radius) {
+    // (defer_warp: the caller redraws them itself -- launch_xw_render(p, 7, ...), beside the cell tables of the same envs)
+    if (p.visible_radius && !defer_warp) {
         if (before_warp) { err = hipStreamWaitEvent(s, before_warp, 0); if (err != hipSuccess) return err; }
         if (warp_epoch_slot) { err = launch_xw_wait(warp_epoch_slot, warp_epoch, p.sync + 4, p.poison_host, s); if (err != hipSuccess) return err; }
         return launch_xw_warp_goals(p, mode != MODE_RESET_ALL, s);

@@ -822,8 +822,11 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
         if (span_sync && s->span_epochs) HIP_TRY(launch_xw_wait(s->d_sync + 5, s->epoch_step, s->d_sync + 4, p.poison_host, s->side));
         else HIP_TRY(hipStreamWaitEvent(s->side, span_sync ? s->ev_cells : s->ev_step, 0));
     }
+    // (span path with a list render to follow: the goal images are redrawn by that render's first launch, beside the cell tables)
+    const bool split = span_sync && render && mode != MODE_RESET_ALL;
     timer_begin(s, s->t_reset, rs);
-    if (span_sync && s->span_epochs) HIP_TRY(launch_xw_reset(p, mode, rs, nullptr, s->d_sync + 6, s->epoch_step));
+    if (split) HIP_TRY(launch_xw_reset(p, mode, rs, nullptr, nullptr, 0, 1));
+    else if (span_sync && s->span_epochs) HIP_TRY(launch_xw_reset(p, mode, rs, nullptr, s->d_sync + 6, s->epoch_step));
     else HIP_TRY(launch_xw_reset(p, mode, rs, span_sync ? s->ev_step : nullptr));
     timer_end(s, s->t_reset, rs);
     if (by_epoch) {
@@ -832,15 +835,15 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
         HIP_TRY(launch_xw_render(p, 1, st));
         return XWB_OK;
     }
-    if (span_sync && render && mode != MODE_RESET_ALL) {
+    if (split) {
         // egocentric span path: the map generator and the front kernels of the new episodes' first frames run on the side
-        // queue, beside the big gather (they write nothing the caller reads; the term gather that shares their buffers is
-        // through first).  Only the short gather that stores those frames runs on the CALLER's stream: it overwrites the
-        // terminal frames, which work queued there before this call may still read (xwb.h xwb_reset_done).
-        // (auto_reset == 2: that gather clears the codes.)
+        // queue, beside the big gather (they write nothing the caller reads).  They follow the step's term gather -- it shares
+        // their buffers -- which also puts them behind its evaluation kernel, the last reader of the old goal images.
+        // Only the short gather that stores those frames runs on the CALLER's stream: it overwrites the terminal frames, which
+        // work queued there before this call may still read (xwb.h xwb_reset_done).  (auto_reset == 2: that gather clears the codes.)
         if (s->span_epochs) HIP_TRY(launch_xw_wait(s->d_sync + 7, s->epoch_step, s->d_sync + 4, p.poison_host, rs));
         else HIP_TRY(hipStreamWaitEvent(rs, s->ev_term, 0));
-        HIP_TRY(launch_xw_render(p, 5, rs));
+        HIP_TRY(launch_xw_render(p, 7, rs));                 // goal images + cell tables in one launch, then the evaluation
         if (s->span_epochs) {
             if (++s->epoch_reset == 0) s->epoch_reset = 1;
             HIP_TRY(launch_xw_signal(s->d_sync + 3, s->epoch_reset, rs));

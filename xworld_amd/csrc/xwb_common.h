@@ -302,9 +302,10 @@ hipError_t launch_xw_wait(const uint32_t *epoch_slot, uint32_t want, uint32_t *p
 // one thread that publishes `value`: queued behind a kernel, it tells the other queue that kernel is complete
 hipError_t launch_xw_signal(uint32_t *epoch_slot, uint32_t value, hipStream_t s);
 // reset envs: mode RESET_ALL -> every env; otherwise the compacted done_list / done_count
-// before_warp (egocentric): the redraw of the goal images waits for it (kernels still reading the old images)
+// before_warp (egocentric): the redraw of the goal images waits for it (kernels still reading the old images);
+// defer_warp: the goal images are left to the caller (launch_xw_render(p, 7, ...): redrawn beside the list's cell tables)
 hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s, hipEvent_t before_warp = nullptr, const uint32_t *warp_epoch_slot = nullptr,
-                           uint32_t warp_epoch = 0);
+                           uint32_t warp_epoch = 0, int defer_warp = 0);
 // compaction of done[] (mode RESET_DONE) or mask (RESET_MASK) into done_list / done_count
 hipError_t launch_xw_compact(const XwParams &p, int mode, hipStream_t s);
 // render: indexed == 0 -> all envs (LDS-resident atlas, persistent workgroups);
