@@ -217,9 +217,9 @@ def test_queue_sync_modes_agree_and_pmc_env_falls_back(extra):
     code = ("import sys, os, hashlib; sys.path.insert(0, %r); import torch\n"
             "from xworld_amd.batched import BatchedSimulator\n"
             "conf = os.path.join(%r, 'xworld_amd', 'confs', 'navigation2d.json')\n"
-            "sim = BatchedSimulator('xworld', {'xwd_conf_path': conf, 'task_mode': 'lang_acquisition', 'max_dim': 7, 'color': True" + extra + "}, num_envs=4096, seed=3, policy_seed=4)\n"
+            "sim = BatchedSimulator('xworld', {'xwd_conf_path': conf, 'task_mode': 'lang_acquisition', 'max_dim': 7, 'color': True" + extra + "}, num_envs=1024, seed=3, policy_seed=4)\n"
             "h = hashlib.sha256()\n"
-            "for t in range(150):\n"
+            "for t in range(120):\n"
             "    if t %% 4 == 3:\n"
             "        sim.step_autoreset(); h.update(sim.obs.cpu().numpy().tobytes())\n"
             "    else:\n"

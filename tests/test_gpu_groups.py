@@ -216,7 +216,7 @@ def test_exclusive_groups_frames_follow_mid_episode_rearrangement(oracle, ego):
     through step_autoreset."""
     _torch()
     from xworld_amd.batched import BatchedSimulator
-    n, steps = 96, 130
+    n, steps = 64, 110
     opts = {"xwd_conf_path": os.path.join(CONF, "navigation2d.json"), "task_mode": "one_channel", "max_dim": 7, "num_blocks": 16,
             "tasks": T2[:1], "tasks2": T3[1:4], "task_groups_exclusive": True, "task_group_weights": [1, 1], "max_steps": 40,
             "color": True, "visible_radius": ego}

@@ -154,15 +154,18 @@ def test_lazy_default_loop_equals_classic(case):
             "from xworld_amd.batched import BatchedSimulator\n"
             "sim = BatchedSimulator('xworld', %r, num_envs=%d, seed=11, policy_seed=5)\n"
             "h = hashlib.sha256()\n"
-            "for t in range(120):\n"
+            "for t in range(100):\n"
             "    sim.step()\n"
             "    for x in (sim.obs, sim.reward, sim.game_over_codes, sim.grid, sim.num_steps, sim.episode): h.update(x.cpu().numpy().tobytes())\n"
             "    sim.reset_done()\n"
             "    for x in (sim.obs, sim.game_over_codes, sim.grid, sim.num_steps, sim.episode): h.update(x.cpu().numpy().tobytes())\n"
-            "assert sim.check_errors() == 0; print('HASH', h.hexdigest(), sim.task_performance())\n") % (ROOT, CASES[case][0], CASES[case][1])
+            "assert sim.check_errors() == 0; print('HASH', h.hexdigest(), sim.task_performance())\n") % (ROOT, CASES[case][0], min(CASES[case][1], 1024))
     import subprocess, sys
     outs = []
-    for env in ({}, {"XWB_NO_LAZY": "1"}, {"XWB_QUEUE_SYNC": "events"}, {"GPU_MAX_HW_QUEUES": "1", "XWB_QUEUE_SYNC": "epochs"}):
+    envs = [{}, {"XWB_NO_LAZY": "1"}]
+    if case == "c4":                           # (the hand-off variants once: they do not depend on the geometry)
+        envs += [{"XWB_QUEUE_SYNC": "events"}, {"GPU_MAX_HW_QUEUES": "1", "XWB_QUEUE_SYNC": "epochs"}]
+    for env in envs:
         e = dict(os.environ)
         e.pop("XWB_QUEUE_SYNC", None)
         e.update(env)

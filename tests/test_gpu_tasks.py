@@ -89,7 +89,7 @@ def test_rollout_all_tasks(oracle, key, tasks):
 def test_rollout_c4_all_tasks_screens(oracle):
     """BASELINE C4 shape (7x7 colour) with the five tasks: obs checksums, rewards and codes of every env-step."""
     torch = _torch()
-    n, steps = 4096, 60
+    n, steps = 1024, 60                # (the oracle renders every frame on one host core: the test's whole cost)
     sim, pal, cfg = _make(oracle, "nav7", n, KINDS, seed=3, policy_seed=8, color=True)
     cfg["color"] = 1
     ref = oracle.xw_rollout(n, oracle.xw_cfg(**cfg), pal, steps, policy_seed=8, render=True)
