@@ -1606,9 +1606,9 @@ hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s, h
         return r == 3 ? ego_span_render<1, 3>(p, t, m, s, ev_front, ev_list, ev_cells) : (r == 5 ? ego_span_render<1, 5>(p, t, m, s, ev_front, ev_list, ev_cells) : ego_span_render<1, 7>(p, t, m, s, ev_front, ev_list, ev_cells));
     }
     // (5 / 6: the front kernels / the gather of the list render alone -- xwb_reset_done runs them on two queues; 7: as 5, with
-    // the goal images of the listed envs redrawn in the same launch as their cell tables)
-    if ((indexed == 1 || indexed == 5 || indexed == 6 || indexed == 7) && xw_ego_span(p) && p.ego_cellsrc_list) {
-        const int parts = indexed == 5 ? 1 : (indexed == 6 ? 2 : (indexed == 7 ? 5 : 3));
+    // the goal images of the listed envs redrawn in the same launch as their cell tables; 8: as 1, with that launch)
+    if ((indexed == 1 || (indexed >= 5 && indexed <= 8)) && xw_ego_span(p) && p.ego_cellsrc_list) {
+        const int parts = indexed == 5 ? 1 : (indexed == 6 ? 2 : (indexed == 7 ? 5 : (indexed == 8 ? 7 : 3)));
         if (CH == 3) return r == 3 ? ego_span_render_list<3, 3>(p, t, s, parts) : (r == 5 ? ego_span_render_list<3, 5>(p, t, s, parts) : ego_span_render_list<3, 7>(p, t, s, parts));
         return r == 3 ? ego_span_render_list<1, 3>(p, t, s, parts) : (r == 5 ? ego_span_render_list<1, 5>(p, t, s, parts) : ego_span_render_list<1, 7>(p, t, s, parts));
     }

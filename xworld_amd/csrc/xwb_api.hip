@@ -966,10 +966,12 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
                 HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
             }
             pr.auto_reset = 1;
+            // (span path: the goal images of the reset envs are redrawn in the list render's first launch, beside their cell tables;
+            // nothing else reads them -- the big render's kernels skip the finished envs)
             timer_begin(s, s->t_reset, s->side);
-            HIP_TRY(launch_xw_reset(pr, MODE_RESET_DONE, s->side));
+            HIP_TRY(launch_xw_reset(pr, MODE_RESET_DONE, s->side, nullptr, nullptr, 0, span ? 1 : 0));
             timer_end(s, s->t_reset, s->side);
-            HIP_TRY(launch_xw_render(pr, 1, s->side));
+            HIP_TRY(launch_xw_render(pr, span ? 8 : 1, s->side));
             if (auto_epochs) {
                 HIP_TRY(launch_xw_signal(s->d_sync + 3, s->epoch_reset, s->side));      // queued behind the list render
                 HIP_TRY(launch_xw_wait(s->d_sync + 3, s->epoch_reset, s->d_sync + 4, p.poison_host, st));
