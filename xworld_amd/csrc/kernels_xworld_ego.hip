@@ -621,28 +621,32 @@ __device__ __forceinline__ void ego_wave_append(bool flag, uint32_t a, uint32_t 
 }
 
 // 64 envs per workgroup: all four wavefronts stage their grids (and the entity types) in LDS, the first one then walks them
-// LIST: the envs of the done list (the frames of new episodes, drawn on the reset's queue) instead of the whole batch
+// LIST: the envs of the done list (the frames of new episodes, drawn on the reset's queue) instead of the whole batch, 16 per
+// workgroup: beside the whole-batch gather, whose 13 workgroups per CU leave about one of their own LDS allocations free, a
+// workgroup that asks for more (64 envs: 13 / 17 / 24 KB at r = 3 / 5 / 7) is not placed until the gather drains
+template <bool LIST> struct EgoCellsGeom { static constexpr int EPW = LIST ? 16 : 64; };
 // ALL_MISS (list of freshly reset envs whose goal images are being redrawn beside this: xw_ego_list_front_kernel): every goal
 // cell in view goes on the miss list, the cache bits are not looked at
 template <int R, bool LIST, bool ALL_MISS>
 __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t *map, int skip_term, const int32_t *count_now, int bid, uint4 *smem4) {
+    constexpr int EPW = EgoCellsGeom<LIST>::EPW;
     const int D = p.max_dim, cells = D * D, tid = threadIdx.x, lane = tid;
-    uint16_t *s_code = reinterpret_cast<uint16_t *>(smem4);                // [64][cells]
-    uint8_t *s_type = reinterpret_cast<uint8_t *>(s_code + 64 * cells);    // [64][cells] type of the entity in a cell, 3 = none
-    __shared__ uint4 s_gc[64];                                             // the envs' goal slot -> cell tables
-    __shared__ uint32_t s_sq[64][R * R];                                   // the cell words, frame order
-    const int e_base = bid * 64, total = LIST ? *count_now : p.n;
+    uint16_t *s_code = reinterpret_cast<uint16_t *>(smem4);                // [EPW][cells]
+    uint8_t *s_type = reinterpret_cast<uint8_t *>(s_code + EPW * cells);   // [EPW][cells] type of the entity in a cell, 3 = none
+    __shared__ uint4 s_gc[EPW];                                             // the envs' goal slot -> cell tables
+    __shared__ uint32_t s_sq[EPW][R * R];                                   // the cell words, frame order
+    const int e_base = bid * EPW, total = LIST ? *count_now : p.n;
     if (e_base >= total) return;
-    const int n_here = total - e_base < 64 ? total - e_base : 64;
-    uint8_t *s_itype = s_type + 64 * cells;                                // [n_icons]
+    const int n_here = total - e_base < EPW ? total - e_base : EPW;
+    uint8_t *s_itype = s_type + EPW * cells;                                // [n_icons]
     uint8_t *s_cls = s_itype + ((p.n_icons + 15) & ~15);                   // [n_icons + 2]
     __shared__ uint8_t s_map[8 * R * R + 8 * R];
-    const bool valid = e_base + lane < total;
+    const bool valid = lane < EPW && e_base + lane < total;
     const int li = valid ? e_base + lane : total - 1;
-    const int e = LIST ? p.done_list[tid < 64 ? li : total - 1] : li, ec = e;
+    const int e = LIST ? p.done_list[tid < EPW ? li : total - 1] : li, ec = e;
     int axy = 0, dir = 0, term = 0;
     int fresh = 0;
-    if (tid < 64) { axy = p.agent_xy[ec]; dir = p.agent_dir[ec] & 3; term = p.term_flag[ec]; fresh = p.fresh[ec]; }
+    if (tid < EPW) { axy = p.agent_xy[ec]; dir = p.agent_dir[ec] & 3; term = p.term_flag[ec]; fresh = p.fresh[ec]; }
     for (int i = tid; i < p.n_icons; i += 256) s_itype[i] = p.icon_type[i];
     for (int i = tid; i < p.n_icons + 2; i += 256) s_cls[i] = p.ego_cls[i];
     for (int i = tid; i < 8 * R * R + 8 * R; i += 256) s_map[i] = map[i];
@@ -652,7 +656,7 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
             const int le = i / cells;
             s_code[i] = (uint16_t)(p.grid[(size_t)p.done_list[e_base + le] * cells + (i - le * cells)] & CELL_ICON_MASK);
         }
-    } else if (n_here == 64) {
+    } else if (n_here == 64) {                              // (whole batch: EPW = 64)
         // 64 consecutive grids = 128 * cells contiguous bytes, a multiple of 16: a few 16-byte loads per lane, all in flight
         // (the element-wise loop below is a chain of a dozen dependent round trips)
         const uint4 *g4 = reinterpret_cast<const uint4 *>(p.grid + (size_t)e_base * cells);
@@ -676,7 +680,7 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
         if (cell < cells) s_type[le * cells + cell] |= (uint8_t)(slot << 2);
     }
     __syncthreads();
-    if (tid >= 64) return;
+    if (tid >= EPW) return;
     const bool active = valid && !(skip_term && term);
     const int ax = axy & 0xffff, ay = axy >> 16;
     const uint16_t *code_e = s_code + lane * cells;
@@ -775,27 +779,41 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
                        (term ? 1u << 27 : 0u) | ((uint32_t)fresh & 3u) << 28 | flat << 30;
         }
     }
-    // the cache bits of the goal cells, fetched together, then one list append per view cell across the wavefront
-    uint32_t vbit[r * r];
+    // the cache bits of the goal cells, fetched together, then one list append for the wavefront's whole lot (one atomic per view
+    // cell was up to r * r dependent round trips).  What outlives the loops is two bit masks, not arrays of r * r registers: at
+    // r = 5 / 7 the kernel took 175 / 256 VGPRs, and the list's copy of it -- the reset's queue runs it beside the whole-batch
+    // gather -- found no room on any SIMD until the gather's wavefronts had drained (it ended when the gather ended).
+    unsigned long long miss = 0;                                // bit k: view cell k shows a goal whose square is not cached
+    if (ALL_MISS) {
+        miss = (unsigned long long)goal_mask_hi << 32 | goal_mask_lo;
+    } else {
+        uint32_t vw[r * r];                                     // (short-lived: every read in flight, then folded into the mask)
 #pragma unroll
-    for (int k = 0; k < r * r; ++k) {
-        const bool goal = ((k < 32 ? goal_mask_lo >> k : goal_mask_hi >> (k - 32)) & 1u) != 0;
-        const int bit = (gslot[k] * r * r + k) * 4 + dir;
-        vbit[k] = goal ? (ALL_MISS ? 0u : (valid_e[bit >> 5] >> (bit & 31)) & 1u) : 1u;
+        for (int k = 0; k < r * r; ++k) {
+            const bool goal = ((k < 32 ? goal_mask_lo >> k : goal_mask_hi >> (k - 32)) & 1u) != 0;
+            const int bit = (gslot[k] * r * r + k) * 4 + dir;
+            vw[k] = valid_e[goal ? bit >> 5 : 0];               // (no branch around the read)
+        }
+#pragma unroll
+        for (int k = 0; k < r * r; ++k) {
+            const bool goal = ((k < 32 ? goal_mask_lo >> k : goal_mask_hi >> (k - 32)) & 1u) != 0;
+            const int bit = (gslot[k] * r * r + k) * 4 + dir;
+            if (goal && !((vw[k] >> (bit & 31)) & 1u)) miss |= 1ull << k;
+        }
     }
-    // one atomic for the wavefront's whole lot (one per view cell was up to r * r dependent round trips)
-    unsigned long long mk[r * r];
     int total_miss = 0;
 #pragma unroll
-    for (int k = 0; k < r * r; ++k) { mk[k] = __ballot(vbit[k] == 0); total_miss += __popcll(mk[k]); }
+    for (int k = 0; k < r * r; ++k) total_miss += __popcll(__ballot((miss >> k) & 1ull));
     if (total_miss == 0) return;
     int base = 0;
     if (lane == 0) base = atomicAdd(p.ego_miss_count, total_miss);
     base = __shfl(base, 0);
 #pragma unroll
     for (int k = 0; k < r * r; ++k) {
-        if (vbit[k] == 0) p.ego_miss[base + __popcll(mk[k] & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)e, (uint32_t)(k | gslot[k] << 8 | dir << 16));
-        base += __popcll(mk[k]);
+        const bool m = (miss >> k) & 1ull;
+        const unsigned long long mk = __ballot(m);
+        if (m) p.ego_miss[base + __popcll(mk & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)e, (uint32_t)(k | gslot[k] << 8 | dir << 16));
+        base += __popcll(mk);
     }
 }
 
@@ -1576,12 +1594,14 @@ hipError_t ego_span_render_list(const XwParams &p0, const EgoTables &t, hipStrea
     const uint32_t *a4 = reinterpret_cast<const uint32_t *>(p.atlas64);
     const size_t cells = (size_t)p.max_dim * p.max_dim;
     const int32_t *cnt = (const int32_t *)p.done_count;
-    const size_t cells_lds = 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15);
+    constexpr int EPW = EgoCellsGeom<true>::EPW;
+    const size_t cells_lds = EPW * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15);
     const int n_cap = p.n < 16384 ? p.n : 16384;               // (workgroups beyond the list leave at once)
     if (parts & 1) {
         // (parts & 4: the goal images of these envs are still to be redrawn -- launch_xw_reset with defer_warp -- in the same launch)
-        if (parts & 4) hipLaunchKernelGGL((xw_ego_list_front_kernel<R>), dim3((p.n + 63) / 64 + 4096), dim3(256), cells_lds, s, p, t.map, a4, cnt, (p.n + 63) / 64);
-        else hipLaunchKernelGGL((xw_ego_cells_kernel<R, true>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, 0, cnt, 0);
+        const int nb_cells = (p.n + EPW - 1) / EPW;
+        if (parts & 4) hipLaunchKernelGGL((xw_ego_list_front_kernel<R>), dim3(nb_cells + 4096), dim3(256), cells_lds, s, p, t.map, a4, cnt, nb_cells);
+        else hipLaunchKernelGGL((xw_ego_cells_kernel<R, true>), dim3(nb_cells), dim3(256), cells_lds, s, p, t.map, 0, cnt, 0);
         const int nb_border = (p.n + EGO_BORDER_EPW - 1) / EGO_BORDER_EPW;
         hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 1024), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, 0, nb_border, cnt, 0);
     }
