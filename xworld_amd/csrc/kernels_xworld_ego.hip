@@ -630,7 +630,7 @@ template <bool LIST> struct EgoCellsGeom { static constexpr int EPW = LIST ? 16 
 template <int R, bool LIST, bool ALL_MISS>
 __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t *map, int skip_term, const int32_t *count_now, int bid, uint4 *smem4) {
     constexpr int EPW = EgoCellsGeom<LIST>::EPW;
-    const int D = p.max_dim, cells = D * D, tid = threadIdx.x, lane = tid;
+    const int D = p.max_dim, cells = D * D, tid = threadIdx.x, lane = tid & 63;
     uint16_t *s_code = reinterpret_cast<uint16_t *>(smem4);                // [EPW][cells]
     uint8_t *s_type = reinterpret_cast<uint8_t *>(s_code + EPW * cells);   // [EPW][cells] type of the entity in a cell, 3 = none
     __shared__ uint4 s_gc[EPW];                                             // the envs' goal slot -> cell tables
@@ -643,10 +643,10 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
     __shared__ uint8_t s_map[8 * R * R + 8 * R];
     const bool valid = lane < EPW && e_base + lane < total;
     const int li = valid ? e_base + lane : total - 1;
-    const int e = LIST ? p.done_list[tid < EPW ? li : total - 1] : li, ec = e;
+    const int e = LIST ? p.done_list[li] : li, ec = e;
     int axy = 0, dir = 0, term = 0;
     int fresh = 0;
-    if (tid < EPW) { axy = p.agent_xy[ec]; dir = p.agent_dir[ec] & 3; term = p.term_flag[ec]; fresh = p.fresh[ec]; }
+    { axy = p.agent_xy[ec]; dir = p.agent_dir[ec] & 3; term = p.term_flag[ec]; fresh = p.fresh[ec]; }
     for (int i = tid; i < p.n_icons; i += 256) s_itype[i] = p.icon_type[i];
     for (int i = tid; i < p.n_icons + 2; i += 256) s_cls[i] = p.ego_cls[i];
     for (int i = tid; i < 8 * R * R + 8 * R; i += 256) s_map[i] = map[i];
@@ -680,11 +680,15 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
         if (cell < cells) s_type[le * cells + cell] |= (uint8_t)(slot << 2);
     }
     __syncthreads();
-    if (tid >= EPW) return;
+    // The walk: lane = env, and every wavefront of the workgroup takes a share of the r * r view cells of the same envs (one
+    // wavefront walking them all was 3.4 / 6.8 / 12.6 thousand instructions at r = 3 / 5 / 7 -- issue-bound with the other
+    // three gone, and at r = 7 more code than the instruction cache holds)
+    constexpr int Q = (R * R + 3) / 4;
+    const int kb = (tid >> 6) * Q;
     const bool active = valid && !(skip_term && term);
     const int ax = axy & 0xffff, ay = axy >> 16;
-    const uint16_t *code_e = s_code + lane * cells;
-    const uint8_t *type_e = s_type + lane * cells;
+    const uint16_t *code_e = s_code + (valid ? lane : 0) * cells;
+    const uint8_t *type_e = s_type + (valid ? lane : 0) * cells;
     auto is_block = [&](int x, int y) { return (unsigned)x < (unsigned)D && (unsigned)y < (unsigned)D && (type_e[y * D + x] & 3) == 1; };
     // XMap::image_masking (xmap.cpp:273-362), as in the kernel above
     constexpr int r = R;
@@ -730,10 +734,12 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
     // A goal: bit 15, bits 0-3 its slot, bits 4-9 the view cell (the cache is indexed by it).
     constexpr int RL = 4 * r * r, CL = RL + 4 * r, INV = CL + 4 * r;
     const uint32_t hd = (uint32_t)dir << 24 | (term ? 1u << 26 : 0u) | ((uint32_t)fresh & 3u) << 27;
-    uint32_t goal_mask_lo = 0, goal_mask_hi = 0;                // view cells that show a goal (r * r <= 49)
-    uint8_t gslot[r * r];
+    unsigned long long goal_mask = 0;                           // this wavefront's view cells that show a goal (r * r <= 49)
+    uint8_t gslot[Q];
 #pragma unroll
-    for (int k = 0; k < r * r; ++k) {
+    for (int j = 0; j < Q; ++j) {
+        const int k = kb + j;
+        if (k >= r * r) break;
         const int gx = x_st - r + k % r, gy = y_st - r + k / r;
         uint32_t info = (uint32_t)((p.n_icons + 1) * 4 + dir) | cls_black << 16;   // outside the map, or in a wall's shadow: black
         int slot = 0;
@@ -744,75 +750,79 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
             else {                                              // a goal: this env's warped copy, through the cache
                 slot = ty >> 2;
                 info = 0x8000u | (uint32_t)slot | (uint32_t)k << 4 | 0xffu << 16;
-                if (k < 32) goal_mask_lo |= 1u << k; else goal_mask_hi |= 1u << (k - 32);
+                goal_mask |= 1ull << k;
             }
         }
-        gslot[k] = (uint8_t)slot;
+        gslot[j] = (uint8_t)slot;
         const int f = s_map[INV + dir * (r * r) + k];
         const uint32_t lines = (s_map[RL + dir * r + f / r] != 0xff ? 1u << 29 : 0u) | (s_map[CL + dir * r + f % r] != 0xff ? 1u << 30 : 0u);
-        s_sq[lane][f] = info | hd | lines;
+        if (valid) s_sq[lane][f] = info | hd | lines;          // (LIST: lanes past EPW have no row)
         if (active) info_e[f] = info | hd | lines;
     }
+    __syncthreads();                                            // (a square's word needs its neighbours', other wavefronts' work)
     // what the gather reads, per square: where its pixels come from (16-byte units: into ego_tab3, keyed by the classes of the
     // cell, the one above and the one to the left -- the cell's own where the neighbour does not show in this square -- or, bit
     // 23, into this env's part of the goal-cell cache), bit 24 / 25 its border row / column is evaluated for this env (a goal
     // in or next to the cell), 26 a border row crosses a border column here, 27 finished by this step, 28-29 fresh[]
     if (!active && valid) {
-        for (int f = 0; f < r * r; ++f) p.ego_cellsrc[(size_t)e * (r * r) + f] = 1u << 27;      // (skipped: finished by this step)
+        for (int f = kb; f < kb + Q && f < r * r; ++f) p.ego_cellsrc[(size_t)e * (r * r) + f] = 1u << 27;      // (skipped: finished by this step)
     }
     if (active) {
-        typedef EgoSq<r> Q;
+        typedef EgoSq<r> Sq;
         const uint32_t nc = (uint32_t)p.ego_ncls, ch_n = (uint32_t)p.channels, entry16 = p.ego_cache_entry / 16;
         uint32_t *src_e = p.ego_cellsrc + (size_t)e * (r * r);
 #pragma unroll
-        for (int f = 0; f < r * r; ++f) {
+        for (int j = 0; j < Q; ++j) {
+            const int f = kb + j;
+            if (f >= r * r) break;
             const uint32_t w = s_sq[lane][f], wa = f >= r ? s_sq[lane][f - r] : w, wl = f % r ? s_sq[lane][f - 1] : w;
             const bool rowb = (w >> 29 & 1u) != 0, colb = (w >> 30 & 1u) != 0, goal = (w & 0x8000u) != 0;
             const bool row_dirty = rowb && ((wa | w) & 0x8000u), col_dirty = colb && ((wl | w) & 0x8000u);
             const uint32_t c = (w >> 16) & 0xffu, ca = rowb && !row_dirty ? (wa >> 16) & 0xffu : c, cl = colb && !col_dirty ? (wl >> 16) & 0xffu : c;
             const uint32_t key = (((uint32_t)dir * nc + c) * nc + ca) * nc + cl;
             const uint32_t off = goal ? (((w & 0xfu) * (r * r) + ((w >> 4) & 0x3fu)) * 4 + dir) * entry16
-                                      : key * ch_n * (Q::PBP / 16) + f * (Q::CBP / 16);
+                                      : key * ch_n * (Sq::PBP / 16) + f * (Sq::CBP / 16);
             // bits 30-31: the table entry is one flat colour (1: 255, 2: 0) -- the gather reads the shared constant line instead
             const uint32_t flat = goal ? 0u : (uint32_t)p.ego_flat[key * (r * r) + f];
             src_e[f] = off | (goal ? 1u << 23 : 0u) | (row_dirty ? 1u << 24 : 0u) | (col_dirty ? 1u << 25 : 0u) | (rowb && colb ? 1u << 26 : 0u) |
                        (term ? 1u << 27 : 0u) | ((uint32_t)fresh & 3u) << 28 | flat << 30;
         }
     }
-    // the cache bits of the goal cells, fetched together, then one list append for the wavefront's whole lot (one atomic per view
-    // cell was up to r * r dependent round trips).  What outlives the loops is two bit masks, not arrays of r * r registers: at
-    // r = 5 / 7 the kernel took 175 / 256 VGPRs, and the list's copy of it -- the reset's queue runs it beside the whole-batch
-    // gather -- found no room on any SIMD until the gather's wavefronts had drained (it ended when the gather ended).
+    // the cache bits of this wavefront's goal cells, fetched together, then one list append for its whole lot (one atomic per view
+    // cell was up to r * r dependent round trips)
     unsigned long long miss = 0;                                // bit k: view cell k shows a goal whose square is not cached
     if (ALL_MISS) {
-        miss = (unsigned long long)goal_mask_hi << 32 | goal_mask_lo;
+        miss = goal_mask;
     } else {
-        uint32_t vw[r * r];                                     // (short-lived: every read in flight, then folded into the mask)
+        uint32_t vw[Q];                                         // (short-lived: every read in flight, then folded into the mask)
 #pragma unroll
-        for (int k = 0; k < r * r; ++k) {
-            const bool goal = ((k < 32 ? goal_mask_lo >> k : goal_mask_hi >> (k - 32)) & 1u) != 0;
-            const int bit = (gslot[k] * r * r + k) * 4 + dir;
-            vw[k] = valid_e[goal ? bit >> 5 : 0];               // (no branch around the read)
+        for (int j = 0; j < Q; ++j) {
+            const int k = kb + j;
+            const bool goal = (goal_mask >> k) & 1ull;
+            const int bit = (gslot[j] * r * r + k) * 4 + dir;
+            vw[j] = valid_e[goal ? bit >> 5 : 0];               // (no branch around the read)
         }
 #pragma unroll
-        for (int k = 0; k < r * r; ++k) {
-            const bool goal = ((k < 32 ? goal_mask_lo >> k : goal_mask_hi >> (k - 32)) & 1u) != 0;
-            const int bit = (gslot[k] * r * r + k) * 4 + dir;
-            if (goal && !((vw[k] >> (bit & 31)) & 1u)) miss |= 1ull << k;
+        for (int j = 0; j < Q; ++j) {
+            const int k = kb + j;
+            const bool goal = (goal_mask >> k) & 1ull;
+            const int bit = (gslot[j] * r * r + k) * 4 + dir;
+            if (goal && !((vw[j] >> (bit & 31)) & 1u)) miss |= 1ull << k;
         }
     }
     int total_miss = 0;
 #pragma unroll
-    for (int k = 0; k < r * r; ++k) total_miss += __popcll(__ballot((miss >> k) & 1ull));
+    for (int j = 0; j < Q; ++j) total_miss += __popcll(__ballot((miss >> (kb + j)) & 1ull));
     if (total_miss == 0) return;
     int base = 0;
     if (lane == 0) base = atomicAdd(p.ego_miss_count, total_miss);
     base = __shfl(base, 0);
 #pragma unroll
-    for (int k = 0; k < r * r; ++k) {
+    for (int j = 0; j < Q; ++j) {
+        const int k = kb + j;
         const bool m = (miss >> k) & 1ull;
         const unsigned long long mk = __ballot(m);
-        if (m) p.ego_miss[base + __popcll(mk & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)e, (uint32_t)(k | gslot[k] << 8 | dir << 16));
+        if (m) p.ego_miss[base + __popcll(mk & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)e, (uint32_t)(k | gslot[j] << 8 | dir << 16));
         base += __popcll(mk);
     }
 }
