@@ -129,11 +129,13 @@ def _walk(game, opts, synced, seed, calls=120, n=1024):
     return out
 
 
-@pytest.mark.parametrize("case", list(WALK))
+@pytest.mark.parametrize("case", list(WALK) + ["xworld_full/events", "xworld_f32/events", "xworld_ego/events", "xworld_ego_gray/events"])
 def test_random_verb_walk_with_the_device_behind_the_host(case):
     import torch
     assert torch.cuda.is_available()
-    game, opts = WALK[case]
+    game, opts = WALK[case.split("/")[0]]
+    if case.endswith("/events"):                   # the hand-overs as event packets instead of epochs in device memory
+        opts = dict(opts, queue_sync="events")
     for seed in (1, 2):
         ref = _walk(game, opts, True, seed)
         got = _walk(game, opts, False, seed)
