@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the batched XWorld simulator on N MI355X (one process per GPU).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload xworld7|xworld7_f32|xworld7_ego3|xworld8|xworld11|simple_game|simple_race]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload xworld7|xworld7_f32|xworld7_ego3|xworld8_ego5|xworld7_ego7|xworld8|xworld11|simple_game|simple_race]
 
 N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -51,6 +51,8 @@ WORKLOADS = {
     "xworld7": ("xworld", {"max_dim": 7, "num_blocks": 16, "color": True}, 32768),
     "xworld7_f32": ("xworld", {"max_dim": 7, "num_blocks": 16, "color": True, "obs_format": "float32"}, 32768),
     "xworld7_ego3": ("xworld", {"max_dim": 7, "num_blocks": 16, "color": True, "visible_radius": 3}, 32768),
+    "xworld8_ego5": ("xworld", {"color": True, "visible_radius": 5}, 32768),                       # 80x80x3 frames
+    "xworld7_ego7": ("xworld", {"max_dim": 7, "num_blocks": 16, "color": True, "visible_radius": 7}, 32768),
     "xworld8": ("xworld", {"color": True}, 32768),
     "xworld11": ("xworld", {"max_dim": 11, "num_blocks": 30, "color": True}, 32768),
     "simple_game": ("simple_game", {"array_size": 64}, 65536),
