@@ -594,8 +594,9 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
 // The frames of the done list's envs (new episodes) take the same three stages over the list, on the reset's queue.
 
 // envs per workgroup of the border-line evaluation (8: 49 us for the evaluation kernel on the C4-sized batch -- four rounds
-// of workgroups that mostly wait for their staging loads; 32: one round)
-constexpr int EGO_BORDER_EPW = 32;
+// of workgroups that mostly wait for their staging loads; 32: one round).  r = 7: 16 -- 49 cells and up to 120 runs / crossings
+// per env make a 32-env workgroup a long serial one (0.3365 -> 0.308 ms per step; 8: 0.306; r = 3 / 5 lose with either)
+template <int R> struct EgoBorderGeom { static constexpr int EPW = R >= 7 ? 16 : 32; };
 // threads per workgroup of the gather kernels (A/B hook: -DEGO_BS=...).  Round 3: 256 threads x 4 chunks = 16 KB spans, four waves
 // per barrier: r = 3 colour 0.236 -> 0.228 ms per step, +2 .. 6 % on every geometry tried; 128 (round 2) and 512 lose
 #ifndef EGO_BS
@@ -906,7 +907,7 @@ template <int CH, int R>
 __device__ __forceinline__ void ego_border_body(const XwParams &p, const uint32_t *atlas4, const EgoTap *tap_h1, const EgoTap *tap_v1,
                                                 const EgoTap *tap_h2, const EgoTap *tap_v2, const uint8_t *map, int skip_term, int block,
                                                 const int32_t *count_now, EgoTap (*s_row)[3], EgoTap (*s_col)[3]) {
-    constexpr int U = 84 / R, O = R * U, EPW = EGO_BORDER_EPW, NL = 2 * (R - 1);
+    constexpr int U = 84 / R, O = R * U, EPW = EgoBorderGeom<R>::EPW, NL = 2 * (R - 1);
     constexpr int NSEG = R * (R - 1), NITEM = 2 * NSEG + (R - 1) * (R - 1);   // row runs, column runs, crossings
     constexpr int RL = 4 * R * R, CL = RL + 4 * R;
     // (s_row / s_col: the kernel's, shared with the other body)
@@ -1531,7 +1532,7 @@ hipError_t ego_span_render(const XwParams &p, const EgoTables &t, int mode, hipS
     const size_t cells_lds = 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15);
     hipLaunchKernelGGL((xw_ego_cells_kernel<R, false>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, skip_front, nullptr, mode == 2 && p.sig_epoch != 0);
     if (ev_cells) { const hipError_t e = hipEventRecord(ev_cells, s); if (e != hipSuccess) return e; }
-    const int nb_border = (p.n + EGO_BORDER_EPW - 1) / EGO_BORDER_EPW;
+    const int nb_border = (p.n + EgoBorderGeom<R>::EPW - 1) / EgoBorderGeom<R>::EPW;
     hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 4096), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, skip_front, nb_border, (const int32_t *)nullptr, publish);
     if (ev_front) { const hipError_t e = hipEventRecord(ev_front, s); if (e != hipSuccess) return e; }
     const int es = p.obs_f32 ? 4 : 1;
@@ -1612,7 +1613,7 @@ hipError_t ego_span_render_list(const XwParams &p0, const EgoTables &t, hipStrea
         const int nb_cells = (p.n + EPW - 1) / EPW;
         if (parts & 4) hipLaunchKernelGGL((xw_ego_list_front_kernel<R>), dim3(nb_cells + 4096), dim3(256), cells_lds, s, p, t.map, a4, cnt, nb_cells);
         else hipLaunchKernelGGL((xw_ego_cells_kernel<R, true>), dim3(nb_cells), dim3(256), cells_lds, s, p, t.map, 0, cnt, 0);
-        const int nb_border = (p.n + EGO_BORDER_EPW - 1) / EGO_BORDER_EPW;
+        const int nb_border = (p.n + EgoBorderGeom<R>::EPW - 1) / EgoBorderGeom<R>::EPW;
         hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 1024), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, 0, nb_border, cnt, 0);
     }
     if (!(parts & 2)) return hipGetLastError();

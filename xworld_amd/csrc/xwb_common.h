@@ -313,7 +313,9 @@ hipError_t launch_xw_compact(const XwParams &p, int mode, hipStream_t s);
 // indexed: 0 = every env, 1 = the compacted done list, 2 = every env whose done code is 0 (the rest follows as a list),
 // 3 = every env, those the step just finished from their terminal snapshot (term_grid)
 hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s, hipEvent_t ev_front = nullptr, hipEvent_t ev_list = nullptr, hipEvent_t ev_cells = nullptr);
-// egocentric: indexed 4 = a step's frames on the span path (kernels_xworld_ego.hip), see ego_span_render
+// egocentric: indexed 4 = a step's frames on the span path (kernels_xworld_ego.hip), see ego_span_render; the list render of the
+// span path in parts (ego_span_render_list): 5 = its two front kernels, 6 = its gather, 7 = as 5 with the listed envs' goal images
+// redrawn in the first launch (launch_xw_reset's defer_warp), 8 = everything, with that first launch
 hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s, hipEvent_t ev_front = nullptr, hipEvent_t ev_list = nullptr, hipEvent_t ev_cells = nullptr);
 bool xw_ego_span(const XwParams &p);
 hipError_t launch_xw_warp_goals(const XwParams &p, bool list, hipStream_t s);
