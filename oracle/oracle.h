@@ -217,6 +217,10 @@ void    orc_xw_stage_poses(orc_xworld *w, const double *poses, int n_entities);
 void    orc_xw_agent_masking(const orc_xworld *w, int *x_st, int *y_st, uint8_t *shadow);
 /* re-render after poses were set by hand (load_map draws no poses): init_screen */
 void    orc_xw_refresh_screen(orc_xworld *w);
+/* XMap::to_image(agent, false, visible_radius), xmap.cpp:125-206: the (r*64)^2 view before XWorldSimulator's two resizes,
+ * interleaved B,G,R; and XItem::get_item_image (xitem.cpp:33-63) of one entity, 64 x 64 x 3 */
+void    orc_xw_agent_view(const orc_xworld *w, uint8_t *view);
+void    orc_xw_entity_image(const orc_xworld *w, int ent, uint8_t *out);
 float   orc_xw_take_actions(orc_xworld *w, int action, int act_rep);
 int     orc_xw_game_over(const orc_xworld *w);
 int     orc_xw_get_lives(const orc_xworld *w);

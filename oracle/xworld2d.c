@@ -910,6 +910,16 @@ void orc_xw_agent_masking(const orc_xworld *w, int *x_st, int *y_st, uint8_t *sh
     orc_xw_image_masking(w, a->x, a->y, w->e_yaw[w->agent_idx], w->cfg.visible_radius, x_st, y_st, shadow);
 }
 void orc_xw_refresh_screen(orc_xworld *w) { init_screen(w); }
+/* XMap::to_image(agent, false, r): the r*64-pixel egocentric view BEFORE the two resizes, interleaved B,G,R */
+void orc_xw_agent_view(const orc_xworld *w, uint8_t *view) {
+    if (w->cfg.visible_radius <= 0 || !w->icons64) abort();
+    orc_xw_ego_view(w, w->cfg.visible_radius, view);
+}
+/* XItem::get_item_image of one entity (its pose applied), 64 x 64 interleaved B,G,R */
+void orc_xw_entity_image(const orc_xworld *w, int ent, uint8_t *out) {
+    if (ent < 0 || ent >= w->n_ents || !w->icons64) abort();
+    orc_xw_item_image(w, ent, out);
+}
 void orc_xw_stage_poses(orc_xworld *w, const double *poses, int n_entities) { w->staged_poses = poses; w->n_staged_poses = n_entities; }
 
 void orc_xw_sentence_names(const orc_xworld *w, int *a, int *b) { *a = w->sent_a; *b = w->sent_b; }

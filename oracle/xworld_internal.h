@@ -85,6 +85,7 @@ struct orc_xworld {
 int  orc_facing_dir(double yaw);                        /* XItem::get_item_facing_dir: 0 right 1 down 2 left 3 up */
 void orc_xw_image_masking(const orc_xworld *w, int ax, int ay, double yaw, int r, int *x_st, int *y_st, uint8_t *shadow);
 void orc_xw_ego_view(const orc_xworld *w, int r, uint8_t *view);
+void orc_xw_item_image(const orc_xworld *w, int ent, uint8_t *out);   /* XItem::get_item_image */
 void orc_xw_rebuild_map(orc_xworld *w);                 /* XWorld::reset(false): rebuild the cube from the entity list */
 int  orc_xw_draw_below(orc_xworld *w, int n);           /* next decision: forced (golden replay) or stream draw */
 /* xworld_tasks.c */

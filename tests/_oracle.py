@@ -164,6 +164,8 @@ def lib():
     sig("orc_xw_stage_poses", None, vp, C.POINTER(C.c_double), C.c_int)
     sig("orc_xw_agent_masking", None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), u8p)
     sig("orc_xw_refresh_screen", None, vp)
+    sig("orc_xw_agent_view", None, vp, u8p)
+    sig("orc_xw_entity_image", None, vp, C.c_int, u8p)
     sig("orc_cv_get_rotation_matrix_2d", None, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double))
     sig("orc_cv_warp_affine_8uc3", None, u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int, C.POINTER(C.c_double), u8p)
     sig("orc_xw_load_map_forced", None, vp, C.c_int, C.POINTER(Entity), C.c_int, i32p, C.c_int, C.c_uint32, C.c_uint32)
@@ -488,6 +490,19 @@ class XWorld:
 
     def refresh_screen(self):
         self.L.orc_xw_refresh_screen(self.h)
+
+    def agent_view(self):
+        """XMap::to_image for the agent: [r*64, r*64, 3] B,G,R before XWorldSimulator's resizes"""
+        s = self.cfg.visible_radius * 64
+        out = np.zeros((s, s, 3), np.uint8)
+        self.L.orc_xw_agent_view(self.h, ptr(out, u8p))
+        return out
+
+    def entity_image(self, ent):
+        """XItem::get_item_image of entity `ent`: [64, 64, 3] B,G,R"""
+        out = np.zeros((64, 64, 3), np.uint8)
+        self.L.orc_xw_entity_image(self.h, int(ent), ptr(out, u8p))
+        return out
 
     def group_state(self, g):
         """(task kind, stage, steps in task, the event its task recorded in the last call, 2-D target x, y) of task group g"""
