@@ -24,7 +24,7 @@ def test_product_frame_equals_reference_frame(oracle, dim, agent, color):
     n = 4
     sim = BatchedSimulator("xworld", {"xwd_conf_path": os.path.join(CONF, "nav_target.json"), "max_dim": dim, "dim": dim,
                                       "task_mode": "lang_acquisition", "tasks": ["XWorld3DNavTarget"],
-                                      "visible_radius": R, "color": color}, num_envs=n)
+                                      "visible_radius": R, "color": color, "num_goals": 3, "num_blocks": 4}, num_envs=n)
     assert sim.screen_dims == (80, 80, 3 if color else 1)
     w, ents, poses = doc_world(oracle, dim, agent, color=int(color))
     pal = w.pal
