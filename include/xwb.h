@@ -31,6 +31,12 @@
 extern "C" {
 #endif
 
+/* libxwb.so is built with -fvisibility=hidden: exactly the functions declared between this push and the pop at the end of
+ * the file are exported (tests/test_abi_and_host.py compares `nm -D` with this header). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 #define XWB_ABI_VERSION 3
 
 enum {
@@ -158,14 +164,17 @@ typedef struct xwb_config {
 } xwb_config;
 
 /* xwb_config.queue_sync.  AUTO: device-side epochs (no event / barrier packets: 12 us per step on the C4 loop) on every caller
- * stream that passes a one-time concurrency probe against the batch's internal stream, events otherwise (the probe fails when
+ * stream that passed a one-time concurrency probe against the batch's internal stream -- the default stream is probed by
+ * xwb_create, any other stream by the caller's xwb_queue_sync_mode(sim, stream, ...) call, which synchronises that stream once;
+ * the step verbs never probe (they stay asynchronous) and use events on a stream nobody probed --, events otherwise (the probe fails when
  * the two streams share one hardware queue -- HIP multiplexes streams onto GPU_MAX_HW_QUEUES queues -- or when a tool
  * serialises kernel execution); the environment variable XWB_QUEUE_SYNC=events|epochs and the presence of a serialising tool
  * (rocprofv3 counter collection, AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING) override AUTO.  EVENTS / EPOCHS force one mode. */
 enum { XWB_QUEUE_SYNC_AUTO = 0, XWB_QUEUE_SYNC_EVENTS = 1, XWB_QUEUE_SYNC_EPOCHS = 2 };
 /* why xwb_queue_sync_mode reports the mode it reports */
 enum { XWB_SYNC_REASON_PROBE_OK = 0, XWB_SYNC_REASON_CONFIG = 1, XWB_SYNC_REASON_ENV = 2, XWB_SYNC_REASON_TOOL = 3,
-       XWB_SYNC_REASON_PROBE_FAILED = 4, XWB_SYNC_REASON_PROBE_ERROR = 5, XWB_SYNC_REASON_NOT_USED = 6 };
+       XWB_SYNC_REASON_PROBE_FAILED = 4, XWB_SYNC_REASON_PROBE_ERROR = 5, XWB_SYNC_REASON_NOT_USED = 6,
+       XWB_SYNC_REASON_NOT_PROBED = 7 /* nobody probed this stream (or it is under graph capture): events */ };
 
 typedef struct xwb_sim xwb_sim;
 
@@ -226,14 +235,28 @@ int xwb_step_n(xwb_sim *sim, int32_t n_steps, int32_t act_rep, void *stream);
 int xwb_check_errors(xwb_sim *sim, void *stream, int32_t *n_bad);
 
 /* How the batch hands work between the caller's `stream` and its internal stream: *mode = XWB_QUEUE_SYNC_EVENTS or
- * XWB_QUEUE_SYNC_EPOCHS for calls made on `stream` (runs the one-time probe of that stream if it has not run yet: synchronises
- * it), *reason = XWB_SYNC_REASON_* (NOT_USED: the game has no internal stream).  Safety of the epoch hand-off: (1) the kernel
+ * XWB_QUEUE_SYNC_EPOCHS for calls made on `stream`.  This call is what PROBES a stream (once; it synchronises `stream` and
+ * the host; skipped -- events, reason NOT_PROBED -- while the stream is under graph capture): a trainer that issues the verbs
+ * on a stream of its own calls it once after creating that stream, *reason = XWB_SYNC_REASON_* (NOT_USED: the game has no internal stream).  Safety of the epoch hand-off: (1) the kernel
  * that publishes an epoch is always enqueued before the kernel that waits for it, so streams that turn out to share a hardware
  * queue, or kernels serialised in submission order, cannot deadlock; (2) the probe; (3) a device-side watchdog: a wait that is
  * not released within 4 s POISONS the batch -- the queues drain, and every later verb of the batch (step, reset, getters,
  * xwb_check_errors) fails with XWB_ERR_STATE; results since the last successful xwb_check_errors are void and the batch can
  * only be destroyed.  Returns XWB_ERR_STATE itself when the batch is poisoned. */
 int xwb_queue_sync_mode(xwb_sim *sim, void *stream, int32_t *mode, int32_t *reason);
+/* Which kernel sequence the LAST step call (xwb_step / xwb_step_autoreset / xwb_step_n) ran -- the verbs choose it from the
+ * configuration and from what the caller did before, and a number measured on one path says nothing
+ * about another: *path = XWB_PATH_*; *sync_mode (nullable) = XWB_QUEUE_SYNC_EVENTS | _EPOCHS of that call (AUTO: the game has
+ * no internal queue); *shadow_breaks (nullable) = how often another verb made the pre-generated episodes stale (after three
+ * the default loop stays on the classic path). */
+enum { XWB_PATH_NONE = 0,        /* SimpleGame / SimpleRace (one kernel), or no step yet */
+       XWB_PATH_CLASSIC = 1,     /* step -> render(all; finished envs from terminal snapshots); reset on the internal queue */
+       XWB_PATH_LAZY = 2,        /* pre-generated episodes installed by xwb_reset_done's list render (the default loop) */
+       XWB_PATH_PREGEN = 3,      /* xwb_step_autoreset: the step kernel itself starts the pre-generated episode */
+       XWB_PATH_EGO_SPAN = 4, XWB_PATH_EGO_PER_ENV = 5 /* egocentric renders, see xwb_ego_render_path */ };
+int xwb_step_path(xwb_sim *sim, int32_t *path, int32_t *sync_mode, int32_t *shadow_breaks);
+/* drops what the batch remembers about `stream` (call before destroying a probed stream: a later stream may reuse the handle) */
+int xwb_queue_sync_forget(xwb_sim *sim, void *stream);
 /* test hook: enqueue on `stream` a wait for an epoch nobody publishes, with a watchdog of budget_us microseconds -- the
  * batch is poisoned once it expires (tests/test_gpu_queue_sync.py) */
 int xwb_debug_stall_handoff(xwb_sim *sim, void *stream, int64_t budget_us);
@@ -392,8 +415,25 @@ int xwb_decode_game_over_code(int32_t code, char *out, size_t cap);
  * n_icons x c x 12 x 12 bytes. */
 int xwb_xw_get_tile_table(const xwb_sim *sim, uint8_t *out_host, size_t cap, size_t *need);
 
-/* timing hook: average duration in microseconds of the named kernel ("render", "step", "reset")
- * over the launches recorded since xwb_profile_begin (hipEvents on the launch stream). */
+/* ---- the draw state: "gather the state, not the pixels" ----
+ * Under full observation a frame is a pure function of the env's cell codes (2 * max_dim^2 bytes against 144 * c * max_dim^2
+ * bytes of pixels: C5 242 B against 52 272 B), so a holder elsewhere -- the root GPU of a sharded batch -- can draw the frames
+ * itself.  xwb_xw_pack_grids writes, for every env, the cell codes its CURRENT observation was drawn from (uint16
+ * [num_envs][max_dim^2], icon + 1, 0 = empty; the teacher's target bit is stripped) and the context-ring operation of its
+ * last draw (uint8[num_envs]: 0 untouched, 1 ring shift, 2 first frame of an episode -- the older context frames start
+ * black); flags_dev may be NULL when context == 1.  Ordered on `stream` behind the verbs queued before it.  With
+ * context > 1 it must follow EVERY verb that draws frames (step, reset_done, ...: a ring is replayed one draw at a time),
+ * else XWB_ERR_STATE.  Egocentric batches: XWB_ERR_STATE (their frames also depend on heading, poses and shadows).
+ * xwb_xw_render_grids draws n_envs frames from such codes with THIS batch's tile table and frame format into
+ * obs_dev [n_envs][bytes_per_env] -- n_envs is the caller's, not num_envs: the root draws the whole sharded batch with the
+ * kernel that draws its own shard (xw_render_all_kernel), byte for byte what the shards drew. */
+int xwb_xw_pack_grids(xwb_sim *sim, uint16_t *grids_dev, uint8_t *flags_dev, void *stream);
+int xwb_xw_render_grids(xwb_sim *sim, const uint16_t *grids_dev, const uint8_t *flags_dev, int32_t n_envs, void *obs_dev,
+                        void *stream);
+
+/* timing hook: average duration in microseconds of the named kernel ("step", "render" = the whole-batch render, "reset" = the
+ * map generator, "list" = the render of the envs a reset started) over the launches recorded since xwb_profile_begin
+ * (hipEvents on the stream each launch runs on). */
 int xwb_profile_begin(xwb_sim *sim);
 int xwb_profile_end(xwb_sim *sim, void *stream, const char *kernel, double *avg_us, int64_t *launches);
 int xwb_profile_stop(xwb_sim *sim);
@@ -415,13 +455,18 @@ int xwb_comm_adopt(void *nccl_comm, int32_t device, xwb_comm **out);
 int xwb_comm_destroy(xwb_comm *comm);
 int xwb_comm_info(const xwb_comm *comm, int32_t *world, int32_t *rank);
 /* ncclGroupStart / ncclGroupEnd: lets several shards that live on ONE rank (two batches on one device, a loopback
- * communicator) post their halves of an exchange as one group */
+ * communicator) post their halves of an exchange as one group.  Shards that share the ROOT's rank must gather their
+ * screens / grids inside such a group (a send to the own rank only matches a receive of the same group; without one the
+ * calls return XWB_ERR_STATE).  Shards that share a rank call in ascending shard order (RCCL matches the sends and
+ * receives between two ranks in issue order) and pass ONE all_dev buffer to xwb_gather_results between them: a shard never
+ * receives the rows of a shard on its own rank, it finds them where that shard's call put them. */
 int xwb_comm_group_start(xwb_comm *comm);
 int xwb_comm_group_end(xwb_comm *comm);
 /* A gather's layout: n_shards shards in global-env-id order, shard i = counts[i] envs held by communicator rank
  * peers[i] (peers == NULL: rank i, the usual one shard per rank); `shard` = the caller's own.
  * xwb_gather_results: every shard's packed (reward, game_over code) rows -- what xwb_bind_results receives, float[count][2] --
- * into float[sum(counts)][2] on every holder: one ncclAllGather (equal shards) or grouped ncclSend / ncclRecv, on `stream`. */
+ * into float[sum(counts)][2] on every holder: one ncclAllGather (equal shards) or grouped ncclSend / ncclRecv, on `stream`.
+ * Empty shards (counts[i] == 0) are legal: they send nothing and still receive everybody's rows. */
 int xwb_gather_results(xwb_comm *comm, const float *packed_dev, float *all_dev, const int32_t *counts, const int32_t *peers,
                        int32_t n_shards, int32_t shard, void *stream);
 /* The screens of every shard as ONE contiguous tensor on the root shard's GPU: dst_dev (root only; else NULL) =
@@ -434,6 +479,23 @@ int xwb_gather_results(xwb_comm *comm, const float *packed_dev, float *all_dev, 
 int xwb_gather_screens_begin(xwb_sim *sim, xwb_comm *comm, void *dst_dev, const int32_t *counts, const int32_t *peers,
                              int32_t n_shards, int32_t shard, int32_t root_shard, void *stream);
 int xwb_gather_screens_end(xwb_comm *comm, void *stream);
+/* The same tensor on the root from 1 / 216 of the bytes (full observation only): every shard ships its draw state
+ * (xwb_xw_pack_grids: 2 * max_dim^2 + 1 bytes per env, packed on `stream` into a staging slab of the communicator) and the
+ * root draws ALL frames into dst_dev with its own batch's render kernel (xwb_xw_render_grids) on the communicator's stream,
+ * behind the receives.  C5: 242 B instead of 52 272 B per env cross a link -- the exchange stops being link-bound (a shard:
+ * 7.9 MB, ~52 us) and the root's HBM write stream is the bound, as it is for any holder of one contiguous tensor
+ * (DESIGN.md "multi-GPU").  Every shard still draws its own frames locally.  Same arguments and completion protocol as
+ * xwb_gather_screens_begin (xwb_gather_screens_end, or xwb_comm_mark / xwb_comm_wait); two staging slabs alternate, a slab
+ * is reused only after the transfer (root: the render) that read it.  context > 1: call after every frame-drawing verb. */
+int xwb_gather_grids_begin(xwb_sim *sim, xwb_comm *comm, void *dst_dev, const int32_t *counts, const int32_t *peers,
+                           int32_t n_shards, int32_t shard, int32_t root_shard, void *stream);
+/* Completion marks for pipelined gathers (two destination tensors alternating): xwb_comm_mark records mark `slot`
+ * (0 .. XWB_COMM_MARKS - 1) on the communicator's stream behind everything begun so far -- inside an open group: when the
+ * outermost group ends --; xwb_comm_wait orders `stream` behind that mark (no-op if the mark was never recorded).
+ * xwb_gather_screens_end = mark + wait on a mark of its own. */
+#define XWB_COMM_MARKS 4
+int xwb_comm_mark(xwb_comm *comm, int32_t slot);
+int xwb_comm_wait(xwb_comm *comm, int32_t slot, void *stream);
 
 /* ---- the reference's thread-local RNG on the host (include/xwb_minstd.h): what XWB_RNG_MINSTD runs per env on the device ----
  * xwb_minstd_seed_thread: the engine state of the nth simulator thread under FLAGS_simulator_seed (simulator_util.cpp:44-52);
@@ -444,6 +506,10 @@ float    xwb_minstd_rand_range(uint32_t *state, float upper);
 
 const char *xwb_last_error(void);
 const char *xwb_version(void);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

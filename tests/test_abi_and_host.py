@@ -32,6 +32,9 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (xwb_[a-z0-9_]+)", out))
     assert declared <= exported
+    # ... and nothing else: no kernel handles, launch helpers or other internals (-fvisibility=hidden + csrc/libxwb.map)
+    everything = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert everything == declared, sorted(everything ^ declared)
 
 
 def test_ctypes_struct_matches_header_layout():

@@ -233,6 +233,12 @@ class BatchedSimulator:
         lib.check(self.L.xwb_queue_sync_mode(self.h, self._stream(stream), C.byref(m), C.byref(r)))
         return ("events" if m.value == lib.XWB_QUEUE_SYNC_EVENTS else "epochs"), lib.SYNC_REASONS[r.value]
 
+    def step_path(self):
+        """xwb_step_path: {"path", "queue_sync", "shadow_breaks"} of the last step call"""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        lib.check(self.L.xwb_step_path(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"path": lib.STEP_PATHS[a.value], "queue_sync": ("auto", "events", "epochs")[b.value], "shadow_breaks": c.value}
+
     def done_count(self, stream=None):
         n = C.c_int32()
         lib.check(self.L.xwb_done_count(self.h, self._stream(stream), C.byref(n)))
@@ -335,6 +341,20 @@ class BatchedSimulator:
         self._bound = tensor
 
     # ------------------------------------------------------------------ per-env host access
+    def pack_grids(self, grids, flags=None, stream=None):
+        """xwb_xw_pack_grids: the draw state of every env -- the cell codes its current frame shows into `grids` (int16 / uint16
+        [num_envs, max_dim * max_dim] device tensor) and the context-ring flag of its last draw into `flags` (uint8 [num_envs];
+        optional when context == 1)."""
+        lib.check(self.L.xwb_xw_pack_grids(self.h, C.c_void_p(grids.data_ptr()), C.c_void_p(flags.data_ptr()) if flags is not None else None,
+                                           self._stream(stream)))
+
+    def render_grids(self, grids, flags, out, n_envs=None, stream=None):
+        """xwb_xw_render_grids: draws n_envs frames (default: the rows of `grids`) from cell codes with this batch's tile table
+        and frame format into `out` [n_envs, ...] -- the root of a sharded batch draws every shard's frames with it."""
+        n = int(grids.shape[0] if n_envs is None else n_envs)
+        lib.check(self.L.xwb_xw_render_grids(self.h, C.c_void_p(grids.data_ptr()), C.c_void_p(flags.data_ptr()) if flags is not None else None,
+                                             n, C.c_void_p(out.data_ptr()), self._stream(stream)))
+
     def env_state(self, env=0, stream=None):
         st = lib.XwbEnvState()
         lib.check(self.L.xwb_get_env_state(self.h, int(env), self._stream(stream), C.byref(st)))

@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libxwb.so")
 SOURCES = ["kernels_simple.hip", "kernels_xworld.hip", "kernels_xworld_reset.hip", "kernels_xworld_ego.hip", "xwb_api.hip", "xwb_comm.hip"]
 HEADERS = [os.path.join(CSRC, "xwb_common.h"), os.path.join(CSRC, "xw_device.h"), os.path.join(CSRC, "xwb_language.h"), os.path.join(os.path.dirname(HERE), "include", "xwb.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
 
 
 def hipcc():
@@ -59,8 +59,8 @@ def build(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-    if force or _stale(LIB, objs):
-        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    if force or _stale(LIB, objs + [os.path.join(CSRC, "libxwb.map")]):
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-Wl,--version-script=" + os.path.join(CSRC, "libxwb.map")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -646,6 +646,30 @@ hipError_t launch_xw_render(const XwParams &p, int indexed, hipStream_t s, hipEv
     return p.channels == 3 ? render_dispatch<3, 1>(p, indexed, s) : render_dispatch<1, 1>(p, indexed, s);
 }
 
+// The draw state of every env -- what a renderer elsewhere needs to reproduce the frames this batch shows (xwb_xw_pack_grids,
+// include/xwb.h "gather the state, not the pixels"): the cell codes each env's CURRENT frame was drawn from (icon + 1, target
+// bit stripped) and the context-ring operation of its last draw (xw_store_chunk's flag: 0 untouched, 1 ring shift, 2 fresh).
+// src = what the last frame-drawing verb read: 0 the live grid with fresh[]; 1 xwb_step's terminal snapshots (render mode 3);
+// 2 a list render (reset_done / reset_masked: the envs it drew are the ones at step 0).
+__global__ __launch_bounds__(256) void xw_pack_grids_kernel(XwParams p, int src, uint16_t *out_grid, uint8_t *out_flag) {
+    const int cells = p.max_dim * p.max_dim;
+    const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= (size_t)p.n * cells) return;
+    const int e = (int)(gi / cells);
+    const bool term = src == 1 && p.term_flag[e];
+    out_grid[gi] = (term ? p.term_grid[gi] : p.grid[gi]) & CELL_ICON_MASK;
+    if (out_flag && gi == (size_t)e * cells) {
+        const bool at_start = p.num_steps[e] == 0;
+        out_flag[e] = (uint8_t)(src == 2 ? (at_start ? 2 : 0) : (term ? 1 : (at_start ? 2 : p.fresh[e])));
+    }
+}
+
+hipError_t launch_xw_pack_grids(const XwParams &p, int src, uint16_t *out_grid, uint8_t *out_flag, hipStream_t s) {
+    const size_t total = (size_t)p.n * p.max_dim * p.max_dim;
+    hipLaunchKernelGGL(xw_pack_grids_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, src, out_grid, out_flag);
+    return hipGetLastError();
+}
+
 hipError_t launch_xw_compact(const XwParams &p, int mode, hipStream_t s) {
     dim3 grid((p.n + 255) / 256), block(256);
     hipLaunchKernelGGL(xw_compact_kernel, grid, block, 0, s, p, mode, p.done_count);

@@ -72,10 +72,14 @@ struct xwb_sim {
     int num_actions = 0;
     uint32_t policy_step = 0;
     bool list_valid = false;
+    // xwb_xw_pack_grids: what the last frame-drawing verb read (xw_pack_grids_kernel's src) and how many such verbs ran since
+    // the last pack (a context ring can only be replayed elsewhere one draw at a time)
+    int frame_src = 0, draws_since_pack = 0;
     bool autoreset_done = false;           // the last step call already reset the envs whose codes are still set
     int count_sel = 0;
     bool profiling = false;
-    KernelTimer t_render, t_step, t_reset;
+    KernelTimer t_render, t_step, t_reset, t_list;   // t_list: the list render (first frames of the envs a reset started)
+    int last_path = XWB_PATH_NONE;           // xwb_step_path: which kernel sequence the last step call ran
     hipStream_t side = nullptr;            // reset of finished envs runs here, beside render_all
     uint32_t *d_minstd = nullptr;          // XWB_RNG_MINSTD: one engine state per env
     uint32_t *d_sync = nullptr;            // device-side epochs of the step / reset kernels (XwParams::sync)
@@ -228,7 +232,9 @@ bool epoch_probe(xwb_sim *s, hipStream_t st, int *reason) {
 }
 
 // may calls on stream `st` hand over through epochs?  (xworld batches only: the other games have no internal stream)
-bool use_epochs(xwb_sim *s, hipStream_t st) {
+// may_probe: only xwb_create (the default stream) and xwb_queue_sync_mode (any stream, an explicit call) run the probe -- it
+// synchronises both streams and the host; the step verbs never do: a stream nobody probed hands over through events.
+bool use_epochs(xwb_sim *s, hipStream_t st, bool may_probe) {
     if (!s->d_sync || !s->side) { s->sync_reason = XWB_SYNC_REASON_NOT_USED; return false; }
     if (s->cfg.queue_sync == XWB_QUEUE_SYNC_EVENTS) { s->sync_reason = XWB_SYNC_REASON_CONFIG; return false; }
     if (s->cfg.queue_sync == XWB_QUEUE_SYNC_EPOCHS) { s->sync_reason = XWB_SYNC_REASON_CONFIG; return true; }
@@ -236,6 +242,12 @@ bool use_epochs(xwb_sim *s, hipStream_t st) {
     const int env = queue_sync_env(&why);
     if (env >= 0) { s->sync_reason = why; return env == 1; }
     for (auto &pr : s->probes) if (pr.st == st) { s->sync_reason = pr.reason; return pr.ok; }
+    if (!may_probe) { s->sync_reason = XWB_SYNC_REASON_NOT_PROBED; return false; }
+    {   // a stream under graph capture cannot be synchronised (the probe would invalidate the capture): events, nothing cached
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        if (cap != hipStreamCaptureStatusNone) { s->sync_reason = XWB_SYNC_REASON_NOT_PROBED; return false; }
+    }
     int reason = 0;
     const bool ok = epoch_probe(s, st, &reason);
     if (s->probes.size() >= 16) s->probes.erase(s->probes.begin());
@@ -800,6 +812,7 @@ int join_regen(xwb_sim *s, hipStream_t st) {
 // regenerated; those envs' frames are rewritten in full by render(list) below, which waits for both.
 int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t st, bool beside_render = false) {
     { const int rcj = join_regen(s, st); if (rcj) return rcj; }
+    if (render) { s->frame_src = mode == MODE_RESET_ALL ? 0 : 2; s->draws_since_pack += 1; }
     if (s->shadow_ok) s->shadow_breaks += 1;
     s->shadow_ok = false;                  // the episodes these envs start now are the ones their shadows held
     XwParams p = xw_params(s);
@@ -832,7 +845,9 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
     if (by_epoch) {
         HIP_TRY(launch_xw_signal(s->d_sync + 3, s->epoch_reset, s->side));     // queued behind the reset kernel
         p.wait_epoch = s->epoch_reset;
+        timer_begin(s, s->t_list, st);
         HIP_TRY(launch_xw_render(p, 1, st));
+        timer_end(s, s->t_list, st);
         return XWB_OK;
     }
     if (split) {
@@ -852,7 +867,9 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
             HIP_TRY(hipEventRecord(s->ev_reset, s->side));
             HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
         }
+        timer_begin(s, s->t_list, st);
         HIP_TRY(launch_xw_render(p, 6, st));
+        timer_end(s, s->t_list, st);
         return XWB_OK;
     }
     if (beside_render) {
@@ -865,7 +882,9 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
             HIP_TRY(launch_xw_render(p, 0, st));
             timer_end(s, s->t_render, st);
         } else {
+            timer_begin(s, s->t_list, st);
             HIP_TRY(launch_xw_render(p, 1, st));
+            timer_end(s, s->t_list, st);
         }
     }
     return XWB_OK;
@@ -888,8 +907,9 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         HIP_TRY(launch_simple_race(p, st));
         timer_end(s, s->t_step, st);
     } else {
-        // hand-over mode of this call (probes `st` the first time it is seen: synchronises it once)
-        const bool epochs = use_epochs(s, st);
+        // hand-over mode of this call: what xwb_create / xwb_queue_sync_mode found out about `st`; events for a stream
+        // nobody probed (no verb synchronises the host by itself)
+        const bool epochs = use_epochs(s, st, false);
         s->step_epochs = epochs;
         // xwb_step_autoreset with pre-generated episodes (XwParams::swap_shadow): the step kernel starts the next episode of
         // the envs it finishes, ONE render draws every env, the side queue regenerates the consumed shadows beside it
@@ -971,7 +991,9 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
             timer_begin(s, s->t_reset, s->side);
             HIP_TRY(launch_xw_reset(pr, MODE_RESET_DONE, s->side, nullptr, nullptr, 0, span ? 1 : 0));
             timer_end(s, s->t_reset, s->side);
+            timer_begin(s, s->t_list, s->side);
             HIP_TRY(launch_xw_render(pr, span ? 8 : 1, s->side));
+            timer_end(s, s->t_list, s->side);
             if (auto_epochs) {
                 HIP_TRY(launch_xw_signal(s->d_sync + 3, s->epoch_reset, s->side));      // queued behind the list render
                 HIP_TRY(launch_xw_wait(s->d_sync + 3, s->epoch_reset, s->d_sync + 4, p.poison_host, st));
@@ -1011,6 +1033,13 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         }
     }
     s->span_step = !autoreset && xw_ego_span(s->xw);
+    s->last_path = s->cfg.game != XWB_XWORLD2D ? XWB_PATH_NONE :
+                   (s->cfg.visible_radius ? (xw_ego_span(s->xw) ? XWB_PATH_EGO_SPAN : XWB_PATH_EGO_PER_ENV) :
+                    (autoreset && s->pregen ? XWB_PATH_PREGEN : (s->step_lazy ? XWB_PATH_LAZY : XWB_PATH_CLASSIC)));
+    if (s->cfg.game == XWB_XWORLD2D) {     // a plain step on the classic path drew the finished envs from their terminal snapshots
+        s->frame_src = (!autoreset && !s->step_lazy && !s->cfg.visible_radius) ? 1 : 0;
+        s->draws_since_pack += 1;
+    }
     s->policy_step += 1;
     s->packed_pos += 1;
     s->autoreset_done = autoreset;
@@ -1156,7 +1185,7 @@ int xwb_create(const xwb_config *cfg, xwb_sim **out) {
     rc = xwb_reset(s, nullptr);
     if (rc) return bail(rc);
     HIP_TRY(hipDeviceSynchronize());
-    if (s->d_sync) (void)use_epochs(s, nullptr);      // probe the default stream now; other streams when they are first seen
+    if (s->d_sync) (void)use_epochs(s, nullptr, true);   // probe the default stream now; other streams: xwb_queue_sync_mode
     *out = s;
     return XWB_OK;
 }
@@ -1171,7 +1200,7 @@ int xwb_destroy(xwb_sim *s) {
     if (s->ev_reset) (void)hipEventDestroy(s->ev_reset);
     if (s->ev_term) (void)hipEventDestroy(s->ev_term);
     if (s->ev_cells) (void)hipEventDestroy(s->ev_cells);
-    for (KernelTimer *t : {&s->t_render, &s->t_step, &s->t_reset})
+    for (KernelTimer *t : {&s->t_render, &s->t_step, &s->t_reset, &s->t_list})
         for (auto &ep : t->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     delete s;
     return XWB_OK;
@@ -1212,13 +1241,16 @@ int xwb_reset_done(xwb_sim *s, void *stream) {
         // shadows of the finished envs and draws their first frames (st); the side queue regenerates what was consumed, for
         // nobody in particular -- the next holder of the done list waits for it device-side
         s->list_valid = false;
+        s->frame_src = 2; s->draws_since_pack += 1;
         XwParams p = xw_params(s);
         p.auto_reset = 2; p.list_swap = 1;
         const bool by_epoch = s->step_epochs;
         if (s->regen_pending && !s->regen_by_epoch) { HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0)); s->regen_pending = false; }
         p.wait_slot = 8;
         p.wait_epoch = s->regen_pending ? s->epoch_regen : 0;
+        timer_begin(s, s->t_list, st);
         HIP_TRY(launch_xw_render(p, 1, st));
+        timer_end(s, s->t_list, st);
         XwParams q = shadow_params(s);
         if (by_epoch) HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->d_sync + 4, p.poison_host, s->side));
         else HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
@@ -1349,9 +1381,25 @@ int xwb_queue_sync_mode(xwb_sim *s, void *stream, int32_t *mode, int32_t *reason
     if (!s || !mode) return fail(XWB_ERR_ARG, "NULL argument");
     XWB_ON_DEVICE(s);
     XWB_LIVE(s);
-    const bool e = use_epochs(s, as_stream(stream));
+    const bool e = use_epochs(s, as_stream(stream), true);
     *mode = e ? XWB_QUEUE_SYNC_EPOCHS : XWB_QUEUE_SYNC_EVENTS;
     if (reason) *reason = s->sync_reason;
+    return XWB_OK;
+}
+
+int xwb_step_path(xwb_sim *s, int32_t *path, int32_t *sync_mode, int32_t *shadow_breaks) {
+    if (!s || !path) return fail(XWB_ERR_ARG, "NULL argument");
+    *path = s->last_path;
+    if (sync_mode) *sync_mode = s->cfg.game == XWB_XWORLD2D ? (s->step_epochs ? XWB_QUEUE_SYNC_EPOCHS : XWB_QUEUE_SYNC_EVENTS) : XWB_QUEUE_SYNC_AUTO;
+    if (shadow_breaks) *shadow_breaks = s->shadow_breaks;
+    return XWB_OK;
+}
+
+int xwb_queue_sync_forget(xwb_sim *s, void *stream) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    hipStream_t st = as_stream(stream);
+    for (size_t i = 0; i < s->probes.size();)
+        if (s->probes[i].st == st) s->probes.erase(s->probes.begin() + (long)i); else ++i;
     return XWB_OK;
 }
 
@@ -1820,6 +1868,9 @@ std::vector<StateArray> state_arrays(xwb_sim *s, bool include_obs) {
     return a;
 }
 
+// version 3 (round 4): per-workgroup reset counts (d_reset_partial, sized by num_envs) replaced the single counter, the
+// exclusive schedule's group order and the task performance counters joined, count_sel lost its rc_sel bit
+constexpr uint32_t XWB_STATE_VERSION = 3;
 struct StateHeader {
     char magic[8];
     uint32_t version, game, num_envs, include_obs, n_arrays, policy_step, count_sel, list_valid;
@@ -1862,7 +1913,7 @@ int xwb_save_state(xwb_sim *s, int32_t include_obs, uint8_t *out_host, size_t ca
     const auto arrays = state_arrays(s, include_obs != 0);
     StateHeader h{};
     memcpy(h.magic, "XWBSTATE", 8);
-    h.version = 2; h.game = (uint32_t)s->cfg.game; h.num_envs = (uint32_t)s->n; h.include_obs = include_obs ? 1u : 0u;
+    h.version = XWB_STATE_VERSION; h.game = (uint32_t)s->cfg.game; h.num_envs = (uint32_t)s->n; h.include_obs = include_obs ? 1u : 0u;
     h.n_arrays = (uint32_t)arrays.size(); h.policy_step = s->policy_step; h.count_sel = (uint32_t)s->count_sel;
     h.list_valid = (s->list_valid ? 1u : 0u) | (s->autoreset_done ? 2u : 0u); h.obs_bytes_per_env = s->obs_bytes_per_env; h.cfg_hash = config_hash(s->cfg);
     uint8_t *w = out_host;
@@ -1883,7 +1934,10 @@ int xwb_load_state(xwb_sim *s, const uint8_t *in_host, size_t bytes) {
     if (bytes < sizeof(StateHeader)) return fail(XWB_ERR_ARG, "not a state blob");
     StateHeader h;
     memcpy(&h, in_host, sizeof h);
-    if (memcmp(h.magic, "XWBSTATE", 8) != 0 || h.version != 2) return fail(XWB_ERR_ARG, "not a state blob of this version");
+    if (memcmp(h.magic, "XWBSTATE", 8) != 0) return fail(XWB_ERR_ARG, "not a state blob");
+    if (h.version != XWB_STATE_VERSION)
+        return fail(XWB_ERR_ARG, "state blob version " + std::to_string(h.version) + ", this library reads version " + std::to_string(XWB_STATE_VERSION) +
+                                 " (the array layout changed: save again with this library)");
     if (h.game != (uint32_t)s->cfg.game || h.num_envs != (uint32_t)s->n || h.obs_bytes_per_env != s->obs_bytes_per_env ||
         h.cfg_hash != config_hash(s->cfg))
         return fail(XWB_ERR_ARG, "state blob was saved from a batch with another configuration");
@@ -1900,6 +1954,7 @@ int xwb_load_state(xwb_sim *s, const uint8_t *in_host, size_t bytes) {
         r += b;
     }
     s->shadow_ok = false; s->regen_pending = false; s->step_lazy = false;
+    s->frame_src = 0; s->draws_since_pack = 0;
     s->policy_step = h.policy_step; s->count_sel = (int)(h.count_sel & 1u); s->list_valid = (h.list_valid & 1u) != 0; s->autoreset_done = (h.list_valid & 2u) != 0;
     if (s->cfg.game == XWB_XWORLD2D) {
         XwParams p = xw_params(s);
@@ -2127,10 +2182,47 @@ int xwb_xw_get_tile_table(const xwb_sim *s, uint8_t *out_host, size_t cap, size_
     return XWB_OK;
 }
 
+int xwb_xw_pack_grids(xwb_sim *s, uint16_t *grids_dev, uint8_t *flags_dev, void *stream) {
+    if (!s || !grids_dev) return fail(XWB_ERR_ARG, "NULL argument");
+    XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
+    if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
+    if (s->cfg.visible_radius) return fail(XWB_ERR_STATE, "egocentric frames are not a function of the cell codes alone (heading, goal poses, shadows): gather the screens");
+    if (s->cfg.context > 1) {
+        if (!flags_dev) return fail(XWB_ERR_ARG, "context > 1 needs the ring flags");
+        if (s->draws_since_pack != 1)
+            return fail(XWB_ERR_STATE, "context > 1: the draw state must be packed after EVERY verb that draws frames (a context ring is "
+                                       "replayed one draw at a time); re-synchronise with the screens themselves");
+    }
+    // (everything a verb leaves behind on the side queue writes the pre-generated episodes, never the live state read here)
+    HIP_TRY(launch_xw_pack_grids(xw_params(s), s->frame_src, grids_dev, flags_dev, as_stream(stream)));
+    s->draws_since_pack = 0;
+    return XWB_OK;
+}
+
+int xwb_xw_render_grids(xwb_sim *s, const uint16_t *grids_dev, const uint8_t *flags_dev, int32_t n_envs, void *obs_dev, void *stream) {
+    if (!s || !grids_dev || !obs_dev) return fail(XWB_ERR_ARG, "NULL argument");
+    XWB_ON_DEVICE(s);
+    if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch");
+    if (s->cfg.visible_radius) return fail(XWB_ERR_STATE, "egocentric batches cannot render from cell codes alone");
+    if (n_envs < 1) return fail(XWB_ERR_ARG, "n_envs must be >= 1");
+    if (s->cfg.context > 1 && !flags_dev) return fail(XWB_ERR_ARG, "context > 1 needs the ring flags");
+    if (reinterpret_cast<uintptr_t>(obs_dev) & 15u) return fail(XWB_ERR_ARG, "obs buffer must be 16-byte aligned");
+    if (reinterpret_cast<uintptr_t>(grids_dev) & 1u) return fail(XWB_ERR_ARG, "grids must be 2-byte aligned");
+    XwParams q = xw_params(s);
+    q.n = n_envs;
+    q.grid = const_cast<uint16_t *>(grids_dev);
+    q.fresh = const_cast<uint8_t *>(flags_dev);
+    q.obs = static_cast<uint8_t *>(obs_dev);
+    q.sig_epoch = 0; q.wait_epoch = 0; q.packed = nullptr;
+    HIP_TRY(launch_xw_render(q, 0, as_stream(stream)));
+    return XWB_OK;
+}
+
 int xwb_profile_begin(xwb_sim *s) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
     s->profiling = true;
-    s->t_render.used = s->t_step.used = s->t_reset.used = 0;
+    s->t_render.used = s->t_step.used = s->t_reset.used = s->t_list.used = 0;
     return XWB_OK;
 }
 
@@ -2141,7 +2233,8 @@ int xwb_profile_end(xwb_sim *s, void *stream, const char *kernel, double *avg_us
     if (!strcmp(kernel, "render")) t = &s->t_render;
     else if (!strcmp(kernel, "step")) t = &s->t_step;
     else if (!strcmp(kernel, "reset")) t = &s->t_reset;
-    else return fail(XWB_ERR_ARG, "kernel must be render | step | reset");
+    else if (!strcmp(kernel, "list")) t = &s->t_list;
+    else return fail(XWB_ERR_ARG, "kernel must be render | step | reset | list");
     HIP_TRY(hipStreamSynchronize(as_stream(stream)));
     double total_ms = 0;
     for (size_t i = 0; i < t->used; ++i) {

@@ -19,6 +19,8 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <functional>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -43,25 +45,27 @@ struct Rccl {
     std::string error;
 };
 
+// resolved once per process; the function-local static's initialiser runs exactly once even when several threads create
+// their first communicator together (one thread per GPU is the pattern this API targets)
 Rccl *rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return &r;
-    tried = true;
-    // the RCCL this process already runs (a communicator handed to xwb_comm_adopt belongs to it), else the system's
-    const char *names[] = {"librccl.so.1", "librccl.so"};
-    for (const char *n : names) if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-    for (const char *n : names) if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (!r.handle) { r.error = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return &r; }
-    bool ok = true;
-    auto sym = [&](const char *name) { void *p = dlsym(r.handle, name); if (!p) { ok = false; r.error = std::string("RCCL lacks ") + name; } return p; };
-#define XWB_RCCL_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(sym(name))
-    XWB_RCCL_SYM(GetVersion, "ncclGetVersion"); XWB_RCCL_SYM(GetUniqueId, "ncclGetUniqueId"); XWB_RCCL_SYM(CommInitRank, "ncclCommInitRank");
-    XWB_RCCL_SYM(CommDestroy, "ncclCommDestroy"); XWB_RCCL_SYM(CommCount, "ncclCommCount"); XWB_RCCL_SYM(CommUserRank, "ncclCommUserRank");
-    XWB_RCCL_SYM(GroupStart, "ncclGroupStart"); XWB_RCCL_SYM(GroupEnd, "ncclGroupEnd"); XWB_RCCL_SYM(Send, "ncclSend"); XWB_RCCL_SYM(Recv, "ncclRecv");
-    XWB_RCCL_SYM(AllGather, "ncclAllGather"); XWB_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+    static Rccl r = [] {
+        Rccl t;
+        // the RCCL this process already runs (a communicator handed to xwb_comm_adopt belongs to it), else the system's
+        const char *names[] = {"librccl.so.1", "librccl.so"};
+        for (const char *n : names) if (!t.handle) t.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        for (const char *n : names) if (!t.handle) t.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!t.handle) { const char *e = dlerror(); t.error = std::string("librccl.so.1 not found: ") + (e ? e : ""); return t; }
+        bool ok = true;
+        auto sym = [&](const char *name) { void *p = dlsym(t.handle, name); if (!p) { ok = false; t.error = std::string("RCCL lacks ") + name; } return p; };
+#define XWB_RCCL_SYM(field, name) t.field = reinterpret_cast<decltype(t.field)>(sym(name))
+        XWB_RCCL_SYM(GetVersion, "ncclGetVersion"); XWB_RCCL_SYM(GetUniqueId, "ncclGetUniqueId"); XWB_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+        XWB_RCCL_SYM(CommDestroy, "ncclCommDestroy"); XWB_RCCL_SYM(CommCount, "ncclCommCount"); XWB_RCCL_SYM(CommUserRank, "ncclCommUserRank");
+        XWB_RCCL_SYM(GroupStart, "ncclGroupStart"); XWB_RCCL_SYM(GroupEnd, "ncclGroupEnd"); XWB_RCCL_SYM(Send, "ncclSend"); XWB_RCCL_SYM(Recv, "ncclRecv");
+        XWB_RCCL_SYM(AllGather, "ncclAllGather"); XWB_RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef XWB_RCCL_SYM
-    if (!ok) r.handle = nullptr;
+        if (!ok) t.handle = nullptr;
+        return t;
+    }();
     return &r;
 }
 
@@ -97,7 +101,28 @@ struct xwb_comm {
     hipStream_t stream = nullptr;          // the exchange runs here, beside the caller's stream
     hipEvent_t ready = nullptr, done = nullptr;
     int in_flight = 0;                     // begins since the last end (several shards may share one communicator)
+    int group_depth = 0;                   // xwb_comm_group_start calls not yet ended: RCCL enqueues their operations at the
+    std::vector<std::function<int()>> after_group;   // outermost end, so what must FOLLOW a transfer on `stream` waits here
+    hipEvent_t marks[XWB_COMM_MARKS] = {};
+    bool mark_set[XWB_COMM_MARKS] = {};
+    // xwb_gather_grids_begin: per batch that gathers through this communicator (one, unless shards share a rank), two staging
+    // slabs that alternate (the draw state a shard sends; on the root the gathered state its render reads);
+    // done[k] = the transfer / render that last read slab k
+    struct Slabs {
+        void *slab[2] = {nullptr, nullptr};
+        size_t bytes[2] = {0, 0};
+        hipEvent_t done[2] = {nullptr, nullptr};
+        bool busy[2] = {false, false};
+        int next = 0;
+    };
+    std::map<const xwb_sim *, Slabs> slabs;
 };
+
+// runs `f` behind the transfers begun so far on c->stream: now, or when the caller's outermost group ends
+static int after_transfers(xwb_comm *c, std::function<int()> f) {
+    if (c->group_depth > 0) { c->after_group.push_back(std::move(f)); return XWB_OK; }
+    return f();
+}
 
 extern "C" {
 
@@ -127,6 +152,7 @@ static int finish_comm(xwb_comm *c) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    for (auto &m : c->marks) HIP_TRY(hipEventCreateWithFlags(&m, hipEventDisableTiming));
     return XWB_OK;
 }
 
@@ -172,6 +198,12 @@ int xwb_comm_destroy(xwb_comm *c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->ready) (void)hipEventDestroy(c->ready);
     if (c->done) (void)hipEventDestroy(c->done);
+    for (auto m : c->marks) if (m) (void)hipEventDestroy(m);
+    for (auto &kv : c->slabs)
+        for (int k = 0; k < 2; ++k) {
+            if (kv.second.done[k]) (void)hipEventDestroy(kv.second.done[k]);
+            if (kv.second.slab[k]) (void)hipFree(kv.second.slab[k]);
+        }
     delete c;
     return XWB_OK;
 }
@@ -187,13 +219,43 @@ int xwb_comm_group_start(xwb_comm *c) {
     if (!c) return fail(XWB_ERR_ARG, "NULL argument");
     Rccl *R = rccl();
     RCCL_TRY(R->GroupStart());
+    c->group_depth += 1;
     return XWB_OK;
 }
 
 int xwb_comm_group_end(xwb_comm *c) {
     if (!c) return fail(XWB_ERR_ARG, "NULL argument");
+    if (c->group_depth < 1) return fail(XWB_ERR_STATE, "xwb_comm_group_end without xwb_comm_group_start");
     Rccl *R = rccl();
-    RCCL_TRY(R->GroupEnd());
+    c->group_depth -= 1;
+    ncclResult_t e = R->GroupEnd();
+    if (c->group_depth > 0) { if (e != ncclSuccess) return fail(XWB_ERR_HIP, std::string("ncclGroupEnd: ") + R->GetErrorString(e)); return XWB_OK; }
+    std::vector<std::function<int()>> todo;
+    todo.swap(c->after_group);
+    if (e != ncclSuccess) return fail(XWB_ERR_HIP, std::string("ncclGroupEnd: ") + R->GetErrorString(e));
+    DeviceGuard g(c->device);
+    for (auto &f : todo) { const int rc = f(); if (rc) return rc; }      // the transfers are on c->stream now
+    return XWB_OK;
+}
+
+int xwb_comm_mark(xwb_comm *c, int32_t slot) {
+    if (!c) return fail(XWB_ERR_ARG, "NULL argument");
+    if (slot < 0 || slot >= XWB_COMM_MARKS) return fail(XWB_ERR_ARG, "mark slot out of range");
+    DeviceGuard g(c->device);
+    return after_transfers(c, [c, slot]() -> int {
+        HIP_TRY(hipEventRecord(c->marks[slot], c->stream));
+        c->mark_set[slot] = true;
+        return XWB_OK;
+    });
+}
+
+int xwb_comm_wait(xwb_comm *c, int32_t slot, void *stream) {
+    if (!c) return fail(XWB_ERR_ARG, "NULL argument");
+    if (slot < 0 || slot >= XWB_COMM_MARKS) return fail(XWB_ERR_ARG, "mark slot out of range");
+    if (c->group_depth > 0) return fail(XWB_ERR_STATE, "xwb_comm_wait inside an open group: its marks are not recorded yet");
+    if (!c->mark_set[slot]) return XWB_OK;
+    DeviceGuard g(c->device);
+    HIP_TRY(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), c->marks[slot], 0));
     return XWB_OK;
 }
 
@@ -223,16 +285,23 @@ int xwb_gather_results(xwb_comm *c, const float *packed_dev, float *all_dev, con
         RCCL_TRY(R->AllGather(packed_dev, all_dev, (size_t)counts[0] * 2, ncclFloat32, c->comm, st));
         return XWB_OK;
     }
-    // ragged shards / several shards per rank: every holder sends its rows to every other holder's rank, one group
+    // ragged shards / several shards per rank, one group.  Both sides apply the same two rules, so every send has its receive:
+    //   shard a SENDS its rows to the rank of every shard b that lives on another rank, iff counts[a] > 0;
+    //   shard b RECEIVES the rows of every shard a that lives on another rank, iff counts[a] > 0
+    // (an empty shard sends nothing and still receives; rows of shards on the caller's own rank are never sent -- those shards
+    // share the caller's all_dev, see xwb.h).  Between two ranks RCCL matches sends and receives in issue order: shards that
+    // share a rank call in ascending shard order.
     std::vector<size_t> off(n_shards + 1, 0);
     for (int i = 0; i < n_shards; ++i) off[i + 1] = off[i] + (size_t)counts[i];
     const int me = peers ? peers[shard] : shard;
-    HIP_TRY(hipMemcpyAsync(all_dev + off[shard] * 2, packed_dev, (size_t)counts[shard] * 8, hipMemcpyDeviceToDevice, st));
+    if (counts[shard] > 0)
+        HIP_TRY(hipMemcpyAsync(all_dev + off[shard] * 2, packed_dev, (size_t)counts[shard] * 8, hipMemcpyDeviceToDevice, st));
     RCCL_TRY(R->GroupStart());
     for (int i = 0; i < n_shards; ++i) {
         const int p = peers ? peers[i] : i;
-        if (i == shard || p == me || counts[i] == 0) continue;
-        ncclResult_t e = R->Recv(all_dev + off[i] * 2, (size_t)counts[i] * 2, ncclFloat32, p, c->comm, st);
+        if (i == shard || p == me) continue;
+        ncclResult_t e = ncclSuccess;
+        if (counts[i] > 0) e = R->Recv(all_dev + off[i] * 2, (size_t)counts[i] * 2, ncclFloat32, p, c->comm, st);
         if (e == ncclSuccess && counts[shard] > 0) e = R->Send(packed_dev, (size_t)counts[shard] * 2, ncclFloat32, p, c->comm, st);
         if (e != ncclSuccess) { (void)R->GroupEnd(); return fail(XWB_ERR_HIP, std::string("ncclSend / ncclRecv: ") + R->GetErrorString(e)); }
     }
@@ -240,31 +309,54 @@ int xwb_gather_results(xwb_comm *c, const float *packed_dev, float *all_dev, con
     return XWB_OK;
 }
 
-int xwb_gather_screens_begin(xwb_sim *sim, xwb_comm *c, void *dst_dev, const int32_t *counts, const int32_t *peers, int32_t n_shards,
-                             int32_t shard, int32_t root_shard, void *stream) {
+// what the two gathers of frames share: arguments, the hand-over from `stream` to the communicator's stream
+struct GatherCtx {
+    int32_t n = 0;
+    size_t bpe = 0;
+    void *obs = nullptr;
+    int root_peer = 0, me = 0;
+    hipStream_t st = nullptr;
+};
+
+static int gather_prologue(xwb_sim *sim, xwb_comm *c, void *dst_dev, const int32_t *counts, const int32_t *peers, int32_t n_shards,
+                           int32_t shard, int32_t root_shard, void *stream, GatherCtx *x) {
     int rc = check_layout(c, counts, peers, n_shards, shard);
     if (rc) return rc;
     if (!sim) return fail(XWB_ERR_ARG, "NULL argument");
     if (root_shard < 0 || root_shard >= n_shards) return fail(XWB_ERR_ARG, "root_shard out of range");
-    void *obs = nullptr;
-    size_t bpe = 0;
-    int32_t n = 0;
-    if ((rc = xwb_obs_dev(sim, &obs, &bpe)) || (rc = xwb_num_envs(sim, &n))) return rc;
-    if (n != counts[shard]) return fail(XWB_ERR_ARG, "counts[shard] is not this batch's num_envs");
+    if ((rc = xwb_obs_dev(sim, &x->obs, &x->bpe)) || (rc = xwb_num_envs(sim, &x->n))) return rc;
+    if (x->n != counts[shard]) return fail(XWB_ERR_ARG, "counts[shard] is not this batch's num_envs");
     if (shard == root_shard && !dst_dev) return fail(XWB_ERR_ARG, "the root needs the destination tensor");
+    x->root_peer = peers ? peers[root_shard] : root_shard;
+    x->me = peers ? peers[shard] : shard;
+    x->st = reinterpret_cast<hipStream_t>(stream);
+    // A shard on the root's own rank reaches the root by a send to that rank, which only a receive of the SAME group matches
+    bool self_exchange = shard != root_shard && x->me == x->root_peer;
+    if (shard == root_shard)
+        for (int i = 0; i < n_shards; ++i) self_exchange = self_exchange || (i != root_shard && counts[i] > 0 && (peers ? peers[i] : i) == x->root_peer);
+    if (self_exchange && c->group_depth < 1)
+        return fail(XWB_ERR_STATE, "shards that share the root's rank gather inside xwb_comm_group_start / _end");
+    return XWB_OK;
+}
+
+int xwb_gather_screens_begin(xwb_sim *sim, xwb_comm *c, void *dst_dev, const int32_t *counts, const int32_t *peers, int32_t n_shards,
+                             int32_t shard, int32_t root_shard, void *stream) {
+    GatherCtx x;
+    int rc = gather_prologue(sim, c, dst_dev, counts, peers, n_shards, shard, root_shard, stream, &x);
+    if (rc) return rc;
     Rccl *R = rccl();
     DeviceGuard g(c->device);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int32_t n = x.n;
+    const size_t bpe = x.bpe;
     // the frames are complete in `stream` order; the transfer runs on the communicator's stream from there on
-    HIP_TRY(hipEventRecord(c->ready, st));
+    HIP_TRY(hipEventRecord(c->ready, x.st));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ready, 0));
     std::vector<size_t> off(n_shards + 1, 0);
     for (int i = 0; i < n_shards; ++i) off[i + 1] = off[i] + (size_t)counts[i] * bpe;
-    const int root_peer = peers ? peers[root_shard] : root_shard, me = peers ? peers[shard] : shard;
     uint8_t *dst = static_cast<uint8_t *>(dst_dev);
     if (shard == root_shard) {
-        if (dst + off[shard] != obs)                  // (bound into its slice with xwb_bind_obs: nothing to copy)
-            HIP_TRY(hipMemcpyAsync(dst + off[shard], obs, (size_t)n * bpe, hipMemcpyDeviceToDevice, c->stream));
+        if (dst + off[shard] != x.obs)                // (bound into its slice with xwb_bind_obs: nothing to copy)
+            HIP_TRY(hipMemcpyAsync(dst + off[shard], x.obs, (size_t)n * bpe, hipMemcpyDeviceToDevice, c->stream));
         RCCL_TRY(R->GroupStart());
         for (int i = 0; i < n_shards; ++i) {
             if (i == root_shard || counts[i] == 0) continue;
@@ -274,15 +366,87 @@ int xwb_gather_screens_begin(xwb_sim *sim, xwb_comm *c, void *dst_dev, const int
         }
         RCCL_TRY(R->GroupEnd());
     } else if (n > 0) {
-        (void)me;
-        RCCL_TRY(R->Send(obs, (size_t)n * bpe, ncclUint8, root_peer, c->comm, c->stream));
+        RCCL_TRY(R->Send(x.obs, (size_t)n * bpe, ncclUint8, x.root_peer, c->comm, c->stream));
     }
     c->in_flight += 1;          // (the completion event is recorded by xwb_gather_screens_end: inside a caller's group the
     return XWB_OK;              //  operations above are only enqueued when the outermost group ends)
 }
 
+int xwb_gather_grids_begin(xwb_sim *sim, xwb_comm *c, void *dst_dev, const int32_t *counts, const int32_t *peers, int32_t n_shards,
+                           int32_t shard, int32_t root_shard, void *stream) {
+    GatherCtx x;
+    int rc = gather_prologue(sim, c, dst_dev, counts, peers, n_shards, shard, root_shard, stream, &x);
+    if (rc) return rc;
+    double X = 0, Y = 0;
+    if ((rc = xwb_get_world_dimensions(sim, &X, &Y, nullptr))) return rc;      // (fails for the games that have no grid)
+    const size_t cells = (size_t)X * (size_t)Y;
+    Rccl *R = rccl();
+    DeviceGuard g(c->device);
+    const bool root = shard == root_shard;
+    size_t total = 0, first = 0;
+    for (int i = 0; i < n_shards; ++i) { if (i < shard) first += (size_t)counts[i]; total += (size_t)counts[i]; }
+    // slab layout: cell codes uint16[envs][cells], then one flag byte per env; the root's slab holds every shard's rows
+    const size_t envs = root ? total : (size_t)x.n;
+    const size_t grid_bytes = (envs * cells * 2 + 15) & ~(size_t)15, need = grid_bytes + ((envs + 15) & ~(size_t)15);
+    xwb_comm::Slabs &sl = c->slabs[sim];
+    const int k = sl.next;
+    sl.next ^= 1;
+    if (!sl.done[k]) HIP_TRY(hipEventCreateWithFlags(&sl.done[k], hipEventDisableTiming));
+    if (sl.bytes[k] < need) {
+        if (c->group_depth > 0 && sl.busy[k])
+            return fail(XWB_ERR_STATE, "the gather's layout grew inside an open group while a transfer of this batch is still queued");
+        HIP_TRY(hipStreamSynchronize(c->stream));                              // (grows on first use / when the layout grows)
+        if (sl.slab[k]) HIP_TRY(hipFree(sl.slab[k]));
+        sl.slab[k] = nullptr; sl.bytes[k] = 0; sl.busy[k] = false;
+        HIP_TRY(hipMalloc(&sl.slab[k], need));
+        sl.bytes[k] = need;
+    }
+    // the transfer (root: the render) that last read this slab is over before this step's state is packed into it
+    if (sl.busy[k]) HIP_TRY(hipStreamWaitEvent(x.st, sl.done[k], 0));
+    uint16_t *grids = static_cast<uint16_t *>(sl.slab[k]);
+    uint8_t *flags = static_cast<uint8_t *>(sl.slab[k]) + grid_bytes;
+    const size_t row0 = root ? first : 0;
+    if (x.n > 0 && (rc = xwb_xw_pack_grids(sim, grids + row0 * cells, flags + row0, x.st))) return rc;
+    HIP_TRY(hipEventRecord(c->ready, x.st));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ready, 0));
+    if (root) {
+        RCCL_TRY(R->GroupStart());
+        size_t row = 0;
+        for (int i = 0; i < n_shards; ++i) {
+            const size_t cnt = (size_t)counts[i];
+            if (i != root_shard && cnt > 0) {
+                const int p = peers ? peers[i] : i;
+                ncclResult_t e = R->Recv(grids + row * cells, cnt * cells * 2, ncclUint8, p, c->comm, c->stream);
+                if (e == ncclSuccess) e = R->Recv(flags + row, cnt, ncclUint8, p, c->comm, c->stream);
+                if (e != ncclSuccess) { (void)R->GroupEnd(); return fail(XWB_ERR_HIP, std::string("ncclRecv: ") + R->GetErrorString(e)); }
+            }
+            row += cnt;
+        }
+        RCCL_TRY(R->GroupEnd());
+    } else if (x.n > 0) {
+        RCCL_TRY(R->GroupStart());
+        ncclResult_t e = R->Send(grids, (size_t)x.n * cells * 2, ncclUint8, x.root_peer, c->comm, c->stream);
+        if (e == ncclSuccess) e = R->Send(flags, (size_t)x.n, ncclUint8, x.root_peer, c->comm, c->stream);
+        if (e != ncclSuccess) { (void)R->GroupEnd(); return fail(XWB_ERR_HIP, std::string("ncclSend: ") + R->GetErrorString(e)); }
+        RCCL_TRY(R->GroupEnd());
+    }
+    c->in_flight += 1;
+    sl.busy[k] = true;
+    hipEvent_t slab_done = sl.done[k];
+    // behind the transfers: the root draws the whole batch from the gathered state; the slab is free again after that
+    return after_transfers(c, [=]() -> int {
+        if (root && total > 0) {
+            const int rr = xwb_xw_render_grids(sim, grids, flags, (int32_t)total, dst_dev, c->stream);
+            if (rr) return rr;
+        }
+        HIP_TRY(hipEventRecord(slab_done, c->stream));
+        return XWB_OK;
+    });
+}
+
 int xwb_gather_screens_end(xwb_comm *c, void *stream) {
     if (!c) return fail(XWB_ERR_ARG, "NULL argument");
+    if (c->group_depth > 0) return fail(XWB_ERR_STATE, "xwb_gather_screens_end inside an open group: the transfers are not enqueued yet");
     if (!c->in_flight) return XWB_OK;
     DeviceGuard g(c->device);
     HIP_TRY(hipEventRecord(c->done, c->stream));

@@ -308,6 +308,8 @@ hipError_t launch_xw_reset(const XwParams &p, int mode, hipStream_t s, hipEvent_
                            uint32_t warp_epoch = 0, int defer_warp = 0);
 // compaction of done[] (mode RESET_DONE) or mask (RESET_MASK) into done_list / done_count
 hipError_t launch_xw_compact(const XwParams &p, int mode, hipStream_t s);
+// the batch's draw state (cell codes its current frames show + context-ring flags) for a renderer elsewhere; src: see the kernel
+hipError_t launch_xw_pack_grids(const XwParams &p, int src, uint16_t *out_grid, uint8_t *out_flag, hipStream_t s);
 // render: indexed == 0 -> all envs (LDS-resident atlas, persistent workgroups);
 //         indexed == 1 -> envs in done_list (atlas through L2)
 // indexed: 0 = every env, 1 = the compacted done list, 2 = every env whose done code is 0 (the rest follows as a list),

@@ -16,7 +16,8 @@ XWB_MAP_NAV, XWB_MAP_WALLS = 0, 1
 XWB_TASKMODE_LANG_ACQ, XWB_TASKMODE_ONE_CHANNEL = 0, 1
 ALIVE, MAX_STEP, DEAD, SUCCESS, LOST_LIFE = 0, 1, 2, 4, 8
 XWB_QUEUE_SYNC_AUTO, XWB_QUEUE_SYNC_EVENTS, XWB_QUEUE_SYNC_EPOCHS = 0, 1, 2
-SYNC_REASONS = ["probe_ok", "config", "env", "tool", "probe_failed", "probe_error", "not_used"]
+STEP_PATHS = ["none", "classic", "lazy", "pregen", "ego_span", "ego_per_env"]
+SYNC_REASONS = ["probe_ok", "config", "env", "tool", "probe_failed", "probe_error", "not_used", "not_probed"]
 
 
 class XwbConfig(C.Structure):
@@ -82,6 +83,8 @@ _SIGS = [
     ("xwb_step_autoreset", C.c_int, [_vp, _vp, C.c_int32, _vp]),
     ("xwb_check_errors", C.c_int, [_vp, _vp, C.POINTER(C.c_int32)]),
     ("xwb_queue_sync_mode", C.c_int, [_vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("xwb_queue_sync_forget", C.c_int, [_vp, _vp]),
+    ("xwb_step_path", C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("xwb_debug_stall_handoff", C.c_int, [_vp, _vp, C.c_int64]),
     ("xwb_obs_dev", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     ("xwb_bind_results", C.c_int, [_vp, _vp]),
@@ -145,6 +148,11 @@ _SIGS = [
     ("xwb_gather_results", C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32, _vp]),
     ("xwb_gather_screens_begin", C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, _vp]),
     ("xwb_gather_screens_end", C.c_int, [_vp, _vp]),
+    ("xwb_gather_grids_begin", C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, _vp]),
+    ("xwb_comm_mark", C.c_int, [_vp, C.c_int32]),
+    ("xwb_comm_wait", C.c_int, [_vp, C.c_int32, _vp]),
+    ("xwb_xw_pack_grids", C.c_int, [_vp, _vp, _vp, _vp]),
+    ("xwb_xw_render_grids", C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, _vp]),
     ("xwb_last_error", C.c_char_p, []),
     ("xwb_version", C.c_char_p, []),
 ]

@@ -329,14 +329,20 @@ class LibComm:
 
 
 class LibScreensGather:
-    """ScreensGather through xwb_gather_screens_begin / _end: same protocol (bind_next / start / latest / drain), same
-    double buffering; the transfers run on the communicator's own stream inside the library."""
+    """ScreensGather through the library (xwb_gather_screens_begin, or mode="grids": xwb_gather_grids_begin -- every shard
+    ships its cell codes, 2 * max_dim^2 + 1 bytes per env, and the root draws all frames itself): same protocol (bind_next /
+    start / latest / drain), same double buffering; the transfers run on the communicator's own stream inside the library.
+    Every destination buffer has its own completion mark (xwb_comm_mark / xwb_comm_wait): waiting for buffer k does not wait
+    for the transfer begun after it, so transfer t really runs beside the kernels of step t + 1.  `stream`: the stream the
+    simulator's verbs are issued on (None = the default stream); begin and the waits are ordered on it."""
 
-    def __init__(self, sim, comm, counts, rank, dst=0, depth=None):
+    def __init__(self, sim, comm, counts, rank, dst=0, depth=None, mode="screens", stream=None):
         import ctypes as C
         from . import lib
-        self.C, self.lib = C, lib
+        assert mode in ("screens", "grids")
+        self.C, self.lib, self.mode = C, lib, mode
         self.sim, self.comm, self.counts, self.rank, self.dst = sim, comm, list(counts), rank, dst
+        self.stream = stream
         self.depth = 2 if sim.cfg.context == 1 else 1
         if depth is not None:
             self.depth = int(depth)
@@ -346,32 +352,43 @@ class LibScreensGather:
         self.off = sum(counts[:rank])
         if rank == dst:
             self.full = [torch.zeros((sum(counts),) + shape, dtype=dtype, device=device) for _ in range(self.depth)]
-            self.local = [f[self.off:self.off + n] for f in self.full]
         else:
             self.full = [None] * self.depth
+        if mode == "grids":
+            # every shard keeps drawing into its own buffer; the root's tensor is drawn by the root from the gathered codes
+            self.local = [None] * self.depth
+        elif rank == dst:
+            self.local = [f[self.off:self.off + n] for f in self.full]
+        else:
             self.local = [torch.zeros((n,) + shape, dtype=dtype, device=device) for _ in range(self.depth)]
         self.c_counts = (C.c_int32 * len(counts))(*counts)
         self.busy = [False] * self.depth
         self.k = self.depth - 1
         self.done_k = None
 
+    def _sp(self):
+        s = self.stream
+        return None if s is None else self.C.c_void_p(int(getattr(s, "cuda_stream", s)))
+
     def _end(self, k):
-        # (one communicator stream: ending the newest transfer also orders the older ones)
         if self.busy[k]:
-            self.lib.check(self.comm.L.xwb_gather_screens_end(self.comm.h, None))
-            self.busy = [False] * self.depth
+            self.lib.check(self.comm.L.xwb_comm_wait(self.comm.h, k, self._sp()))
+            self.busy[k] = False
             self.done_k = k
 
     def bind_next(self):
         self.k = (self.k + 1) % self.depth
         self._end(self.k)
-        self.sim.bind_obs(self.local[self.k])
+        if self.local[self.k] is not None:
+            self.sim.bind_obs(self.local[self.k])
 
     def start(self):
         C = self.C
         dst = self.full[self.k]
-        self.lib.check(self.comm.L.xwb_gather_screens_begin(self.sim.h, self.comm.h, C.c_void_p(dst.data_ptr()) if dst is not None else None,
-                                                            self.c_counts, None, len(self.counts), self.rank, self.dst, None))
+        begin = self.comm.L.xwb_gather_grids_begin if self.mode == "grids" else self.comm.L.xwb_gather_screens_begin
+        self.lib.check(begin(self.sim.h, self.comm.h, C.c_void_p(dst.data_ptr()) if dst is not None else None,
+                             self.c_counts, None, len(self.counts), self.rank, self.dst, self._sp()))
+        self.lib.check(self.comm.L.xwb_comm_mark(self.comm.h, self.k))
         self.busy[self.k] = True
         if self.depth == 1:
             self._end(self.k)
@@ -382,10 +399,46 @@ class LibScreensGather:
         return self.full[k] if (self.rank == self.dst and self.done_k is not None) else None
 
     def drain(self):
-        for k in range(self.depth):
-            self._end(k)
+        for i in range(self.depth):
+            self._end((self.k + 1 + i) % self.depth)
         self.done_k = self.k
         return self.full[self.k] if self.rank == self.dst else None
+
+
+class GridsGather:
+    """The grids gather over torch.distributed (any backend): every shard packs its draw state (BatchedSimulator.pack_grids),
+    the packed rows travel with gather_slabs, the root draws the whole batch (render_grids) into ONE contiguous tensor.
+    Synchronous per step (the packed rows are a few MB: C5 7.9 MB per shard); the library path (LibScreensGather
+    mode="grids") is the pipelined one.  context > 1: call after every verb that draws frames."""
+
+    def __init__(self, sim, counts, rank, dst=0, group=None):
+        self.sim, self.counts, self.rank, self.dst, self.group = sim, list(counts), rank, dst, group
+        d = sim.cfg.max_dim
+        n, device = counts[rank], sim.obs.device
+        self.total = sum(counts)
+        # one row per env: cell codes as 2 * d * d bytes, then the ring flag, then a pad byte (rows stay 2-byte aligned)
+        self.row = 2 * d * d + 2
+        self.cells = d * d
+        self.grids = torch.zeros((n, d * d), dtype=torch.int16, device=device)
+        self.flags = torch.zeros((n,), dtype=torch.uint8, device=device)
+        self.rows = torch.zeros((n, self.row), dtype=torch.uint8, device=device)
+        if rank == dst:
+            self.all_rows = torch.zeros((self.total, self.row), dtype=torch.uint8, device=device)
+            self.full = torch.zeros((self.total,) + tuple(sim.obs.shape[1:]), dtype=sim.obs.dtype, device=device)
+        else:
+            self.all_rows = self.full = None
+
+    def __call__(self):
+        self.sim.pack_grids(self.grids, self.flags)
+        self.rows[:, :2 * self.cells] = self.grids.view(torch.uint8).view(-1, 2 * self.cells)
+        self.rows[:, 2 * self.cells] = self.flags
+        gather_slabs(self.rows, self.all_rows, self.counts, self.rank, self.dst, self.group)
+        if self.rank != self.dst:
+            return None
+        g = self.all_rows[:, :2 * self.cells].contiguous().view(torch.int16).view(self.total, self.cells)
+        f = self.all_rows[:, 2 * self.cells].contiguous()
+        self.sim.render_grids(g, f, self.full)
+        return self.full
 
 
 def lib_gather_results(comm, packed, out, counts, rank):
