@@ -116,6 +116,29 @@ def measured_traffic(workload):
                                            "traffic_stale": t.get("source_sha16") != now}
 
 
+def write_ceiling(nbytes, dev, reps=24):
+    """The bandwidth anchor of THIS run: a pure write stream of the observation batch's size (hipMemsetAsync through
+    torch.Tensor.zero_, and a fill kernel), timed with events on the current stream, in this process, on this box, before the
+    timed regions -- what `roofline.achieved` can be read against besides the 8 TB/s spec."""
+    import torch
+    buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    out = {}
+    for name, fn in (("memset", lambda: buf.zero_()), ("fill_kernel", lambda: buf.fill_(7))):
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) / reps * 1e3
+        out[name] = {"us": us, "GBps": nbytes / us / 1e3}
+    del buf
+    return out
+
+
 def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
@@ -201,6 +224,57 @@ def cpu_baseline(workload, seed, seconds_target=8.0):
                       "in %.1f s; one thread alone: %d env-steps in %.1f s" % (done, workload, cores, wall, n * steps, dt)}
 
 
+def gather_block(sim, mode, lib_comm, depth, world, n_local, steps, sg_regions):
+    """One screens_gather block from its timed regions: what crossed the links, the bound that applies, the ceilings."""
+    shard_bytes = n_local * sim.obs_bytes_per_env
+    sg_med = statistics.median(sg_regions)
+    if mode == "screens":
+        link_bytes = shard_bytes
+        bound = {"bound": "xGMI link (every remote shard has ONE link to the root)"}
+    else:
+        link_bytes = n_local * (2 * sim.cfg.max_dim ** 2 + 1)
+        # the root writes every frame of the whole batch once more: its HBM write stream bounds the step
+        root_s = world * shard_bytes / (HBM_PEAK_GBS * 1e9)
+        bound = {"bound": "the root's HBM write stream (it draws all %d frames from the gathered cell codes)" % (n_local * world),
+                 "root_render_bound_ms_per_step": root_s * 1e3, "root_render_bound_ceiling": n_local * world / root_s}
+    link_s = link_bytes / (XGMI_LINK_GBS * 1e9)
+    if lib_comm is not None:
+        by = "libxwb.so (xwb_gather_%s_begin + xwb_comm_mark / _wait: ncclSend / ncclRecv on the communicator's stream)" % mode
+    elif mode == "grids":
+        by = "torch.distributed batch_isend_irecv of the packed cell codes + xwb_xw_render_grids on the root (sharding.GridsGather)"
+    else:
+        by = "torch.distributed batch_isend_irecv"
+    return {"mode": mode, "ms_per_step": sg_med / steps * 1e3, "value": n_local * world * steps / sg_med, "unit": "env-steps/s",
+            "bytes_into_root_per_step": link_bytes * (world - 1), "link_bound_ms_per_step": link_s * 1e3,
+            "link_bound_ceiling": n_local * world / link_s, "link_GBps_assumed": XGMI_LINK_GBS,
+            "achieved_GBps_per_link": link_bytes / (sg_med / steps) / 1e9,
+            "overlap": "double-buffered: transfer of step t beside the kernels of step t+1" if depth == 2 else
+                       ("none (context ring)" if sim.cfg.context > 1 else "none (the few MB of cell codes are gathered synchronously)"),
+            "issued_by": by, "regions_ms_per_step": {"min": min(sg_regions) / steps * 1e3, "max": max(sg_regions) / steps * 1e3},
+            **bound}
+
+
+def make_gather(sim, mode, lib_comm, counts, rank):
+    from xworld_amd import sharding
+    if lib_comm is not None:
+        return sharding.LibScreensGather(sim, lib_comm, counts, rank, mode=mode)
+    return sharding.GridsGather(sim, counts, rank) if mode == "grids" else sharding.ScreensGather(sim, counts, rank)
+
+
+def gather_regions(sim, mode, lib_comm, counts, rank, world, n_local, K, R, args, set_screens, timed_region, fence):
+    """R timed regions of the loop with every step's frames gathered on rank 0 by `mode`; returns (block, gather object)."""
+    g = make_gather(sim, mode, lib_comm, counts, rank)
+    set_screens(g)
+    try:
+        for _ in range(2 * K):
+            set_screens.one_step()
+        regs = [timed_region() for _ in range(R)]
+        fence()
+    finally:
+        set_screens(None)
+    return gather_block(sim, mode, lib_comm, g.depth, world, n_local, args.steps, regs), g
+
+
 def c5_block(args, world, rank, local_rank, dev, K):
     """BASELINE.json config C5 -- XWorld2D 11x11, 32 768 envs per GPU (262 144 over 8), "sharded 8 x MI355X with RCCL gather
     of screens" -- as a sub-object of the N > 1 line: the same loop as the main measurement on the xworld11 workload, once
@@ -257,24 +331,29 @@ def c5_block(args, world, rank, local_rank, dev, K):
         if not int(flag.item()):
             break
     dev_regions = [region() for _ in range(3)]
-    state["screens"] = sharding.ScreensGather(sim, counts, rank)
-    for _ in range(4):
-        one_step()
-    sg_regions = [region() for _ in range(3)]
-    fence()
-    state["screens"] = None
+    lib_comm = sharding.LibComm(rank, world, local_rank) if args.exchange == "lib" else None
+    gathers = {}
+    for mode in (("screens", "grids") if args.gather == "both" else (args.gather,)):
+        try:
+            g = make_gather(sim, mode, lib_comm, counts, rank)
+            state["screens"] = g
+            for _ in range(4):
+                one_step()
+            regs = [region() for _ in range(3)]
+            fence()
+            gathers[mode] = gather_block(sim, mode, lib_comm, g.depth, world, n_local, K, regs)
+        except Exception as e:
+            gathers[mode] = {"error": "%s: %s" % (type(e).__name__, e)}
+        state["screens"] = None
     errs = sim.check_errors()
-    shard_bytes = n_local * sim.obs_bytes_per_env
-    link_s = shard_bytes / (XGMI_LINK_GBS * 1e9)
-    d_med, s_med = statistics.median(dev_regions), statistics.median(sg_regions)
+    d_med = statistics.median(dev_regions)
+    first = "screens" if "screens" in gathers else "grids"
     out = {"workload": "xworld11", "config": "BASELINE C5: 11x11, 132x132x3 u8, %d envs per GPU, %d in all" % (n_local, n_local * world),
            "value": n_local * world * K / d_med, "unit": "env-steps/s", "ms_per_step": d_med / K * 1e3,
            "exchange": "all_gather(reward,done) per step, screens device-resident", "regions": 3, "steps_per_region": K,
-           "action_errors": errs,
-           "screens_gather": {"value": n_local * world * K / s_med, "ms_per_step": s_med / K * 1e3,
-                              "bytes_into_root_per_step": shard_bytes * (world - 1), "link_bound_ms_per_step": link_s * 1e3,
-                              "link_bound_ceiling": n_local * world / link_s, "link_GBps_assumed": XGMI_LINK_GBS,
-                              "achieved_GBps_per_link": shard_bytes / (s_med / K) / 1e9}}
+           "action_errors": errs, "screens_gather": gathers[first]}
+    if first == "screens" and "grids" in gathers:
+        out["screens_gather"] = dict(gathers["screens"], grids=gathers["grids"])
     sim.close()
     return out
 
@@ -301,7 +380,13 @@ def main():
                     "a multiple; every step still writes its reward / code / observation")
     ap.add_argument("--exchange", default="torch", choices=["torch", "lib"], help="N > 1 screens gather: torch.distributed "
                     "point-to-point (default) or libxwb.so's own RCCL calls (xwb_gather_screens_begin / _end; backend nccl only)")
+    ap.add_argument("--gather", default="both", choices=["screens", "grids", "both"], help="N > 1, full observation: what crosses "
+                    "the links per step -- every shard's pixels (screens), or its cell codes with the root drawing all frames "
+                    "(grids: xwb_gather_grids_begin, needs --exchange lib), or one set of regions each (both; grids only with --exchange lib)")
     ap.add_argument("--c5", action="store_true", help="N > 1: add the BASELINE C5 block (xworld11); on by itself at N = 8")
+    ap.add_argument("--force-exchange", action="store_true", help="N = 1: initialise torch.distributed (world size 1) and issue the "
+                    "N > 1 run's exchanges all the same -- the RCCL all-gather of results, the gather objects -- so that no line of "
+                    "the multi-GPU path runs for the first time on the 8-GPU box")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo with every rank "
                     "on the visible GPUs modulo their count only exercises the N > 1 code path on a smaller box)")
     args = ap.parse_args()
@@ -323,6 +408,18 @@ def main():
             dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
+        if args.force_exchange:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            kw = {"device_id": torch.device("cuda", 0)} if args.backend == "nccl" else {}
+            if "MASTER_ADDR" in os.environ and "MASTER_PORT" in os.environ:
+                dist.init_process_group(args.backend, world_size=1, rank=0, **kw)
+            else:
+                import socket
+                sk = socket.socket()
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+                sk.close()
+                dist.init_process_group(args.backend, init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0, **kw)
     dev = torch.device("cuda", local_rank)
     n_local = args.envs_per_gpu or WORKLOADS[args.workload][2]
     sim = make_sim(args.workload, n_local, local_rank, rank * n_local, args.seed)
@@ -334,8 +431,9 @@ def main():
 
     from xworld_amd import sharding
     counts = [n_local] * world
-    results = sharding.ResultGather(counts, rank, dev) if world > 1 else None
-    with_screens = world > 1 and not args.no_screens_gather
+    forced = world == 1 and args.force_exchange
+    results = sharding.ResultGather(counts, rank, dev, force_collective=forced) if (world > 1 or forced) else None
+    with_screens = (world > 1 or forced) and not args.no_screens_gather
     screens = None                                   # ScreensGather while the screens regions run
 
     loop = {"autoreset": args.autoreset}             # which call sequence one_step() issues
@@ -373,9 +471,14 @@ def main():
         if screens is not None:
             screens.drain()
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or forced:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def set_screens(g):
+        nonlocal screens
+        screens = g
+    set_screens.one_step = one_step
 
     def bcast_int(v):
         if world == 1:
@@ -430,6 +533,9 @@ def main():
     for _ in range(spin_calls):                          # clocks warm, caches and allocator settled
         one_step()
 
+    # the run's own bandwidth anchor (rank-local, clocks warm): a pure write stream of the observation batch's size
+    ceiling = write_ceiling(n_local * sim.obs_bytes_per_env, dev)
+
     def timed_region():
         fence()
         t0 = time.perf_counter()
@@ -453,49 +559,54 @@ def main():
     ev_regions = [timed_region() for _ in range(R)]
     kern = "render" if is_xworld else "step"
     kern_us, kern_n = sim.profile_end(kern)
+    # every kernel of the step, not only the dominant one (each timed on the stream it runs on; the map generator runs on the
+    # batch's internal queue BESIDE the render, so the sum is not the step time)
+    kernels_us = {}
+    for kname in (("step", "render", "reset", "list") if is_xworld else ("step", "reset")):
+        us, nl = sim.profile_end(kname)
+        if nl:
+            kernels_us[kname] = {"avg_us": us, "launches": nl}
     sim.profile_stop()
+    path_default = sim.step_path()
 
     # ---- a second, shorter measurement in the same run: the fused call xwb_step_autoreset (the reference example loop's
     # `if game_over: reset_game()` inside the step: a finished env's observation is the first frame of its next episode,
     # its terminal frame is not materialised -- NOT the loop `value` is quoted on) ----
     ar_line = None
-    if is_xworld and fused == 1 and not args.autoreset:
+    if fused == 1 and not args.autoreset:
         loop["autoreset"] = True
         for _ in range(K):
             one_step()
         ar_regions = [timed_region() for _ in range(3)]
+        ar_path = sim.step_path()
         loop["autoreset"] = False
         ar_med = statistics.median(ar_regions)
-        ar_line = {"loop": "step_autoreset (terminal frames of finished envs not materialised)", "regions": 3,
+        ar_line = {"loop": "step_autoreset (terminal frames of finished envs not materialised)" if is_xworld else
+                           "step_autoreset (one launch per step: the step kernel resets the envs it finishes)", "regions": 3,
                    "ms_per_step": ar_med / args.steps * 1e3, "value": n_local * world * args.steps / ar_med, "unit": "env-steps/s",
-                   "step_loop_frac": n_local * per_step * args.steps / ar_med / 1e9 / HBM_PEAK_GBS}
+                   "step_loop_frac": n_local * per_step * args.steps / ar_med / 1e9 / HBM_PEAK_GBS, "path": ar_path}
         one_step()                                       # back in the default loop before anything else is measured
 
-    # ---- N > 1: the same loop with the screens of every shard gathered into one tensor on rank 0 ----
+    # ---- N > 1: the same loop with the screens of every shard gathered into one tensor on rank 0: the pixels themselves
+    # (link-bound), and -- full observation, library exchange -- the cell codes with the root drawing every frame ----
     sg_line = None
     if with_screens:
-        lib_comm = None
-        if args.exchange == "lib":
-            lib_comm = sharding.LibComm(rank, world, local_rank)
-            screens = sharding.LibScreensGather(sim, lib_comm, counts, rank)
-        else:
-            screens = sharding.ScreensGather(sim, counts, rank)
-        for _ in range(2 * K):
-            one_step()
-        sg_regions = [timed_region() for _ in range(R)]
-        fence()
-        sg_med = statistics.median(sg_regions)
-        shard_bytes = n_local * sim.obs_bytes_per_env
-        link_s = shard_bytes / (XGMI_LINK_GBS * 1e9)
-        sg_line = {"ms_per_step": sg_med / args.steps * 1e3, "value": n_local * world * args.steps / sg_med,
-                   "unit": "env-steps/s", "bytes_into_root_per_step": shard_bytes * (world - 1),
-                   "link_bound_ms_per_step": link_s * 1e3, "link_bound_ceiling": n_local * world / link_s,
-                   "link_GBps_assumed": XGMI_LINK_GBS, "achieved_GBps_per_link": shard_bytes / (sg_med / args.steps) / 1e9,
-                   "overlap": "double-buffered: transfer of step t beside the kernels of step t+1" if screens.depth == 2 else "none (context ring)",
-                   "issued_by": "libxwb.so (xwb_gather_screens_begin/_end: ncclSend / ncclRecv on the communicator's stream)" if lib_comm else
-                                "torch.distributed batch_isend_irecv",
-                   "regions_ms_per_step": {"min": min(sg_regions) / args.steps * 1e3, "max": max(sg_regions) / args.steps * 1e3}}
-        screens = None                                   # (the batch keeps the buffer it is bound to alive)
+        lib_comm = sharding.LibComm(rank, world, local_rank) if args.exchange == "lib" else None
+        grids_ok = is_xworld and not sim.cfg.visible_radius
+        modes = [m for m in (("screens", "grids") if args.gather == "both" else (args.gather,)) if m == "screens" or grids_ok]
+        blocks = {}
+        for mode in modes:
+            try:
+                blocks[mode], screens = gather_regions(sim, mode, lib_comm, counts, rank, world, n_local, K, R, args, set_screens, timed_region, fence)
+            except Exception as e:                       # a second measurement must not take the line down with it
+                blocks[mode] = {"error": "%s: %s" % (type(e).__name__, e)}
+            screens = None                               # (the batch keeps the buffer it is bound to alive)
+        sg_line = dict(blocks[modes[0]])
+        sg_line["mode"] = modes[0]
+        if len(modes) > 1:
+            sg_line["grids"] = blocks["grids"]
+        elif args.gather != "screens" and not grids_ok:
+            sg_line["grids"] = {"skipped": "needs a full-observation xworld workload (a frame must be a function of the cell codes)"}
     errs = sim.check_errors()
     assert errs == 0
     # ---- N > 1: BASELINE C5 (xworld11, 8 x 32 768 envs, RCCL gather of screens) as a block of the same line ----
@@ -530,15 +641,19 @@ def main():
                        "obs": list(sim.obs.shape[1:]), "seed": args.seed, "policy": "uniform random, drawn on device",
                        "loop": ("step_n(%d): %d steps per launch, auto-reset" % (fused, fused)) if fused > 1 else
                                ("step_autoreset" if args.autoreset else "step + reset_done"),
-                       "exchange": "all_gather(reward,done) per step, screens device-resident" if world > 1 else "none",
+                       "exchange": "all_gather(reward,done) per step, screens device-resident" if (world > 1 or forced) else "none",
                        "parallelism": "env-sharded x%d" % world},
             "regions": {"repetitions": R, "statistic": "median", "steps_per_region": args.steps,
                         "ms_per_step_min": min(regions) / args.steps * 1e3, "ms_per_step_max": max(regions) / args.steps * 1e3,
                         "ms_per_step_all": [r / args.steps * 1e3 for r in regions],
                         "untimed_before": {"warmup_steps": args.warmup, "spin_steps": spin_calls * fused,
                                            "spin_seconds_target": args.spin_seconds, "probe_steps": probe_calls * fused}},
+            "path": path_default,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
+                         "write_ceiling_GBps": ceiling["memset"]["GBps"], "write_ceiling": ceiling,
+                         "frac_of_write_ceiling": achieved / ceiling["memset"]["GBps"] if ceiling["memset"]["GBps"] else None,
+                         "kernels_us": kernels_us,
                          "kernel_avg_us": kern_us, "kernel_launches": kern_n,
                          "algorithmic_bytes_per_launch": n_local * per_launch * fused,
                          "algorithmic_bytes_per_env_step": per_step,
@@ -563,11 +678,13 @@ def main():
                                          min(args.parity_envs, n_local), probe_calls)
             if frames is not None:
                 line["parity"]["frames"] = frames
+        if forced:
+            line["forced_exchange"] = "world size 1: the N > 1 run's collectives were issued all the same (they move nothing between GPUs)"
         if not args.no_cpu_baseline and world == 1:          # rank 0, N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.workload, args.seed)
         print(json.dumps(line))
     sim.close()
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

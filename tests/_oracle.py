@@ -12,7 +12,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+# XWB_ORACLE_LIB: another build of the same sources (tools/sanitize.sh: oracle/_asan/liboracle.so, `make -C oracle asan`)
+LIB_PATH = os.environ.get("XWB_ORACLE_LIB") or os.path.join(ORACLE_DIR, "liboracle.so")
 
 u8p = C.POINTER(C.c_uint8)
 i32p = C.POINTER(C.c_int32)

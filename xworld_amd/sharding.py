@@ -60,30 +60,39 @@ class _Staged:
             dst.copy_(src)
 
 
-def _p2p_gather(local, out_root, counts, rank, dst, group):
-    """isend / irecv of every rank's slab into its slice of out_root on `dst`; returns the work handles."""
-    world = len(counts)
-    offsets = [sum(counts[:r]) for r in range(world)]
-    if _needs_staging(local, group):
+def _p2p_gather(locals_by_shard, out_root, counts, peers, rank, dst, group):
+    """isend / irecv of every shard's slab into its slice of out_root on the holder of shard `dst`; returns the work handles.
+    Shard i lives on rank peers[i]; `locals_by_shard` = {shard: slab} of the shards THIS rank holds (one shard per rank in
+    production: {rank: local}, peers = 0 .. world - 1; several shards on one rank -- a loopback on one GPU -- take the very
+    same lines: the sends to the own rank and the matching receives leave in one batch)."""
+    n_shards = len(counts)
+    offsets = [sum(counts[:i]) for i in range(n_shards)]
+    root_rank = peers[dst]
+    some = next(iter(locals_by_shard.values()))
+    if _needs_staging(some, group):
         handles = []
-        if rank == dst:
+        if rank == root_rank:
             copies = []
-            for r in range(world):
-                if r == dst or counts[r] == 0:
+            for i in range(n_shards):
+                if i == dst or counts[i] == 0 or peers[i] == rank:
                     continue
-                host = torch.empty((counts[r],) + tuple(out_root.shape[1:]), dtype=out_root.dtype)
-                handles.append(dist.irecv(host, r, group=group))
-                copies.append((out_root[offsets[r]:offsets[r] + counts[r]], host))
+                host = torch.empty((counts[i],) + tuple(out_root.shape[1:]), dtype=out_root.dtype)
+                handles.append(dist.irecv(host, peers[i], group=group))
+                copies.append((out_root[offsets[i]:offsets[i] + counts[i]], host))
+            for i, t in locals_by_shard.items():            # (gloo: shards on the root's own rank are plain copies)
+                if i != dst and counts[i] > 0:
+                    copies.append((out_root[offsets[i]:offsets[i] + counts[i]], t))
             handles.append(_Staged(copies))     # waited last: the receives above are complete by then
             return _Ordered(handles)
-        if counts[rank] > 0:
-            handles.append(dist.isend(local.cpu(), dst, group=group))
+        for i, t in locals_by_shard.items():
+            if counts[i] > 0:
+                handles.append(dist.isend(t.cpu(), root_rank, group=group))
         return _Ordered(handles)
-    if rank == dst:
-        ops = [dist.P2POp(dist.irecv, out_root[offsets[r]:offsets[r] + counts[r]], r, group=group)
-               for r in range(world) if r != dst and counts[r] > 0]
-    else:
-        ops = [dist.P2POp(dist.isend, local, dst, group=group)] if counts[rank] > 0 else []
+    ops = []
+    if rank == root_rank:
+        ops += [dist.P2POp(dist.irecv, out_root[offsets[i]:offsets[i] + counts[i]], peers[i], group=group)
+                for i in range(n_shards) if i != dst and counts[i] > 0]
+    ops += [dist.P2POp(dist.isend, t, root_rank, group=group) for i, t in locals_by_shard.items() if i != dst and counts[i] > 0]
     global _P2P_BROKEN
     if not _P2P_BROKEN:
         try:
@@ -93,7 +102,9 @@ def _p2p_gather(local, out_root, counts, rank, dst, group):
             import warnings
             warnings.warn("batched point-to-point failed (%s): screens travel by all_gather from now on" % e)
             _P2P_BROKEN = True
-    return _allgather_fallback(local, out_root, counts, rank, dst, group)
+    if len(locals_by_shard) != 1 or list(peers) != list(range(n_shards)):
+        raise RuntimeError("the all_gather fallback needs one shard per rank")
+    return _allgather_fallback(some, out_root, counts, rank, dst, group)
 
 
 _P2P_BROKEN = False
@@ -105,7 +116,12 @@ def _allgather_fallback(local, out_root, counts, rank, dst, group):
     m = max(counts)
     pad = local if counts[rank] == m else torch.cat([local, local.new_zeros((m - counts[rank],) + tuple(local.shape[1:]))])
     tmp = local.new_empty((world * m,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(tmp, pad.contiguous(), group=group)
+    if _needs_staging(local, group):
+        host = torch.empty(tuple(tmp.shape), dtype=tmp.dtype)
+        dist.all_gather_into_tensor(host, pad.contiguous().cpu(), group=group)
+        tmp.copy_(host)
+    else:
+        dist.all_gather_into_tensor(tmp, pad.contiguous(), group=group)
     if rank == dst:
         off = 0
         for r in range(world):
@@ -124,21 +140,26 @@ class _Ordered:
             h.wait()
 
 
-def gather_slabs(local, out_root, counts, rank, dst=0, group=None, async_op=False):
-    """Every rank's `local` [count_r, ...] slab into out_root[offset_r : offset_r + count_r] on `dst`
-    (the root's own slab is copied unless it already aliases its slice).  async_op: returns a handle whose
-    wait() orders the current stream behind the transfer instead of waiting here."""
-    world = len(counts)
-    if rank == dst:
+def gather_shards(locals_by_shard, out_root, counts, peers, rank, dst=0, group=None, async_op=False):
+    """Every shard's slab into out_root[offset_i : offset_i + count_i] on the rank that holds shard `dst` (that shard's own
+    slab is copied unless it already aliases its slice).  `locals_by_shard` = {shard: [count_i, ...] slab} of the shards this
+    rank holds, shard i living on rank peers[i].  async_op: returns a handle whose wait() orders the current stream behind
+    the transfer instead of waiting here."""
+    if dst in locals_by_shard:
         off = sum(counts[:dst])
         mine = out_root[off:off + counts[dst]]
-        if mine.data_ptr() != local.data_ptr():
-            mine.copy_(local)
-    work = _p2p_gather(local, out_root, counts, rank, dst, group) if world > 1 else _Ordered([])
+        if mine.data_ptr() != locals_by_shard[dst].data_ptr():
+            mine.copy_(locals_by_shard[dst])
+    work = _p2p_gather(locals_by_shard, out_root, counts, list(peers), rank, dst, group) if len(counts) > 1 else _Ordered([])
     if async_op:
         return work
     work.wait()
-    return out_root if rank == dst else None
+    return out_root if dst in locals_by_shard else None
+
+
+def gather_slabs(local, out_root, counts, rank, dst=0, group=None, async_op=False):
+    """gather_shards with one shard per rank (shard r on rank r): what every N > 1 run uses."""
+    return gather_shards({rank: local}, out_root, counts, range(len(counts)), rank, dst, group, async_op)
 
 
 class ResultGather:
@@ -152,9 +173,12 @@ class ResultGather:
     caller-owned [n, 2] tensor instead (e.g. one row of a per-step record the simulator wrote through
     bind_results); the caller then keeps it untouched until finish().  `__call__` = start + finish."""
 
-    def __init__(self, counts, rank, device, dst=0, group=None):
+    def __init__(self, counts, rank, device, dst=0, group=None, force_collective=False):
         self.counts, self.rank, self.dst, self.group = list(counts), rank, dst, group
         self.world = len(counts)
+        # a world of one needs no exchange; force_collective issues the collective all the same (a single-GPU run of the
+        # very RCCL call the N > 1 run makes: tests/test_gpu_nccl_branch.py, bench.py --force-exchange)
+        self.force = bool(force_collective)
         self.equal = len(set(counts)) == 1
         n = counts[rank]
         self.total = sum(counts)
@@ -183,7 +207,7 @@ class ResultGather:
                 packed[:, 0] = reward
                 packed[:, 1] = game_over.to(torch.float32)
         work = None
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             out.copy_(packed)
         elif self.equal and not _needs_staging(packed, self.group):
             work = dist.all_gather_into_tensor(out, packed, group=self.group, async_op=True)
@@ -427,6 +451,21 @@ class GridsGather:
             self.full = torch.zeros((self.total,) + tuple(sim.obs.shape[1:]), dtype=sim.obs.dtype, device=device)
         else:
             self.all_rows = self.full = None
+
+    # the ScreensGather protocol (bench.py drives every gather through it); nothing is pipelined here: depth 1
+    depth = 1
+
+    def bind_next(self):
+        pass
+
+    def start(self):
+        self()
+
+    def latest(self):
+        return self.full
+
+    def drain(self):
+        return self.full
 
     def __call__(self):
         self.sim.pack_grids(self.grids, self.flags)
