@@ -260,6 +260,7 @@ def test_full_size_c5_shard(oracle):
     for t in range(steps):
         sim.reset_done()
         sample.reset_done()
+        sample.check_frames(sim, ("after reset_done", t))               # the first frames of new episodes, as the C4 test
         sim.step()
         sample.step(sim)
         sample.check_frames(sim, ("after step", t))
