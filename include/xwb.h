@@ -37,7 +37,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define XWB_ABI_VERSION 3
+#define XWB_ABI_VERSION 4
 
 enum {
     XWB_OK = 0,
@@ -161,7 +161,22 @@ typedef struct xwb_config {
     double   task_group_weight2;     /* the exclusive branch's shuffle only */
     int32_t  queue_sync;             /* XWB_QUEUE_SYNC_*: how the batch's two internal queues hand over inside a step (see
                                       * xwb_queue_sync_mode) */
+    /* Debug configuration: A/B switches of the library's own kernel paths -- every path gives the same results, byte for
+     * byte; the tests hold one against the other.  All zero in production.  Per batch (the reference keeps such switches as
+     * process-global gflags).  The ONE process-wide override: the environment variable XWB_DEBUG, a comma-separated list of
+     * the lower-case flag names (no_pregen, no_lazy, ego_no_cache, ego_no_span, ego_no_flat) and of ego_per=N, ego_pad=N,
+     * render_shape=64x2|256x2, read once at the first xwb_create and OR-ed into every batch created afterwards (for tools
+     * that cannot reach the configuration).  Besides it only XWB_QUEUE_SYNC is read from the environment. */
+    int32_t  debug_flags;            /* XWB_DEBUG_* */
+    int32_t  debug_ego_per;          /* egocentric gather: 16-byte chunks per lane, 2 | 4 | 8; 0 = the default (4) */
+    int32_t  debug_ego_pad;          /* egocentric gather: extra LDS bytes a workgroup asks for, + 1 (0 = the default occupancy cap) */
+    int32_t  debug_render_shape;     /* full-observation render_all: 0 = 128 threads x 2 chunks (default), 1 = 64 x 2, 2 = 256 x 2 */
 } xwb_config;
+enum { XWB_DEBUG_NO_PREGEN = 1,      /* no pre-generated episodes: every verb on the classic path */
+       XWB_DEBUG_NO_LAZY = 2,        /* xwb_step + xwb_reset_done on the classic path (xwb_step_autoreset keeps its pre-generation) */
+       XWB_DEBUG_EGO_NO_CACHE = 4,   /* egocentric: no cache of rendered goal cells (and hence no span path) */
+       XWB_DEBUG_EGO_NO_SPAN = 8,    /* egocentric: one workgroup per env instead of the span path */
+       XWB_DEBUG_EGO_NO_FLAT = 16 }; /* egocentric span path: no shared constant line for one-colour squares */
 
 /* xwb_config.queue_sync.  AUTO: device-side epochs (no event / barrier packets: 12 us per step on the C4 loop) on every caller
  * stream that passed a one-time concurrency probe against the batch's internal stream -- the default stream is probed by

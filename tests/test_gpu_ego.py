@@ -269,15 +269,13 @@ def test_ego_autoreset_skip_and_context(oracle):
 
 @pytest.mark.parametrize("key,r,opts", [("nav7", 3, dict(color=True)), ("nav8", 3, dict(color=False, context=2)),
                                         ("nav7", 5, dict(color=True, obs_format="float32")), ("nav11", 7, dict(color=True, context=3))])
-def test_ego_span_path_equals_per_env_path(oracle, key, r, opts, monkeypatch):
+def test_ego_span_path_equals_per_env_path(oracle, key, r, opts):
     """The two egocentric renders (the span path -- cells, evaluated pixels, gather -- and one workgroup per env) draw the same
     frames through every verb: step + reset_done, step_autoreset, masked resets; context rings and float32 frames included."""
     torch = _torch()
     n = 700                                                # not a multiple of the kernels' env groups (64, 8)
     a, _, _ = _make(oracle, key, n, r, seed=11, policy_seed=3, **opts)
-    monkeypatch.setenv("XWB_EGO_NO_SPAN", "1")
-    b, _, _ = _make(oracle, key, n, r, seed=11, policy_seed=3, **opts)
-    monkeypatch.delenv("XWB_EGO_NO_SPAN")
+    b, _, _ = _make(oracle, key, n, r, seed=11, policy_seed=3, debug=["ego_no_span"], **opts)     # xwb_config.debug_flags
     assert a.ego_render_path == "span" and b.ego_render_path == "per_env"
     for sim in (a, b):
         sim.reset()

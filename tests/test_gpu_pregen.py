@@ -73,11 +73,7 @@ def test_pregen_with_other_verbs_in_between():
     n = 2048
     a = BatchedSimulator("xworld", opts, num_envs=n, seed=3, policy_seed=9)
     b = BatchedSimulator("xworld", dict(opts), num_envs=n, seed=3, policy_seed=9)
-    os.environ["XWB_NO_PREGEN"] = "1"
-    try:
-        c = BatchedSimulator("xworld", dict(opts), num_envs=n, seed=3, policy_seed=9)     # the same calls without pre-generation
-    finally:
-        del os.environ["XWB_NO_PREGEN"]
+    c = BatchedSimulator("xworld", dict(opts, debug=["no_pregen"]), num_envs=n, seed=3, policy_seed=9)     # the same calls without pre-generation
     mask = torch.zeros(n, dtype=torch.uint8, device="cuda")
     mask[5::97] = 1
     blob = None
@@ -146,7 +142,7 @@ def test_pregen_rollout_against_the_oracle(oracle):
 @pytest.mark.parametrize("case", ["c4", "ctx3_gray", "walls_2d"])
 def test_lazy_default_loop_equals_classic(case):
     """xwb_step + xwb_reset_done with pre-generated episodes (no terminal snapshot in the step, the list render installs the
-    shadows) against the classic path (XWB_NO_LAZY: snapshot, reset on the side queue beside the render): the frames after the
+    shadows) against the classic path (XWB_DEBUG=no_lazy: snapshot, reset on the side queue beside the render): the frames after the
     step (terminal frames included), after reset_done, rewards, codes, counters, grids -- byte for byte."""
     torch = _torch()
     from xworld_amd.batched import BatchedSimulator
@@ -162,7 +158,7 @@ def test_lazy_default_loop_equals_classic(case):
             "assert sim.check_errors() == 0; print('HASH', h.hexdigest(), sim.task_performance())\n") % (ROOT, CASES[case][0], min(CASES[case][1], 1024))
     import subprocess, sys
     outs = []
-    envs = [{}, {"XWB_NO_LAZY": "1"}]
+    envs = [{}, {"XWB_DEBUG": "no_lazy"}]             # (the process-wide override of xwb_config.debug_flags, through a child process)
     if case == "c4":                           # (the hand-off variants once: they do not depend on the geometry)
         envs += [{"XWB_QUEUE_SYNC": "events"}, {"GPU_MAX_HW_QUEUES": "1", "XWB_QUEUE_SYNC": "epochs"}]
     for env in envs:
@@ -179,7 +175,7 @@ def test_lazy_default_loop_equals_classic(case):
 def test_random_verb_sequences_equal_the_classic_paths(seed):
     """A seeded random walk over the verbs (step, step_autoreset, step_n, reset_done, masked / single-env / whole-batch resets,
     explicit actions with skipped envs, a checkpoint round trip) on a batch with pre-generated episodes and on one without
-    (XWB_NO_PREGEN): identical frames, counters, grids and results after every verb -- the host-side state machine (stale
+    (debug no_pregen): identical frames, counters, grids and results after every verb -- the host-side state machine (stale
     shadows, pending regeneration, lazy / classic hand-back after three breaks) has no observable effect."""
     torch = _torch()
     from xworld_amd.batched import BatchedSimulator
@@ -187,11 +183,7 @@ def test_random_verb_sequences_equal_the_classic_paths(seed):
     opts = dict(opts, max_steps=23)
     n = 1024
     a = BatchedSimulator("xworld", opts, num_envs=n, seed=seed, policy_seed=seed + 7)
-    os.environ["XWB_NO_PREGEN"] = "1"
-    try:
-        c = BatchedSimulator("xworld", dict(opts), num_envs=n, seed=seed, policy_seed=seed + 7)
-    finally:
-        del os.environ["XWB_NO_PREGEN"]
+    c = BatchedSimulator("xworld", dict(opts, debug=["no_pregen"]), num_envs=n, seed=seed, policy_seed=seed + 7)
     rng = np.random.default_rng(seed)
     mask = torch.zeros(n, dtype=torch.uint8, device="cuda")
     verbs = ["step", "step", "step", "reset_done", "reset_done", "autoreset", "autoreset", "step_n", "masked", "env", "reset", "actions", "ckpt"]

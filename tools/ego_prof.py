@@ -1,6 +1,6 @@
 """Per-phase time of the one-workgroup-per-env egocentric render (a build with XWB_EXTRA_FLAGS=-DXWB_EGO_PROF only; the span
 path is switched off for the measurement):
-    XWB_EXTRA_FLAGS=-DXWB_EGO_PROF python -m xworld_amd.build --force && XWB_EGO_NO_SPAN=1 python tools/ego_prof.py [r] [map key]
+    XWB_EXTRA_FLAGS=-DXWB_EGO_PROF python -m xworld_amd.build --force && XWB_DEBUG=ego_no_span python tools/ego_prof.py [r] [map key]
 Prints the 100 MHz wall-clock ticks workgroup leaders spent between the barriers of xw_render_ego_kernel, summed over
 workgroups, as a share of the total."""
 import ctypes as C

@@ -1,5 +1,5 @@
 """Soak of the two egocentric renders against each other: the span path (cells -> evaluated pixels -> gather) and one workgroup per
-env (XWB_EGO_NO_SPAN=1) must draw the same frames through step / reset_done / step_autoreset -- 8192 envs x 200 steps per case:
+env (debug ego_no_span) must draw the same frames through step / reset_done / step_autoreset -- 8192 envs x 200 steps per case:
 r = 3 / 5 / 7, colour and gray, context rings, float32 frames, curriculum, no wall shadows.  python tools/ego_soak.py (on a GPU)"""
 import os, sys, itertools
 sys.path.insert(0, '/root/repo')
@@ -7,10 +7,7 @@ import torch
 from xworld_amd.batched import BatchedSimulator
 CONF = '/root/repo/xworld_amd/confs/'
 def make(opts, n, seed, no_span):
-    if no_span: os.environ['XWB_EGO_NO_SPAN'] = '1'
-    else: os.environ.pop('XWB_EGO_NO_SPAN', None)
-    s = BatchedSimulator('xworld', opts, num_envs=n, seed=seed, policy_seed=seed + 1)
-    os.environ.pop('XWB_EGO_NO_SPAN', None)
+    s = BatchedSimulator('xworld', dict(opts, debug=['ego_no_span'] if no_span else []), num_envs=n, seed=seed, policy_seed=seed + 1)
     return s
 cases = [
   dict(xwd_conf_path=CONF+'navigation2d.json', task_mode='lang_acquisition', max_dim=7, dim=7, num_blocks=16, visible_radius=3, color=True),

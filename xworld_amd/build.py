@@ -12,8 +12,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libxwb.so")
-SOURCES = ["kernels_simple.hip", "kernels_xworld.hip", "kernels_xworld_reset.hip", "kernels_xworld_ego.hip", "xwb_api.hip", "xwb_comm.hip"]
-HEADERS = [os.path.join(CSRC, "xwb_common.h"), os.path.join(CSRC, "xw_device.h"), os.path.join(CSRC, "xwb_language.h"), os.path.join(os.path.dirname(HERE), "include", "xwb.h")]
+SOURCES = ["kernels_simple.hip", "kernels_xworld.hip", "kernels_xworld_reset.hip", "kernels_xworld_ego.hip",
+           "xwb_create.hip", "xwb_verbs.hip", "xwb_getters.hip", "xwb_checkpoint.hip", "xwb_comm.hip"]
+HEADERS = [os.path.join(CSRC, "xwb_common.h"), os.path.join(CSRC, "xw_device.h"), os.path.join(CSRC, "xwb_language.h"), os.path.join(CSRC, "xwb_sim.h"),
+           os.path.join(os.path.dirname(HERE), "include", "xwb.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
 

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
     }
 }
 
-// render_all launch shape: XWB_RENDER_SHAPE = "<threads>x<chunks per lane>" overrides the default (A/B hook)
+// render_all launch shape: xwb_config.debug_render_shape overrides the default (A/B switch)
 template <int DIM_T, int CH, int BS, int PER, int SKIP, int ES>
 static hipError_t render_all_shape(const XwParams &p, hipStream_t s) {
     const unsigned long long n_chunks = (unsigned long long)p.n * (CH * 9 * ES * p.max_dim * p.max_dim);
@@ -609,12 +609,7 @@ template <int DIM_T, int CH, int SKIP, int ES>
 static hipError_t render_all(const XwParams &p, hipStream_t s) {
     // measured on C4 / 8x8 / 11x11 (profiles/r1/render_shapes.txt): 128 x 2 is best everywhere (8 KiB spans, up to
     // 16 two-wave groups per CU); one chunk per lane leaves too few bytes per barrier, four too few groups in flight
-    static int shape = -1;
-    if (shape < 0) {
-        shape = 0;
-        if (const char *ev = getenv("XWB_RENDER_SHAPE")) shape = !strcmp(ev, "64x2") ? 1 : (!strcmp(ev, "256x2") ? 2 : 0);
-    }
-    switch (shape) {
+    switch (p.dbg_render_shape) {                            // (xwb_config.debug_render_shape: A/B switch)
         case 1: return render_all_shape<DIM_T, CH, 64, 2, SKIP, ES>(p, s);
         case 2: return render_all_shape<DIM_T, CH, 256, 2, SKIP, ES>(p, s);
         default: return render_all_shape<DIM_T, CH, 128, 2, SKIP, ES>(p, s);

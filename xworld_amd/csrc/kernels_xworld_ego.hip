@@ -1539,12 +1539,12 @@ hipError_t ego_span_render(const XwParams &p, const EgoTables &t, int mode, hipS
     const unsigned long long n_chunks = (unsigned long long)p.n * (FB / (16 / es));
     const int32_t *cnt = (const int32_t *)p.done_count;
     const unsigned list_blocks = (unsigned)(p.n < 2048 ? p.n : 2048);
-    // A/B hooks: XWB_EGO_PER = 16-byte chunks per lane (2 | 4), XWB_EGO_PAD = bytes of LDS a workgroup asks for on top of its own.
+    // A/B switches (xwb_config.debug_ego_per / debug_ego_pad): 16-byte chunks per lane (2 | 4 | 8), bytes of LDS a workgroup asks for on top of its own.
     // Default padding: 13 workgroups per CU instead of 16 -- the kernels of a reset_done on the other queue (map generator,
     // goal images, list render: 256-thread groups, up to 31 KB of LDS) otherwise never find room beside this one and run
     // after it (0.292 -> 0.271 ms per step on the C4-sized batch).
-    static const int per = getenv("XWB_EGO_PER") ? atoi(getenv("XWB_EGO_PER")) : 4;
-    static const int pad_env = getenv("XWB_EGO_PAD") ? atoi(getenv("XWB_EGO_PAD")) : -1;
+    const int per = p.dbg_ego_per ? p.dbg_ego_per : 4;
+    const int pad_env = p.dbg_ego_pad - 1;
 #define EGO_PAD(ESV, PERV) (pad_env >= 0 ? pad_env : (163840 / 13 - EgoSpanGeom<CH, R, ESV, PERV>::LDS > 0 ? 163840 / 13 - EgoSpanGeom<CH, R, ESV, PERV>::LDS : 0))
 #define EGO_GATHER_BIG(CTXV, ESV, PERV) hipLaunchKernelGGL((xw_ego_gather_kernel<CH, R, CTXV, ESV, PERV>), dim3((unsigned)((n_chunks + EGO_BS * PERV - 1) / (EGO_BS * PERV))), dim3(EGO_BS), EGO_PAD(ESV, PERV), s, p, skip_gather, publish)
 #define EGO_GATHER(CTXV, ESV) do { \

@@ -68,7 +68,7 @@ __device__ __forceinline__ void xw_publish_epoch(uint32_t *epoch_slot, uint32_t 
 }
 
 // Wait (one lane spins, the workgroup follows through the barrier) until *epoch_slot has reached `want` (wrap-safe).
-// Host-side invariant (xwb_api.hip): the kernel that publishes an epoch is ALWAYS enqueued before the kernel that waits for
+// Host-side invariant (xwb_verbs.hip): the kernel that publishes an epoch is ALWAYS enqueued before the kernel that waits for
 // it, so two streams that share one in-order hardware queue (HIP multiplexes streams onto GPU_MAX_HW_QUEUES queues), or a tool
 // that serialises kernels in submission order, run publisher-then-waiter and the loop never spins; only when the queues run
 // concurrently does the waiter poll, and then its publisher is already in flight.  Each (batch, caller stream) pair is also

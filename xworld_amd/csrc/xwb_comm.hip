@@ -24,7 +24,7 @@
 #include <string>
 #include <vector>
 
-extern "C" __attribute__((visibility("hidden"))) int xwb_internal_fail(int code, const char *msg);     // xwb_api.hip: sets xwb_last_error on this thread
+extern "C" __attribute__((visibility("hidden"))) int xwb_internal_fail(int code, const char *msg);     // xwb_create.hip: sets xwb_last_error on this thread
 
 namespace {
 

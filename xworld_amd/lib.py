@@ -10,12 +10,13 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libxwb.so")
 
-XWB_ABI_VERSION = 3
+XWB_ABI_VERSION = 4
 XWB_SIMPLE_GAME, XWB_SIMPLE_RACE, XWB_XWORLD2D = 0, 1, 2
 XWB_MAP_NAV, XWB_MAP_WALLS = 0, 1
 XWB_TASKMODE_LANG_ACQ, XWB_TASKMODE_ONE_CHANNEL = 0, 1
 ALIVE, MAX_STEP, DEAD, SUCCESS, LOST_LIFE = 0, 1, 2, 4, 8
 XWB_QUEUE_SYNC_AUTO, XWB_QUEUE_SYNC_EVENTS, XWB_QUEUE_SYNC_EPOCHS = 0, 1, 2
+DEBUG_FLAGS = {"no_pregen": 1, "no_lazy": 2, "ego_no_cache": 4, "ego_no_span": 8, "ego_no_flat": 16}
 STEP_PATHS = ["none", "classic", "lazy", "pregen", "ego_span", "ego_per_env"]
 SYNC_REASONS = ["probe_ok", "config", "env", "tool", "probe_failed", "probe_error", "not_used", "not_probed"]
 
@@ -42,6 +43,7 @@ class XwbConfig(C.Structure):
         ("task_groups_exclusive", C.c_int32),
         ("task_group_weight", C.c_double), ("task_group_weight2", C.c_double),
         ("queue_sync", C.c_int32),
+        ("debug_flags", C.c_int32), ("debug_ego_per", C.c_int32), ("debug_ego_pad", C.c_int32), ("debug_render_shape", C.c_int32),
     ]
 
 
