@@ -61,10 +61,10 @@ class BatchedSimulator:
         cfg.queue_sync = ("auto", "events", "epochs").index(qs)
         # xwb_config "Debug configuration": A/B switches of the library's own paths, e.g. debug=["no_pregen"]
         dbg = opts.get("debug", ())
-        for name in ([dbg] if isinstance(dbg, str) else dbg):
-            if name not in lib.DEBUG_FLAGS:
-                raise RuntimeError("unknown debug switch %r (one of %s)" % (name, sorted(lib.DEBUG_FLAGS)))
-            cfg.debug_flags |= lib.DEBUG_FLAGS[name]
+        for switch in ([dbg] if isinstance(dbg, str) else dbg):
+            if switch not in lib.DEBUG_FLAGS:
+                raise RuntimeError("unknown debug switch %r (one of %s)" % (switch, sorted(lib.DEBUG_FLAGS)))
+            cfg.debug_flags |= lib.DEBUG_FLAGS[switch]
         cfg.debug_ego_per = int(opts.get("debug_ego_per", 0))
         cfg.debug_ego_pad = int(opts.get("debug_ego_pad", 0))
         cfg.debug_render_shape = int(opts.get("debug_render_shape", 0))
