@@ -16,8 +16,12 @@ for W in "$@"; do
   tail -c 300 $OUT/bench_$W.json | head -c 300; echo
 done
 python bench.py --workload xworld7 --autoreset --no-cpu-baseline > $OUT/bench_xworld7_autoreset.json 2>/dev/null || true
-# the other egocentric radii: plain bench lines (parity + frame gates), no counter pass
-for W in xworld8_ego5 xworld7_ego7; do python bench.py --workload $W > $OUT/bench_$W.json 2>/dev/null || true; done
+# SQ / TA / TCP counters of the egocentric span path per radius (tools/pmc_ego_span.sh)
+for RM in "3 7" "5 8" "7 7"; do
+  set -- $RM
+  bash tools/pmc_ego_span.sh $1 $2 > /dev/null 2>&1
+  { echo "== commit ${GIT_HEAD:-unknown} (tools/pmc_ego_span.sh $1 $2) =="; cat gpurun_out/pmc_ego_span_r$1/summary.txt; } > $OUT/ego_r$1_span_counters.txt
+done
 python tools/ego_sweep.py > $OUT/ego_sweep.txt 2>&1 || true
 python bench.py --steps 20 --warmup 5 > $OUT/bench_xworld7_driver_args.json 2>/dev/null || true
 ls -la $OUT
