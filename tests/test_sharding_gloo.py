@@ -115,6 +115,24 @@ def _worker(rank, world, port, total, q):
             if rank == 0:
                 exp = ((g[:, None] * 3 + 4 + torch.arange(12 * context)[None, :]) % 251).to(torch.uint8).reshape(total, context, 3, 4)
                 assert torch.equal(final, exp)
+        # several shards per rank (gather_shards: shard i lives on rank peers[i]), ragged, one of them empty -- the layout the
+        # one-GPU tests of the nccl branch use (tests/test_gpu_nccl_branch.py), here over gloo with two shards per rank
+        ns = 2 * world
+        sc = [5, 0, 3, 7, 2, 4][:ns]
+        peers = [i // 2 for i in range(ns)]
+        offs = [sum(sc[:i]) for i in range(ns)]
+        mine = {i: (torch.arange(offs[i], offs[i] + sc[i])[:, None] * 3 + torch.arange(6)[None, :]).to(torch.int32) for i in range(ns) if peers[i] == rank}
+        for root_shard in (0, ns - 1):
+            holder = peers[root_shard]
+            out = torch.full((sum(sc), 6), -1, dtype=torch.int32) if rank == holder else None
+            got = sharding.gather_shards(mine, out, sc, peers, rank, dst=root_shard)
+            if rank == holder:
+                exp = (torch.arange(sum(sc))[:, None] * 3 + torch.arange(6)[None, :]).to(torch.int32)
+                assert torch.equal(got, exp), (root_shard, got)
+            else:
+                assert got is None
+        rgf = sharding.ResultGather([4], 0, torch.device("cpu"), force_collective=True) if world == 1 else None
+        assert rgf is None
         assert sharding.backend_info() == {"world_size": world, "backend": "gloo", "version": None}
         dist.barrier()
         q.put((rank, "ok"))

@@ -88,11 +88,22 @@ def _p2p_gather(locals_by_shard, out_root, counts, peers, rank, dst, group):
             if counts[i] > 0:
                 handles.append(dist.isend(t.cpu(), root_rank, group=group))
         return _Ordered(handles)
-    ops = []
+    ops, local_copies = [], []
+    # shards on the root's own rank: RCCL matches a send to the own rank with a receive of the same batch (what the one-GPU
+    # test of this branch relies on); other backends copy
+    self_p2p = dist.get_backend(group) == "nccl"
     if rank == root_rank:
         ops += [dist.P2POp(dist.irecv, out_root[offsets[i]:offsets[i] + counts[i]], peers[i], group=group)
-                for i in range(n_shards) if i != dst and counts[i] > 0]
-    ops += [dist.P2POp(dist.isend, t, root_rank, group=group) for i, t in locals_by_shard.items() if i != dst and counts[i] > 0]
+                for i in range(n_shards) if i != dst and counts[i] > 0 and (self_p2p or peers[i] != rank)]
+    for i, t in locals_by_shard.items():
+        if i == dst or counts[i] == 0:
+            continue
+        if rank == root_rank and not self_p2p:
+            local_copies.append((out_root[offsets[i]:offsets[i] + counts[i]], t))
+        else:
+            ops.append(dist.P2POp(dist.isend, t, root_rank, group=group))
+    for d, t in local_copies:
+        d.copy_(t)
     global _P2P_BROKEN
     if not _P2P_BROKEN:
         try:
