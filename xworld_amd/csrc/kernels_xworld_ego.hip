@@ -602,6 +602,12 @@ template <int R> struct EgoBorderGeom { static constexpr int EPW = R >= 7 ? 16 :
 #ifndef EGO_BS
 #define EGO_BS 256
 #endif
+// Round 4: a wavefront computes exactly the units its own lanes' pieces read and hands them over lane to lane (ds_bpermute):
+// no LDS arrays, no barrier between the two phases, the four wavefronts of a workgroup run independently up to the one
+// barrier in front of the stores (A/B hook: -DEGO_UNIT_SHFL=0 = round 3's LDS hand-over)
+#ifndef EGO_UNIT_SHFL
+#define EGO_UNIT_SHFL 1
+#endif
 
 // a square's pixels in the span path's sources (ego_tab3, the goal-cell cache): [channel][U rows][UP bytes], rows padded to whole
 // 16-byte pieces
@@ -1072,7 +1078,15 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
     constexpr unsigned GB = 4 * O, GPP = O / 4, GPF = CH * GPP;             // bytes per row group; groups per plane, per frame
     constexpr int NG = (SB + GB - 1) / GB + 1;                              // row groups a span can touch
     constexpr int NU = NG * R, PPU = Q::UDP, PPR = Q::UDP / 4;              // units (square column major), pieces per unit, per row
-    constexpr int ITP = (NU * PPU + BS - 1) / BS, ITU = (NU + BS - 1) / BS;
+    constexpr int ITP = (NU * PPU + BS - 1) / BS;
+#if EGO_UNIT_SHFL
+    // unit slots of a wavefront: iteration `it` of the pieces loop reads the UPI units it * (BS / PPU) + wave * UPI + [0, UPI);
+    // slot k = it * UPI + j is computed by lane k % 64 (its k / 64-th unit)
+    constexpr int UPI = 64 / PPU, UPW = ITP * UPI, ITU = (UPW + 63) / 64;
+    static_assert(64 % PPU == 0 && BS % 64 == 0, "whole units per wavefront");
+#else
+    constexpr int ITU = (NU + BS - 1) / BS;
+#endif
     constexpr int NE = SB / (int)FB + 2;                                    // envs a span can touch
     constexpr int cpf = (int)FB / BPC;
     constexpr int NL = 2 * (R - 1);
@@ -1080,8 +1094,10 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
     static_assert(4 * Q::UP <= 128, "a unit fits the constant line");
     __shared__ uint4 s_out4[(GB + SB + GB) / 16];
     __shared__ uint32_t s_env[NE];                                          // a cell word of each env: its flags
+#if !EGO_UNIT_SHFL
     __shared__ const uint8_t *s_usrc[NU];
     __shared__ int s_uo[NU];                                                // the unit's first dword in s_out | flags << 24, -1: none
+#endif
     uint32_t *s_out = reinterpret_cast<uint32_t *>(s_out4);
     const int tid = threadIdx.x;
     const unsigned br = cr * BPC, be = br + (unsigned)nc * BPC;             // bytes, from the start of env e0's frame
@@ -1091,12 +1107,28 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
     const unsigned g0 = br / GB, g1 = (be + GB - 1) / GB;                   // row groups, counted from env e0's first
     if (tid >= BS - ne) s_env[BS - 1 - tid] = p.ego_cellsrc[((size_t)e0 + (BS - 1 - tid)) * RR];
     const size_t env_cache = (size_t)p.num_goals * (RR * 4) * p.ego_cache_entry;
-    int uo[ITU];
+    int uo[ITU];                                                            // the unit's first dword in s_out | flags << 24, -1: none
+    const uint8_t *usrc_r[ITU];
+    uint32_t pcb[ITU], prow[ITU][UD], pcol[ITU][4];                         // the patch data of this lane's units (see below)
 #pragma unroll
     for (int iu = 0; iu < ITU; ++iu) {
+        pcb[iu] = 0;
+#pragma unroll
+        for (int d = 0; d < UD; ++d) prow[iu][d] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pcol[iu][j] = 0;
+    }
+#pragma unroll
+    for (int iu = 0; iu < ITU; ++iu) {
+#if EGO_UNIT_SHFL
+        const int k = iu * 64 + (tid & 63), itk = k / UPI;
+        const int ut = k < UPW ? itk * (BS / PPU) + (tid >> 6) * UPI + (k - itk * UPI) : NU;
+#else
         const int ut = iu * BS + tid;
+#endif
         const unsigned fx = (unsigned)ut / NG, gq = g0 + ((unsigned)ut - fx * NG);
         uo[iu] = -1;
+        usrc_r[iu] = p.ego_tab3;
         if (ut < NU && gq < g1) {
             const unsigned le = gq / GPF, gi = gq - le * GPF, ch = gi / GPP, oy0 = 4u * (gi - ch * GPP), fy = oy0 / (unsigned)U, py0 = oy0 - fy * U;
             uint32_t w = p.ego_cellsrc[((size_t)e0 + le) * RR + fy * R + fx];
@@ -1106,15 +1138,36 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
             const uint8_t *base = cached ? p.ego_cache + ((size_t)e0 + le) * env_cache : p.ego_tab3;
             const uint8_t *from = base + (size_t)(w & 0x7fffffu) * 16 + ch * (cached ? (unsigned)Q::CBP : (unsigned)Q::PBP) + py0 * Q::UP;
             // a flat square: every unit of it is the same 4 * UP bytes -- one line shared by the whole batch (L1-resident)
-            s_usrc[ut] = flat ? p.ego_constline + (flat - 1u) * 128u : from;
+            const uint8_t *usrc = flat ? p.ego_constline + (flat - 1u) * 128u : from;
+            usrc_r[iu] = usrc;
             // what this lane places itself: bit 0 the first row (evaluated for this env), bit 1 the first dword of every row
             // (an evaluated border column), bit 2 the first dword of the first row (the crossing)
             const bool f_row = (w >> 24 & 1u) && py0 == 0, f_col = (w >> 25 & 1u) != 0, f_x = (w >> 26 & 1u) && py0 == 0 && !f_col;
             uo[iu] = ((int)(GB + gq * GB - br) / 4 + (int)(fx * UD)) | (f_row ? 1 << 24 : 0) | (f_col ? 2 << 24 : 0) | (f_x ? 4 << 24 : 0);
+            // What this lane will place itself (rare: a goal in or next to the cell, a crossing) is fetched NOW, with the
+            // cell word just read: the round trip runs under the barrier and the pieces' own loads instead of after them
+            // (round 4: it was a dependent round trip at the end of nearly every workgroup, ~0.4 of its ~6 us)
+            if (f_row || f_col || f_x) {
+                const uint8_t *lines = p.ego_border + (((size_t)e0 + le) * NL * CH + ch) * O, *src = usrc;
+                if (f_col || f_x) pcb[iu] = *(g_u32)(lines + (size_t)(R - 1 + fx - 1) * (CH * O) + oy0);
+                if (f_row) {
+                    const uint8_t *row = lines + (size_t)(fy - 1) * (CH * O) + fx * U;
+#pragma unroll
+                    for (int d = 0; d < UD; ++d) prow[iu][d] = *(g_u32)(row + 4 * d);
+                }
+                if (f_col || f_x) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pcol[iu][j] = *(g_u32)(src + j * Q::UP);
+                }
+            }
         }
-        if (ut < NU) s_uo[ut] = uo[iu];
+#if !EGO_UNIT_SHFL
+        if (ut < NU) { s_uo[ut] = uo[iu]; s_usrc[ut] = usrc_r[iu]; }
+#endif
     }
+#if !EGO_UNIT_SHFL
     __syncthreads();
+#endif
     // ---- one lane per 16-byte piece
     {
         u32x4 q[ITP];
@@ -1123,10 +1176,21 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
         for (int it = 0; it < ITP; ++it) {
             const int P = it * BS + tid, u = P / PPU;
             pi[it] = P - u * PPU;
+#if EGO_UNIT_SHFL
+            // the unit of this piece sits in slot it * UPI + lane / PPU of this wavefront: lane (slot % 64)'s (slot / 64)-th
+            const int reg = (it * UPI) / 64;                  // (the loop is unrolled: a constant)
+            const int from_lane = (it * UPI) % 64 + (tid & 63) / PPU;
+            po[it] = __shfl(uo[reg], from_lane);
+            const unsigned long long a = (unsigned long long)usrc_r[reg];
+            const unsigned lo = (unsigned)__shfl((int)(unsigned)a, from_lane), hi = (unsigned)__shfl((int)(unsigned)(a >> 32), from_lane);
+            const uint8_t *from = (const uint8_t *)((unsigned long long)hi << 32 | lo) + 16 * pi[it];
+            (void)u;
+#else
             po[it] = s_uo[P < NU * PPU ? u : 0];
             if (P >= NU * PPU) po[it] = -1;
-            // (no branch around the load: all of a lane's pieces are in flight together; an idle lane reads the table's start)
             const uint8_t *from = s_usrc[P < NU * PPU ? u : 0] + 16 * pi[it];
+#endif
+            // (no branch around the load: all of a lane's pieces are in flight together; an idle lane reads the table's start)
             q[it] = *(g_u32x4)(po[it] >= 0 ? from : p.ego_tab3);
         }
 #pragma unroll
@@ -1154,20 +1218,16 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
             }
         }
     }
-    // ---- the unit lanes place what the pieces left (rare: a goal in or next to the cell, a crossing)
+    // ---- the unit lanes place what the pieces left (rare: a goal in or next to the cell, a crossing), from what they fetched above
 #pragma unroll
     for (int iu = 0; iu < ITU; ++iu) {
         if (uo[iu] < 0 || !(uo[iu] >> 24)) continue;
-        const int ut = iu * BS + tid, o = uo[iu] & 0xffffff, fl = uo[iu] >> 24;
-        const unsigned fx = (unsigned)ut / NG, gq = g0 + ((unsigned)ut - fx * NG);
-        const unsigned le = gq / GPF, gi = gq - le * GPF, ch = gi / GPP, oy0 = 4u * (gi - ch * GPP), fy = oy0 / (unsigned)U;
-        const uint8_t *lines = p.ego_border + (((size_t)e0 + le) * NL * CH + ch) * O, *src = s_usrc[ut];
-        const uint32_t cb = (fl & 6) ? *(g_u32)(lines + (size_t)(R - 1 + fx - 1) * (CH * O) + oy0) : 0u;
+        const int o = uo[iu] & 0xffffff, fl = uo[iu] >> 24;
+        const uint32_t cb = pcb[iu];
         if (fl & 1) {
-            const uint8_t *row = lines + (size_t)(fy - 1) * (CH * O) + fx * U;
 #pragma unroll
             for (int d = 0; d < UD; ++d) {
-                uint32_t w = *(g_u32)(row + 4 * d);
+                uint32_t w = prow[iu][d];
                 if (d == 0 && (fl & 2)) w = (w & ~0xffu) | (cb & 0xffu);
                 s_out[o + d] = w;
             }
@@ -1176,8 +1236,7 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j == 0 ? (fl & 1) != 0 : !(fl & 2)) continue;
-                const uint32_t w = *(g_u32)(src + j * Q::UP);
-                s_out[o + j * (O / 4)] = (w & ~0xffu) | ((cb >> (8 * j)) & 0xffu);
+                s_out[o + j * (O / 4)] = (pcol[iu][j] & ~0xffu) | ((cb >> (8 * j)) & 0xffu);
             }
         }
     }
