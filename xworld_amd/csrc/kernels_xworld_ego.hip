@@ -602,12 +602,13 @@ template <int R> struct EgoBorderGeom { static constexpr int EPW = R >= 7 ? 16 :
 #ifndef EGO_BS
 #define EGO_BS 256
 #endif
-// Round 4: a wavefront computes exactly the units its own lanes' pieces read and hands them over lane to lane (ds_bpermute):
-// no LDS arrays, no barrier between the two phases, the four wavefronts of a workgroup run independently up to the one
-// barrier in front of the stores (A/B hook: -DEGO_UNIT_SHFL=0 = round 3's LDS hand-over)
-#ifndef EGO_UNIT_SHFL
-#define EGO_UNIT_SHFL 1
-#endif
+// Round 4, r >= 5: a wavefront computes exactly the units its own lanes' pieces read and hands them over lane to lane
+// (ds_bpermute) -- no LDS arrays, no barrier between the two phases, the four wavefronts of a workgroup run independently up to
+// the one barrier in front of the stores, 3-4 KB less LDS per workgroup (r = 7: 7 -> 8 waves per SIMD).  Measured on one box
+// (same run, both builds; the whole-batch render's four launches): r = 5 231.3 -> 221.6 us, r = 7 247.0 -> 245.4 us, but r = 3
+// 202.8 -> 208.4 us (fifteen ds_bpermute per lane against ten LDS reads, and only 40 of a wavefront's 64 lanes hold a unit):
+// r = 3 keeps round 3's hand-over through LDS.
+template <int R> struct EgoUnitShfl { static constexpr bool value = R >= 5; };
 
 // a square's pixels in the span path's sources (ego_tab3, the goal-cell cache): [channel][U rows][UP bytes], rows padded to whole
 // 16-byte pieces
@@ -1079,14 +1080,11 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
     constexpr int NG = (SB + GB - 1) / GB + 1;                              // row groups a span can touch
     constexpr int NU = NG * R, PPU = Q::UDP, PPR = Q::UDP / 4;              // units (square column major), pieces per unit, per row
     constexpr int ITP = (NU * PPU + BS - 1) / BS;
-#if EGO_UNIT_SHFL
-    // unit slots of a wavefront: iteration `it` of the pieces loop reads the UPI units it * (BS / PPU) + wave * UPI + [0, UPI);
-    // slot k = it * UPI + j is computed by lane k % 64 (its k / 64-th unit)
-    constexpr int UPI = 64 / PPU, UPW = ITP * UPI, ITU = (UPW + 63) / 64;
+    // SHFL: unit slots of a wavefront -- iteration `it` of the pieces loop reads the UPI units it * (BS / PPU) + wave * UPI +
+    // [0, UPI); slot k = it * UPI + j is computed by lane k % 64 (its k / 64-th unit)
+    constexpr bool SHFL = EgoUnitShfl<R>::value;
+    constexpr int UPI = 64 / PPU, UPW = ITP * UPI, ITU = SHFL ? (UPW + 63) / 64 : (NU + BS - 1) / BS;
     static_assert(64 % PPU == 0 && BS % 64 == 0, "whole units per wavefront");
-#else
-    constexpr int ITU = (NU + BS - 1) / BS;
-#endif
     constexpr int NE = SB / (int)FB + 2;                                    // envs a span can touch
     constexpr int cpf = (int)FB / BPC;
     constexpr int NL = 2 * (R - 1);
@@ -1094,10 +1092,8 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
     static_assert(4 * Q::UP <= 128, "a unit fits the constant line");
     __shared__ uint4 s_out4[(GB + SB + GB) / 16];
     __shared__ uint32_t s_env[NE];                                          // a cell word of each env: its flags
-#if !EGO_UNIT_SHFL
-    __shared__ const uint8_t *s_usrc[NU];
-    __shared__ int s_uo[NU];                                                // the unit's first dword in s_out | flags << 24, -1: none
-#endif
+    __shared__ const uint8_t *s_usrc[SHFL ? 1 : NU];
+    __shared__ int s_uo[SHFL ? 1 : NU];                                     // the unit's first dword in s_out | flags << 24, -1: none
     uint32_t *s_out = reinterpret_cast<uint32_t *>(s_out4);
     const int tid = threadIdx.x;
     const unsigned br = cr * BPC, be = br + (unsigned)nc * BPC;             // bytes, from the start of env e0's frame
@@ -1120,12 +1116,8 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
     }
 #pragma unroll
     for (int iu = 0; iu < ITU; ++iu) {
-#if EGO_UNIT_SHFL
         const int k = iu * 64 + (tid & 63), itk = k / UPI;
-        const int ut = k < UPW ? itk * (BS / PPU) + (tid >> 6) * UPI + (k - itk * UPI) : NU;
-#else
-        const int ut = iu * BS + tid;
-#endif
+        const int ut = !SHFL ? iu * BS + tid : (k < UPW ? itk * (BS / PPU) + (tid >> 6) * UPI + (k - itk * UPI) : NU);
         const unsigned fx = (unsigned)ut / NG, gq = g0 + ((unsigned)ut - fx * NG);
         uo[iu] = -1;
         usrc_r[iu] = p.ego_tab3;
@@ -1161,13 +1153,9 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
                 }
             }
         }
-#if !EGO_UNIT_SHFL
-        if (ut < NU) { s_uo[ut] = uo[iu]; s_usrc[ut] = usrc_r[iu]; }
-#endif
+        if (!SHFL && ut < NU) { s_uo[ut] = uo[iu]; s_usrc[ut] = usrc_r[iu]; }
     }
-#if !EGO_UNIT_SHFL
-    __syncthreads();
-#endif
+    if (!SHFL) __syncthreads();
     // ---- one lane per 16-byte piece
     {
         u32x4 q[ITP];
@@ -1176,20 +1164,20 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
         for (int it = 0; it < ITP; ++it) {
             const int P = it * BS + tid, u = P / PPU;
             pi[it] = P - u * PPU;
-#if EGO_UNIT_SHFL
-            // the unit of this piece sits in slot it * UPI + lane / PPU of this wavefront: lane (slot % 64)'s (slot / 64)-th
-            const int reg = (it * UPI) / 64;                  // (the loop is unrolled: a constant)
-            const int from_lane = (it * UPI) % 64 + (tid & 63) / PPU;
-            po[it] = __shfl(uo[reg], from_lane);
-            const unsigned long long a = (unsigned long long)usrc_r[reg];
-            const unsigned lo = (unsigned)__shfl((int)(unsigned)a, from_lane), hi = (unsigned)__shfl((int)(unsigned)(a >> 32), from_lane);
-            const uint8_t *from = (const uint8_t *)((unsigned long long)hi << 32 | lo) + 16 * pi[it];
-            (void)u;
-#else
-            po[it] = s_uo[P < NU * PPU ? u : 0];
-            if (P >= NU * PPU) po[it] = -1;
-            const uint8_t *from = s_usrc[P < NU * PPU ? u : 0] + 16 * pi[it];
-#endif
+            const uint8_t *from;
+            if (SHFL) {
+                // the unit of this piece sits in slot it * UPI + lane / PPU of this wavefront: lane (slot % 64)'s (slot / 64)-th
+                const int reg = SHFL ? (it * UPI) / 64 : 0;    // (the loop is unrolled: a constant)
+                const int from_lane = (it * UPI) % 64 + (tid & 63) / PPU;
+                po[it] = __shfl(uo[reg], from_lane);
+                const unsigned long long a = (unsigned long long)usrc_r[reg];
+                const unsigned lo = (unsigned)__shfl((int)(unsigned)a, from_lane), hi = (unsigned)__shfl((int)(unsigned)(a >> 32), from_lane);
+                from = (const uint8_t *)((unsigned long long)hi << 32 | lo) + 16 * pi[it];
+            } else {
+                po[it] = s_uo[P < NU * PPU ? u : 0];
+                if (P >= NU * PPU) po[it] = -1;
+                from = s_usrc[P < NU * PPU ? u : 0] + 16 * pi[it];
+            }
             // (no branch around the load: all of a lane's pieces are in flight together; an idle lane reads the table's start)
             q[it] = *(g_u32x4)(po[it] >= 0 ? from : p.ego_tab3);
         }
