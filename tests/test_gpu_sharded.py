@@ -129,7 +129,14 @@ def test_bench_two_ranks_on_one_gpu(workload, extra):
     assert line["config"]["total_envs"] == 2048 and line["value"] > 0
     assert line["rccl"] == {"world_size": 2, "backend": "gloo", "version": None}
     sg = line["screens_gather"]
-    assert sg["value"] > 0 and sg["link_bound_ceiling"] > 0 and sg["bytes_into_root_per_step"] > 0
+    assert sg["value"] > 0 and sg["link_bound_ceiling"] > 0 and sg["bytes_into_root_per_step"] > 0 and sg["mode"] == "screens"
+    if workload == "xworld7":                             # full observation: the same loop with the cell codes gathered instead
+        gg = sg["grids"]
+        assert "error" not in gg, gg
+        assert gg["mode"] == "grids" and gg["value"] > 0 and gg["root_render_bound_ceiling"] > 0
+        assert gg["bytes_into_root_per_step"] == 1024 * (2 * 49 + 1) and gg["bytes_into_root_per_step"] * 200 < sg["bytes_into_root_per_step"]
+    else:
+        assert "skipped" in sg["grids"]
     assert line["regions"]["repetitions"] == 3 and len(line["regions"]["ms_per_step_all"]) == 3
     assert line["parity"]["mismatches"] == 0 and line["parity"]["checked_env_steps"] > 0
     assert "cpu_baseline" not in line                     # rank 0 at N = 1 only
@@ -138,5 +145,6 @@ def test_bench_two_ranks_on_one_gpu(workload, extra):
         assert "error" not in c5, c5
         assert c5["workload"] == "xworld11" and c5["value"] > 0 and c5["action_errors"] == 0
         assert c5["screens_gather"]["value"] > 0 and c5["screens_gather"]["link_bound_ceiling"] > 0
+        assert c5["screens_gather"]["grids"]["value"] > 0 and "error" not in c5["screens_gather"]["grids"]
     else:
         assert "c5" not in line
