@@ -1090,7 +1090,7 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
     constexpr int NL = 2 * (R - 1);
     static_assert(GB % 16 == 0 && U % 4 == 0, "aligned pieces");
     static_assert(4 * Q::UP <= 128, "a unit fits the constant line");
-    __shared__ uint4 s_out4[(GB + SB + GB) / 16];
+    __shared__ uint4 s_out4[(GB + SB + GB) / 16 + 17];                      // (+ the dump of dwords nobody wants, see below: 64 + 3 dwords)
     __shared__ uint32_t s_env[NE];                                          // a cell word of each env: its flags
     __shared__ const uint8_t *s_usrc[SHFL ? 1 : NU];
     __shared__ int s_uo[SHFL ? 1 : NU];                                     // the unit's first dword in s_out | flags << 24, -1: none
@@ -1159,11 +1159,13 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
     // ---- one lane per 16-byte piece
     {
         u32x4 q[ITP];
-        int po[ITP], pi[ITP];
+        int po[ITP];
+        // (PPU divides BS: the place of a lane's piece inside its unit is the same in every iteration)
+        static_assert(BS % PPU == 0, "a lane's piece index inside its unit does not change from iteration to iteration");
+        const int pi0 = tid % PPU;
 #pragma unroll
         for (int it = 0; it < ITP; ++it) {
             const int P = it * BS + tid, u = P / PPU;
-            pi[it] = P - u * PPU;
             const uint8_t *from;
             if (SHFL) {
                 // the unit of this piece sits in slot it * UPI + lane / PPU of this wavefront: lane (slot % 64)'s (slot / 64)-th
@@ -1172,37 +1174,64 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
                 po[it] = __shfl(uo[reg], from_lane);
                 const unsigned long long a = (unsigned long long)usrc_r[reg];
                 const unsigned lo = (unsigned)__shfl((int)(unsigned)a, from_lane), hi = (unsigned)__shfl((int)(unsigned)(a >> 32), from_lane);
-                from = (const uint8_t *)((unsigned long long)hi << 32 | lo) + 16 * pi[it];
+                from = (const uint8_t *)((unsigned long long)hi << 32 | lo) + 16 * pi0;
             } else {
                 po[it] = s_uo[P < NU * PPU ? u : 0];
                 if (P >= NU * PPU) po[it] = -1;
-                from = s_usrc[P < NU * PPU ? u : 0] + 16 * pi[it];
+                from = s_usrc[P < NU * PPU ? u : 0] + 16 * pi0;
             }
             // (no branch around the load: all of a lane's pieces are in flight together; an idle lane reads the table's start)
             q[it] = *(g_u32x4)(po[it] >= 0 ? from : p.ego_tab3);
         }
+        // Placing the dwords, r <= 5, is branch-free (round 4): a dword that is not this piece's to write -- an idle lane, the
+        // padding of a row's last piece, a dword the unit lane places itself -- goes to a per-lane dump slot behind the span
+        // instead of around a divergent branch (the loop was a dozen exec-mask regions per piece: 376 scalar instructions per
+        // wavefront against 445 vector ones at r = 3; now 241 / 418).  Which dwords a lane may lose depends on its piece's
+        // place in the unit, which is the same in every iteration.  Kernel trace, same box, both builds: gather r = 3
+        // 133.2 -> 127.8 us, r = 5 render 232.8 -> 215.9 us; r = 7 154.4 -> 168.8 us -- its rows are ONE 12-byte piece, the
+        // branchy form stores them with fewer, wider LDS writes -- so r = 7 keeps the branches.
+        constexpr int LASTD = UD - 4 * (PPR - 1);                                      // dwords of a row's last piece
+        constexpr bool BRANCH_FREE = R <= 5;
+        const int j0 = pi0 / PPR, h0 = pi0 - j0 * PPR;
+        if (BRANCH_FREE) {
+            // (one dump slot per lane: sixty-four lanes storing to ONE address serialise)
+            const int DUMP = (int)(GB + SB + GB) / 4 + (tid & 63);
+            const int lane_off = j0 * (O / 4) + 4 * h0;
+            const int kill_all = j0 == 0 ? 1 : 0;                                      // fl & 1: the unit lane places the whole first row
+            const int kill_0 = h0 == 0 ? (2 | (j0 == 0 ? 4 : 0)) : 0;                  // fl & 2 / 4: ... the first dword of every / of the first row
+            const bool pad2 = h0 == PPR - 1 && LASTD <= 2, pad3 = h0 == PPR - 1 && LASTD <= 3;
 #pragma unroll
-        for (int it = 0; it < ITP; ++it) {
-            if (po[it] < 0) continue;
-            const uint32_t w[4] = {q[it].x, q[it].y, q[it].z, q[it].w};
-            const int o = po[it] & 0xffffff, fl = po[it] >> 24;
-            const int j = pi[it] / PPR, h = pi[it] - j * PPR;
-            uint32_t *dst = s_out + o + j * (O / 4) + 4 * h;
-            constexpr int LASTD = UD - 4 * (PPR - 1);                                  // dwords of a row's last piece
-            if (fl == 0) {
-                dst[0] = w[0];
-                if (LASTD > 1 || h < PPR - 1) dst[1] = w[1];
-                if (LASTD > 2 || h < PPR - 1) dst[2] = w[2];
-                if (LASTD > 3 || h < PPR - 1) dst[3] = w[3];
-                continue;
+            for (int it = 0; it < ITP; ++it) {
+                const int fl = po[it] >> 24;                                           // (-1 for an idle lane: every test below kills)
+                const bool dead = po[it] < 0 || (fl & kill_all);
+                const int base = dead ? DUMP : (po[it] & 0xffffff) + lane_off;
+                s_out[(fl & kill_0) ? DUMP : base] = q[it].x;
+                s_out[base + 1] = q[it].y;
+                if (!(PPR == 1 && LASTD <= 2)) s_out[pad2 ? DUMP + 2 : base + 2] = q[it].z;      // (a row that is one piece: known at compile time)
+                if (!(PPR == 1 && LASTD <= 3)) s_out[pad3 ? DUMP + 3 : base + 3] = q[it].w;
             }
-            const bool first = h == 0 && ((fl & 2) || (j == 0 && (fl & 4)));        // its first dword is the unit lane's
-            if (j == 0 && (fl & 1)) continue;                                          // the whole row is
+        } else {
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                if (h == PPR - 1 && d >= LASTD) continue;                               // padding
-                if (d == 0 && first) continue;
-                dst[d] = w[d];
+            for (int it = 0; it < ITP; ++it) {
+                if (po[it] < 0) continue;
+                const uint32_t w[4] = {q[it].x, q[it].y, q[it].z, q[it].w};
+                const int o = po[it] & 0xffffff, fl = po[it] >> 24;
+                uint32_t *dst = s_out + o + j0 * (O / 4) + 4 * h0;
+                if (fl == 0) {
+                    dst[0] = w[0];
+                    if (LASTD > 1 || h0 < PPR - 1) dst[1] = w[1];
+                    if (LASTD > 2 || h0 < PPR - 1) dst[2] = w[2];
+                    if (LASTD > 3 || h0 < PPR - 1) dst[3] = w[3];
+                    continue;
+                }
+                const bool first = h0 == 0 && ((fl & 2) || (j0 == 0 && (fl & 4)));  // its first dword is the unit lane's
+                if (j0 == 0 && (fl & 1)) continue;                                     // the whole row is
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if (h0 == PPR - 1 && d >= LASTD) continue;                          // padding
+                    if (d == 0 && first) continue;
+                    dst[d] = w[d];
+                }
             }
         }
     }
