@@ -1262,6 +1262,18 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
     const float scale = (float)(1 / 255.0);
     bool any_skip = false;                                                  // (uniform: a scalar branch)
     if (skip_term) for (int i = 0; i < ne; ++i) any_skip |= (s_env[i] >> 27 & 1u) != 0;
+    if (CTX1 && ES == 1 && !any_skip && nc == SPAN) {
+        // the usual workgroup -- a whole span of back-to-back uint8 frames, nobody skipped -- under ONE scalar branch: PER LDS reads
+        // and PER stores per lane, no per-chunk tests (round 4)
+        u32x4 *dst = reinterpret_cast<u32x4 *>(obs4 + ((size_t)e0 * cpf + cr)) + tid;
+#pragma unroll
+        for (int kk = 0; kk < PER; ++kk) {
+            const uint4 val = s_out4[GB / 16 + kk * BS + tid];
+            u32x4 nv = {val.x, val.y, val.z, val.w};
+            __builtin_nontemporal_store(nv, dst + kk * BS);
+        }
+        return;
+    }
 #pragma unroll
     for (int kk = 0; kk < PER; ++kk) {
         const int c = kk * BS + tid;
