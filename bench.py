@@ -62,10 +62,11 @@ POLICY_SEED = 0x5EED
 REC_BYTES_CAP = 6 << 30      # the per-step (reward, game_over) record: a ring of at most this many bytes
 
 
-def make_sim(workload, n_envs, device, gid0, seed=0xC0FFEE):
+def make_sim(workload, n_envs, device, gid0, seed=0xC0FFEE, **extra):
     from xworld_amd.batched import BatchedSimulator
     game, opts, _ = WORKLOADS[workload]
     opts = dict(opts)
+    opts.update(extra)
     if game == "xworld":
         opts["xwd_conf_path"] = os.path.join(ROOT, "xworld_amd", "confs", "navigation2d.json")       # the five XWorld3DNav tasks
         opts["task_mode"] = "lang_acquisition"
@@ -587,6 +588,34 @@ def main():
                    "step_loop_frac": n_local * per_step * args.steps / ar_med / 1e9 / HBM_PEAK_GBS, "path": ar_path}
         one_step()                                       # back in the default loop before anything else is measured
 
+    # ---- the OTHER path of the default loop (weak point of round 3: "a trainer can end up on a path the bench never timed"):
+    # a second batch of the same workload held on the classic kernel sequence (xwb_config.debug_flags no_pregen = what a batch
+    # runs after three foreign resets, or with a curriculum / minstd / exclusive groups), timed with the same loop, 3 regions ----
+    classic_line = None
+    if is_xworld and world == 1 and fused == 1 and not args.autoreset and path_default["path"] == "lazy":
+        sim2 = make_sim(args.workload, n_local, local_rank, 0, args.seed, debug=["no_pregen"])
+
+        def classic_region():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                sim2.step()
+                sim2.reset_done()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        for _ in range(max(W, 20)):
+            sim2.step()
+            sim2.reset_done()
+        t_end = time.perf_counter() + min(args.spin_seconds, 0.2)
+        while time.perf_counter() < t_end:
+            classic_region()
+        c_med = statistics.median([classic_region() for _ in range(3)])
+        classic_line = {"loop": "step + reset_done on the classic path (terminal snapshots, map generator beside the render, list render)",
+                        "regions": 3, "ms_per_step": c_med / args.steps * 1e3, "value": n_local * args.steps / c_med, "unit": "env-steps/s",
+                        "step_loop_frac": n_local * per_step * args.steps / c_med / 1e9 / HBM_PEAK_GBS, "path": sim2.step_path()}
+        assert sim2.check_errors() == 0
+        sim2.close()
+
     # ---- N > 1: the same loop with the screens of every shard gathered into one tensor on rank 0: the pixels themselves
     # (link-bound), and -- full observation, library exchange -- the cell codes with the root drawing every frame ----
     sg_line = None
@@ -665,6 +694,8 @@ def main():
         }
         if ar_line is not None:
             line["step_autoreset"] = ar_line
+        if classic_line is not None:
+            line["classic_path"] = classic_line
         if sg_line is not None:
             line["screens_gather"] = sg_line
         if c5 is not None:

@@ -1,0 +1,114 @@
+"""Round-4 host-side behaviour of the C ABI: the per-batch debug configuration and its one process-wide override
+(XWB_DEBUG), xwb_step_path, probing only on explicit calls (xwb_queue_sync_mode / xwb_queue_sync_forget), the checkpoint
+blob's version check.  Reference behaviour being replaced: process-global gflags (simulator.cpp:21-27)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAV = os.path.join(ROOT, "xworld_amd", "confs", "navigation2d.json")
+OPTS = {"xwd_conf_path": NAV, "task_mode": "lang_acquisition", "max_dim": 7, "color": True}
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def test_step_path_reports_the_kernel_sequence():
+    torch = _torch()
+    from xworld_amd.batched import BatchedSimulator
+    sim = BatchedSimulator("xworld", OPTS, num_envs=512, seed=3)
+    assert sim.step_path()["path"] == "none"                       # no step yet
+    sim.step(); sim.reset_done()
+    assert sim.step_path() == {"path": "lazy", "queue_sync": sim.queue_sync_mode()[0], "shadow_breaks": 0}
+    sim.step_autoreset()
+    assert sim.step_path()["path"] == "pregen"
+    mask = torch.zeros(512, dtype=torch.uint8, device="cuda")
+    mask[3] = 1
+    for k in range(3):                                             # three foreign resets: the default loop falls back for good
+        sim.step(); sim.reset_masked(mask); sim.reset_done()
+    sim.step()
+    p = sim.step_path()
+    assert p["path"] == "classic" and p["shadow_breaks"] >= 3
+    sim.close()
+    for opts, want in ((dict(OPTS, debug=["no_pregen"]), "classic"), (dict(OPTS, debug=["no_lazy"]), "classic"),
+                       (dict(OPTS, obs_format="float32"), "classic"), (dict(OPTS, visible_radius=3), "ego_span"),
+                       (dict(OPTS, visible_radius=3, debug=["ego_no_span"]), "ego_per_env")):
+        s = BatchedSimulator("xworld", opts, num_envs=256)
+        s.step()
+        assert s.step_path()["path"] == want, (opts, s.step_path())
+        s.close()
+    sg = BatchedSimulator("simple_game", {"array_size": 8}, num_envs=64)
+    sg.step()
+    assert sg.step_path() == {"path": "none", "queue_sync": "auto", "shadow_breaks": 0}
+    sg.close()
+    with pytest.raises(Exception, match="unknown debug switch"):
+        BatchedSimulator("xworld", dict(OPTS, debug=["nonsense"]), num_envs=8)
+
+
+def test_debug_env_override_is_read_once_per_process():
+    """XWB_DEBUG: the one process-wide override of xwb_config.debug_flags (for tools that cannot reach the configuration)."""
+    _torch()
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from xworld_amd.batched import BatchedSimulator\n"
+            "s = BatchedSimulator('xworld', %r, num_envs=256)\n"
+            "s.step(); print('PATH', s.step_path()['path'], s.ego_render_path)\n") % (ROOT, dict(OPTS, visible_radius=3))
+    for env, want in (({}, "PATH ego_span span"), ({"XWB_DEBUG": "ego_no_span,bogus_entry"}, "PATH ego_per_env per_env")):
+        e = dict(os.environ)
+        e.pop("XWB_DEBUG", None)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=300)
+        assert r.returncode == 0 and want in r.stdout, (r.stdout, r.stderr[-1500:])
+        assert ("unknown entry 'bogus_entry'" in r.stderr) == bool(env)
+
+
+def test_streams_are_probed_only_on_request():
+    """No step verb synchronises the host: a stream nobody probed hands over through events; xwb_queue_sync_mode probes it."""
+    torch = _torch()
+    from xworld_amd import lib
+    from xworld_amd.batched import BatchedSimulator
+    sim = BatchedSimulator("xworld", OPTS, num_envs=1024, seed=5)
+    ref = BatchedSimulator("xworld", OPTS, num_envs=1024, seed=5)
+    default_mode = sim.queue_sync_mode()                          # the default stream was probed by xwb_create
+    assert default_mode[1] in ("probe_ok", "probe_failed", "tool", "env")
+    mine = torch.cuda.Stream()
+    for t in range(5):
+        sim.step(stream=mine); sim.reset_done(stream=mine)
+        ref.step(); ref.reset_done()
+    assert sim.step_path()["queue_sync"] == "events"              # never probed: events
+    mode = sim.queue_sync_mode(mine)                              # the explicit probe
+    assert mode[1] in ("probe_ok", "probe_failed", "tool", "env")
+    for t in range(5):
+        sim.step(stream=mine); sim.reset_done(stream=mine)
+        ref.step(); ref.reset_done()
+    assert sim.step_path()["queue_sync"] == mode[0]
+    lib.check(sim.L.xwb_queue_sync_forget(sim.h, C.c_void_p(mine.cuda_stream)))
+    sim.step(stream=mine); ref.step()
+    assert sim.step_path()["queue_sync"] == "events"              # forgotten: events again
+    mine.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(sim.obs, ref.obs) and torch.equal(sim.reward, ref.reward)
+    sim.close(); ref.close()
+
+
+def test_checkpoint_blob_of_another_version_is_named():
+    _torch()
+    from xworld_amd.batched import BatchedSimulator
+    sim = BatchedSimulator("simple_game", {"array_size": 16}, num_envs=64)
+    sim.step()
+    blob = bytearray(sim.save_state())
+    assert blob[:8] == b"XWBSTATE" and int(np.frombuffer(bytes(blob[8:12]), np.uint32)[0]) == 3
+    blob[8:12] = np.uint32(2).tobytes()                            # what round 3 wrote
+    with pytest.raises(Exception, match="version 2"):
+        sim.load_state(np.frombuffer(bytes(blob), np.uint8))
+    blob[:8] = b"NOTSTATE"
+    with pytest.raises(Exception, match="not a state blob"):
+        sim.load_state(np.frombuffer(bytes(blob), np.uint8))
+    sim.close()
