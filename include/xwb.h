@@ -229,8 +229,9 @@ int xwb_reset_env(xwb_sim *sim, int32_t env, void *stream);
  * Out-of-range action ids set the env's error flag (see xwb_check_errors) and leave that env untouched. */
 int xwb_step(xwb_sim *sim, const int32_t *actions_dev, int32_t act_rep, void *stream);
 
-/* xwb_step with the action ids in HOST memory (int32[num_envs]): copied to the device on `stream` first
- * (4 bytes per env over PCIe; the only host->device traffic of a step). */
+/* xwb_step with the action ids in HOST memory (int32[num_envs]): 4 bytes per env over PCIe, the only host->device traffic of a
+ * step.  Page-locked memory (hipHostMalloc / hipHostRegister, torch pin_memory) is read by the step kernel in place -- keep it
+ * unchanged until `stream` has passed the call --; pageable memory is copied to the device on `stream` first. */
 int xwb_step_host(xwb_sim *sim, const int32_t *actions_host, int32_t act_rep, void *stream);
 
 /* xwb_step followed by xwb_reset_done in one call, with a single render of the final state

@@ -112,3 +112,32 @@ def test_checkpoint_blob_of_another_version_is_named():
     with pytest.raises(Exception, match="not a state blob"):
         sim.load_state(np.frombuffer(bytes(blob), np.uint8))
     sim.close()
+
+
+def test_step_host_pageable_and_pinned_actions():
+    """xwb_step_host: pageable host memory is staged through the device, page-locked memory is read by the step kernel in
+    place; both equal the device-pointer call, skipped envs (XWB_ACTION_SKIP) and bad ids included."""
+    torch = _torch()
+    from xworld_amd.batched import BatchedSimulator
+    n = 2048
+    sims = [BatchedSimulator("xworld", OPTS, num_envs=n, seed=9) for _ in range(3)]
+    rng = np.random.default_rng(4)
+    pinned = torch.empty(n, dtype=torch.int32).pin_memory()
+    for t in range(40):
+        a = rng.integers(-1, 4, n).astype(np.int32)
+        if t == 7:
+            a[11] = 9                                               # out of range: counted, env untouched
+        sims[0].step(torch.from_numpy(a).cuda())
+        sims[1].step_host(a)                                        # pageable numpy memory
+        torch.cuda.synchronize()                                    # (the pinned buffer is rewritten below: the last call has read it)
+        pinned.copy_(torch.from_numpy(a))
+        sims[2].step_host(pinned)
+        for s in sims:
+            s.reset_done()
+        torch.cuda.synchronize()
+        for s in sims[1:]:
+            assert torch.equal(s.obs, sims[0].obs) and torch.equal(s.reward, sims[0].reward), t
+            assert torch.equal(s.game_over_codes, sims[0].game_over_codes) and torch.equal(s.actions, sims[0].actions), t
+    assert [s.check_errors() for s in sims] == [1, 1, 1]
+    for s in sims:
+        s.close()

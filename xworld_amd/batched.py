@@ -223,6 +223,12 @@ class BatchedSimulator:
         ptr = None if actions is None else C.c_void_p(actions.data_ptr())
         lib.check(self.L.xwb_step(self.h, ptr, int(act_rep), self._stream(stream)))
 
+    def step_host(self, actions, act_rep=1, stream=None):
+        """xwb_step_host: the action ids in HOST memory -- a numpy int32 array or a CPU torch tensor (a pinned one is read by
+        the step kernel in place: keep it unchanged until `stream` has passed the call)."""
+        ptr = actions.data_ptr() if hasattr(actions, "data_ptr") else actions.ctypes.data
+        lib.check(self.L.xwb_step_host(self.h, C.c_void_p(ptr), int(act_rep), self._stream(stream)))
+
     def step_n(self, n_steps, act_rep=1, stream=None):
         """n_steps x step_autoreset under the built-in random policy; one launch for the simple games."""
         lib.check(self.L.xwb_step_n(self.h, int(n_steps), int(act_rep), self._stream(stream)))
