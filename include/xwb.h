@@ -439,7 +439,8 @@ int xwb_xw_get_tile_table(const xwb_sim *sim, uint8_t *out_host, size_t cap, siz
  * last draw (uint8[num_envs]: 0 untouched, 1 ring shift, 2 first frame of an episode -- the older context frames start
  * black); flags_dev may be NULL when context == 1.  Ordered on `stream` behind the verbs queued before it.  With
  * context > 1 it must follow EVERY verb that draws frames (step, reset_done, ...: a ring is replayed one draw at a time),
- * else XWB_ERR_STATE.  Egocentric batches: XWB_ERR_STATE (their frames also depend on heading, poses and shadows).
+ * else XWB_ERR_STATE -- also after the map-replay hooks (xwb_xw_load_map*, xwb_xw_refresh_obs), which redraw one env out of
+ * turn.  Egocentric batches: XWB_ERR_STATE (their frames also depend on heading, poses and shadows).
  * xwb_xw_render_grids draws n_envs frames from such codes with THIS batch's tile table and frame format into
  * obs_dev [n_envs][bytes_per_env] -- n_envs is the caller's, not num_envs: the root draws the whole sharded batch with the
  * kernel that draws its own shard (xw_render_all_kernel), byte for byte what the shards drew. */

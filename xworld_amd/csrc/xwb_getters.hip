@@ -327,6 +327,8 @@ int xwb_xw_load_map_task(xwb_sim *s, int32_t env, const uint16_t *grid_host, int
     HIP_TRY(hipMemcpy(p.done_count, &cnt, 4, hipMemcpyHostToDevice));
     if (p.visible_radius) HIP_TRY(launch_xw_warp_goals(p, true, nullptr));
     HIP_TRY(launch_xw_render(p, 1, nullptr));
+    s->frame_src = 0; s->draws_since_pack += 2;            // (xwb_xw_pack_grids: one env redrawn out of turn -- a context ring elsewhere
+                                                           //  cannot follow that: context > 1 must re-synchronise with the screens)
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(p.done_count, 0, 4));
     s->list_valid = false;
@@ -404,6 +406,8 @@ int xwb_xw_refresh_obs(xwb_sim *s, int32_t env) {
     HIP_TRY(hipMemcpy(s->d_fresh + env, &two, 1, hipMemcpyHostToDevice));
     if (p.visible_radius) HIP_TRY(launch_xw_warp_goals(p, true, nullptr));
     HIP_TRY(launch_xw_render(p, 1, nullptr));
+    s->frame_src = 0; s->draws_since_pack += 2;            // (xwb_xw_pack_grids: one env redrawn out of turn -- a context ring elsewhere
+                                                           //  cannot follow that: context > 1 must re-synchronise with the screens)
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(p.done_count, 0, 4));
     s->list_valid = false;
