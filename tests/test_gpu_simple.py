@@ -207,6 +207,40 @@ def test_simple_race_kat_survey(oracle):
     sim.close()
 
 
+@pytest.mark.parametrize("name,k", [("straight", 3), ("circle", 16)])
+def test_simple_race_reference_frames_through_the_product(oracle, name, k):
+    """The reference's own rendered SimpleRace frames (tests/test_oracle_race_doc_images.py: doc/simple_race_{1,2}.png carry the
+    get_screen values of their state as text): the car is put one unit step behind a state that prints exactly the image's
+    numbers, the HIP kernel drives it there (action 1 of the full manoeuvre set: forward, no turn), and its observation must
+    equal the oracle's bit for bit AND print the image's five numbers."""
+    torch = _torch()
+    from test_oracle_race_doc_images import FRAMES, PI, printed_state, solve
+    from xworld_amd.batched import BatchedSimulator
+    hits, _ = solve(oracle, name)
+    assert list(hits) == [k]
+    pts = np.array(hits[k])
+    x, y = pts.mean(axis=0)                                           # the middle of the region: away from its rounding edges
+    ang = np.float32((PI / 2 + k * PI / 10) % (2 * PI))
+    f = FRAMES[name]
+    opts = dict(track_width=f["opts"]["track_width"], track_length=f["opts"].get("track_length", 100.0),
+                track_radius=f["opts"].get("track_radius", 30.0), track_type="circle" if f["opts"]["track_type"] else "straight",
+                race_full_manouver=True)
+    sim = BatchedSimulator("simple_race", opts, num_envs=4)
+    g = oracle.SimpleRace(race_full_manouver=1, **f["opts"])
+    g.reset_game()
+    x0, y0 = np.float32(x - np.cos(float(ang))), np.float32(y - np.sin(float(ang)))
+    sim.race_set_car(2, float(x0), float(y0), float(ang))
+    g.set_car(float(x0), float(y0), float(ang))
+    acts = torch.full((4,), -1, dtype=torch.int32, device="cuda")
+    acts[2] = 1
+    sim.step(acts)
+    r = np.float32(g.take_actions(1))
+    obs = sim.env_obs(2).view(np.float32)
+    assert np.array_equal(obs.view(np.uint32), g.state_screen().view(np.uint32)) and np.float32(float(sim.reward[2])) == r
+    assert printed_state(obs) == f["printed"], (printed_state(obs), f["printed"])
+    sim.close()
+
+
 def test_simple_race_full_size_c3(oracle, trig):
     """BASELINE config C3: 65 536 envs, straight track, 2.6 M env-steps: every reward bit, code and observation, against
     the libm oracle (independent of the kernels' include/xwb_trig.h) and against the oracle on xwb_trig.h.  Mismatches are
