@@ -241,6 +241,28 @@ def test_simple_race_reference_frames_through_the_product(oracle, name, k):
     sim.close()
 
 
+@pytest.mark.parametrize("name", ["circle", "straight"])
+def test_simple_race_walk_into_the_reference_frame(oracle, name):
+    """tests/test_oracle_race_doc_images.py WALKS: from reset, the default action set drives the HIP kernel into the state the
+    reference's frame shows; its observation prints the image's numbers and every step equals the oracle's bit for bit."""
+    torch = _torch()
+    from test_oracle_race_doc_images import FRAMES, WALKS, printed_state
+    from xworld_amd.batched import BatchedSimulator
+    f = FRAMES[name]
+    opts = dict(track_width=f["opts"]["track_width"], track_length=f["opts"].get("track_length", 100.0),
+                track_radius=f["opts"].get("track_radius", 30.0), track_type="circle" if f["opts"]["track_type"] else "straight")
+    sim = BatchedSimulator("simple_race", opts, num_envs=3)
+    g = oracle.SimpleRace(**f["opts"])
+    g.reset_game()
+    for a in WALKS[name]:
+        sim.step(torch.full((3,), a, dtype=torch.int32, device="cuda"))
+        r = np.float32(g.take_actions(a))
+        assert np.float32(float(sim.reward[1])) == r
+        assert np.array_equal(sim.env_obs(1).view(np.uint32), g.state_screen().view(np.uint32))
+    assert printed_state(sim.env_obs(1).view(np.float32)) == f["printed"]
+    sim.close()
+
+
 def test_simple_race_full_size_c3(oracle, trig):
     """BASELINE config C3: 65 536 envs, straight track, 2.6 M env-steps: every reward bit, code and observation, against
     the libm oracle (independent of the kernels' include/xwb_trig.h) and against the oracle on xwb_trig.h.  Mismatches are

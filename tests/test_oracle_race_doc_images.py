@@ -112,3 +112,38 @@ def test_get_screen_prints_what_the_reference_frame_shows(oracle, name, k_expect
     ix, iy = int((tip[0] + 0.5) / SCALE), int((tip[1] + 0.5) / SCALE)
     near = a[iy - 2:iy + 3, ix - 2:ix + 3]
     assert (near.min(axis=2) > 150).any(), "no arrow where the heading points"
+
+
+# Walks of the default two-action set (each action: turn by +-PI/10, then one unit forward; BaseCar::move, :227-235) from
+# RaceEngine::reset_game's deterministic start that END in the frames' states.  Found by a search over the lattice the walks
+# span (positions = start + sums of the twenty unit headings).  Circle: among ALL walks of <= 30 steps exactly one end
+# point (heading PI/2 - 4 PI/10, 10 steps -- the fewest the distance allows -- reached by three orders of the same steps)
+# prints the image's numbers; the region that prints them measures 0.2 x 0.02 px, the ~10^4 end points of such walks are
+# spread over ~600 px^2, so this is the frame's own action history up to order, not a coincidence: it pins the start
+# position and heading, the turn and forward step sizes and their order.  Straight: the region is larger (0.4 x 2 px); the
+# 27-step walk below (the fewest steps the distance allows; one end point, 66 orders) is one of many that fit -- weak
+# evidence, kept as a regression value.
+WALKS = {"circle": [0, 1, 0, 1, 1, 0, 1, 1, 1, 1],
+         "straight": [0, 0, 1, 0, 1, 0] + [0, 1] * 10 + [0]}
+
+
+@pytest.mark.parametrize("name", ["circle", "straight"])
+def test_a_walk_from_reset_ends_in_the_frame(oracle, name):
+    f = FRAMES[name]
+    g = oracle.SimpleRace(**f["opts"])
+    g.reset_game()
+    for a in WALKS[name]:
+        g.take_actions(a)
+        assert g.game_over() == 0
+    assert printed_state(g.screen()) == f["printed"]
+    cx, cy = measured_car(name)
+    x, y, _ = g.car()
+    assert np.hypot(x - cx, y - cy) < 1.5                             # where the image shows the car
+    if name == "circle":                                             # every other order of a step changes the end point's print
+        for i in range(len(WALKS[name])):
+            alt = list(WALKS[name])
+            alt[i] ^= 1
+            g.reset_game()
+            for a in alt:
+                g.take_actions(a)
+            assert printed_state(g.screen()) != f["printed"], i
