@@ -233,15 +233,16 @@ def gather_block(sim, mode, lib_comm, depth, world, n_local, steps, sg_regions):
         link_bytes = shard_bytes
         bound = {"bound": "xGMI link (every remote shard has ONE link to the root)"}
     else:
+        mode_note = {"local_render": mode != "grids_nodraw"}
         link_bytes = n_local * (2 * sim.cfg.max_dim ** 2 + 1)
         # the root writes every frame of the whole batch once more: its HBM write stream bounds the step
         root_s = world * shard_bytes / (HBM_PEAK_GBS * 1e9)
         bound = {"bound": "the root's HBM write stream (it draws all %d frames from the gathered cell codes)" % (n_local * world),
-                 "root_render_bound_ms_per_step": root_s * 1e3, "root_render_bound_ceiling": n_local * world / root_s}
+                 "root_render_bound_ms_per_step": root_s * 1e3, "root_render_bound_ceiling": n_local * world / root_s, **mode_note}
     link_s = link_bytes / (XGMI_LINK_GBS * 1e9)
     if lib_comm is not None:
-        by = "libxwb.so (xwb_gather_%s_begin + xwb_comm_mark / _wait: ncclSend / ncclRecv on the communicator's stream)" % mode
-    elif mode == "grids":
+        by = "libxwb.so (xwb_gather_%s_begin + xwb_comm_mark / _wait: ncclSend / ncclRecv on the communicator's stream)" % mode.split("_")[0]
+    elif mode.startswith("grids"):
         by = "torch.distributed batch_isend_irecv of the packed cell codes + xwb_xw_render_grids on the root (sharding.GridsGather)"
     else:
         by = "torch.distributed batch_isend_irecv"
@@ -256,10 +257,13 @@ def gather_block(sim, mode, lib_comm, depth, world, n_local, steps, sg_regions):
 
 
 def make_gather(sim, mode, lib_comm, counts, rank):
+    """mode: screens | grids | grids_nodraw (= grids with every shard's own pixel stores off: xwb_xw_set_draw(sim, 0))"""
     from xworld_amd import sharding
+    m = "grids" if mode.startswith("grids") else "screens"
+    sim.set_draw(mode != "grids_nodraw") if mode.startswith("grids") else None
     if lib_comm is not None:
-        return sharding.LibScreensGather(sim, lib_comm, counts, rank, mode=mode)
-    return sharding.GridsGather(sim, counts, rank) if mode == "grids" else sharding.ScreensGather(sim, counts, rank)
+        return sharding.LibScreensGather(sim, lib_comm, counts, rank, mode=m)
+    return sharding.GridsGather(sim, counts, rank) if m == "grids" else sharding.ScreensGather(sim, counts, rank)
 
 
 def gather_regions(sim, mode, lib_comm, counts, rank, world, n_local, K, R, args, set_screens, timed_region, fence):
@@ -273,6 +277,14 @@ def gather_regions(sim, mode, lib_comm, counts, rank, world, n_local, K, R, args
         fence()
     finally:
         set_screens(None)
+        if mode == "grids_nodraw":                           # back to a batch that draws, its own buffer made current from its draw state
+            import torch
+            sim.set_draw(True)
+            d = sim.cfg.max_dim
+            gr = torch.empty((n_local, d * d), dtype=torch.int16, device=sim.obs.device)
+            fl = torch.empty((n_local,), dtype=torch.uint8, device=sim.obs.device)
+            sim.pack_grids(gr, fl)
+            sim.render_grids(gr, fl, sim.obs)
     return gather_block(sim, mode, lib_comm, g.depth, world, n_local, args.steps, regs), g
 
 
@@ -334,7 +346,7 @@ def c5_block(args, world, rank, local_rank, dev, K):
     dev_regions = [region() for _ in range(3)]
     lib_comm = sharding.LibComm(rank, world, local_rank) if args.exchange == "lib" else None
     gathers = {}
-    for mode in (("screens", "grids") if args.gather == "both" else (args.gather,)):
+    for mode in (("screens", "grids", "grids_nodraw") if args.gather == "both" else (args.gather,)):
         try:
             g = make_gather(sim, mode, lib_comm, counts, rank)
             state["screens"] = g
@@ -355,6 +367,8 @@ def c5_block(args, world, rank, local_rank, dev, K):
            "action_errors": errs, "screens_gather": gathers[first]}
     if first == "screens" and "grids" in gathers:
         out["screens_gather"] = dict(gathers["screens"], grids=gathers["grids"])
+        if "grids_nodraw" in gathers:
+            out["screens_gather"]["grids_no_local_render"] = gathers["grids_nodraw"]
     sim.close()
     return out
 
@@ -381,7 +395,7 @@ def main():
                     "a multiple; every step still writes its reward / code / observation")
     ap.add_argument("--exchange", default="torch", choices=["torch", "lib"], help="N > 1 screens gather: torch.distributed "
                     "point-to-point (default) or libxwb.so's own RCCL calls (xwb_gather_screens_begin / _end; backend nccl only)")
-    ap.add_argument("--gather", default="both", choices=["screens", "grids", "both"], help="N > 1, full observation: what crosses "
+    ap.add_argument("--gather", default="both", choices=["screens", "grids", "grids_nodraw", "both"], help="N > 1, full observation: what crosses "
                     "the links per step -- every shard's pixels (screens), or its cell codes with the root drawing all frames "
                     "(grids: xwb_gather_grids_begin, needs --exchange lib), or one set of regions each (both; grids only with --exchange lib)")
     ap.add_argument("--c5", action="store_true", help="N > 1: add the BASELINE C5 block (xworld11); on by itself at N = 8")
@@ -622,7 +636,7 @@ def main():
     if with_screens:
         lib_comm = sharding.LibComm(rank, world, local_rank) if args.exchange == "lib" else None
         grids_ok = is_xworld and not sim.cfg.visible_radius
-        modes = [m for m in (("screens", "grids") if args.gather == "both" else (args.gather,)) if m == "screens" or grids_ok]
+        modes = [m for m in (("screens", "grids", "grids_nodraw") if args.gather == "both" else (args.gather,)) if m == "screens" or grids_ok]
         blocks = {}
         for mode in modes:
             try:
@@ -634,6 +648,8 @@ def main():
         sg_line["mode"] = modes[0]
         if len(modes) > 1:
             sg_line["grids"] = blocks["grids"]
+            if "grids_nodraw" in blocks:
+                sg_line["grids_no_local_render"] = blocks["grids_nodraw"]
         elif args.gather != "screens" and not grids_ok:
             sg_line["grids"] = {"skipped": "needs a full-observation xworld workload (a frame must be a function of the cell codes)"}
     errs = sim.check_errors()

@@ -445,6 +445,13 @@ int xwb_xw_get_tile_table(const xwb_sim *sim, uint8_t *out_host, size_t cap, siz
  * obs_dev [n_envs][bytes_per_env] -- n_envs is the caller's, not num_envs: the root draws the whole sharded batch with the
  * kernel that draws its own shard (xw_render_all_kernel), byte for byte what the shards drew. */
 int xwb_xw_pack_grids(xwb_sim *sim, uint16_t *grids_dev, uint8_t *flags_dev, void *stream);
+/* A batch whose frames are drawn elsewhere need not draw them itself: xwb_xw_set_draw(sim, 0) turns the pixel stores of
+ * every verb off (the renders still run, as one workgroup or over the done list, for their bookkeeping: queue epochs,
+ * installing pre-generated episodes, the fresh / done flags) -- the observation buffer is then stale, xwb_xw_pack_grids is
+ * how the frames leave; on = 1 turns them back on (the next verb that draws every env -- xwb_reset, or a render from
+ * xwb_xw_pack_grids + xwb_xw_render_grids into the batch's own buffer -- makes the buffer current again).  Full
+ * observation only.  A step of the C4 batch is then the step kernel and the list pass: ~25 us instead of ~113. */
+int xwb_xw_set_draw(xwb_sim *sim, int32_t on);
 int xwb_xw_render_grids(xwb_sim *sim, const uint16_t *grids_dev, const uint8_t *flags_dev, int32_t n_envs, void *obs_dev,
                         void *stream);
 

@@ -236,3 +236,51 @@ def test_gather_results_with_an_empty_shard():
     assert torch.equal(allres[:5], packed[0]) and torch.equal(allres[5:], packed[2])
     assert L.xwb_comm_group_end(comm.h) != 0                                # unbalanced end
     comm.close()
+
+
+@pytest.mark.parametrize("case", ["nav7_color", "walls7_ctx3", "nav7_f32", "nav8_curriculum"])
+@pytest.mark.parametrize("loop", ["step+reset_done", "step_autoreset"])
+def test_a_batch_that_does_not_draw_feeds_a_renderer(case, loop):
+    """xwb_xw_set_draw(sim, 0): the verbs store no pixels, the draw state still leaves through xwb_xw_pack_grids, and a
+    renderer fed with it alone reproduces, frame for frame, the observation buffer of an identical batch that does draw --
+    rewards, codes and state included (the renders' bookkeeping -- epochs, installs, flags -- still runs)."""
+    torch = _torch()
+    from xworld_amd.batched import BatchedSimulator
+    n = 768
+    a = BatchedSimulator("xworld", CASES[case], num_envs=n, seed=13, policy_seed=2)
+    b = BatchedSimulator("xworld", CASES[case], num_envs=n, seed=13, policy_seed=2)
+    grids, flags, mirror = _bufs(torch, b)
+    b.pack_grids(grids, flags)                                            # the first frames, drawn by xwb_create
+    b.render_grids(grids, flags, mirror)
+    b.set_draw(False)
+    stale = b.obs.clone()
+
+    def check(tag):
+        b.pack_grids(grids, flags)
+        b.render_grids(grids, flags, mirror)
+        torch.cuda.synchronize()
+        assert torch.equal(mirror, a.obs), (case, loop, tag, int((mirror != a.obs).sum()))
+        assert torch.equal(b.reward, a.reward) and torch.equal(b.game_over_codes, a.game_over_codes), tag
+        assert torch.equal(b.grid, a.grid) and torch.equal(b.num_steps, a.num_steps), tag
+
+    for t in range(60):
+        for s in (a, b):
+            if loop == "step_autoreset":
+                s.step_autoreset()
+            else:
+                s.step()
+        check(2 * t)
+        if loop != "step_autoreset":
+            a.reset_done(); b.reset_done()
+            check(2 * t + 1)
+    assert torch.equal(b.obs, stale)                                       # nothing was drawn into the batch's own buffer
+    assert a.task_performance() == b.task_performance() and b.check_errors() == 0
+    b.set_draw(True)
+    for s in (a, b):
+        s.reset()
+    assert torch.equal(a.obs, b.obs)                                       # a verb that draws every env makes the buffer current again
+    ego = BatchedSimulator("xworld", dict(CASES["nav7_color"], visible_radius=3), num_envs=8)
+    with pytest.raises(Exception, match="egocentric"):
+        ego.set_draw(False)
+    for s in (a, b, ego):
+        s.close()

@@ -36,10 +36,15 @@ SCRIPT = textwrap.dedent('''
     from xworld_amd.batched import BatchedSimulator
     info = sharding.backend_info()
     assert info["backend"] == "nccl" and info["world_size"] == 1 and info["version"], info
+    dist.barrier()                                                            # the communicator (and its streams) exist now
     conf = os.path.join(%(root)r, "xworld_amd", "confs", "navigation2d.json")
     opts = {"xwd_conf_path": conf, "task_mode": "lang_acquisition", "max_dim": 7, "color": True}
     counts = [300, 212]
     whole = BatchedSimulator("xworld", opts, num_envs=512, seed=8, policy_seed=3)
+    # the FIRST batch created after the communicator: its internal queue must still run beside the caller's stream (xwb_create
+    # re-selects the stream when the concurrency probe fails) -- every rank of a multi-GPU run is in this position
+    if "XWB_QUEUE_SYNC" not in os.environ:
+        assert whole.queue_sync_mode() == ("epochs", "probe_ok"), whole.queue_sync_mode()
     shards = [BatchedSimulator("xworld", opts, num_envs=300, seed=8, policy_seed=3, env_gid0=0),
               BatchedSimulator("xworld", opts, num_envs=212, seed=8, policy_seed=3, env_gid0=300)]
     dev = torch.device("cuda", 0)

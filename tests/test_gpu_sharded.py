@@ -135,6 +135,8 @@ def test_bench_two_ranks_on_one_gpu(workload, extra):
         assert "error" not in gg, gg
         assert gg["mode"] == "grids" and gg["value"] > 0 and gg["root_render_bound_ceiling"] > 0
         assert gg["bytes_into_root_per_step"] == 1024 * (2 * 49 + 1) and gg["bytes_into_root_per_step"] * 200 < sg["bytes_into_root_per_step"]
+        nd = sg["grids_no_local_render"]                   # the same with every shard's own pixel stores off (xwb_xw_set_draw)
+        assert "error" not in nd and nd["value"] > 0 and nd["local_render"] is False and gg["local_render"] is True
     else:
         assert "skipped" in sg["grids"]
     assert line["regions"]["repetitions"] == 3 and len(line["regions"]["ms_per_step_all"]) == 3

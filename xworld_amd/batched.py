@@ -356,6 +356,10 @@ class BatchedSimulator:
         self._bound = tensor
 
     # ------------------------------------------------------------------ per-env host access
+    def set_draw(self, on):
+        """xwb_xw_set_draw: False = the verbs store no pixels (frames are drawn elsewhere from pack_grids); obs is then stale."""
+        lib.check(self.L.xwb_xw_set_draw(self.h, int(bool(on))))
+
     def pack_grids(self, grids, flags=None, stream=None):
         """xwb_xw_pack_grids: the draw state of every env -- the cell codes its current frame shows into `grids` (int16 / uint16
         [num_envs, max_dim * max_dim] device tensor) and the context-ring flag of its last draw into `flags` (uint8 [num_envs];

@@ -463,6 +463,7 @@ __global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
     const int ncode = (e1 - e0 + 1) * cells;
     // this kernel running = the step kernel queued before it is complete: tell the reset kernel's queue (xw_device.h)
     if (p.sig_epoch && blockIdx.x == 0 && tid == 0) xw_publish_epoch(p.sync + 1, p.sig_epoch);
+    if (p.no_draw) return;                                 // (xwb_xw_set_draw(sim, 0): launched with one workgroup, for the epoch)
     for (int i = tid; i < ncode; i += BS) {
         const size_t gi = (size_t)e0 * cells + i;
         // (TERM: the flag, the live cell and the snapshot's cell are fetched together and selected -- flag-then-cell was two
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
             __syncthreads();
         }
         uint4 *frame0 = reinterpret_cast<uint4 *>(p.obs) + (size_t)e * ctx * cpf;
-        for (int cc = threadIdx.x; cc < cpf; cc += 256) {
+        for (int cc = threadIdx.x; cc < (p.no_draw ? 0 : cpf); cc += 256) {          // (drawing off: the install and the flags below only)
             const uint4 v = xw_expand_chunk<DIM_T, CH, ES>(p.atlas, s_grid, cc, D);
             xw_store_chunk(frame0, cc, cpf, ctx, p.list_flag, v);
         }
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
 template <int DIM_T, int CH, int BS, int PER, int SKIP, int ES>
 static hipError_t render_all_shape(const XwParams &p, hipStream_t s) {
     const unsigned long long n_chunks = (unsigned long long)p.n * (CH * 9 * ES * p.max_dim * p.max_dim);
-    const unsigned blocks = (unsigned)((n_chunks + BS * PER - 1) / (BS * PER));
+    const unsigned blocks = p.no_draw ? 1u : (unsigned)((n_chunks + BS * PER - 1) / (BS * PER));
     if (p.context == 1) hipLaunchKernelGGL((xw_render_all_kernel<DIM_T, CH, true, BS, PER, SKIP, ES>), dim3(blocks), dim3(BS), 0, s, p);
     else hipLaunchKernelGGL((xw_render_all_kernel<DIM_T, CH, false, BS, PER, SKIP, ES>), dim3(blocks), dim3(BS), 0, s, p);
     return hipGetLastError();

@@ -292,6 +292,7 @@ struct XwParams {
     int wait_slot;               // the list render's wait: sync[wait_slot] >= wait_epoch (3: the reset kernel's epoch, 8: the regeneration's)
     uint32_t *minstd;            // nullable: XWB_RNG_MINSTD, one libstdc++ minstd_rand0 state per env: the teacher's task draw
     int dbg_ego_per, dbg_ego_pad, dbg_render_shape;   // xwb_config.debug_* (launch-shape A/B switches; 0 = defaults)
+    int no_draw;                 // xwb_xw_set_draw(sim, 0): the renders keep their bookkeeping (epochs, installs, fresh / done flags) and store no pixels
 };
 hipError_t launch_xw_step(const XwParams &p, hipStream_t s);
 // exclusive scheduling of two groups: the idle stages of the XWorld3DNav* group that the step kernel deferred (idle_list)

@@ -67,6 +67,7 @@ struct xwb_sim {
     // xwb_xw_pack_grids: what the last frame-drawing verb read (xw_pack_grids_kernel's src) and how many such verbs ran since
     // the last pack (a context ring can only be replayed elsewhere one draw at a time)
     int frame_src = 0, draws_since_pack = 0;
+    bool draw_off = false;                 // xwb_xw_set_draw(sim, 0): frames are not drawn (their consumer draws them from xwb_xw_pack_grids)
     bool autoreset_done = false;           // the last step call already reset the envs whose codes are still set
     int count_sel = 0;
     bool profiling = false;
@@ -182,6 +183,10 @@ inline bool is_poisoned(xwb_sim *s) {
 // ---- xwb_verbs.hip ----
 // may calls on stream `st` hand over through epochs?  may_probe: only xwb_create and xwb_queue_sync_mode run the probe
 bool use_epochs(xwb_sim *s, hipStream_t st, bool may_probe);
+// the concurrency probe itself: do kernels of `st` and of the batch's internal queue run side by side?  (synchronises both)
+bool epoch_probe(xwb_sim *s, hipStream_t st, int *reason);
+// -1: the environment / a tool does not override the hand-over mode, 0: events, 1: epochs
+int queue_sync_env(int *reason);
 void timer_begin(xwb_sim *s, KernelTimer &t, hipStream_t st);
 void timer_end(xwb_sim *s, KernelTimer &t, hipStream_t st);
 SgParams sg_params(xwb_sim *s);

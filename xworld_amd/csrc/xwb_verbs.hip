@@ -165,6 +165,7 @@ XwParams xw_params(xwb_sim *s) {
     p.obs = static_cast<uint8_t *>(s->d_obs);
     p.packed = packed_slot(s);
     p.policy_step = s->policy_step;
+    p.no_draw = s->draw_off ? 1 : 0;
     p.list_flag = 2;
     p.done_count = s->d_done_count + s->count_sel;
     p.done_count_next = s->d_done_count + (1 - s->count_sel);
@@ -663,6 +664,14 @@ int xwb_bind_obs(xwb_sim *s, void *obs_dev) {
     return XWB_OK;
 }
 
+int xwb_xw_set_draw(xwb_sim *s, int32_t on) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    if (s->cfg.game != XWB_XWORLD2D) return fail(XWB_ERR_STATE, "not an xworld batch (the other games write their observation inside the step kernel)");
+    if (s->cfg.visible_radius && !on) return fail(XWB_ERR_STATE, "egocentric frames cannot be drawn elsewhere from the cell codes: they stay on");
+    s->draw_off = !on;
+    return XWB_OK;
+}
+
 int xwb_xw_pack_grids(xwb_sim *s, uint16_t *grids_dev, uint8_t *flags_dev, void *stream) {
     if (!s || !grids_dev) return fail(XWB_ERR_ARG, "NULL argument");
     XWB_ON_DEVICE(s);
@@ -695,7 +704,7 @@ int xwb_xw_render_grids(xwb_sim *s, const uint16_t *grids_dev, const uint8_t *fl
     q.grid = const_cast<uint16_t *>(grids_dev);
     q.fresh = const_cast<uint8_t *>(flags_dev);
     q.obs = static_cast<uint8_t *>(obs_dev);
-    q.sig_epoch = 0; q.wait_epoch = 0; q.packed = nullptr;
+    q.sig_epoch = 0; q.wait_epoch = 0; q.packed = nullptr; q.no_draw = 0;
     HIP_TRY(launch_xw_render(q, 0, as_stream(stream)));
     return XWB_OK;
 }

@@ -154,6 +154,7 @@ _SIGS = [
     ("xwb_comm_mark", C.c_int, [_vp, C.c_int32]),
     ("xwb_comm_wait", C.c_int, [_vp, C.c_int32, _vp]),
     ("xwb_xw_pack_grids", C.c_int, [_vp, _vp, _vp, _vp]),
+    ("xwb_xw_set_draw", C.c_int, [_vp, C.c_int32]),
     ("xwb_xw_render_grids", C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, _vp]),
     ("xwb_last_error", C.c_char_p, []),
     ("xwb_version", C.c_char_p, []),
