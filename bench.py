@@ -309,14 +309,14 @@ def c5_block(args, world, rank, local_rank, dev, K):
             state["screens"].bind_next()
         state["calls"] += 1
         sim.step()
-        results.finish()
+        results.finish(convert=False)
         results.start(packed=packed[(state["calls"] - 1) % 2])
         sim.reset_done()
         if state["screens"] is not None:
             state["screens"].start()
 
     def fence():
-        results.finish()
+        results.finish(convert=False)
         if state["screens"] is not None:
             state["screens"].drain()
         torch.cuda.synchronize()
@@ -416,7 +416,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            from xworld_amd.sharding import nccl_init_kwargs
+            dist.init_process_group("nccl", **nccl_init_kwargs(torch.device("cuda", local_rank)))
         else:
             local_rank = local_rank % torch.cuda.device_count()
             torch.cuda.set_device(local_rank)
@@ -425,7 +426,8 @@ def main():
         torch.cuda.set_device(0)
         if args.force_exchange:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            kw = {"device_id": torch.device("cuda", 0)} if args.backend == "nccl" else {}
+            from xworld_amd.sharding import nccl_init_kwargs
+            kw = nccl_init_kwargs(torch.device("cuda", 0)) if args.backend == "nccl" else {}
             if "MASTER_ADDR" in os.environ and "MASTER_PORT" in os.environ:
                 dist.init_process_group(args.backend, world_size=1, rank=0, **kw)
             else:
@@ -460,7 +462,7 @@ def main():
             return
         # finish the gather of the previous step (it ran beside this step's kernels), start this step's: the step
         # kernel wrote (reward, code) straight into the record's slot, no packing kernels
-        results.finish()
+        results.finish(convert=False)
         results.start(packed=rec[0][(calls[0] - 1) % rec[0].shape[0]])
 
     def one_step():
@@ -482,7 +484,7 @@ def main():
 
     def fence():
         if results is not None:
-            results.finish()
+            results.finish(convert=False)
         if screens is not None:
             screens.drain()
         torch.cuda.synchronize()

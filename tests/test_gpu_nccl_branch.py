@@ -31,8 +31,9 @@ SCRIPT = textwrap.dedent('''
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%(port)d", world_size=1, rank=0, device_id=torch.device("cuda", 0))
     from xworld_amd import sharding
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%(port)d", world_size=1, rank=0,
+                            **sharding.nccl_init_kwargs(torch.device("cuda", 0)))
     from xworld_amd.batched import BatchedSimulator
     info = sharding.backend_info()
     assert info["backend"] == "nccl" and info["world_size"] == 1 and info["version"], info

@@ -149,7 +149,13 @@ int xwb_comm_unique_id(uint8_t out[XWB_COMM_ID_BYTES]) {
 
 static int finish_comm(xwb_comm *c) {
     DeviceGuard g(c->device);
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {   // the communicator's stream comes from the HIGH-priority pool of hardware queues: streams of one priority share a few
+        // hardware queues in creation order, and a transfer that waits for an event at the head of the queue a batch's map
+        // generator uses holds the generator back until the render it should run beside is over ("queues")
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); greatest = 0; }
+        HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
+    }
     HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
     for (auto &m : c->marks) HIP_TRY(hipEventCreateWithFlags(&m, hipEventDisableTiming));

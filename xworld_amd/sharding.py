@@ -173,6 +173,23 @@ def gather_slabs(local, out_root, counts, rank, dst=0, group=None, async_op=Fals
     return gather_shards({rank: local}, out_root, counts, range(len(counts)), rank, dst, group, async_op)
 
 
+def nccl_init_kwargs(device):
+    """Keyword arguments for dist.init_process_group("nccl", ...) on a rank that also steps a batch: bind the device and put
+    the communicator's internal stream at high priority.  Why: HIP maps streams of one priority onto a small pool of hardware
+    queues (4), in creation order; a communication stream that lands on the hardware queue of the batch's internal stream
+    queues the per-step exchange IN FRONT of the next map generator and behind the event it waits for -- the generator then
+    follows the render instead of running beside it (kernel trace, one MI355X, C4, world of one: 0.209 ms per step against
+    0.113 without an exchange; with a high-priority communication stream, which comes from another pool: 0.128)."""
+    kw = {"device_id": device}
+    try:
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+        kw["pg_options"] = opts
+    except Exception:                                    # a build without the option: the defaults still work, only slower
+        pass
+    return kw
+
+
 class ResultGather:
     """Per-step gather of (reward, game_over) to `dst`.  Equal shard sizes -> one all_gather_into_tensor of a packed
     [n, 2] float tensor; ragged shards -> point-to-point into slices.
@@ -230,7 +247,9 @@ class ResultGather:
             work = gather_slabs(packed, out, self.counts, self.rank, self.dst, self.group, async_op=True)
         self.pending = (work, k)
 
-    def finish(self):
+    def finish(self, convert=True):
+        """-> (reward, code) of the exchange started last, on `dst` (None, None elsewhere).  convert=False: the codes stay the
+        float column the shards wrote (no conversion kernel on the root's stream)."""
         if self.pending is None:
             return None, None
         work, k = self.pending
@@ -240,7 +259,7 @@ class ResultGather:
         if self.rank != self.dst:
             return None, None
         out = self.out[k]
-        return out[:, 0], out[:, 1].to(torch.uint8)
+        return out[:, 0], (out[:, 1].to(torch.uint8) if convert else out[:, 1])
 
     def __call__(self, reward, game_over):
         self.start(reward, game_over)
