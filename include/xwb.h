@@ -183,7 +183,9 @@ enum { XWB_DEBUG_NO_PREGEN = 1,      /* no pre-generated episodes: every verb on
  * xwb_create, any other stream by the caller's xwb_queue_sync_mode(sim, stream, ...) call, which synchronises that stream once;
  * the step verbs never probe (they stay asynchronous) and use events on a stream nobody probed --, events otherwise (the probe fails when
  * the two streams share one hardware queue -- HIP multiplexes streams onto GPU_MAX_HW_QUEUES queues -- or when a tool
- * serialises kernel execution); the environment variable XWB_QUEUE_SYNC=events|epochs and the presence of a serialising tool
+ * serialises kernel execution; a probe that finds no concurrency first replaces the batch's internal stream by one that does
+ * run beside the probed stream and beside every stream that passed before -- a shared hardware queue would also put the map
+ * generator behind the render instead of beside it --, and fails only when no such stream is found); the environment variable XWB_QUEUE_SYNC=events|epochs and the presence of a serialising tool
  * (rocprofv3 counter collection, AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING) override AUTO.  EVENTS / EPOCHS force one mode. */
 enum { XWB_QUEUE_SYNC_AUTO = 0, XWB_QUEUE_SYNC_EVENTS = 1, XWB_QUEUE_SYNC_EPOCHS = 2 };
 /* why xwb_queue_sync_mode reports the mode it reports */

@@ -98,6 +98,34 @@ def test_streams_are_probed_only_on_request():
     sim.close(); ref.close()
 
 
+def test_internal_stream_is_chosen_to_run_beside_the_callers():
+    """HIP maps streams onto a few hardware queues: whichever of many caller streams a batch is probed on, the batch ends up
+    with an internal stream that runs beside it (xwb_queue_sync_mode re-selects the internal stream when the probe finds no
+    concurrency), streams that passed earlier keep passing, and the results do not depend on any of it."""
+    torch = _torch()
+    from xworld_amd.batched import BatchedSimulator
+    if os.environ.get("XWB_QUEUE_SYNC"):
+        pytest.skip("the hand-over mode is forced from the environment")
+    streams = [torch.cuda.Stream() for _ in range(9)]             # more streams than hardware queues: some share one
+    ref = BatchedSimulator("xworld", OPTS, num_envs=2048, seed=6)
+    sims = [BatchedSimulator("xworld", OPTS, num_envs=2048, seed=6) for _ in streams]
+    if ref.queue_sync_mode()[1] == "tool":
+        pytest.skip("a tool serialises kernels")
+    for sim, st in zip(sims, streams):
+        assert sim.queue_sync_mode(st) == ("epochs", "probe_ok"), (st, sim.queue_sync_mode(st))
+        assert sim.queue_sync_mode() == ("epochs", "probe_ok")     # the default stream, probed by xwb_create, still passes
+    for t in range(12):
+        ref.step(); ref.reset_done()
+        for sim, st in zip(sims, streams):
+            sim.step(stream=st); sim.reset_done(stream=st)
+    torch.cuda.synchronize()
+    for sim in sims:
+        assert sim.step_path()["queue_sync"] == "epochs"
+        assert torch.equal(sim.obs, ref.obs) and torch.equal(sim.reward, ref.reward)
+        sim.close()
+    ref.close()
+
+
 def test_checkpoint_blob_of_another_version_is_named():
     _torch()
     from xworld_amd.batched import BatchedSimulator

@@ -630,28 +630,16 @@ int xwb_create(const xwb_config *cfg, xwb_sim **out) {
     if (rc) return bail(rc);
     HIP_TRY(hipDeviceSynchronize());
     if (s->d_sync) {
-        // HIP maps streams onto a few hardware queues in creation order (GPU_MAX_HW_QUEUES, 4 by default): an internal queue
-        // that lands on the CALLER's hardware queue runs nothing beside the caller's kernels -- the map generator then follows
-        // the render it was meant to hide behind.  Seen with the FIRST batch created after an RCCL communicator (which creates
-        // streams of its own): 0.190 instead of 0.112 ms per C4 step, in events mode because the probe failed too -- what
-        // every rank of a multi-GPU run would have got.  So: if the probe finds no concurrency, try the next few streams and
-        // keep the first one that runs beside the default stream.  (Not under a tool that serialises kernels: nothing would pass.)
-        int why = 0;
+        // the default stream is probed now (other streams: xwb_queue_sync_mode); the probe also re-selects the internal stream
+        // when it shares the caller's hardware queue (side_beside, xwb_verbs.hip).  Forced modes and tools skip the probe in
+        // use_epochs: the internal stream is still chosen, unless a tool serialises kernels (nothing would pass).
+        int why = 0, reason = 0;
         const bool tool = queue_sync_env(&why) == 0 && why == XWB_SYNC_REASON_TOOL;
-        int reason = 0;
-        if (!tool && !epoch_probe(s, nullptr, &reason) && reason == XWB_SYNC_REASON_PROBE_FAILED) {
-            std::vector<hipStream_t> rejected;
-            for (int attempt = 0; attempt < 7; ++attempt) {
-                hipStream_t alt = nullptr;
-                if (hipStreamCreateWithFlags(&alt, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
-                rejected.push_back(s->side);                   // (kept alive until the choice is made: the next stream maps elsewhere)
-                s->side = alt;
-                if (epoch_probe(s, nullptr, &reason) || reason != XWB_SYNC_REASON_PROBE_FAILED) break;
-            }
-            for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
-        }
-        s->probes.clear();
-        (void)use_epochs(s, nullptr, true);                     // the default stream's verdict, cached; other streams: xwb_queue_sync_mode
+        (void)use_epochs(s, nullptr, true);
+        const int verdict = s->sync_reason;
+        const bool probed = verdict == XWB_SYNC_REASON_PROBE_OK || verdict == XWB_SYNC_REASON_PROBE_FAILED || verdict == XWB_SYNC_REASON_PROBE_ERROR;
+        if (!probed && !tool) (void)side_beside(s, nullptr, &reason);
+        s->sync_reason = verdict;
     }
     *out = s;
     return XWB_OK;

@@ -185,6 +185,8 @@ inline bool is_poisoned(xwb_sim *s) {
 bool use_epochs(xwb_sim *s, hipStream_t st, bool may_probe);
 // the concurrency probe itself: do kernels of `st` and of the batch's internal queue run side by side?  (synchronises both)
 bool epoch_probe(xwb_sim *s, hipStream_t st, int *reason);
+// the probe, re-selecting the internal stream when it shares `st`'s hardware queue
+bool side_beside(xwb_sim *s, hipStream_t st, int *reason);
 // -1: the environment / a tool does not override the hand-over mode, 0: events, 1: epochs
 int queue_sync_env(int *reason);
 void timer_begin(xwb_sim *s, KernelTimer &t, hipStream_t st);

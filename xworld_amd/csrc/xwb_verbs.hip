@@ -60,6 +60,38 @@ bool epoch_probe(xwb_sim *s, hipStream_t st, int *reason) {
     return true;
 }
 
+// Make s->side a stream whose kernels run beside those of `st`.  HIP maps streams onto a few hardware queues
+// (GPU_MAX_HW_QUEUES, 4) in creation order; an internal queue that shares the CALLER's hardware queue runs nothing beside the
+// caller's kernels: the map generator then follows the render it was meant to hide behind (C4: 0.190 instead of 0.113 ms per
+// step -- seen with the first batch created after an RCCL communicator, and with pool streams of the caller).  If the probe
+// of (st, side) finds no concurrency, up to seven further streams are tried; a candidate must also still run beside every
+// stream that passed its probe earlier.  The old stream is idle when it is replaced (the probe drains it).  Returns the
+// verdict for `st`; nothing changes when no candidate passes.
+bool side_beside(xwb_sim *s, hipStream_t st, int *reason) {
+    if (epoch_probe(s, st, reason) || *reason != XWB_SYNC_REASON_PROBE_FAILED) return *reason == XWB_SYNC_REASON_PROBE_OK;
+    std::vector<hipStream_t> keep;
+    for (auto &pr : s->probes) if (pr.ok && pr.st != st) keep.push_back(pr.st);
+    hipStream_t original = s->side;
+    std::vector<hipStream_t> rejected;                              // kept alive until the choice is made: the next one maps elsewhere
+    bool found = false;
+    for (int attempt = 0; attempt < 7 && !found; ++attempt) {
+        hipStream_t alt = nullptr;
+        if (hipStreamCreateWithFlags(&alt, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        s->side = alt;
+        int r = 0;
+        found = epoch_probe(s, st, &r);
+        for (size_t k = 0; found && k < keep.size(); ++k) found = epoch_probe(s, keep[k], &r);
+        if (!found) rejected.push_back(alt);
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    if (!found) { s->side = original; *reason = XWB_SYNC_REASON_PROBE_FAILED; return false; }
+    (void)hipStreamDestroy(original);
+    for (size_t i = 0; i < s->probes.size();)                       // verdicts of "no concurrency" were about the old stream
+        if (!s->probes[i].ok) s->probes.erase(s->probes.begin() + (long)i); else ++i;
+    *reason = XWB_SYNC_REASON_PROBE_OK;
+    return true;
+}
+
 // may calls on stream `st` hand over through epochs?  (xworld batches only: the other games have no internal stream)
 // may_probe: only xwb_create (the default stream) and xwb_queue_sync_mode (any stream, an explicit call) run the probe -- it
 // synchronises both streams and the host; the step verbs never do: a stream nobody probed hands over through events.
@@ -78,7 +110,7 @@ bool use_epochs(xwb_sim *s, hipStream_t st, bool may_probe) {
         if (cap != hipStreamCaptureStatusNone) { s->sync_reason = XWB_SYNC_REASON_NOT_PROBED; return false; }
     }
     int reason = 0;
-    const bool ok = epoch_probe(s, st, &reason);
+    const bool ok = side_beside(s, st, &reason);
     if (s->probes.size() >= 16) s->probes.erase(s->probes.begin());
     s->probes.push_back(xwb_sim::StreamProbe{st, ok, reason});
     s->sync_reason = reason;
