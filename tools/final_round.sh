@@ -19,7 +19,7 @@ GIT_HEAD=$HEAD bash tools/profile_round.sh $TAG xworld7 xworld7_f32 xworld8 xwor
   timeout 900 python tools/ego_soak.py 2>&1 | tail -14
   timeout 900 python tools/soak_pregen.py 2>&1 | tail -3
   timeout 600 python tools/pcie_rate.py 2>&1 | tail -3
-  timeout 600 python tools/leak_check.py 2>&1 | tail -4
+  timeout 600 python tools/leak_check.py 2>&1 | grep "^no leak"
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 } > $OUT/soak.txt
 for X in torch lib; do
