@@ -416,8 +416,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             torch.cuda.set_device(local_rank)
-            from xworld_amd.sharding import nccl_init_kwargs
-            dist.init_process_group("nccl", **nccl_init_kwargs(torch.device("cuda", local_rank)))
+            from xworld_amd.sharding import init_nccl
+            init_nccl(torch.device("cuda", local_rank))
         else:
             local_rank = local_rank % torch.cuda.device_count()
             torch.cuda.set_device(local_rank)

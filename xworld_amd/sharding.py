@@ -190,6 +190,16 @@ def nccl_init_kwargs(device):
     return kw
 
 
+def init_nccl(device, **kw):
+    """dist.init_process_group("nccl", ...) with nccl_init_kwargs; a torch build whose init_process_group does not take the
+    options falls back to the plain call (same results, the slower queue layout nccl_init_kwargs describes)."""
+    extra = nccl_init_kwargs(device)
+    try:
+        return dist.init_process_group("nccl", **extra, **kw)
+    except TypeError:
+        return dist.init_process_group("nccl", device_id=device, **kw)
+
+
 class ResultGather:
     """Per-step gather of (reward, game_over) to `dst`.  Equal shard sizes -> one all_gather_into_tensor of a packed
     [n, 2] float tensor; ragged shards -> point-to-point into slices.
