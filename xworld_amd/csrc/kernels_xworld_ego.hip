@@ -863,11 +863,24 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
     const int cap = p.n * (p.num_goals < R * R ? p.num_goals : R * R);
     uint2 item = p.ego_miss[first < cap ? first : cap - 1];
     const int cnt = *p.ego_miss_count;
-    if (first >= cnt) return;                              // (most workgroups: the list is short)
+    // (the tables are requested before the count is looked at: waiting for it first put one more round trip -- 4 of this
+    // body's 23 us -- in front of them; the workgroups that then leave have asked for a few hundred bytes for nothing)
     const int lw = ego_layout_words(O4, R);
-    for (int i = tid; i < 4 * 2 * O; i += 256) { const int d = i / (2 * O), rem = i - d * 2 * O; s_flags[d][rem / O][rem % O] = layout[d * lw + (rem / O) * O4 + rem % O]; }
-    if (tid < 4 * R * R) s_inv[tid] = map[8 * R + 4 * R * R + tid];
-    ego_compose_taps(s_row, s_col, tap_h1, tap_v1, tap_h2, tap_v2, O, tid, 256);
+    constexpr int NF = (4 * 2 * O + 255) / 256;
+    uint16_t fl[NF];
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+        const int i = tid + q * 256, d = i / (2 * O), rem = i - d * 2 * O;
+        fl[q] = i < 4 * 2 * O ? layout[d * lw + (rem / O) * O4 + rem % O] : (uint16_t)0;
+    }
+    const uint8_t inv = tid < 4 * R * R ? map[8 * R + 4 * R * R + tid] : (uint8_t)0;
+    if (first >= cnt) return;                              // (most workgroups: the list is short)
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+        const int i = tid + q * 256, d = i / (2 * O), rem = i - d * 2 * O;
+        if (i < 4 * 2 * O) s_flags[d][rem / O][rem % O] = fl[q];
+    }
+    if (tid < 4 * R * R) s_inv[tid] = inv;
     const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
     for (int it = first; it < cnt; it += nblocks / PARTS) {
         if (it != first) item = p.ego_miss[it];
@@ -927,7 +940,6 @@ __device__ __forceinline__ void ego_border_body(const XwParams &p, const uint32_
     const int tid = threadIdx.x, e_base = block * EPW, total = count_now ? *count_now : p.n;      // (a count: the done list's envs)
     if (e_base >= total) return;
     if (tid == 0) { s_nrun = 0; s_ncross = 0; }
-    ego_compose_taps(s_row, s_col, tap_h1, tap_v1, tap_h2, tap_v2, O, tid, 256);
     for (int i = tid; i < 4 * R * R + 8 * R; i += 256) s_map[i] = map[i];
     for (int i = tid; i < EPW * R * R; i += 256) {
         const int le = i / (R * R), f = i - le * (R * R), ix = e_base + le < total ? e_base + le : total - 1;
@@ -995,10 +1007,14 @@ __device__ __forceinline__ void ego_border_body(const XwParams &p, const uint32_
 template <int CH, int R>
 __global__ __launch_bounds__(256) void xw_ego_eval_kernel(XwParams p, const uint32_t *atlas4, const EgoTap *tap_h1, const EgoTap *tap_v1,
                                                           const EgoTap *tap_h2, const EgoTap *tap_v2, const uint16_t *layout, const uint8_t *map,
-                                                          int skip_term, int nb_border, const int32_t *list_count, int publish) {
+                                                          int skip_term, int nb_border, const int32_t *list_count, int publish, const EgoTap *comp) {
     // (this kernel running = the cells kernel queued before it is complete: xw_device.h, epochs instead of event packets)
     if (publish && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 5, p.sig_epoch);
     __shared__ EgoTap s_row[84][3], s_col[84][3];         // composed taps: one copy for whichever body this workgroup runs
+    {   // (the host composed them: xw_ego_tables -- requested here, in front of everything else either body waits for)
+        constexpr int O = R * (84 / R);
+        for (int i = threadIdx.x; i < 3 * O; i += 256) { (&s_row[0][0])[i] = comp[i]; (&s_col[0][0])[i] = comp[3 * O + i]; }
+    }
     if ((int)blockIdx.x < nb_border) ego_border_body<CH, R>(p, atlas4, tap_h1, tap_v1, tap_h2, tap_v2, map, skip_term, blockIdx.x, list_count, s_row, s_col);
     else ego_miss_body<CH, R>(p, atlas4, tap_h1, tap_v1, tap_h2, tap_v2, layout, map, (int)blockIdx.x - nb_border, (int)gridDim.x - nb_border, s_row, s_col);
 }
@@ -1561,11 +1577,19 @@ hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int 
         if (cmap[i] == 0xff || cmap[i] >= r * r) { span = false; continue; }     // (a permutation per heading, or no span path)
         cmap[(size_t)4 * r * r + 8 * r + (size_t)(i / (r * r)) * r * r + cmap[i]] = (uint8_t)(i % (r * r));
     }
-    hipError_t err = hipMalloc(&d, tap_bytes + lay_bytes + cmap.size());
+    // the composed taps of an output row / column (ego_compose_taps: the two intermediate indices' taps and the output tap), so
+    // that a kernel whose workgroups live for one chain of dependent reads gets them in ONE read instead of two
+    std::vector<EgoTap> comp((size_t)6 * O);
+    for (int i = 0; i < O; ++i) {
+        comp[(size_t)3 * i + 0] = v1[v2[i].s0]; comp[(size_t)3 * i + 1] = v1[v2[i].s1]; comp[(size_t)3 * i + 2] = v2[i];
+        comp[(size_t)3 * (O + i) + 0] = h1[h2[i].s0]; comp[(size_t)3 * (O + i) + 1] = h1[h2[i].s1]; comp[(size_t)3 * (O + i) + 2] = h2[i];
+    }
+    hipError_t err = hipMalloc(&d, tap_bytes + lay_bytes + cmap.size() + comp.size() * sizeof(EgoTap));
     if (err != hipSuccess) return err;
     err = hipMemcpy(d, all.data(), tap_bytes, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(d + tap_bytes, lay.data(), lay_bytes, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(d + tap_bytes + lay_bytes, cmap.data(), cmap.size(), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d + tap_bytes + lay_bytes + cmap.size(), comp.data(), comp.size() * sizeof(EgoTap), hipMemcpyHostToDevice);
     *dev_out = reinterpret_cast<EgoTap *>(d);
     *fast_out = fast ? 1 : 0;
     if (span_out) *span_out = fast && span ? 1 : 0;
@@ -1574,13 +1598,15 @@ hipError_t xw_ego_tables(int r, int max_dim, int out_dim, EgoTap **dev_out, int 
 }
 
 namespace {
-struct EgoTables { const EgoTap *h1, *v1, *h2, *v2; const uint16_t *lut; const uint8_t *map; };
+struct EgoTables { const EgoTap *h1, *v1, *h2, *v2; const uint16_t *lut; const uint8_t *map; const EgoTap *comp; };   // comp: [2][O][3] rows, columns
 EgoTables ego_tables_of(const XwParams &p) {
     const int P = 64 * p.max_dim, O = p.out_dim;
     EgoTables t;
     t.h1 = reinterpret_cast<const EgoTap *>(p.ego_taps); t.v1 = t.h1 + P; t.h2 = t.v1 + P; t.v2 = t.h2 + O;
     t.lut = reinterpret_cast<const uint16_t *>(t.v2 + O);
     t.map = reinterpret_cast<const uint8_t *>(t.lut + (size_t)4 * ego_layout_words((O + 3) & ~3, p.visible_radius));
+    const int r = p.visible_radius;
+    t.comp = reinterpret_cast<const EgoTap *>(t.map + (size_t)((8 * r * r + 8 * r + 15) & ~15));
     return t;
 }
 size_t ego_frame_bytes(const XwParams &p) { return (size_t)((p.channels * p.out_dim * p.out_dim + 15) & ~15); }
@@ -1621,7 +1647,7 @@ hipError_t ego_span_render(const XwParams &p, const EgoTables &t, int mode, hipS
     hipLaunchKernelGGL((xw_ego_cells_kernel<R, false>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, skip_front, nullptr, mode == 2 && p.sig_epoch != 0);
     if (ev_cells) { const hipError_t e = hipEventRecord(ev_cells, s); if (e != hipSuccess) return e; }
     const int nb_border = (p.n + EgoBorderGeom<R>::EPW - 1) / EgoBorderGeom<R>::EPW;
-    hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 4096), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, skip_front, nb_border, (const int32_t *)nullptr, publish);
+    hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 4096), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, skip_front, nb_border, (const int32_t *)nullptr, publish, t.comp);
     if (ev_front) { const hipError_t e = hipEventRecord(ev_front, s); if (e != hipSuccess) return e; }
     const int es = p.obs_f32 ? 4 : 1;
     const unsigned long long n_chunks = (unsigned long long)p.n * (FB / (16 / es));
@@ -1702,7 +1728,7 @@ hipError_t ego_span_render_list(const XwParams &p0, const EgoTables &t, hipStrea
         if (parts & 4) hipLaunchKernelGGL((xw_ego_list_front_kernel<R>), dim3(nb_cells + 4096), dim3(256), cells_lds, s, p, t.map, a4, cnt, nb_cells);
         else hipLaunchKernelGGL((xw_ego_cells_kernel<R, true>), dim3(nb_cells), dim3(256), cells_lds, s, p, t.map, 0, cnt, 0);
         const int nb_border = (p.n + EgoBorderGeom<R>::EPW - 1) / EgoBorderGeom<R>::EPW;
-        hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 1024), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, 0, nb_border, cnt, 0);
+        hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 1024), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, 0, nb_border, cnt, 0, t.comp);
     }
     if (!(parts & 2)) return hipGetLastError();
     const int es = p.obs_f32 ? 4 : 1;
