@@ -117,12 +117,14 @@ def measured_traffic(workload):
                                            "traffic_stale": t.get("source_sha16") != now}
 
 
-def write_ceiling(nbytes, dev, reps=24):
+def write_ceiling(buf, reps=24):
     """The bandwidth anchor of THIS run: a pure write stream of the observation batch's size (hipMemsetAsync through
-    torch.Tensor.zero_, and a fill kernel), timed with events on the current stream, in this process, on this box, before the
-    timed regions -- what `roofline.achieved` can be read against besides the 8 TB/s spec."""
+    torch.Tensor.zero_, and a fill kernel), timed with events on the current stream, in this process, on this box -- what
+    `roofline.achieved` can be read against besides the 8 TB/s spec.  It runs AFTER the timed and the event regions (round 4
+    ran it between the spin and the timed regions: the first regions then paid for whatever it disturbed and the driver's
+    20-step median landed in that ramp), on a buffer allocated before the warm-up and kept until the process ends."""
     import torch
-    buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    nbytes = buf.numel()
     out = {}
     for name, fn in (("memset", lambda: buf.zero_()), ("fill_kernel", lambda: buf.fill_(7))):
         for _ in range(4):
@@ -136,8 +138,14 @@ def write_ceiling(nbytes, dev, reps=24):
         torch.cuda.synchronize()
         us = a.elapsed_time(b) / reps * 1e3
         out[name] = {"us": us, "GBps": nbytes / us / 1e3}
-    del buf
     return out
+
+
+def region_trend(regions):
+    """(median of the last third - median of the first third) / median of all: a settled run is within +-1 %."""
+    k = max(1, len(regions) // 3)
+    med = statistics.median(regions)
+    return (statistics.median(regions[-k:]) - statistics.median(regions[:k])) / med if med > 0 else 0.0
 
 
 def _oracle():
@@ -537,21 +545,31 @@ def main():
     est = (time.perf_counter() - t0) / 10
     spin_calls = bcast_int(min(200000, math.ceil(max(0.0, args.spin_seconds) / max(est, 1e-7))))
     screens_regions = R if with_screens else 0
-    total_calls = 13 + W + spin_calls + 2 * R * K + screens_regions * K + (2 * K if with_screens else 0) + 4 * K
+    total_calls = 13 + W + spin_calls + 24 * K + 2 * R * K + screens_regions * K + (2 * K if with_screens else 0) + 4 * K
     slots = int(max(2, min(total_calls, REC_BYTES_CAP // (n_local * 8))))
     rec[0] = torch.zeros((slots, n_local, 2), dtype=torch.float32, device=dev)
     # the probe's 13 calls happened with another ring: restart the slot counter with the library's (bind resets it)
     sim.bind_results_ring(rec[0])
     probe_calls = calls[0]
     calls[0] = 0
+    # the write-ceiling anchor's buffer: allocated before the warm-up, freed with the process (nothing is allocated or freed
+    # between the spin and the last timed region)
+    ceiling_buf = torch.empty(int(n_local * sim.obs_bytes_per_env), dtype=torch.uint8, device=dev)
 
     for _ in range(W):
         one_step()
-    for _ in range(spin_calls):                          # clocks warm, caches and allocator settled
-        one_step()
-
-    # the run's own bandwidth anchor (rank-local, clocks warm): a pure write stream of the observation batch's size
-    ceiling = write_ceiling(n_local * sim.obs_bytes_per_env, dev)
+    # clocks warm, caches and allocator settled: spin by WALL TIME (a count derived from the cold probe above is too short on a
+    # fresh box: its first steps run several times slower than the settled loop), every rank the same number of steps ...
+    spun = 0
+    t_end = time.perf_counter() + max(0.0, args.spin_seconds)
+    while spun < 400000:
+        for _ in range(50):
+            one_step()
+        spun += 50
+        fence() if world > 1 else torch.cuda.synchronize()
+        if not bcast_int(1 if time.perf_counter() < t_end else 0):
+            break
+    spin_calls = spun
 
     def timed_region():
         fence()
@@ -565,6 +583,15 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt
+
+    # ... then unreported K-step regions until three in a row agree within 1 % (at most 24: a short region on a box that has
+    # just been handed over measures the box settling, not the code)
+    settle = []
+    while len(settle) < 24:
+        settle.append(timed_region())
+        ok = len(settle) >= 3 and max(settle[-3:]) <= 1.01 * min(settle[-3:])
+        if bcast_int(1 if ok else 0):
+            break
 
     # ---- the timed regions: exactly K steps each between two barrier + synchronize fences, max over ranks ----
     regions = [timed_region() for _ in range(R)]
@@ -585,6 +612,10 @@ def main():
             kernels_us[kname] = {"avg_us": us, "launches": nl}
     sim.profile_stop()
     path_default = sim.step_path()
+    # the run's own bandwidth anchor (rank-local, clocks warm), behind everything the headline and the roofline are read from
+    ceiling = write_ceiling(ceiling_buf)
+    for _ in range(K):                                   # and the loop itself warm again before the secondary measurements
+        one_step()
 
     # ---- a second, shorter measurement in the same run: the fused call xwb_step_autoreset (the reference example loop's
     # `if game_over: reset_game()` inside the step: a finished env's observation is the first frame of its next episode,
@@ -693,8 +724,10 @@ def main():
             "regions": {"repetitions": R, "statistic": "median", "steps_per_region": args.steps,
                         "ms_per_step_min": min(regions) / args.steps * 1e3, "ms_per_step_max": max(regions) / args.steps * 1e3,
                         "ms_per_step_all": [r / args.steps * 1e3 for r in regions],
+                        "trend": region_trend(regions),
                         "untimed_before": {"warmup_steps": args.warmup, "spin_steps": spin_calls * fused,
-                                           "spin_seconds_target": args.spin_seconds, "probe_steps": probe_calls * fused}},
+                                           "spin_seconds_target": args.spin_seconds, "probe_steps": probe_calls * fused,
+                                           "settle_regions": len(settle)}},
             "path": path_default,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,

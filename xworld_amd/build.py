@@ -52,6 +52,15 @@ def source_fingerprint():
 def build(force=False, verbose=False):
     cc = hipcc()
     objs = []
+    # a build with other flags than the last one (a lab build with XWB_EXTRA_FLAGS, or the build after one) recompiles everything
+    stamp = os.path.join(CSRC, ".build_flags")
+    flags_now = " ".join(FLAGS + os.environ.get("XWB_EXTRA_FLAGS", "").split())
+    try:
+        with open(stamp) as fh:
+            force = force or fh.read() != flags_now
+    except OSError:
+        force = True
+    jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
@@ -60,12 +69,20 @@ def build(force=False, verbose=False):
             cmd = [cc] + FLAGS + os.environ.get("XWB_EXTRA_FLAGS", "").split() + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            jobs.append(cmd)
+    if jobs:                                                # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            for rc in ex.map(subprocess.call, jobs):
+                if rc != 0:
+                    raise subprocess.CalledProcessError(rc, "hipcc")
     if force or _stale(LIB, objs + [os.path.join(CSRC, "libxwb.map")]):
         cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-Wl,--version-script=" + os.path.join(CSRC, "libxwb.map")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    with open(stamp, "w") as fh:
+        fh.write(flags_now)
     return LIB
 
 

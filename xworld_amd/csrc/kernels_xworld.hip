@@ -27,6 +27,14 @@
 
 namespace xwb {
 
+#ifdef XWB_STEP_PROF
+// lab build (XWB_EXTRA_FLAGS=-DXWB_STEP_PROF, tools/step_prof.py): 100 MHz stamps of the LAST launch's workgroups
+__device__ unsigned long long g_step_prof[2][4096][6];    // [0] xw_step_kernel, [1] xw_render_list_kernel
+#define SP_T(which, k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096 && threadIdx.x < 64) g_step_prof[which][blockIdx.x][k] = wall_clock64(); } while (0)
+#else
+#define SP_T(which, k)
+#endif
+
 // wave-aggregated append of the lanes with `flag` set: one atomic per wavefront
 __device__ __forceinline__ void wave_append(bool flag, int value, int32_t *list, int32_t *count) {
     unsigned long long m = __ballot(flag);
@@ -39,17 +47,34 @@ __device__ __forceinline__ void wave_append(bool flag, int value, int32_t *list,
     if (flag) list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
 }
 
+// ... the same with a second value per entry (the done list's episode counters: done_ep)
+__device__ __forceinline__ void wave_append2(bool flag, int value, uint32_t value2, int32_t *list, uint32_t *list2, int32_t *count) {
+    unsigned long long m = __ballot(flag);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, leader);
+    if (flag) {
+        const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+        list[k] = value;
+        list2[k] = value2;
+    }
+}
+
 // What one teach() call hands a task group's stage (Task::py_stage pushes the same into the Python env)
 struct StepCtx {
     int e, D, ax, ay, steps, hit, hit_cell, ddx, ddy, vx, vy;
     bool success;
     int level;
+    bool hit_is_goal;           // the item bumped into is a goal (icon type 0)
 };
 
 // One task group's stage in one Teacher::teach call: group G's task FSM (ts_in / tsteps_in -> ts_out / tsteps_out), the
 // reward it adds to the teacher buffer and the event it leaves there (every py_stage overwrites it).
 template <int G>
-__device__ __forceinline__ void teach_group(const XwParams &p, const StepCtx &c, const uint8_t *s_icon_type, int ts, int tsteps_in,
+__device__ __forceinline__ void teach_group(const XwParams &p, const StepCtx &c, int ts, int tsteps_in,
                                             double &rew, int &event, int &ts_out, int &tsteps_out, bool &defer_idle) {
     defer_idle = false;
     const int e = c.e, D = c.D, ax = c.ax, ay = c.ay, steps = c.steps, hit = c.hit, hit_cell = c.hit_cell;
@@ -106,7 +131,7 @@ __device__ __forceinline__ void teach_group(const XwParams &p, const StepCtx &c,
             record = 0;
             timeup = true;
             stage = STAGE_TERMINAL;
-        } else if (hit != 0 && ddx == vx && ddy == vy && s_icon_type[(hit & CELL_ICON_MASK) - 1] == 0) {
+        } else if (hit != 0 && ddx == vx && ddy == vy && c.hit_is_goal) {
             // _reach_object: id in collisions and |theta| < pi/4, i.e. the goal was bumped into along the
             // heading: MOVE_DOWN under full observation (yaw stays 1.5707963), MOVE_FORWARD in egocentric mode.
             // Target / Near / Avoid: the reached goal is in self.target (cell bit 15, set by the idle stage)
@@ -145,12 +170,185 @@ __device__ __forceinline__ void teach_group(const XwParams &p, const StepCtx &c,
 }
 
 // ------------------------------------------------------------------- step --
-__global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
-    // The kernel is a chain of dependent memory round trips for a few thousand wavefronts (it moves ~1 MB): everything
-    // that does not depend on a previous load is fetched in the first round trip -- the env's scalars, and the icon type
-    // table into LDS, which turns the "is the thing I bumped into a goal" lookup at the end of the chain into an LDS read.
-    __shared__ uint8_t s_icon_type[4096];                  // xw_setup: n_icons <= 4000
-    const int e = blockIdx.x * 256 + threadIdx.x;
+// What the step reads of an env before it moves (one round trip, every load independent of the others)
+struct StepIn {
+    int axy, steps, ts, tsteps, ts2, tsteps2, dir, level, action;
+    uint32_t ep;
+    uint4 gc;                                              // the env's goal-slot table (goal_cells)
+};
+// ... and what the move leaves for the teacher
+struct Move {
+    int ax, ay, hit, hit_cell, ddx, ddy, vx, vy, dir;
+    bool success;
+};
+
+// The common configuration -- full observation, ONE XWorld3DNav* task group, no curriculum, no minstd engines, no exclusive
+// scheduling (what pre-generated episodes need as well).  (A kernel specialised on it by overwriting those fields of its
+// by-value XwParams was tried: the struct then lives in scratch memory -- 1 KB per lane -- and the kernel takes twice as long.)
+inline bool xw_fast_config(const XwParams &p) {
+    return !p.visible_radius && p.n_tasks2 == 0 && !p.group2d && p.curriculum == 0.0 && !p.minstd && !p.exclusive && !p.idle_list;
+}
+
+__device__ __forceinline__ void xw_load_step_in(const XwParams &p, int e, StepIn &in) {
+    in.axy = p.agent_xy[e]; in.steps = p.num_steps[e]; in.ts = p.task_state[e]; in.tsteps = p.task_steps[e];
+    in.ts2 = 0; in.tsteps2 = 0; in.dir = 1; in.level = 0; in.action = 0; in.ep = 0;
+    if (p.n_tasks2 > 0) { in.ts2 = p.task_state2[e]; in.tsteps2 = p.task_steps2[e]; }
+    if (p.visible_radius) in.dir = p.agent_dir[e];
+    if (p.curriculum != 0) in.level = p.cur_level[e];
+    if (p.actions) in.action = p.actions[e];
+    if (p.swap_shadow == 2) in.ep = p.episode[e];
+    in.gc = reinterpret_cast<const uint4 *>(p.goal_cells)[e];
+}
+
+// XAgent::act x act_rep on the env's grid.  `lg` = a private copy of the grid the move reads and keeps current (LDS);
+// `g` = the live grid, whose two changed cells are stored as well when it is given.
+__device__ __forceinline__ Move xw_move(const XwParams &p, int e, int a, int axy, int dir_in, uint16_t *lg, uint16_t *g) {
+    const int D = p.max_dim;
+    Move m;
+    m.ax = axy & 0xffff; m.ay = axy >> 16;
+    m.dir = dir_in;
+    const uint16_t agent_code = lg[m.ay * D + m.ax];
+    m.ddx = a == 2 ? -1 : (a == 3 ? 1 : 0);             // MOVE_LEFT / MOVE_RIGHT
+    m.ddy = a == 0 ? -1 : (a == 1 ? 1 : 0);             // MOVE_UP / MOVE_DOWN
+    m.vx = 0; m.vy = 1;                                  // heading: entities keep yaw 1.5707963 (+y) under full observation
+    m.hit = 0; m.hit_cell = 0;
+    m.success = false;
+    for (int i = 0; i < p.act_rep; ++i) {
+        if (p.visible_radius) {
+            // XAgent::act, xitem.cpp:103-155: MOVE_FORWARD, MOVE_BACKWARD, MOVE_LEFT_FPV, MOVE_RIGHT_FPV relative to
+            // the heading; TURN_LEFT / TURN_RIGHT change the yaw and "move" onto the agent's own cell, which
+            // XMap::move_item refuses (xmap.cpp:76-101): a turn is an unsuccessful action without contacts
+            int dir = m.dir;
+            if (a == 4) dir = (dir + 3) & 3;
+            else if (a == 5) dir = (dir + 1) & 3;
+            m.dir = dir;
+            p.agent_dir[e] = (uint8_t)dir;
+            m.vx = dir == 0 ? 1 : (dir == 2 ? -1 : 0);
+            m.vy = dir == 1 ? 1 : (dir == 3 ? -1 : 0);
+            const int lx = m.vy, ly = -m.vx;            // MOVE_LEFT_FPV: right->up, down->right, left->down, up->left
+            m.ddx = a == 0 ? m.vx : (a == 1 ? -m.vx : (a == 2 ? lx : (a == 3 ? -lx : 0)));
+            m.ddy = a == 0 ? m.vy : (a == 1 ? -m.vy : (a == 2 ? ly : (a == 3 ? -ly : 0)));
+        }
+        const int tx = m.ax + m.ddx, ty = m.ay + m.ddy;
+        m.success = false;
+        if (p.visible_radius && a >= 4) continue;       // a turn
+        if (tx >= 0 && ty >= 0 && tx < D && ty < D) {
+            const int code = lg[ty * D + tx];
+            if (code == 0) {                             // XMap::move_item: empty cell -> move
+                lg[m.ay * D + m.ax] = 0;
+                lg[ty * D + tx] = agent_code;
+                if (g) { g[m.ay * D + m.ax] = 0; g[ty * D + tx] = agent_code; }
+                m.ax = tx; m.ay = ty;
+                m.success = true;
+            } else {
+                m.hit = code;                            // contact_list -> "collision:<id>" event
+                m.hit_cell = ty * D + tx;
+            }
+        }
+    }
+    return m;
+}
+
+// Teacher::teach + XWorldSimulator::game_over for one env after its move, and the stores of everything the step leaves
+// behind except the grid.
+__device__ __forceinline__ void xw_teach_store(const XwParams &p, int e, const StepIn &in, const Move &m, bool &is_done, bool &idle3d) {
+    const int D = p.max_dim;
+    const int steps = in.steps + 1;                       // GameSimulator::take_actions: once per call
+    const int hit = m.hit, hit_cell = m.hit_cell;
+    // "the item bumped into is a goal": its cell is in the env's goal-slot table (0xff = no goal; cell 255 exists on a
+    // 16 x 16 map only, where the icon's type is looked up instead)
+    bool hit_is_goal = false;
+    if (hit != 0) {
+        if (D > 15) hit_is_goal = p.icon_type[(hit & CELL_ICON_MASK) - 1] == 0;
+        else {
+            const uint32_t rep = (uint32_t)hit_cell * 0x01010101u;
+            auto has = [&](uint32_t w) { const uint32_t x = w ^ rep; return ((x - 0x01010101u) & ~x & 0x80808080u) != 0u; };
+            hit_is_goal = has(in.gc.x) || has(in.gc.y) || has(in.gc.z) || has(in.gc.w);
+        }
+    }
+    StepCtx cx{e, D, m.ax, m.ay, steps, hit, hit_cell, m.ddx, m.ddy, m.vx, m.vy, m.success, in.level, hit_is_goal};
+    const int ld_ts = in.ts, ld_tsteps = in.tsteps, ld_ts2 = in.ts2, ld_tsteps2 = in.tsteps2;
+    double rew = 0.0;
+    int event = EV_NONE;
+    if (p.exclusive && p.n_tasks2 > 0) {
+        // Teacher::teach, exclusive branch (teacher.cpp:209-220): re-sort the groups, then run ONE: the last busy
+        // group of the sorted list (the reference's loop has no break), else its first.  A busy 3-D group stays busy
+        // until the game resets (its "terminal" stage returns "terminal"), a 2-D one until it is back in "idle".
+        const int go = p.grp_order[e];
+        const int first = xw_sort_groups(p, e, p.episode[e], (uint32_t)steps, go & 1), second = first ^ 1;
+        const bool busy0 = task_stage(ld_ts) != STAGE_IDLE, busy1 = task_stage(ld_ts2) != STAGE_IDLE;
+        const bool busy_first = first ? busy1 : busy0, busy_second = first ? busy0 : busy1;
+        const int pick = busy_second ? second : (busy_first ? first : first);
+        int ts_new, tsteps_new;
+        double r0;
+        bool defer;
+        if (pick == 0) {
+            teach_group<0>(p, cx, ld_ts, ld_tsteps, r0, event, ts_new, tsteps_new, defer);
+            p.task_state[e] = ts_new;
+            p.task_steps[e] = tsteps_new;
+        } else {
+            teach_group<1>(p, cx, ld_ts2, ld_tsteps2, r0, event, ts_new, tsteps_new, defer);
+            p.task_state2[e] = ts_new;
+            p.task_steps2[e] = tsteps_new;
+        }
+        rew = 0.0 + r0;
+        idle3d = defer;
+        p.grp_order[e] = (uint8_t)(first | (pick << 1));
+    } else {
+        // Teacher::teach (teacher.cpp:207-230), groups run non-exclusively in conf order: each group's Task stage adds
+        // its reward to the teacher buffer and overwrites the buffer's event ("" included); only the first py_stage
+        // of a teach() sees this step's collisions (XWorldSimulator::get_events_of_game clears them,
+        // xworld_simulator.cpp:118-122).  One group is the usual case.
+        bool defer;
+        if (p.exclusive && p.minstd) {      // one group: the sort still draws once from the reference's engine
+            uint32_t x = p.minstd[e];
+            (void)xwb_minstd_rand_range_state(&x, (float)p.group_weight[0]);
+            p.minstd[e] = x;
+        }
+        {
+            int ts_new, tsteps_new;
+            double r0;
+            teach_group<0>(p, cx, ld_ts, ld_tsteps, r0, event, ts_new, tsteps_new, defer);
+            rew = 0.0 + r0;                             // add_teacher_reward on a cleared buffer
+            p.task_state[e] = ts_new;
+            p.task_steps[e] = tsteps_new;
+        }
+        if (p.n_tasks2 > 0) {
+            cx.hit = 0;                                 // game_events_ was consumed by the first group's py_stage
+            int ts_new, tsteps_new;
+            double r1;
+            teach_group<1>(p, cx, ld_ts2, ld_tsteps2, r1, event, ts_new, tsteps_new, defer);
+            rew += r1;
+            p.task_state2[e] = ts_new;
+            p.task_steps2[e] = tsteps_new;
+        }
+    }
+    float r = 0.0f;                                 // SimulatorInterface::take_actions
+    r += 0.0f;                                      // XWorldSimulator::take_action returns 0
+    r = (float)((double)r + rew);                   // r += teacher_->give_reward() (double)
+    const int code = done_code(p, steps, event);
+    p.agent_xy[e] = m.ax | (m.ay << 16);
+    p.num_steps[e] = steps;
+    p.success[e] = m.success ? 1 : 0;
+    p.reward[e] = r;
+    p.done[e] = (uint8_t)code;
+    if (p.packed) p.packed[e] = make_float2(r, (float)code);
+    is_done = code != ALIVE;
+}
+
+__global__ __launch_bounds__(64) void xw_step_kernel(XwParams p) {
+    // The kernel is a chain of dependent memory round trips for a few hundred wavefronts (it moves ~4 MB): everything that
+    // does not depend on a previous load is fetched in the FIRST round trip -- the env's scalars, its goal-slot table (which
+    // answers "is the thing I bumped into a goal" without a look-up at the end of the chain) and the GRIDS of the wavefront's
+    // 64 envs, one contiguous block read cooperatively with 16-byte loads into LDS: the move then reads its cells from LDS
+    // instead of paying a second round trip that depends on the agent's position.  One wavefront per workgroup: 512 workgroups
+    // at C4, so every CU has one or two (256-thread groups left half the chip idle).
+    SP_T(0, 0);
+    extern __shared__ uint4 s_dyn[];                       // [64][max_dim^2] cell codes of this wavefront's envs
+    uint16_t *s_grid = reinterpret_cast<uint16_t *>(s_dyn);
+    const int lane = threadIdx.x;
+    const int e0 = blockIdx.x * 64, e = e0 + lane;
+    const int cells_all = p.max_dim * p.max_dim;
     int32_t *count_now = p.done_count;
     if (e == 0) {
         // (pre-generated episodes: the regeneration of the previous step's list may still be reading that list and its count --
@@ -160,20 +358,23 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
     }
     bool is_done = false, idle3d = false;
     if (e == 0 && p.idle_count_next) *p.idle_count_next = 0;
-    int ld_axy = 0, ld_steps = 0, ld_ts = 0, ld_tsteps = 0, ld_dir = 1, ld_level = 0, ld_ts2 = 0, ld_tsteps2 = 0;
-    if (e < p.n) {
-        ld_axy = p.agent_xy[e]; ld_steps = p.num_steps[e]; ld_ts = p.task_state[e]; ld_tsteps = p.task_steps[e];
-        if (p.n_tasks2 > 0) { ld_ts2 = p.task_state2[e]; ld_tsteps2 = p.task_steps2[e]; }
-        if (p.visible_radius) ld_dir = p.agent_dir[e];
-        if (p.curriculum != 0) ld_level = p.cur_level[e];
-    }
-    for (int i = threadIdx.x * 4; i < p.n_icons; i += 1024) {          // (the table is padded to a multiple of 4 bytes)
-        *reinterpret_cast<uint32_t *>(s_icon_type + i) = *reinterpret_cast<const uint32_t *>(p.icon_type + i);
+    StepIn in{};
+    in.dir = 1;
+    in.gc = make_uint4(~0u, ~0u, ~0u, ~0u);
+    if (e < p.n) xw_load_step_in(p, e, in);
+    {
+        const int n_here = p.n - e0 < 64 ? p.n - e0 : 64;
+        const int total = n_here * cells_all;              // u16 elements of this block; the block starts 16-byte aligned
+        const uint16_t *src = p.grid + (size_t)e0 * cells_all;
+        const int full = total / 8;
+        for (int c = lane; c < full; c += 64) s_dyn[c] = reinterpret_cast<const uint4 *>(src)[c];
+        for (int k = full * 8 + lane; k < total; k += 64) s_grid[k] = src[k];
     }
     __syncthreads();
+    SP_T(0, 1);
     if (e < p.n) {
         const int NA = p.visible_radius ? 6 : 4;           // XAgent legal_actions_, xitem.cpp:80-87
-        int a = p.actions ? p.actions[e] : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step, NA);
+        const int a = p.actions ? in.action : policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step, NA);
         p.actions_out[e] = a;
         // render hand-off flag: 0 = env untouched (leave its context ring alone), 1 = stepped, 2 = fresh (reset)
         p.fresh[e] = (unsigned)a < (unsigned)NA ? 1 : 0;
@@ -182,118 +383,12 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
         } else if ((unsigned)a >= (unsigned)NA) {   // CHECK_LT(action_idx, get_num_actions())
             atomicAdd(p.err_count, 1);
         } else {
-            const int D = p.max_dim;
-            uint16_t *g = p.grid + (size_t)e * D * D;
-            const int axy = ld_axy;
-            int ax = axy & 0xffff, ay = axy >> 16;
-            const int steps = ld_steps + 1;                // GameSimulator::take_actions: once per call
-            const uint16_t agent_code = g[ay * D + ax];
-            int ddx = a == 2 ? -1 : (a == 3 ? 1 : 0);         // MOVE_LEFT / MOVE_RIGHT
-            int ddy = a == 0 ? -1 : (a == 1 ? 1 : 0);         // MOVE_UP / MOVE_DOWN
-            int vx = 0, vy = 1;                                // heading: entities keep yaw 1.5707963 (+y) under full observation
-            int hit = 0, hit_cell = 0;
-            bool success = false;
-            for (int i = 0; i < p.act_rep; ++i) {
-                if (p.visible_radius) {
-                    // XAgent::act, xitem.cpp:103-155: MOVE_FORWARD, MOVE_BACKWARD, MOVE_LEFT_FPV, MOVE_RIGHT_FPV relative to
-                    // the heading; TURN_LEFT / TURN_RIGHT change the yaw and "move" onto the agent's own cell, which
-                    // XMap::move_item refuses (xmap.cpp:76-101): a turn is an unsuccessful action without contacts
-                    int dir = ld_dir;
-                    if (a == 4) dir = (dir + 3) & 3;
-                    else if (a == 5) dir = (dir + 1) & 3;
-                    ld_dir = dir;
-                    p.agent_dir[e] = (uint8_t)dir;
-                    vx = dir == 0 ? 1 : (dir == 2 ? -1 : 0);
-                    vy = dir == 1 ? 1 : (dir == 3 ? -1 : 0);
-                    const int lx = vy, ly = -vx;               // MOVE_LEFT_FPV: right->up, down->right, left->down, up->left
-                    ddx = a == 0 ? vx : (a == 1 ? -vx : (a == 2 ? lx : (a == 3 ? -lx : 0)));
-                    ddy = a == 0 ? vy : (a == 1 ? -vy : (a == 2 ? ly : (a == 3 ? -ly : 0)));
-                }
-                const int tx = ax + ddx, ty = ay + ddy;
-                success = false;
-                if (p.visible_radius && a >= 4) continue;      // a turn
-                if (tx >= 0 && ty >= 0 && tx < D && ty < D) {
-                    const int code = g[ty * D + tx];
-                    if (code == 0) {                        // XMap::move_item: empty cell -> move
-                        g[ay * D + ax] = 0;
-                        g[ty * D + tx] = agent_code;
-                        ax = tx; ay = ty;
-                        success = true;
-                    } else {
-                        hit = code;                         // contact_list -> "collision:<id>" event
-                        hit_cell = ty * D + tx;
-                    }
-                }
-            }
-            StepCtx cx{e, D, ax, ay, steps, hit, hit_cell, ddx, ddy, vx, vy, success, ld_level};
-            double rew = 0.0;
-            int event = EV_NONE;
-            if (p.exclusive && p.n_tasks2 > 0) {
-                // Teacher::teach, exclusive branch (teacher.cpp:209-220): re-sort the groups, then run ONE: the last busy
-                // group of the sorted list (the reference's loop has no break), else its first.  A busy 3-D group stays busy
-                // until the game resets (its "terminal" stage returns "terminal"), a 2-D one until it is back in "idle".
-                const int go = p.grp_order[e];
-                const int first = xw_sort_groups(p, e, p.episode[e], (uint32_t)steps, go & 1), second = first ^ 1;
-                const bool busy0 = task_stage(ld_ts) != STAGE_IDLE, busy1 = task_stage(ld_ts2) != STAGE_IDLE;
-                const bool busy_first = first ? busy1 : busy0, busy_second = first ? busy0 : busy1;
-                const int pick = busy_second ? second : (busy_first ? first : first);
-                int ts_new, tsteps_new;
-                double r0;
-                bool defer;
-                if (pick == 0) {
-                    teach_group<0>(p, cx, s_icon_type, ld_ts, ld_tsteps, r0, event, ts_new, tsteps_new, defer);
-                    p.task_state[e] = ts_new;
-                    p.task_steps[e] = tsteps_new;
-                } else {
-                    teach_group<1>(p, cx, s_icon_type, ld_ts2, ld_tsteps2, r0, event, ts_new, tsteps_new, defer);
-                    p.task_state2[e] = ts_new;
-                    p.task_steps2[e] = tsteps_new;
-                }
-                rew = 0.0 + r0;
-                idle3d = defer;
-                p.grp_order[e] = (uint8_t)(first | (pick << 1));
-            } else {
-                // Teacher::teach (teacher.cpp:207-230), groups run non-exclusively in conf order: each group's Task stage adds
-                // its reward to the teacher buffer and overwrites the buffer's event ("" included); only the first py_stage
-                // of a teach() sees this step's collisions (XWorldSimulator::get_events_of_game clears them,
-                // xworld_simulator.cpp:118-122).  One group is the usual case.
-                bool defer;
-                if (p.exclusive && p.minstd) {      // one group: the sort still draws once from the reference's engine
-                    uint32_t x = p.minstd[e];
-                    (void)xwb_minstd_rand_range_state(&x, (float)p.group_weight[0]);
-                    p.minstd[e] = x;
-                }
-                {
-                    int ts_new, tsteps_new;
-                    double r0;
-                    teach_group<0>(p, cx, s_icon_type, ld_ts, ld_tsteps, r0, event, ts_new, tsteps_new, defer);
-                    rew = 0.0 + r0;                             // add_teacher_reward on a cleared buffer
-                    p.task_state[e] = ts_new;
-                    p.task_steps[e] = tsteps_new;
-                }
-                if (p.n_tasks2 > 0) {
-                    cx.hit = 0;                                 // game_events_ was consumed by the first group's py_stage
-                    int ts_new, tsteps_new;
-                    double r1;
-                    teach_group<1>(p, cx, s_icon_type, ld_ts2, ld_tsteps2, r1, event, ts_new, tsteps_new, defer);
-                    rew += r1;
-                    p.task_state2[e] = ts_new;
-                    p.task_steps2[e] = tsteps_new;
-                }
-            }
-            float r = 0.0f;                                 // SimulatorInterface::take_actions
-            r += 0.0f;                                      // XWorldSimulator::take_action returns 0
-            r = (float)((double)r + rew);                   // r += teacher_->give_reward() (double)
-            const int code = done_code(p, steps, event);
-            p.agent_xy[e] = ax | (ay << 16);
-            p.num_steps[e] = steps;
-            p.success[e] = success ? 1 : 0;
-            p.reward[e] = r;
-            p.done[e] = (uint8_t)code;
-            if (p.packed) p.packed[e] = make_float2(r, (float)code);
-            is_done = code != ALIVE;
+            // the live grid gets the move's two cells; they are read from (and kept current in) the wavefront's LDS copy
+            const Move m = xw_move(p, e, a, in.axy, in.dir, s_grid + lane * cells_all, p.grid + (size_t)e * cells_all);
+            xw_teach_store(p, e, in, m, is_done, idle3d);
         }
     }
+    SP_T(0, 2);
     if (p.swap_shadow == 2) {
         // a plain step whose reset_done will install pre-generated episodes (list_swap): nothing to install here, but the list
         // appended below may still be read by the previous step's regeneration
@@ -341,31 +436,35 @@ __global__ __launch_bounds__(256) void xw_step_kernel(XwParams p) {
             }
         }
     }
-    wave_append(is_done, e, p.done_list, count_now);
+    // (lazy path: the list carries each env's episode counter, so the installing list render finds the shadow slot without a
+    // round trip of its own)
+    if (p.swap_shadow == 2) wave_append2(is_done, e, in.ep, p.done_list, p.done_ep, count_now);
+    else wave_append(is_done, e, p.done_list, count_now);
     if (p.idle_list) wave_append(idle3d, e, p.idle_list, p.idle_count);
+    SP_T(0, 3);
     // "this step finished the env": stays put until the next step, whatever a reset_done does to the done codes meanwhile
     if (e < p.n) p.term_flag[e] = is_done ? 1 : 0;
+    SP_T(0, 4);
     if (!p.visible_radius && !p.swap_shadow) {
         // terminal snapshot: the frame of a finished env is rendered from this copy, which lets xwb_reset_done rebuild
         // the live grid on the side stream while the big render is still running.  The wavefront copies the grids of
         // its finished envs together (consecutive lanes = consecutive cells).
         unsigned long long m = __ballot(is_done);
-        const int cells = p.max_dim * p.max_dim, lane = threadIdx.x & 63;
-        if (m) __threadfence();                            // the agent's move was stored by one lane, the copy reads it from all
+        __syncthreads();                                   // (one wavefront: the lanes' LDS copies are complete)
         while (m) {
             const int j = __ffsll((long long)m) - 1;
             m &= m - 1;
             const int ej = __shfl(e, j);
-            const uint16_t *g = p.grid + (size_t)ej * cells;
-            uint16_t *t = p.term_grid + (size_t)ej * cells;
-            for (int c = lane; c < cells; c += 64) t[c] = g[c];
+            uint16_t *t = p.term_grid + (size_t)ej * cells_all;
+            for (int c = lane; c < cells_all; c += 64) t[c] = s_grid[j * cells_all + c];
         }
     }
 }
 
 hipError_t launch_xw_step(const XwParams &p, hipStream_t s) {
-    dim3 grid((p.n + 255) / 256), block(256);
-    hipLaunchKernelGGL(xw_step_kernel, grid, block, 0, s, p);
+    dim3 grid((p.n + 63) / 64), block(64);
+    const size_t lds = ((size_t)64 * p.max_dim * p.max_dim * 2 + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(xw_step_kernel, grid, block, lds, s, p);
     return hipGetLastError();
 }
 
@@ -538,7 +637,10 @@ __global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
     }
 }
 
-// the compacted list of freshly reset envs: one env per workgroup pass, tile table through L1/L2
+// the compacted list of freshly reset envs, tile table through L1/L2.  A frame is cut into `parts` pieces of at most 512
+// chunks, one workgroup pass each: a lane owns at most two chunks and has the eight gathers of both in flight before its first
+// store (one env per workgroup looped five times over load -> store: 10.8 us for the ~115 envs a C4 step finishes).  The chain
+// of a workgroup: {count, list entry, its episode counter, epoch} -> grid -> gathers -> stores.
 template <int DIM_T, int CH, int ES>
 __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const int32_t *count_now) {
     __shared__ uint16_t s_grid[XW_MAX_DIM * XW_MAX_DIM];
@@ -546,32 +648,40 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
     const int cells = D * D;
     const int ctx = p.context;
     const int cpf = CH * 9 * cells * ES;
+    const int parts = (cpf + 511) / 512, per = (cpf + parts - 1) / parts;
     // first round trip: the count, this workgroup's first list entry (the list is the step kernel's, complete long ago) and
     // the epoch, together
+    SP_T(1, 0);
     const int cnt = *count_now;
-    const int e_first = p.done_list[(int)blockIdx.x < p.n ? blockIdx.x : 0];
-    if ((int)blockIdx.x >= cnt) return;                   // nothing to draw (and nothing to wait for)
+    const int i_first = (int)blockIdx.x / parts;
+    const int e_first = p.done_list[i_first < p.n ? i_first : 0];
+    const uint32_t ep_first = p.list_swap ? p.done_ep[i_first < p.n ? i_first : 0] : 0u;
+    const long long items = (long long)cnt * parts;
+    if ((long long)blockIdx.x >= items) { SP_T(1, 5); return; }   // nothing to draw (and nothing to wait for)
+    SP_T(1, 1);
     // The listed envs were regenerated by a reset kernel on the other queue; its epoch stands in for a barrier packet.
     // Normally that kernel finished long ago.  When it has not, the spinning workgroups must not be able to fill the machine:
     // the kernels that publish the epoch need wave slots of their own.  render_list() therefore launches at most half the
     // machine's wave slots when a wait is attached (a batch whose envs all finish on one step otherwise parks one spinning
     // workgroup in every slot: seen as a 4 s stall on the 8x8 workload, where many envs time out on the same step).
     if (p.wait_epoch) xw_wait_epoch(p.sync + p.wait_slot, p.wait_epoch, p.sync + 4, p.poison_host);
-    for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
-        const int e = i == (int)blockIdx.x ? e_first : p.done_list[i];
+    for (long long b = blockIdx.x; b < items; b += gridDim.x) {
+        const int i = (int)(b / parts), part = (int)(b - (long long)i * parts);
+        const bool first = b == (long long)blockIdx.x;
+        const int e = first ? e_first : p.done_list[i];
         __syncthreads();
         if (p.list_swap) {
             // xwb_reset_done with pre-generated episodes: install the env's next episode (what the reset kernel made for it
-            // beside an earlier render) -- the grid through this workgroup, the scalars through its first thread -- and draw it
-            const uint32_t ep_old = p.episode[e];
+            // beside an earlier render) -- the grid through the workgroup of the frame's first piece, the scalars through its
+            // first thread -- and draw it.  Every piece reads the SHADOW grid (nothing rewrites it beside this kernel).
+            const uint32_t ep_old = first ? ep_first : p.done_ep[i];
             const size_t es = (size_t)((ep_old + 1u) & 1u) * (size_t)p.n + (size_t)e;
             for (int k = threadIdx.x; k < cells; k += 256) {
                 const uint16_t code = p.sh_grid[es * cells + k];
-                p.grid[(size_t)e * cells + k] = code;
+                if (part == 0) p.grid[(size_t)e * cells + k] = code;
                 s_grid[k] = code & CELL_ICON_MASK;
             }
-            __syncthreads();                              // (every thread has read the episode counter)
-            if (threadIdx.x == 0) {
+            if (part == 0 && threadIdx.x == 64) {         // (a lane of the second wavefront: beside the first one's gathers)
                 p.agent_xy[e] = p.sh_agent_xy[es];
                 p.task_state[e] = p.sh_task_state[es];
                 p.task_steps[e] = 0;
@@ -585,14 +695,20 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
             }
         } else {
             for (int k = threadIdx.x; k < cells; k += 256) s_grid[k] = p.grid[(size_t)e * cells + k] & CELL_ICON_MASK;
-            __syncthreads();
         }
+        __syncthreads();
         uint4 *frame0 = reinterpret_cast<uint4 *>(p.obs) + (size_t)e * ctx * cpf;
-        for (int cc = threadIdx.x; cc < (p.no_draw ? 0 : cpf); cc += 256) {          // (drawing off: the install and the flags below only)
-            const uint4 v = xw_expand_chunk<DIM_T, CH, ES>(p.atlas, s_grid, cc, D);
-            xw_store_chunk(frame0, cc, cpf, ctx, p.list_flag, v);
-        }
-        if (threadIdx.x == 0 && p.list_flag == 2) { p.fresh[e] = 0; if (p.auto_reset == 2) p.done[e] = 0; }
+        SP_T(1, 2);
+        const int lo = part * per, hi = p.no_draw ? 0 : (lo + per < cpf ? lo + per : cpf);   // (drawing off: the install and the flags only)
+        const int c0 = lo + threadIdx.x, c1 = c0 + 256;
+        // (branch-free: a lane without a chunk gathers the piece's first one again and stores nothing)
+        const uint4 v0 = xw_expand_chunk<DIM_T, CH, ES>(p.atlas, s_grid, c0 < hi ? c0 : lo, D);
+        const uint4 v1 = xw_expand_chunk<DIM_T, CH, ES>(p.atlas, s_grid, c1 < hi ? c1 : lo, D);
+        SP_T(1, 3);
+        if (c0 < hi) xw_store_chunk(frame0, c0, cpf, ctx, p.list_flag, v0);
+        if (c1 < hi) xw_store_chunk(frame0, c1, cpf, ctx, p.list_flag, v1);
+        if (part == 0 && threadIdx.x == 0 && p.list_flag == 2) { p.fresh[e] = 0; if (p.auto_reset == 2) p.done[e] = 0; }
+        SP_T(1, 4);
     }
 }
 
@@ -673,3 +789,9 @@ hipError_t launch_xw_compact(const XwParams &p, int mode, hipStream_t s) {
 }
 
 }  // namespace xwb
+
+#ifdef XWB_STEP_PROF
+extern "C" __attribute__((visibility("default"))) int xwb_debug_step_prof(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(xwb::g_step_prof), sizeof(unsigned long long) * 2 * 4096 * 6) == hipSuccess ? 0 : -1;
+}
+#endif

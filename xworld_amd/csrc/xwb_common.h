@@ -255,6 +255,7 @@ struct XwParams {
     uint8_t *done;
     uint8_t *obs;                // [n][context][channels][12*max_dim][12*max_dim]
     int32_t *done_list;          // compacted env ids
+    uint32_t *done_ep;           // lazy path (swap_shadow == 2): episode counter of each listed env at the step that listed it
     int32_t *done_count;         // counter the current step / compaction appends to
     int32_t *done_count_next;    // the other one of the pair; zeroed by the step kernel
     int32_t *err_count;

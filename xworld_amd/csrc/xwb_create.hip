@@ -267,6 +267,7 @@ int xw_setup(xwb_sim *s) {
         if ((rc = dev_alloc(s, &s->d_sh_goal_cells, (size_t)2 * n * XW_MAX_GOALS))) return rc;
     }
     if ((rc = dev_alloc(s, &s->d_done_list, n))) return rc;
+    if ((rc = dev_alloc(s, &s->d_done_ep, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_done_count, 2))) return rc;
     if ((rc = dev_alloc(s, &s->d_fresh, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_icon_type, ((size_t)c.n_icons + 3) & ~(size_t)3))) return rc;   // the step kernel stages it dword-wise
@@ -398,7 +399,7 @@ int xw_setup(xwb_sim *s) {
     p.num_steps = s->d_num_steps; p.episode = s->d_episode; p.success = s->d_success; p.fresh = s->d_fresh;
     p.reward = s->d_reward; p.done = s->d_done; p.obs = static_cast<uint8_t *>(s->d_obs);
     p.packed = nullptr;                     // set per call (xw_params)
-    p.done_list = s->d_done_list; p.done_count = s->d_done_count; p.done_count_next = s->d_done_count + 1;
+    p.done_list = s->d_done_list; p.done_ep = s->d_done_ep; p.done_count = s->d_done_count; p.done_count_next = s->d_done_count + 1;
     p.err_count = s->d_err;
     if (c.visible_radius > 0) {
         if ((rc = dev_alloc(s, &s->d_ego_tab, xw_ego_tab_bytes(p)))) return rc;

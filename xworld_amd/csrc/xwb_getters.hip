@@ -252,6 +252,15 @@ int xwb_xw_load_map_task(xwb_sim *s, int32_t env, const uint16_t *grid_host, int
     } else if (dim != s->cfg.dim) return fail(XWB_ERR_ARG, "dim differs from the batch's dim");
     const int D = s->cfg.max_dim;
     if (agent_x < 0 || agent_y < 0 || agent_x >= D || agent_y >= D) return fail(XWB_ERR_ARG, "agent outside the map");
+    {   // the goal-slot table (XW_MAX_GOALS cells per env) is what the step kernel's "bumped into a goal" test reads
+        int goals = 0;
+        for (int c = 0; c < D * D; ++c) {
+            const int icon = (int)(grid_host[c] & XWB_CELL_ICON_MASK) - 1;
+            if (icon >= s->cfg.n_icons) return fail(XWB_ERR_ARG, "cell code beyond the palette");
+            if (icon >= 0 && s->icon_type_h[icon] == XWB_ICON_GOAL) goals++;
+        }
+        if (goals > XW_MAX_GOALS) return fail(XWB_ERR_ARG, "a map holds at most 16 goals");
+    }
     HIP_TRY(hipDeviceSynchronize());
     s->shadow_ok = false; s->regen_pending = false;
     const size_t cells = (size_t)D * D;

@@ -116,7 +116,7 @@ struct xwb_sim {
     bool step_lazy = false;                // the last plain step kept no terminal snapshot: its reset_done installs shadows
     int shadow_breaks = 0;                 // times another verb made the shadows stale (the lazy default path gives up after a few)
     uint32_t epoch_regen = 0;
-    uint32_t *d_sh_ep = nullptr;
+    uint32_t *d_sh_ep = nullptr, *d_done_ep = nullptr;
     uint8_t *d_sh_goal_cells = nullptr;
     uint16_t *d_sh_grid = nullptr;
     int32_t *d_sh_agent = nullptr, *d_sh_task_state = nullptr, *d_sh_task_state2 = nullptr;
