@@ -183,7 +183,7 @@ def test_simple_race_rollout(oracle, case, trig):
     sim.close()
 
 
-def test_simple_race_kat_survey(oracle):
+def test_simple_race_kat_survey_reward_unpinned_by_reference(oracle):
     """SURVEY.md 8(a) known answers (straight defaults, legal actions {4,7}) through the product."""
     torch = _torch()
     from xworld_amd.batched import BatchedSimulator

@@ -157,7 +157,7 @@ def test_render_vs_canvas_oracle(oracle, key, color, context):
 
 
 @pytest.mark.parametrize("color", [True, False])
-def test_tile_table_every_icon(oracle, color):
+def test_tile_table_every_icon_resize_unpinned_by_reference(oracle, color):
     """Each icon's 12x12 tile == the oracle's full render of a map holding only that icon (next to the agent)."""
     _torch()
     sim, pal, cfg = _make(oracle, "nav8", 1, color=color)

@@ -89,7 +89,7 @@ def test_philox_known_answers(oracle):
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
-def test_simple_race_survey_kats(oracle):
+def test_simple_race_survey_kats_reward_unpinned_by_reference(oracle):
     r = oracle.SimpleRace()
     r.reset_game()
     exp_obs = [(1, 0, 0, -0.800000012), (0.95105654, -0.309016943, -0.0309020989, -0.780978978),
