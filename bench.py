@@ -141,6 +141,56 @@ def write_ceiling(buf, reps=24):
     return out
 
 
+# ---- N > 1: a hung collective must cost a block of the line, not the line.  Every measurement behind the main one runs as a
+# PHASE with its own deadline; a daemon thread on every rank watches it.  When a phase overruns, rank 0 prints the line as far
+# as it got (the overrun phase and everything not reached recorded as {"error": ...}) and every rank leaves with os._exit(0):
+# a process group whose RCCL kernels hang cannot be torn down politely.
+WATCH = {"line": None, "phase": None, "deadline": None, "rank": 0, "fired": False, "pending": []}
+
+
+def _watchdog_loop():
+    import threading
+    while True:
+        time.sleep(0.5)
+        dl = WATCH["deadline"]
+        if dl is None or time.perf_counter() < dl:
+            continue
+        WATCH["fired"] = True
+        if WATCH["rank"] == 0 and WATCH["line"] is not None:
+            line = dict(WATCH["line"])
+            msg = "watchdog: phase '%s' exceeded its %.0f s" % (WATCH["phase"], WATCH.get("budget", 0.0))
+            line["watchdog"] = {"error": msg, "not_reached": list(WATCH["pending"])}
+            sys.stdout.write(json.dumps(line) + "\n")
+            sys.stdout.flush()
+        elif WATCH["rank"] == 0 and not WATCH.get("printed"):
+            sys.stderr.write("bench.py watchdog: phase '%s' overran before the main measurement was complete\n" % WATCH["phase"])
+        os._exit(0 if (WATCH["line"] is not None or WATCH.get("printed")) else 3)
+
+
+def watch_start(rank):
+    import threading
+    WATCH["rank"] = rank
+    threading.Thread(target=_watchdog_loop, daemon=True).start()
+
+
+class phase:
+    """with phase("name", seconds): ... -- the block's deadline for the watchdog (None: no deadline)"""
+
+    def __init__(self, name, seconds):
+        self.name, self.seconds = name, seconds
+
+    def __enter__(self):
+        WATCH["phase"], WATCH["budget"] = self.name, self.seconds or 0.0
+        WATCH["deadline"] = None if not self.seconds else time.perf_counter() + self.seconds
+        self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        WATCH["deadline"] = None
+        WATCH.setdefault("phase_seconds", {})[self.name] = round(time.perf_counter() - self.t0, 2)
+        return False
+
+
 def region_trend(regions):
     """(median of the last third - median of the first third) / median of all: a settled run is within +-1 %."""
     k = max(1, len(regions) // 3)
@@ -308,7 +358,8 @@ def c5_block(args, world, rank, local_rank, dev, K):
     sim = make_sim("xworld11", n_local, local_rank, rank * n_local, args.seed)
     counts = [n_local] * world
     results = sharding.ResultGather(counts, rank, dev)
-    packed = torch.zeros((2, n_local, 2), dtype=torch.float32, device=dev)
+    # (eight slots: with the exchanges released, a slot is rewritten eight steps after it was shipped)
+    packed = torch.zeros((8, n_local, 2), dtype=torch.float32, device=dev)
     sim.bind_results_ring(packed)
     state = {"screens": None, "calls": 0}
 
@@ -317,14 +368,14 @@ def c5_block(args, world, rank, local_rank, dev, K):
             state["screens"].bind_next()
         state["calls"] += 1
         sim.step()
-        results.finish(convert=False)
-        results.start(packed=packed[(state["calls"] - 1) % 2])
+        (results.finish(convert=False) if args.results_wait else results.release())
+        results.start(packed=packed[(state["calls"] - 1) % 8])
         sim.reset_done()
         if state["screens"] is not None:
             state["screens"].start()
 
     def fence():
-        results.finish(convert=False)
+        results.drain()
         if state["screens"] is not None:
             state["screens"].drain()
         torch.cuda.synchronize()
@@ -410,6 +461,11 @@ def main():
     ap.add_argument("--force-exchange", action="store_true", help="N = 1: initialise torch.distributed (world size 1) and issue the "
                     "N > 1 run's exchanges all the same -- the RCCL all-gather of results, the gather objects -- so that no line of "
                     "the multi-GPU path runs for the first time on the 8-GPU box")
+    ap.add_argument("--results-wait", action="store_true", help="N > 1: order the step's stream behind every step's all-gather of "
+                    "(reward, done) (ResultGather.finish one step late) instead of letting it go (release): what a trainer that reads "
+                    "the results on the root every step pays")
+    ap.add_argument("--phase-timeout", type=float, default=240.0, help="N > 1: seconds a secondary measurement (screens gather mode, "
+                    "C5 block, step_autoreset) may take before the watchdog prints the line without it; the main measurement gets 3x")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo with every rank "
                     "on the visible GPUs modulo their count only exercises the N > 1 code path on a smaller box)")
     args = ap.parse_args()
@@ -446,6 +502,12 @@ def main():
                 sk.close()
                 dist.init_process_group(args.backend, init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0, **kw)
     dev = torch.device("cuda", local_rank)
+    guarded = world > 1 or args.force_exchange
+    PT = args.phase_timeout if guarded else None
+    watch_start(rank)
+    WATCH["pending"] = ["main", "step_autoreset", "screens_gather", "c5", "parity"]
+    WATCH["phase"], WATCH["budget"] = "main (set-up, frame gate, warm-up)", 3 * (PT or 0.0)
+    WATCH["deadline"] = None if not PT else time.perf_counter() + 3 * PT
     n_local = args.envs_per_gpu or WORKLOADS[args.workload][2]
     sim = make_sim(args.workload, n_local, local_rank, rank * n_local, args.seed)
     per_step, per_launch, kernel_name = algorithmic_bytes(args.workload, sim)
@@ -470,7 +532,7 @@ def main():
             return
         # finish the gather of the previous step (it ran beside this step's kernels), start this step's: the step
         # kernel wrote (reward, code) straight into the record's slot, no packing kernels
-        results.finish(convert=False)
+        (results.finish(convert=False) if args.results_wait else results.release())
         results.start(packed=rec[0][(calls[0] - 1) % rec[0].shape[0]])
 
     def one_step():
@@ -492,7 +554,7 @@ def main():
 
     def fence():
         if results is not None:
-            results.finish(convert=False)
+            results.drain()
         if screens is not None:
             screens.drain()
         torch.cuda.synchronize()
@@ -571,11 +633,14 @@ def main():
             break
     spin_calls = spun
 
+    host_issue = []                                      # seconds the host spent issuing the K steps of each region (before the fence)
+
     def timed_region():
         fence()
         t0 = time.perf_counter()
         for _ in range(K):
             one_step()
+        host_issue.append(time.perf_counter() - t0)
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -586,6 +651,8 @@ def main():
 
     # ... then unreported K-step regions until three in a row agree within 1 % (at most 24: a short region on a box that has
     # just been handed over measures the box settling, not the code)
+    WATCH["deadline"] = None if not PT else time.perf_counter() + 3 * PT
+    WATCH["phase"], WATCH["budget"] = "main", 3 * (PT or 0.0)
     settle = []
     while len(settle) < 24:
         settle.append(timed_region())
@@ -594,8 +661,10 @@ def main():
             break
 
     # ---- the timed regions: exactly K steps each between two barrier + synchronize fences, max over ranks ----
+    del host_issue[:]
     regions = [timed_region() for _ in range(R)]
     dt_med = statistics.median(regions)
+    host_us_per_step = statistics.median(host_issue) / args.steps * 1e6
 
     # ---- R more regions with hipEvents around every launch of the dominant kernel (on its launch stream, recorded
     # inside libxwb) to get that kernel's average duration for the roofline ----
@@ -616,6 +685,72 @@ def main():
     ceiling = write_ceiling(ceiling_buf)
     for _ in range(K):                                   # and the loop itself warm again before the secondary measurements
         one_step()
+    WATCH["deadline"] = None
+    # N ranks on N devices, in the record itself: every rank's device as torch names it, and RCCL's own count of the communicator
+    ranks_seen = {}
+    if world > 1 or forced:
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(dev), "index": torch.cuda.current_device(),
+                "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", ""))}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        ranks_seen = {"ranks": everyone, "ranks_seen": len({(r["local_rank"], r["uuid"]) for r in everyone})}
+
+    def core_line():
+        total_envs = n_local * world
+        value = total_envs * args.steps / dt_med
+        # algorithmic bytes of one launch = per-step bytes x the steps that launch runs
+        achieved = n_local * per_launch * fused / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
+        traffic, traffic_info = measured_traffic(args.workload) if n_local == WORKLOADS[args.workload][2] else (None, {"traffic_source": None})
+        line = {
+            "metric": "env-steps/sec (batched random policy)",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_med / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": ("f32 (f64 trig)" if WORKLOADS[args.workload][0] == "simple_race" else
+                      ("u8 state, f32 frames (pixel * 1/255)" if sim.obs_is_float else "u8")),
+            "data": "synthetic",
+            "config": {"workload": args.workload, "envs_per_gpu": n_local, "total_envs": total_envs,
+                       "obs": list(sim.obs.shape[1:]), "seed": args.seed, "policy": "uniform random, drawn on device",
+                       "loop": ("step_n(%d): %d steps per launch, auto-reset" % (fused, fused)) if fused > 1 else
+                               ("step_autoreset" if args.autoreset else "step + reset_done"),
+                       "exchange": ("all_gather(reward,done) per step (%s), screens device-resident" %
+                                    ("the step's stream waits for it one step late" if args.results_wait else "released: no reader on the step's stream"))
+                                   if (world > 1 or forced) else "none",
+                       "parallelism": "env-sharded x%d" % world},
+            "regions": {"repetitions": R, "statistic": "median", "steps_per_region": args.steps,
+                        "ms_per_step_min": min(regions) / args.steps * 1e3, "ms_per_step_max": max(regions) / args.steps * 1e3,
+                        "ms_per_step_all": [r / args.steps * 1e3 for r in regions],
+                        "trend": region_trend(regions),
+                        "untimed_before": {"warmup_steps": args.warmup, "spin_steps": spin_calls * fused,
+                                           "spin_seconds_target": args.spin_seconds, "probe_steps": probe_calls * fused,
+                                           "settle_regions": len(settle)}},
+            "path": path_default,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
+                         "write_ceiling_GBps": ceiling["memset"]["GBps"], "write_ceiling": ceiling,
+                         "frac_of_write_ceiling": achieved / ceiling["memset"]["GBps"] if ceiling["memset"]["GBps"] else None,
+                         "kernels_us": kernels_us,
+                         "kernel_avg_us": kern_us, "kernel_launches": kern_n,
+                         "algorithmic_bytes_per_launch": n_local * per_launch * fused,
+                         "algorithmic_bytes_per_env_step": per_step,
+                         "step_loop_GBps": total_envs * per_step * args.steps / dt_med / 1e9,
+                         "step_loop_frac": total_envs * per_step * args.steps / dt_med / 1e9 / HBM_PEAK_GBS / world,
+                         **traffic_info},
+            "timed_with_events_ms_per_step": statistics.median(ev_regions) / args.steps * 1e3,
+            "host_us_per_step": host_us_per_step,
+            "rccl": dict(sharding.backend_info(), **ranks_seen),
+        }
+        return line
+
+    if rank == 0:
+        WATCH["line"] = core_line()
+        WATCH["pending"] = [x for x in WATCH["pending"] if x != "main"]
 
     # ---- a second, shorter measurement in the same run: the fused call xwb_step_autoreset (the reference example loop's
     # `if game_over: reset_game()` inside the step: a finished env's observation is the first frame of its next episode,
@@ -623,9 +758,10 @@ def main():
     ar_line = None
     if fused == 1 and not args.autoreset:
         loop["autoreset"] = True
-        for _ in range(K):
-            one_step()
-        ar_regions = [timed_region() for _ in range(3)]
+        with phase("step_autoreset", PT):
+            for _ in range(K):
+                one_step()
+            ar_regions = [timed_region() for _ in range(3)]
         ar_path = sim.step_path()
         loop["autoreset"] = False
         ar_med = statistics.median(ar_regions)
@@ -634,6 +770,9 @@ def main():
                    "ms_per_step": ar_med / args.steps * 1e3, "value": n_local * world * args.steps / ar_med, "unit": "env-steps/s",
                    "step_loop_frac": n_local * per_step * args.steps / ar_med / 1e9 / HBM_PEAK_GBS, "path": ar_path}
         one_step()                                       # back in the default loop before anything else is measured
+        if rank == 0:
+            WATCH["line"]["step_autoreset"] = ar_line
+    WATCH["pending"] = [x for x in WATCH["pending"] if x != "step_autoreset"]
 
     # ---- the OTHER path of the default loop (weak point of round 3: "a trainer can end up on a path the bench never timed"):
     # a second batch of the same workload held on the classic kernel sequence (xwb_config.debug_flags no_pregen = what a batch
@@ -673,10 +812,17 @@ def main():
         blocks = {}
         for mode in modes:
             try:
-                blocks[mode], screens = gather_regions(sim, mode, lib_comm, counts, rank, world, n_local, K, R, args, set_screens, timed_region, fence)
+                with phase("screens_gather:" + mode, PT):
+                    blocks[mode], screens = gather_regions(sim, mode, lib_comm, counts, rank, world, n_local, K, R, args, set_screens, timed_region, fence)
             except Exception as e:                       # a second measurement must not take the line down with it
                 blocks[mode] = {"error": "%s: %s" % (type(e).__name__, e)}
             screens = None                               # (the batch keeps the buffer it is bound to alive)
+            if rank == 0:                                # (what the watchdog would print if a later mode hangs)
+                WATCH["line"].setdefault("screens_gather", {"mode": modes[0]})
+                if mode == modes[0]:
+                    WATCH["line"]["screens_gather"] = dict(blocks[mode], mode=mode)
+                else:
+                    WATCH["line"]["screens_gather"][{"grids": "grids", "grids_nodraw": "grids_no_local_render"}.get(mode, mode)] = blocks[mode]
         sg_line = dict(blocks[modes[0]])
         sg_line["mode"] = modes[0]
         if len(modes) > 1:
@@ -685,64 +831,24 @@ def main():
                 sg_line["grids_no_local_render"] = blocks["grids_nodraw"]
         elif args.gather != "screens" and not grids_ok:
             sg_line["grids"] = {"skipped": "needs a full-observation xworld workload (a frame must be a function of the cell codes)"}
+    WATCH["pending"] = [x for x in WATCH["pending"] if x != "screens_gather"]
     errs = sim.check_errors()
     assert errs == 0
     # ---- N > 1: BASELINE C5 (xworld11, 8 x 32 768 envs, RCCL gather of screens) as a block of the same line ----
     c5 = None
     if world > 1 and (args.c5 or world == 8) and args.workload != "xworld11":
         try:
-            c5 = c5_block(args, world, rank, local_rank, dev, K)
+            with phase("c5", 2 * PT if PT else None):
+                c5 = c5_block(args, world, rank, local_rank, dev, K)
         except Exception as e:                           # the main line must not die with its second measurement
             c5 = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            WATCH["line"]["c5"] = c5
+    WATCH["pending"] = [x for x in WATCH["pending"] if x != "c5"]
 
     if rank == 0:
-        total_envs = n_local * world
-        value = total_envs * args.steps / dt_med
-        # algorithmic bytes of one launch = per-step bytes x the steps that launch runs
-        achieved = n_local * per_launch * fused / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
-        traffic, traffic_info = measured_traffic(args.workload) if n_local == WORKLOADS[args.workload][2] else (None, {"traffic_source": None})
-        line = {
-            "metric": "env-steps/sec (batched random policy)",
-            "value": value,
-            "unit": "env-steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt_med / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": ("f32 (f64 trig)" if WORKLOADS[args.workload][0] == "simple_race" else
-                      ("u8 state, f32 frames (pixel * 1/255)" if sim.obs_is_float else "u8")),
-            "data": "synthetic",
-            "config": {"workload": args.workload, "envs_per_gpu": n_local, "total_envs": total_envs,
-                       "obs": list(sim.obs.shape[1:]), "seed": args.seed, "policy": "uniform random, drawn on device",
-                       "loop": ("step_n(%d): %d steps per launch, auto-reset" % (fused, fused)) if fused > 1 else
-                               ("step_autoreset" if args.autoreset else "step + reset_done"),
-                       "exchange": "all_gather(reward,done) per step, screens device-resident" if (world > 1 or forced) else "none",
-                       "parallelism": "env-sharded x%d" % world},
-            "regions": {"repetitions": R, "statistic": "median", "steps_per_region": args.steps,
-                        "ms_per_step_min": min(regions) / args.steps * 1e3, "ms_per_step_max": max(regions) / args.steps * 1e3,
-                        "ms_per_step_all": [r / args.steps * 1e3 for r in regions],
-                        "trend": region_trend(regions),
-                        "untimed_before": {"warmup_steps": args.warmup, "spin_steps": spin_calls * fused,
-                                           "spin_seconds_target": args.spin_seconds, "probe_steps": probe_calls * fused,
-                                           "settle_regions": len(settle)}},
-            "path": path_default,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
-                         "write_ceiling_GBps": ceiling["memset"]["GBps"], "write_ceiling": ceiling,
-                         "frac_of_write_ceiling": achieved / ceiling["memset"]["GBps"] if ceiling["memset"]["GBps"] else None,
-                         "kernels_us": kernels_us,
-                         "kernel_avg_us": kern_us, "kernel_launches": kern_n,
-                         "algorithmic_bytes_per_launch": n_local * per_launch * fused,
-                         "algorithmic_bytes_per_env_step": per_step,
-                         "step_loop_GBps": total_envs * per_step * args.steps / dt_med / 1e9,
-                         "step_loop_frac": total_envs * per_step * args.steps / dt_med / 1e9 / HBM_PEAK_GBS / world,
-                         **traffic_info},
-            "timed_with_events_ms_per_step": statistics.median(ev_regions) / args.steps * 1e3,
-            "rccl": sharding.backend_info(),
-        }
+        line = WATCH["line"]
+        line["phase_seconds"] = WATCH.get("phase_seconds", {})
         if ar_line is not None:
             line["step_autoreset"] = ar_line
         if classic_line is not None:
@@ -765,10 +871,14 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # rank 0, N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.workload, args.seed)
         print(json.dumps(line))
+        sys.stdout.flush()
+    WATCH["printed"] = True
     sim.close()
     if world > 1 or forced:
-        dist.barrier()
-        dist.destroy_process_group()
+        with phase("teardown", PT):                          # (the line is out: a hang here only costs the exit)
+            WATCH["line"] = None
+            dist.barrier()
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

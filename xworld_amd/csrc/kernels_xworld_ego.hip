@@ -1084,8 +1084,25 @@ struct EgoSpanGeom {
 // the cell (its lines are evaluated per env into ego_border) or where a border row crosses a border column (four cells)
 // does the unit's lane place a row or first dwords itself -- the pieces leave those dwords alone.
 // flag_all: the context flag of every env touched (list render), -1: the cell words say.
-template <int CH, int R, bool CTX1, int ES, int PER>
-__device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, unsigned cr, int nc, int skip_term, int flag_all) {
+// The span's LDS belongs to the kernel (EGO_GATHER_LDS declares it; the fused kernel lays it over its front's arrays).
+// FUSED (xw_ego_fused_kernel): the cell words and the evaluated border lines of the envs from e0 on are in LDS (csrc, lines_lds)
+// instead of ego_cellsrc / ego_border, and the barriers order LDS only -- the workgroup goes on to its next span with this one's
+// stores still on their way.
+struct EgoGatherLds { uint4 *out4; uint32_t *env; const uint8_t **usrc; int *uo; };
+#define EGO_GATHER_LDS(G, R_, name) \
+    __shared__ uint4 name##_out4[(G::GB + G::SB + G::GB) / 16 + 17]; \
+    __shared__ uint32_t name##_env[G::SB / (int)G::FB + 2]; \
+    __shared__ const uint8_t *name##_usrc[EgoUnitShfl<R_>::value ? 1 : G::NU]; \
+    __shared__ int name##_uo[EgoUnitShfl<R_>::value ? 1 : G::NU]; \
+    const EgoGatherLds name{name##_out4, name##_env, name##_usrc, name##_uo}
+__device__ __forceinline__ void ego_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+template <int CH, int R, bool CTX1, int ES, int PER, bool FUSED = false>
+__device__ __forceinline__ void ego_gather_span(const XwParams &p, const EgoGatherLds &lds, unsigned e0, unsigned cr, int nc, int skip_term, int flag_all,
+                                                const uint32_t *csrc = nullptr, const uint8_t *lines_lds = nullptr) {
     typedef EgoSq<R> Q;
     constexpr int BS = EGO_BS, SPAN = BS * PER;
     constexpr int U = Q::U, UD = Q::UD, O = R * U, RR = R * R;
@@ -1106,10 +1123,11 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
     constexpr int NL = 2 * (R - 1);
     static_assert(GB % 16 == 0 && U % 4 == 0, "aligned pieces");
     static_assert(4 * Q::UP <= 128, "a unit fits the constant line");
-    __shared__ uint4 s_out4[(GB + SB + GB) / 16 + 17];                      // (+ the dump of dwords nobody wants, see below: 64 + 3 dwords)
-    __shared__ uint32_t s_env[NE];                                          // a cell word of each env: its flags
-    __shared__ const uint8_t *s_usrc[SHFL ? 1 : NU];
-    __shared__ int s_uo[SHFL ? 1 : NU];                                     // the unit's first dword in s_out | flags << 24, -1: none
+    static_assert(NE == EgoSpanGeom<CH, R, ES, PER>::SB / (int)EgoSpanGeom<CH, R, ES, PER>::FB + 2 && NU == EgoSpanGeom<CH, R, ES, PER>::NU, "EGO_GATHER_LDS sizes");
+    uint4 *const s_out4 = lds.out4;                                         // [(GB + SB + GB) / 16 + 17] (+ the dump of dwords nobody wants, see below: 64 + 3 dwords)
+    uint32_t *const s_env = lds.env;                                        // [NE] a cell word of each env: its flags
+    const uint8_t **const s_usrc = lds.usrc;                                // [SHFL ? 1 : NU]
+    int *const s_uo = lds.uo;                                               // [SHFL ? 1 : NU] the unit's first dword in s_out | flags << 24, -1: none
     uint32_t *s_out = reinterpret_cast<uint32_t *>(s_out4);
     const int tid = threadIdx.x;
     const unsigned br = cr * BPC, be = br + (unsigned)nc * BPC;             // bytes, from the start of env e0's frame
@@ -1117,7 +1135,7 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
     typedef const unsigned int __attribute__((address_space(1))) *g_u32;
     typedef const u32x4 __attribute__((address_space(1))) *g_u32x4;
     const unsigned g0 = br / GB, g1 = (be + GB - 1) / GB;                   // row groups, counted from env e0's first
-    if (tid >= BS - ne) s_env[BS - 1 - tid] = p.ego_cellsrc[((size_t)e0 + (BS - 1 - tid)) * RR];
+    if (tid >= BS - ne) s_env[BS - 1 - tid] = FUSED ? csrc[(BS - 1 - tid) * RR] : p.ego_cellsrc[((size_t)e0 + (BS - 1 - tid)) * RR];
     const size_t env_cache = (size_t)p.num_goals * (RR * 4) * p.ego_cache_entry;
     int uo[ITU];                                                            // the unit's first dword in s_out | flags << 24, -1: none
     const uint8_t *usrc_r[ITU];
@@ -1139,7 +1157,7 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
         usrc_r[iu] = p.ego_tab3;
         if (ut < NU && gq < g1) {
             const unsigned le = gq / GPF, gi = gq - le * GPF, ch = gi / GPP, oy0 = 4u * (gi - ch * GPP), fy = oy0 / (unsigned)U, py0 = oy0 - fy * U;
-            uint32_t w = p.ego_cellsrc[((size_t)e0 + le) * RR + fy * R + fx];
+            uint32_t w = FUSED ? csrc[le * RR + fy * R + fx] : p.ego_cellsrc[((size_t)e0 + le) * RR + fy * R + fx];
             if (skip_term && (w >> 27 & 1u)) w = 0;
             const bool cached = (w >> 23 & 1u) != 0;
             const uint32_t flat = w >> 30;
@@ -1156,12 +1174,23 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
             // cell word just read: the round trip runs under the barrier and the pieces' own loads instead of after them
             // (round 4: it was a dependent round trip at the end of nearly every workgroup, ~0.4 of its ~6 us)
             if (f_row || f_col || f_x) {
-                const uint8_t *lines = p.ego_border + (((size_t)e0 + le) * NL * CH + ch) * O, *src = usrc;
-                if (f_col || f_x) pcb[iu] = *(g_u32)(lines + (size_t)(R - 1 + fx - 1) * (CH * O) + oy0);
-                if (f_row) {
-                    const uint8_t *row = lines + (size_t)(fy - 1) * (CH * O) + fx * U;
+                const uint8_t *src = usrc;
+                if (FUSED) {
+                    const uint8_t *lines = lines_lds + (le * NL * CH + ch) * O;
+                    if (f_col || f_x) pcb[iu] = *reinterpret_cast<const uint32_t *>(lines + (R - 1 + fx - 1) * (CH * O) + oy0);
+                    if (f_row) {
+                        const uint8_t *row = lines + (fy - 1) * (CH * O) + fx * U;
 #pragma unroll
-                    for (int d = 0; d < UD; ++d) prow[iu][d] = *(g_u32)(row + 4 * d);
+                        for (int d = 0; d < UD; ++d) prow[iu][d] = *reinterpret_cast<const uint32_t *>(row + 4 * d);
+                    }
+                } else {
+                    const uint8_t *lines = p.ego_border + (((size_t)e0 + le) * NL * CH + ch) * O;
+                    if (f_col || f_x) pcb[iu] = *(g_u32)(lines + (size_t)(R - 1 + fx - 1) * (CH * O) + oy0);
+                    if (f_row) {
+                        const uint8_t *row = lines + (size_t)(fy - 1) * (CH * O) + fx * U;
+#pragma unroll
+                        for (int d = 0; d < UD; ++d) prow[iu][d] = *(g_u32)(row + 4 * d);
+                    }
                 }
                 if (f_col || f_x) {
 #pragma unroll
@@ -1171,7 +1200,7 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
         }
         if (!SHFL && ut < NU) { s_uo[ut] = uo[iu]; s_usrc[ut] = usrc_r[iu]; }
     }
-    if (!SHFL) __syncthreads();
+    if (!SHFL) { if (FUSED) ego_lds_barrier(); else __syncthreads(); }
     // ---- one lane per 16-byte piece
     {
         u32x4 q[ITP];
@@ -1273,7 +1302,7 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, unsigned e0, 
             }
         }
     }
-    __syncthreads();
+    if (FUSED) ego_lds_barrier(); else __syncthreads();
     uint4 *obs4 = reinterpret_cast<uint4 *>(p.obs);
     const float scale = (float)(1 / 255.0);
     bool any_skip = false;                                                  // (uniform: a scalar branch)
@@ -1328,7 +1357,8 @@ __global__ __launch_bounds__(EGO_BS) void xw_ego_gather_kernel(XwParams p, int s
     const unsigned n_chunks = (unsigned)p.n * G::cpf, c_lo = blockIdx.x * G::SPAN;
     const unsigned e0 = c_lo / G::cpf;
     if (blockIdx.x == 0 && threadIdx.x == 0) *p.ego_miss_count = 0;         // the kernels before this one consumed the list
-    ego_gather_span<CH, R, CTX1, ES, PER>(p, e0, c_lo - e0 * G::cpf, (int)(n_chunks - c_lo < (unsigned)G::SPAN ? n_chunks - c_lo : G::SPAN), skip_term, -1);
+    EGO_GATHER_LDS(G, R, lds);
+    ego_gather_span<CH, R, CTX1, ES, PER>(p, lds, e0, c_lo - e0 * G::cpf, (int)(n_chunks - c_lo < (unsigned)G::SPAN ? n_chunks - c_lo : G::SPAN), skip_term, -1);
 }
 
 // the frames of the listed envs, from what the front kernels left of them (terminal frames: p.list_flag = 1)
@@ -1337,16 +1367,340 @@ __global__ __launch_bounds__(EGO_BS) void xw_ego_gather_list_kernel(XwParams p, 
     typedef EgoSpanGeom<CH, R, ES, 2> G;
     if (publish && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 6, p.sig_epoch);      // the evaluation kernel is through
     const int cnt = *count_now, part = blockIdx.x % G::SPE;
+    EGO_GATHER_LDS(G, R, lds);
     for (int item = blockIdx.x / G::SPE; item < cnt; item += gridDim.x / G::SPE) {
         const int e = p.done_list[item], cr = part * G::SPAN;
         __syncthreads();
-        ego_gather_span<CH, R, CTX1, ES, 2>(p, (unsigned)e, (unsigned)cr, G::cpf - cr < G::SPAN ? G::cpf - cr : G::SPAN, 0, p.list_flag);
+        ego_gather_span<CH, R, CTX1, ES, 2>(p, lds, (unsigned)e, (unsigned)cr, G::cpf - cr < G::SPAN ? G::cpf - cr : G::SPAN, 0, p.list_flag);
         // (as the list render of the other path: the first frame of a new episode consumes fresh[] and, where the reset left
         // that to the render, the done code)
         if (part == 0 && threadIdx.x == 0 && p.list_flag == 2) { p.fresh[e] = 0; if (p.auto_reset == 2) p.done[e] = 0; }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) *p.ego_miss_count = 0;          // (the list this path's cells kernel filled is consumed)
 }
+
+#ifdef XWB_EGO_FUSED_LAB
+// ------------------------------------------------------------------------------------------------ fused span render ----
+// LAB BUILD ONLY (XWB_EXTRA_FLAGS=-DXWB_EGO_FUSED_LAB, tools/lab/ego_fused_ab.sh; selected with XWB_DEBUG=ego_fused=N).  Built,
+// frame-exact (tests/test_gpu_ego.py, test_gpu_doc_image.py green under it) and SLOWER than the three-kernel path -- measured
+// round 5, r = 3, C4-sized batch, same box: this kernel 426 us (evaluation stubbed: ~170 us) against cells 19 + eval 42 + gather
+// 126 us; profiles/NOTES.md "round 5: the fused egocentric render" says why.  Kept out of the product build.
+// Round 5: ONE kernel in which a workgroup owns E consecutive envs end to end -- cell table -> the
+// pixels that have to be evaluated (border runs next to goals, crossings: into LDS, never to HBM; goal cells the cache lacks:
+// into the cache) -> the gather of their frames, span after span, with the stores of a span on their way while the next one is
+// assembled (ego_lds_barrier: the barriers order LDS only).  The three-kernel form above runs its two front kernels -- chains of
+// dependent round trips over a few thousand wavefronts -- with HBM idle (~60 us of a 190 us render at r = 3); here the front of a
+// workgroup runs under the stores of the workgroups that started before it.
+// E = 8: 8 frames of 84 x 84 x {1, 3} bytes are a whole number of 128-byte lines, so every workgroup starts on a line (80 x 80
+// frames do for every E).
+struct EgoFusedFront {
+    EgoTap row[84][3], col[84][3];                 // composed taps (evaluation only)
+    uint4 gc[8];                                    // goal slot -> cell tables
+    int axy[8];
+    uint8_t dir[8], term[8], fresh[8], edir[8];
+    int nrun, ncross, nmiss, pad;
+};
+template <int R, int E>
+struct EgoFusedLds {
+    static constexpr int RR = R * R, NSEG = R * (R - 1);
+    // byte offsets into the workgroup's dynamic LDS of what follows the fixed part; cells = max_dim^2, ni = n_icons
+    static constexpr int CELLS = (int)((sizeof(EgoFusedFront) + 15) & ~15u);       // EgoCell[E][RR]
+    static constexpr int GCELLS = CELLS + E * RR * (int)sizeof(EgoCell);             // EgoCell[RR]: "every cell shows this goal's image"
+    static constexpr int SQ = GCELLS + RR * (int)sizeof(EgoCell);                    // uint32[E][RR]
+    static constexpr int MISS = SQ + E * RR * 4;                                      // uint32[E * RR]
+    static constexpr int RUNS = MISS + E * RR * 4;                                    // uint16[E * 2 * NSEG]
+    static constexpr int CROSS = RUNS + ((E * 2 * NSEG * 2 + 15) & ~15);              // uint16[E * (R - 1)^2]
+    static constexpr int GOAL = CROSS + ((E * (R - 1) * (R - 1) * 2 + 15) & ~15);     // uint8[E][RR]
+    static constexpr int MAP = GOAL + ((E * RR + 15) & ~15);                          // uint8[8 RR + 8 R]
+    static constexpr int CODE = MAP + ((8 * RR + 8 * R + 15) & ~15);                  // uint16[E][cells], then uint8 type[E][cells], itype[ni], cls[ni + 2]
+    __host__ __device__ static constexpr int type_off(int cells) { return CODE + ((E * cells * 2 + 15) & ~15); }
+    __host__ __device__ static constexpr int itype_off(int cells) { return type_off(cells) + ((E * cells + 15) & ~15); }
+    __host__ __device__ static constexpr int cls_off(int cells, int ni) { return itype_off(cells) + ((ni + 15) & ~15); }
+    __host__ __device__ static constexpr int front_bytes(int cells, int ni) { return cls_off(cells, ni) + ((ni + 2 + 15) & ~15); }
+};
+
+template <int CH, int R, bool CTX1, int ES, int PER, int E>
+__global__ __launch_bounds__(EGO_BS) void xw_ego_fused_kernel(XwParams p, const uint8_t *map, const EgoTap *comp, const uint16_t *layout,
+                                                              const uint32_t *atlas4, int skip_term, int publish_step, int publish_list, int no_eval) {
+    typedef EgoSpanGeom<CH, R, ES, PER> G;
+    typedef EgoSq<R> Sq;
+    typedef EgoFusedLds<R, E> L;
+    constexpr int BS = EGO_BS, RR = R * R, U = 84 / R, O = R * U, NL = 2 * (R - 1), TPE = BS / E;
+    constexpr int NSEG = R * (R - 1), NITEM = 2 * NSEG + (R - 1) * (R - 1);
+    constexpr int RL = 4 * RR, CL = RL + 4 * R, INV = CL + 4 * R;
+    static_assert(E <= 8 && BS % E == 0 && E * 16 <= BS, "lanes per env");
+    extern __shared__ uint4 smem4[];
+    __shared__ uint32_t s_src[E][RR];                        // the squares' source words (what ego_cellsrc holds on the three-kernel path)
+    __shared__ uint4 s_border4[(E * NL * CH * O + 15) / 16]; // the evaluated border lines of the workgroup's envs: [env][line][channel][O]
+    uint8_t *const s_border = reinterpret_cast<uint8_t *>(s_border4);
+    uint8_t *const sm = reinterpret_cast<uint8_t *>(smem4);
+    EgoFusedFront &F = *reinterpret_cast<EgoFusedFront *>(sm);
+    EgoCell (*s_cells)[RR] = reinterpret_cast<EgoCell (*)[RR]>(sm + L::CELLS);
+    EgoCell *s_gcells = reinterpret_cast<EgoCell *>(sm + L::GCELLS);
+    uint32_t (*s_sq)[RR] = reinterpret_cast<uint32_t (*)[RR]>(sm + L::SQ);
+    uint32_t *s_miss = reinterpret_cast<uint32_t *>(sm + L::MISS);
+    uint16_t *s_runs = reinterpret_cast<uint16_t *>(sm + L::RUNS), *s_cross = reinterpret_cast<uint16_t *>(sm + L::CROSS);
+    uint8_t (*s_goal)[RR] = reinterpret_cast<uint8_t (*)[RR]>(sm + L::GOAL);
+    uint8_t *s_map = sm + L::MAP;
+    const int tid = threadIdx.x, D = p.max_dim, cells = D * D, ni = p.n_icons;
+    uint16_t *s_code = reinterpret_cast<uint16_t *>(sm + L::CODE);
+    uint8_t *s_type = sm + L::type_off(cells), *s_itype = sm + L::itype_off(cells), *s_cls = sm + L::cls_off(cells, ni);
+    const int e_base = (int)blockIdx.x * E;
+    const int n_here = p.n - e_base < E ? p.n - e_base : E;
+    if (blockIdx.x == 0 && tid == 0) {
+        // this kernel running = everything queued before it is complete: the step kernel (xwb_step_autoreset), or the three short
+        // kernels that drew the step's terminal frames from the list (xwb_step: nothing reads the finished envs' grids, goal
+        // images or the list's buffers any more)
+        if (publish_step) xw_publish_epoch(p.sync + 1, p.sig_epoch);
+        if (publish_list) { xw_publish_epoch(p.sync + 5, p.sig_epoch); xw_publish_epoch(p.sync + 6, p.sig_epoch); xw_publish_epoch(p.sync + 7, p.sig_epoch); }
+    }
+    // ---- A. the cell table (ego_cells_body, for E envs): first round trip -- everything that depends on nothing
+    {
+        constexpr int NGI = (E * XW_MAX_DIM * XW_MAX_DIM + BS - 1) / BS;
+        uint16_t gv[NGI];
+        const uint16_t *g = p.grid + (size_t)e_base * cells;
+#pragma unroll
+        for (int q = 0; q < NGI; ++q) { const int i = q * BS + tid; gv[q] = i < n_here * cells ? g[i] : (uint16_t)0; }
+        int axy = 0, dir = 0, term = 0, fresh = 0;
+        uint4 gc = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (tid < n_here) {
+            const int e = e_base + tid;
+            axy = p.agent_xy[e]; dir = p.agent_dir[e] & 3; term = p.term_flag[e]; fresh = p.fresh[e];
+            gc = reinterpret_cast<const uint4 *>(p.goal_cells)[e];
+        }
+        const uint8_t it0 = tid < ni ? p.icon_type[tid] : (uint8_t)0, it1 = tid + BS < ni ? p.icon_type[tid + BS] : (uint8_t)0;
+        const uint8_t cl0 = tid < ni + 2 ? p.ego_cls[tid] : (uint8_t)0, cl1 = tid + BS < ni + 2 ? p.ego_cls[tid + BS] : (uint8_t)0;
+        const uint8_t mp0 = tid < 8 * RR + 8 * R ? map[tid] : (uint8_t)0, mp1 = tid + BS < 8 * RR + 8 * R ? map[tid + BS] : (uint8_t)0;
+        uint4 tp = make_uint4(0, 0, 0, 0);
+        constexpr int TAP4 = 3 * O / 2;                      // uint4 (two taps) per table
+        if (!no_eval && (tid & 127) < TAP4) tp = reinterpret_cast<const uint4 *>(comp)[(tid >> 7) * TAP4 + (tid & 127)];
+#pragma unroll
+        for (int q = 0; q < NGI; ++q) { const int i = q * BS + tid; if (i < n_here * cells) s_code[i] = gv[q] & CELL_ICON_MASK; }
+        if (tid < E) { F.axy[tid] = axy; F.dir[tid] = (uint8_t)dir; F.term[tid] = (uint8_t)term; F.fresh[tid] = (uint8_t)fresh; F.gc[tid] = gc; }
+        if (tid < ni) s_itype[tid] = it0;
+        if (tid + BS < ni) s_itype[tid + BS] = it1;
+        for (int i = tid + 2 * BS; i < ni; i += BS) s_itype[i] = p.icon_type[i];
+        if (tid < ni + 2) s_cls[tid] = cl0;
+        if (tid + BS < ni + 2) s_cls[tid + BS] = cl1;
+        for (int i = tid + 2 * BS; i < ni + 2; i += BS) s_cls[i] = p.ego_cls[i];
+        if (tid < 8 * RR + 8 * R) s_map[tid] = mp0;
+        if (tid + BS < 8 * RR + 8 * R) s_map[tid + BS] = mp1;
+        static_assert(8 * 49 + 8 * 7 <= 2 * BS, "the map in two reads per lane");
+        if (!no_eval && (tid & 127) < TAP4) reinterpret_cast<uint4 *>(tid < 128 ? &F.row[0][0] : &F.col[0][0])[tid & 127] = tp;
+        if (tid == 0) { F.nrun = 0; F.ncross = 0; F.nmiss = 0; }
+    }
+    ego_lds_barrier();
+    for (int i = tid; i < n_here * cells; i += BS) { const int code = s_code[i]; s_type[i] = code ? s_itype[code - 1] : (uint8_t)3; }
+    ego_lds_barrier();
+    // the goal slot of a cell rides in its type byte (bits 2-5)
+    if (tid < n_here * XW_MAX_GOALS) {
+        const int le = tid / XW_MAX_GOALS, slot = tid - le * XW_MAX_GOALS;
+        const int cell = reinterpret_cast<const uint8_t *>(&F.gc[le])[slot];
+        if (cell < cells) s_type[le * cells + cell] |= (uint8_t)(slot << 2);
+    }
+    ego_lds_barrier();
+    // the walk: TPE lanes per env, each with the env's shadow mask (computed redundantly: a short serial chain of LDS reads) and a
+    // share of its r * r view cells
+    const int le = tid / TPE, j0 = tid - le * TPE;
+    const bool valid = le < n_here;
+    const int lv = valid ? le : 0, e = e_base + lv;
+    const int axy = F.axy[lv], dir = F.dir[lv], term = F.term[lv], fresh = F.fresh[lv];
+    const bool active = valid && !(skip_term && term);
+    {
+        const int ax = axy & 0xffff, ay = axy >> 16;
+        const uint16_t *code_e = s_code + lv * cells;
+        const uint8_t *type_e = s_type + lv * cells;
+        auto is_block = [&](int x, int y) { return (unsigned)x < (unsigned)D && (unsigned)y < (unsigned)D && (type_e[y * D + x] & 3) == 1; };
+        // XMap::image_masking (xmap.cpp:273-362), as in ego_cells_body
+        constexpr int r = R;
+        int major_x = 0, major_y = 0, minor_x = 0, minor_y = 0, scan_x0 = 0, scan_y0 = 0, xa = ax + r, ya = ay + r;
+        if (dir == 0) { xa += r / 2; major_y = 1; minor_x = 1; }
+        else if (dir == 3) { ya -= r / 2; major_x = 1; minor_y = -1; scan_y0 = r - 1; }
+        else if (dir == 2) { xa -= r / 2; major_y = 1; minor_x = -1; scan_x0 = r - 1; }
+        else { ya += r / 2; major_x = 1; minor_y = 1; }
+        const int x_st = xa - r / 2, y_st = ya - r / 2;
+        uint32_t ray = (1u << r) - 1u;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int o = side ? 1 : -1;
+            bool block = false;
+            int rx = ax, ry = ay;
+#pragma unroll
+            for (int k = 1; k <= r / 2; ++k) {
+                rx += o * major_x; ry += o * major_y;
+                if (block) ray &= ~(1u << (r / 2 + o * k));
+                if (is_block(rx, ry)) block = true;
+            }
+        }
+        unsigned long long shadow = 0;
+#pragma unroll
+        for (int t = 0; t < r; ++t) {
+            bool block = !((ray >> t) & 1u);
+            int cx = scan_x0 + t * major_x, cy = scan_y0 + t * major_y;
+#pragma unroll
+            for (int j = 0; j < r; ++j) {
+                if (block) shadow |= 1ull << (cy * r + cx);
+                if (is_block(x_st - r + cx, y_st - r + cy)) block = true;
+                cx += minor_x; cx = cx < 0 ? cx + r : (cx >= r ? cx - r : cx);
+                cy += minor_y; cy = cy < 0 ? cy + r : (cy >= r ? cy - r : cy);
+            }
+        }
+        if (p.no_wall_shadow) shadow = 0;
+        const uint32_t cls_white = s_cls[ni], cls_black = s_cls[ni + 1];
+        const uint32_t hd = (uint32_t)dir << 24 | (term ? 1u << 26 : 0u) | ((uint32_t)fresh & 3u) << 27;
+        for (int k = j0; k < RR; k += TPE) {
+            const int gx = x_st - r + k % r, gy = y_st - r + k / r;
+            uint32_t info = (uint32_t)((ni + 1) * 4 + dir) | cls_black << 16;
+            if (active && (unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && !((shadow >> k) & 1ull)) {
+                const int code = code_e[gy * D + gx], ty = type_e[gy * D + gx];
+                if (code == 0) info = (uint32_t)(ni * 4 + dir) | cls_white << 16;
+                else if ((ty & 3) != 0) info = (uint32_t)((code - 1) * 4 + dir) | (uint32_t)s_cls[code - 1] << 16;
+                else info = 0x8000u | (uint32_t)(ty >> 2) | (uint32_t)k << 4 | 0xffu << 16;
+            }
+            const int f = s_map[INV + dir * RR + k];
+            const uint32_t lines = (s_map[RL + dir * r + f / r] != 0xff ? 1u << 29 : 0u) | (s_map[CL + dir * r + f % r] != 0xff ? 1u << 30 : 0u);
+            if (valid) s_sq[le][f] = info | hd | lines;
+        }
+    }
+    ego_lds_barrier();
+    // the squares' source words (second round trip: the flat-colour table, the cache bits of the goal cells in view)
+    if (valid) {
+        const uint32_t nc = (uint32_t)p.ego_ncls, ch_n = (uint32_t)p.channels, entry16 = p.ego_cache_entry / 16;
+        const uint32_t *valid_e = p.ego_cache_valid + (size_t)e * p.ego_cache_words;
+        for (int f = j0; f < RR; f += TPE) {
+            if (!active) { s_src[le][f] = 1u << 27; continue; }
+            const uint32_t w = s_sq[le][f], wa = f >= R ? s_sq[le][f - R] : w, wl = f % R ? s_sq[le][f - 1] : w;
+            const bool rowb = (w >> 29 & 1u) != 0, colb = (w >> 30 & 1u) != 0, goal = (w & 0x8000u) != 0;
+            const bool row_dirty = rowb && ((wa | w) & 0x8000u), col_dirty = colb && ((wl | w) & 0x8000u);
+            const uint32_t c = (w >> 16) & 0xffu, ca = rowb && !row_dirty ? (wa >> 16) & 0xffu : c, cl = colb && !col_dirty ? (wl >> 16) & 0xffu : c;
+            const uint32_t key = (((uint32_t)dir * nc + c) * nc + ca) * nc + cl;
+            const uint32_t slot = w & 0xfu, k = (w >> 4) & 0x3fu;
+            const uint32_t off = goal ? ((slot * RR + k) * 4 + dir) * entry16 : key * ch_n * (Sq::PBP / 16) + f * (Sq::CBP / 16);
+            const int bit = (int)((slot * RR + k) * 4 + dir);
+            const uint32_t flat = goal ? 0u : (uint32_t)p.ego_flat[key * RR + f];
+            const uint32_t vw = goal ? valid_e[bit >> 5] : ~0u;
+            if (goal && !((vw >> (bit & 31)) & 1u) && !no_eval) s_miss[atomicAdd(&F.nmiss, 1)] = (uint32_t)le | k << 8 | slot << 16 | (uint32_t)dir << 24;
+            s_src[le][f] = off | (goal ? 1u << 23 : 0u) | (row_dirty ? 1u << 24 : 0u) | (col_dirty ? 1u << 25 : 0u) | (rowb && colb ? 1u << 26 : 0u) |
+                           (term ? 1u << 27 : 0u) | ((uint32_t)fresh & 3u) << 28 | flat << 30;
+        }
+    }
+    // ---- B. the pixels that have to be evaluated
+    if (!no_eval) {
+        // the view-cell descriptors of the workgroup's envs (ego_border_body)
+        for (int i = tid; i < n_here * RR; i += BS) {
+            const int l2 = i / RR, f = i - l2 * RR;
+            const uint32_t info = s_sq[l2][f];
+            const int d2 = (int)(info >> 24) & 3, k = s_map[d2 * RR + f];
+            const uint32_t *white = atlas4 + (size_t)ni * 4096, *black = white + 1;
+            EgoCell c{black, 0, -1};
+            const int t = (int)((info & 0x7fffu) >> 2);
+            if (info & 0x8000u) c = EgoCell{p.goal_img + ((size_t)(e_base + l2) * p.num_goals + (info & 0xfu)) * 4096, -1, -1};
+            else if (t == ni) c.img = white;
+            else if (t < ni) {
+                c = EgoCell{atlas4 + (size_t)t * 4096, -1, t * 4 + d2};
+                if (s_itype[t] == 2 && d2 != 1) c.img = atlas4 + p.ego_agent_rot[t] + (size_t)(d2 == 0 ? 0 : (d2 == 2 ? 1 : 2)) * 4096;
+            }
+            s_cells[l2][k] = c;
+            s_goal[l2][k] = (info & 0x8000u) ? 1 : 0;
+        }
+        if (tid < E) F.edir[tid] = (uint8_t)(tid < n_here && !(skip_term && F.term[tid]) ? F.dir[tid] : 4);
+        ego_lds_barrier();
+        for (int i = tid; i < E * NITEM; i += BS) {
+            const int l2 = i / NITEM, it = i - l2 * NITEM, d2 = F.edir[l2];
+            bool need = false;
+            if (d2 < 4) {
+                const uint8_t *cm = s_map + d2 * RR;
+                if (it < NSEG) {
+                    const int fy = it / R + 1, fx = it % R;
+                    need = s_map[RL + d2 * R + fy] != 0xff && (s_goal[l2][cm[(fy - 1) * R + fx]] | s_goal[l2][cm[fy * R + fx]]);
+                } else if (it < 2 * NSEG) {
+                    const int q = it - NSEG, fx = q / R + 1, fy = q % R;
+                    need = s_map[CL + d2 * R + fx] != 0xff && (s_goal[l2][cm[fy * R + fx - 1]] | s_goal[l2][cm[fy * R + fx]]);
+                } else {
+                    const int q = it - 2 * NSEG, fy = q / (R - 1) + 1, fx = q % (R - 1) + 1;
+                    need = s_map[RL + d2 * R + fy] != 0xff && s_map[CL + d2 * R + fx] != 0xff;
+                }
+            }
+            if (need) {
+                if (it < 2 * NSEG) s_runs[atomicAdd(&F.nrun, 1)] = (uint16_t)i;
+                else s_cross[atomicAdd(&F.ncross, 1)] = (uint16_t)i;
+            }
+        }
+        ego_lds_barrier();
+        const uint32_t *white = atlas4 + (size_t)ni * 4096, *black = white + 1;
+        {
+            const int nrun = F.nrun, ncross = F.ncross;
+            constexpr int UPL = U <= 16 ? 16 : 32;                 // lanes per run
+            for (int i = tid; i < nrun * UPL + ncross; i += BS) {
+                const bool is_run = i < nrun * UPL;
+                const int gi = is_run ? s_runs[i / UPL] : s_cross[i - nrun * UPL], j = is_run ? i % UPL : 0;
+                if (j >= U) continue;
+                const int l2 = gi / NITEM, it = gi - l2 * NITEM, d2 = F.edir[l2];
+                int ox, oy, line, o;
+                if (it < NSEG) {
+                    const int fy = it / R + 1, fx = it % R;
+                    ox = fx * U + j; oy = fy * U; line = fy - 1; o = ox;
+                } else if (it < 2 * NSEG) {
+                    const int q = it - NSEG, fx = q / R + 1, fy = q % R;
+                    ox = fx * U; oy = fy * U + j; line = R - 1 + fx - 1; o = oy;
+                } else {
+                    const int q = it - 2 * NSEG, fy = q / (R - 1) + 1, fx = q % (R - 1) + 1;
+                    ox = fx * U; oy = fy * U; line = R - 1 + fx - 1; o = oy;
+                }
+                EgoCtx ctx{s_cells[l2], white, black, R, 64 * R, d2};
+                ego_pixel<CH, -1, false>(ctx, F.row, F.col, s_border + (l2 * NL + line) * (CH * O), O, o, ox, oy, 0);
+            }
+        }
+        // goal cells the cache does not hold (ego_miss_body): one at a time, all lanes on its U x U pixels
+        const int nmiss = F.nmiss;
+        const int lw = ego_layout_words(O, R);
+        for (int m = 0; m < nmiss; ++m) {
+            const uint32_t item = s_miss[m];
+            const int l2 = item & 0xff, k = (item >> 8) & 0xff, slot = (item >> 16) & 0xff, d2 = (item >> 24) & 3, e2 = e_base + l2;
+            ego_lds_barrier();
+            if (tid < RR) s_gcells[tid] = EgoCell{p.goal_img + ((size_t)e2 * p.num_goals + slot) * 4096, -1, -1};
+            ego_lds_barrier();
+            const int f = s_map[INV + d2 * RR + k];
+            const int x0 = (f % R) * U, y0 = (f / R) * U;
+            const uint16_t *rt = layout + (size_t)d2 * lw, *ct = rt + O;
+            EgoCtx ctx{s_gcells, white, black, R, 64 * R, d2};
+            const int entry = (slot * RR + k) * 4 + d2;
+            uint8_t *dst = p.ego_cache + ((size_t)e2 * p.num_goals * (RR * 4) + entry) * p.ego_cache_entry;
+            for (int j = tid; j < U * U; j += BS) {
+                const int py = j / U, px = j - py * U, ox = x0 + px, oy = y0 + py;
+                const uint32_t fl = (uint32_t)rt[oy] | (uint32_t)ct[ox];
+                if (!(fl & EGO_BORDER)) {
+                    if (fl & EGO_EDGE) ego_pixel<CH, -1, false>(ctx, F.row, F.col, dst, Sq::CBP, py * Sq::UP + px, ox, oy, 0);
+                    else ego_pixel<CH, -1, true>(ctx, F.row, F.col, dst, Sq::CBP, py * Sq::UP + px, ox, oy, 0);
+                }
+            }
+            if (tid == 0) atomicOr(p.ego_cache_valid + (size_t)e2 * p.ego_cache_words + (entry >> 5), 1u << (entry & 31));
+        }
+        if (nmiss) __threadfence();                          // the gather below reads those cache entries back through L2
+    }
+    ego_lds_barrier();                                       // (the front's arrays are dead: the gather's lie over them)
+    // ---- C. the frames, span after span
+    EgoGatherLds lds;
+    lds.out4 = smem4;
+    lds.env = reinterpret_cast<uint32_t *>(smem4 + ((G::GB + G::SB + G::GB) / 16 + 17));
+    lds.usrc = reinterpret_cast<const uint8_t **>(lds.env + ((G::SB / (int)G::FB + 2 + 3) & ~3));
+    lds.uo = reinterpret_cast<int *>(lds.usrc + (EgoUnitShfl<R>::value ? 2 : G::NU));
+    const unsigned total = (unsigned)n_here * G::cpf;
+    for (unsigned c = 0; c < total; c += G::SPAN) {
+        if (c) ego_lds_barrier();                            // (every lane has read the previous span out of LDS)
+        const unsigned q = c / G::cpf;
+        ego_gather_span<CH, R, CTX1, ES, PER, true>(p, lds, (unsigned)e_base + q, c - q * G::cpf, (int)(total - c < (unsigned)G::SPAN ? total - c : G::SPAN),
+                                                    skip_term, -1, &s_src[q][0], s_border + q * (NL * CH * O));
+    }
+}
+template <int CH, int R, int ES, int PER, int E>
+static size_t ego_fused_lds_bytes(int cells, int ni) {
+    typedef EgoSpanGeom<CH, R, ES, PER> G;
+    const size_t gather = ((G::GB + G::SB + G::GB) / 16 + 17) * 16 + ((G::SB / (int)G::FB + 2 + 3) & ~3) * 4 + (EgoUnitShfl<R>::value ? 2 : G::NU) * 12;
+    const size_t front = (size_t)EgoFusedLds<R, E>::front_bytes(cells, ni);
+    return (gather > front ? gather : front) + 16;
+}
+#endif  // XWB_EGO_FUSED_LAB
 
 // The warped 64x64 image of every goal of the listed envs (XItem::get_item_image, xitem.cpp:46-60): cv::warpAffine with
 // the goal's inverse matrix, INTER_LINEAR, BORDER_CONSTANT white.  A goal keeps its pose for the whole episode, so this
@@ -1631,6 +1985,8 @@ hipError_t launch_xw_ego_build_tab(const XwParams &p, hipStream_t s) {
 }
 
 namespace {
+template <int CH, int R>
+hipError_t ego_span_render_list(const XwParams &p0, const EgoTables &t, hipStream_t s, int parts);
 // mode 0: every env; 2: every env the last step did not finish (a reset runs beside this: their state is in flux);
 // 4: a step's frames -- every env, the finished ones first and from the list (p.list_flag says how their context moves),
 //    ev_cells recorded once nothing reads the grids and agents any more (a reset's map generator may start), ev_front once
@@ -1643,6 +1999,29 @@ hipError_t ego_span_render(const XwParams &p, const EgoTables &t, int mode, hipS
     const int skip_front = mode == 2, skip_gather = mode != 0;
     // mode 4 without events: the hand-overs to the reset's queue are epochs, published by the kernel that FOLLOWS the producer
     const int publish = mode == 4 && !ev_front && p.sig_epoch != 0;
+#ifdef XWB_EGO_FUSED_LAB
+    if (p.dbg_ego_fused && !p.obs_f32) {
+        // the fused kernel (xw_ego_fused_kernel).  mode 4: the step's terminal frames first, through the list's three short
+        // kernels (p.list_flag = 1: the caller set it); once the fused kernel runs, nothing reads the finished envs' state,
+        // their goal images or the list's buffers any more -- every hand-over to the reset's queue is due at that point.
+        if (mode == 4) {
+            const hipError_t e = ego_span_render_list<CH, R>(p, t, s, 3);
+            if (e != hipSuccess) return e;
+            if (ev_cells) { const hipError_t e2 = hipEventRecord(ev_cells, s); if (e2 != hipSuccess) return e2; }
+            if (ev_front) { const hipError_t e2 = hipEventRecord(ev_front, s); if (e2 != hipSuccess) return e2; }
+            if (ev_list) { const hipError_t e2 = hipEventRecord(ev_list, s); if (e2 != hipSuccess) return e2; }
+        }
+        const int no_eval = (p.dbg_ego_fused >> 1) & 1, variant = p.dbg_ego_fused >> 4;
+        const int publish_step = mode == 2 && p.sig_epoch != 0;
+#define EGO_FUSED(CTXV, PERV, EV) hipLaunchKernelGGL((xw_ego_fused_kernel<CH, R, CTXV, 1, PERV, EV>), dim3((unsigned)((p.n + EV - 1) / EV)), dim3(EGO_BS), \
+            (ego_fused_lds_bytes<CH, R, 1, PERV, EV>((int)cells, p.n_icons)), s, p, t.map, t.comp, t.lut, a4, skip_gather, publish_step, publish, no_eval)
+#define EGO_FUSED_V(CTXV) do { if (variant == 1) EGO_FUSED(CTXV, 2, 8); else if (variant == 2) EGO_FUSED(CTXV, 4, 4); else EGO_FUSED(CTXV, 4, 8); } while (0)
+        if (p.context == 1) EGO_FUSED_V(true); else EGO_FUSED_V(false);
+#undef EGO_FUSED_V
+#undef EGO_FUSED
+        return hipGetLastError();
+    }
+#endif
     const size_t cells_lds = 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15);
     hipLaunchKernelGGL((xw_ego_cells_kernel<R, false>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, skip_front, nullptr, mode == 2 && p.sig_epoch != 0);
     if (ev_cells) { const hipError_t e = hipEventRecord(ev_cells, s); if (e != hipSuccess) return e; }

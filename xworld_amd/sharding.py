@@ -257,6 +257,28 @@ class ResultGather:
             work = gather_slabs(packed, out, self.counts, self.rank, self.dst, self.group, async_op=True)
         self.pending = (work, k)
 
+    def release(self):
+        """Let go of the exchange started last WITHOUT ordering the caller's stream behind it: nobody on this stream reads its
+        result (a rollout whose policy acts on device-resident shards; the root's trainer would call finish()).  The collective
+        still runs, on the backend's own stream, in order with the ones before and after it -- so the two output buffers are
+        reused safely -- and `last()` names the newest buffer that is certainly complete: the one released two starts ago.
+        What this saves is the barrier packet `finish()` puts on the caller's stream every step."""
+        if self.pending is None:
+            return
+        work, k = self.pending
+        self.pending = None
+        self._released = getattr(self, "_released", [])
+        self._released.append((work, k))
+        del self._released[:-2]                              # (keep the handles of the two exchanges that may still be in flight)
+
+    def drain(self):
+        """Waits (stream-side) for every released exchange: call before reading `out`, or before tearing the group down."""
+        for work, _ in getattr(self, "_released", []):
+            if work is not None:
+                work.wait()
+        self._released = []
+        return self.finish(convert=False)
+
     def finish(self, convert=True):
         """-> (reward, code) of the exchange started last, on `dst` (None, None elsewhere).  convert=False: the codes stay the
         float column the shards wrote (no conversion kernel on the root's stream)."""
