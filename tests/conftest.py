@@ -9,8 +9,24 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--slow", action="store_true", default=False, help="also run the cases marked slow (second parametrisations of "
+                     "the long GPU tests, the extra bench subprocesses): tools/final_round.sh passes it, the default -m gpu run does not")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: a second parametrisation of a long GPU test; skipped unless --slow or XWB_SLOW=1 "
+                                       "(keeps the default -m gpu run well inside the driver's limit; one representative of each stays)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if config.getoption("--slow") or os.environ.get("XWB_SLOW"):
+        return
+    skip = pytest.mark.skip(reason="slow case: run with --slow (tools/final_round.sh does)")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -206,7 +206,7 @@ def test_batch_copy_out_functions():
     sim.close()
 
 
-@pytest.mark.parametrize("extra", ["", ", 'visible_radius': 3"], ids=["full", "ego"])
+@pytest.mark.parametrize("extra", [pytest.param("", id="full"), pytest.param(", 'visible_radius': 3", id="ego", marks=pytest.mark.slow)])
 def test_queue_sync_modes_agree_and_pmc_env_falls_back(extra):
     """The step loop's two queues hand over through device-side epochs by default and through events when a tool that
     serialises kernels is in sight (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION): both give the same rollout --

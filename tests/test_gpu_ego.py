@@ -129,7 +129,7 @@ def test_reference_ego_traces_through_product(oracle, kind):
 @pytest.mark.parametrize("key,r,color,context", [("nav7", 3, True, 1), ("nav8", 5, False, 1), ("nav7", 7, True, 2),
                                                  ("nav11", 3, True, 1), ("nav8_dim5", 1, True, 1),
                                                  # 81 and 77 pixel edges: frames that are not whole 16-byte chunks
-                                                 ("nav11", 9, True, 2), ("nav11", 11, False, 1)])
+                                                 pytest.param("nav11", 9, True, 2, marks=pytest.mark.slow), ("nav11", 11, False, 1)])
 def test_ego_frames_with_host_poses(oracle, key, r, color, context):
     """Frames bit for bit: maps from the oracle's generator are loaded into the product with the goal poses set through
     the host (same libm as the oracle), then both run the same action strings."""

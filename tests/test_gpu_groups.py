@@ -209,7 +209,7 @@ def test_exclusive_groups_reset_and_rollout(oracle, case):
     sim.close()
 
 
-@pytest.mark.parametrize("ego", [0, 3], ids=["full", "ego"])
+@pytest.mark.parametrize("ego", [pytest.param(0, id="full"), pytest.param(3, id="ego", marks=pytest.mark.slow)])
 def test_exclusive_groups_frames_follow_mid_episode_rearrangement(oracle, ego):
     """Frames of an exclusive two-group rollout against the oracle's renderer: the map a mid-episode idle stage leaves is
     what the next frame shows (also the terminal frame when the same step ends the game), through step + reset_done and

@@ -98,7 +98,7 @@ def test_device_tensor_exchanges_over_nccl_world_of_one():
     assert out.returncode == 0 and "NCCL_BRANCH_OK 25" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
 
 
-@pytest.mark.parametrize("exchange", ["torch", "lib"])
+@pytest.mark.parametrize("exchange", ["torch", pytest.param("lib", marks=pytest.mark.slow)])
 def test_bench_forced_exchange_reports_rccl(exchange):
     """torchrun --nproc-per-node 1 bench.py --gpus 1 --backend nccl --force-exchange: the line says which RCCL ran."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",

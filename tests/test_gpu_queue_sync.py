@@ -75,7 +75,7 @@ def _sub(queue_sync, extra, env):
     return line[1], line[2], line[3]
 
 
-@pytest.mark.parametrize("extra", [None, {"visible_radius": 3}], ids=["full", "ego"])
+@pytest.mark.parametrize("extra", [pytest.param(None, id="full"), pytest.param({"visible_radius": 3}, id="ego", marks=pytest.mark.slow)])
 def test_probe_falls_back_on_a_shared_hardware_queue(extra):
     ref, m0, r0 = _sub("events", extra, {})
     assert (m0, r0) == ("events", "config")
@@ -97,7 +97,7 @@ def test_probe_falls_back_on_a_shared_hardware_queue(extra):
     assert h == ref and (m, r) == ("events", "tool"), (m, r)
 
 
-@pytest.mark.parametrize("extra", [None, {"visible_radius": 3}], ids=["full", "ego"])
+@pytest.mark.parametrize("extra", [pytest.param(None, id="full"), pytest.param({"visible_radius": 3}, id="ego", marks=pytest.mark.slow)])
 def test_foreign_streams_with_work_in_flight(extra):
     torch = _torch()
     ref, _ = _rollout_hash("events", extra, n=2048, steps=60)

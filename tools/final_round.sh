@@ -7,7 +7,7 @@ TAG=${1:-r4}
 OUT=$PWD/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 HEAD=${GIT_HEAD:-unknown}
-{ echo "== python -m pytest tests -q -m gpu at commit $HEAD, one MI355X =="; timeout 2400 python -m pytest tests -q -m gpu --timeout 600 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path"; } > $OUT/gputest.txt
+{ echo "== python -m pytest tests -q -m gpu at commit $HEAD, one MI355X =="; timeout 2400 python -m pytest tests -q -m gpu --slow --timeout 600 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path"; } > $OUT/gputest.txt
 tail -2 $OUT/gputest.txt
 GIT_HEAD=$HEAD bash tools/profile_round.sh $TAG xworld7 xworld7_f32 xworld8 xworld11 xworld7_ego3 xworld8_ego5 xworld7_ego7 simple_game simple_race > $OUT/profile_round.log 2>&1
 {
