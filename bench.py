@@ -693,7 +693,8 @@ def main():
                 "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", ""))}
         everyone = [None] * world
         dist.all_gather_object(everyone, mine)
-        ranks_seen = {"ranks": everyone, "ranks_seen": len({(r["local_rank"], r["uuid"]) for r in everyone})}
+        ranks_seen = {"ranks": everyone, "ranks_seen": len({r["rank"] for r in everyone}),
+                      "devices_seen": len({r["uuid"] or r["index"] for r in everyone})}
 
     def core_line():
         total_envs = n_local * world

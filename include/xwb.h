@@ -515,6 +515,10 @@ int xwb_gather_screens_end(xwb_comm *comm, void *stream);
  * is reused only after the transfer (root: the render) that read it.  context > 1: call after every frame-drawing verb. */
 int xwb_gather_grids_begin(xwb_sim *sim, xwb_comm *comm, void *dst_dev, const int32_t *counts, const int32_t *peers,
                            int32_t n_shards, int32_t shard, int32_t root_shard, void *stream);
+/* Frees the staging slabs `comm` keeps for `sim` (xwb_gather_grids_begin allocates them on first use, keyed by the batch):
+ * call before xwb_destroy(sim) when the communicator outlives the batch -- otherwise they are only freed by xwb_comm_destroy.
+ * Waits for the communicator's stream; XWB_ERR_STATE inside an open group. */
+int xwb_comm_release_sim(xwb_comm *comm, const xwb_sim *sim);
 /* Completion marks for pipelined gathers (two destination tensors alternating): xwb_comm_mark records mark `slot`
  * (0 .. XWB_COMM_MARKS - 1) on the communicator's stream behind everything begun so far -- inside an open group: when the
  * outermost group ends --; xwb_comm_wait orders `stream` behind that mark (no-op if the mark was never recorded).

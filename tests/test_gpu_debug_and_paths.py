@@ -167,5 +167,28 @@ def test_step_host_pageable_and_pinned_actions():
             assert torch.equal(s.obs, sims[0].obs) and torch.equal(s.reward, sims[0].reward), t
             assert torch.equal(s.game_over_codes, sims[0].game_over_codes) and torch.equal(s.actions, sims[0].actions), t
     assert [s.check_errors() for s in sims] == [1, 1, 1]
+    # what the kernel would read as int32 pairs, or past the end, is refused before it gets there
+    for bad in (np.zeros(n, dtype=np.int64), np.zeros(n - 1, dtype=np.int32), np.zeros((n, 2), dtype=np.int32)[:, 0],
+                torch.zeros(n, dtype=torch.int64), torch.zeros(n, dtype=torch.int32, device="cuda")):
+        with pytest.raises(ValueError, match="step_host"):
+            sims[1].step_host(bad)
     for s in sims:
         s.close()
+
+
+def test_a_new_torch_stream_is_probed_before_its_first_verb():
+    """A PyTorch user on a non-default stream must not end up on the event hand-over without being told: BatchedSimulator
+    probes a stream handle the first time it sees it; xwb_step_path then reports that call's mode."""
+    torch = _torch()
+    from xworld_amd.batched import BatchedSimulator
+    sim = BatchedSimulator("xworld", OPTS, num_envs=512, seed=3)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        sim.step(stream=st)
+        sim.reset_done(stream=st)
+    st.synchronize()
+    mode, reason = sim.queue_sync_mode(st)
+    assert reason != "not_probed", (mode, reason)
+    assert sim.step_path()["queue_sync"] in ("epochs", "events")
+    assert int(st.cuda_stream) in sim._streams_seen
+    sim.close()

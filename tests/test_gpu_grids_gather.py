@@ -119,7 +119,8 @@ def test_render_grids_draws_any_number_of_envs():
 
 SHARDED = [("c4", {"xwd_conf_path": NAV, "task_mode": "lang_acquisition", "max_dim": 7, "color": True}, [20000, 12768], 12),
            ("c5_shard", {"xwd_conf_path": NAV, "task_mode": "lang_acquisition", "max_dim": 11, "num_blocks": 30, "color": True}, [16384, 16384], 8),
-           ("ragged_ctx2", {"xwd_conf_path": NAV, "task_mode": "lang_acquisition", "context": 2}, [384, 200, 0, 57], 30)]
+           ("ragged_ctx2", {"xwd_conf_path": NAV, "task_mode": "lang_acquisition", "context": 2}, [384, 200, 0, 57], 30),
+           ("single", {"xwd_conf_path": NAV, "task_mode": "lang_acquisition", "max_dim": 7, "color": True}, [3000], 4)]
 
 
 @pytest.mark.parametrize("name,opts,counts,steps", SHARDED, ids=[s[0] for s in SHARDED])
@@ -180,6 +181,26 @@ def test_grids_gather_on_a_loopback_communicator(name, opts, counts, steps):
     if len(live) > 1:
         assert L.xwb_gather_grids_begin(shards[live[1]].h, comm.h, None, c_counts, peers, ns, live[1], root, None) != 0
         assert b"group" in L.xwb_last_error()
+    # a third gather of one batch inside ONE open group would reuse a slab whose transfer is only queued: refused, and the
+    # refusal leaves the rotation alone -- the next well-formed gather is still exact
+    if not ring and len(live) == 1:
+        i = live[0]
+        dstp = C.c_void_p(by_grids[0].data_ptr())
+        lib.check(L.xwb_comm_group_start(comm.h))
+        lib.check(L.xwb_gather_grids_begin(shards[i].h, comm.h, dstp, c_counts, peers, ns, i, root, None))
+        lib.check(L.xwb_gather_grids_begin(shards[i].h, comm.h, dstp, c_counts, peers, ns, i, root, None))
+        assert L.xwb_gather_grids_begin(shards[i].h, comm.h, dstp, c_counts, peers, ns, i, root, None) != 0
+        assert b"more than two gathers" in L.xwb_last_error()
+        assert L.xwb_comm_release_sim(comm.h, shards[i].h) != 0 and b"open group" in L.xwb_last_error()
+        lib.check(L.xwb_comm_group_end(comm.h))
+        lib.check(L.xwb_gather_screens_end(comm.h, None))
+        check(steps, 1)
+    # the slabs a communicator keeps for a batch can be handed back before the batch goes (they are re-made on demand)
+    for i in live:
+        lib.check(L.xwb_comm_release_sim(comm.h, shards[i].h))
+    check(steps + 1, 0)
+    for i in live:
+        lib.check(L.xwb_comm_release_sim(comm.h, shards[i].h))
     for s in [whole] + [shards[i] for i in live]:
         s.close()
     comm.close()

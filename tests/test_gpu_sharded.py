@@ -128,7 +128,11 @@ def test_bench_two_ranks_on_one_gpu(workload, extra):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["warmup"] == 2 and line["scaling"] == "weak"
     assert line["config"]["total_envs"] == 2048 and line["value"] > 0
-    assert line["rccl"] == {"world_size": 2, "backend": "gloo", "version": None}
+    rc = line["rccl"]
+    assert (rc["world_size"], rc["backend"], rc["version"]) == (2, "gloo", None)
+    # the record itself shows which rank ran on which device (here: two ranks sharing the box's one GPU)
+    assert rc["ranks_seen"] == 2 and rc["devices_seen"] == 1 and [r["rank"] for r in rc["ranks"]] == [0, 1]
+    assert "watchdog" not in line and "screens_gather:screens" in line["phase_seconds"]
     sg = line["screens_gather"]
     assert sg["value"] > 0 and sg["link_bound_ceiling"] > 0 and sg["bytes_into_root_per_step"] > 0 and sg["mode"] == "screens"
     if workload == "xworld7":                             # full observation: the same loop with the cell codes gathered instead

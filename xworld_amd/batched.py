@@ -163,6 +163,8 @@ class BatchedSimulator:
             cfg.icon_name = self.palette.icon_name.ctypes.data
             cfg.icon_colored = self.palette.icon_colored.ctypes.data
         self.cfg = cfg
+        self._streams_seen = set()                           # stream handles whose hand-over mode was probed (see _stream)
+        self._host_actions = None
         self.obs_is_float = name == "simple_race" or (name == "xworld" and cfg.obs_format == 1)
         h = C.c_void_p()
         lib.check(self.L.xwb_create(C.byref(cfg), C.byref(h)))
@@ -199,11 +201,26 @@ class BatchedSimulator:
         except Exception:
             pass
 
-    @staticmethod
-    def _stream(stream):
+    def _stream(self, stream):
+        """The stream handle for the C ABI.  A stream this batch has not seen is probed ONCE (xwb_queue_sync_mode: may the two
+        queues hand over through epochs on it?) -- the step verbs never probe by themselves, so a PyTorch user on a non-default
+        stream would otherwise run the event hand-over (the slower path, ~12 us per xworld step) without being told.  The
+        probe synchronises the stream, so it is skipped while the stream is being captured into a graph (xwb.h)."""
         if stream is None:
             return None
-        return C.c_void_p(int(getattr(stream, "cuda_stream", stream)))
+        h = int(getattr(stream, "cuda_stream", stream))
+        if h and h not in self._streams_seen and self.cfg.game == lib.XWB_XWORLD2D:
+            capturing = False
+            try:
+                import torch
+                capturing = bool(torch.cuda.is_current_stream_capturing())
+            except Exception:                                # pragma: no cover
+                capturing = False
+            if not capturing:
+                self._streams_seen.add(h)
+                m, r = C.c_int32(), C.c_int32()
+                lib.check(self.L.xwb_queue_sync_mode(self.h, C.c_void_p(h), C.byref(m), C.byref(r)))
+        return C.c_void_p(h)
 
     # ------------------------------------------------------------------ batched verbs
     def reset(self, stream=None):
@@ -226,7 +243,19 @@ class BatchedSimulator:
     def step_host(self, actions, act_rep=1, stream=None):
         """xwb_step_host: the action ids in HOST memory -- a numpy int32 array or a CPU torch tensor (a pinned one is read by
         the step kernel in place: keep it unchanged until `stream` has passed the call)."""
-        ptr = actions.data_ptr() if hasattr(actions, "data_ptr") else actions.ctypes.data
+        # the kernel reads int32 action ids straight from this memory: anything else would be read as garbage without an error
+        if hasattr(actions, "data_ptr"):
+            import torch
+            if actions.is_cuda or actions.dtype != torch.int32 or actions.numel() != self.num_envs or not actions.is_contiguous():
+                raise ValueError("step_host: a contiguous CPU int32 tensor of num_envs = %d action ids is required (got %s %s, cuda=%s)"
+                                 % (self.num_envs, tuple(actions.shape), actions.dtype, actions.is_cuda))
+            ptr = actions.data_ptr()
+        else:
+            import numpy as np
+            if not isinstance(actions, np.ndarray) or actions.dtype != np.int32 or actions.size != self.num_envs or not actions.flags["C_CONTIGUOUS"]:
+                raise ValueError("step_host: a C-contiguous numpy int32 array of num_envs = %d action ids is required" % self.num_envs)
+            ptr = actions.ctypes.data
+        self._host_actions = actions                         # kept alive until the next call (a pinned buffer is read in place)
         lib.check(self.L.xwb_step_host(self.h, C.c_void_p(ptr), int(act_rep), self._stream(stream)))
 
     def step_n(self, n_steps, act_rep=1, stream=None):

@@ -2026,7 +2026,8 @@ hipError_t ego_span_render(const XwParams &p, const EgoTables &t, int mode, hipS
     hipLaunchKernelGGL((xw_ego_cells_kernel<R, false>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, skip_front, nullptr, mode == 2 && p.sig_epoch != 0);
     if (ev_cells) { const hipError_t e = hipEventRecord(ev_cells, s); if (e != hipSuccess) return e; }
     const int nb_border = (p.n + EgoBorderGeom<R>::EPW - 1) / EgoBorderGeom<R>::EPW;
-    hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 4096), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, skip_front, nb_border, (const int32_t *)nullptr, publish, t.comp);
+    const int nb_miss = p.dbg_ego_miss_blocks ? p.dbg_ego_miss_blocks : 4096;    // (a multiple of 4: four workgroups per goal cell)
+    hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + nb_miss), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, skip_front, nb_border, (const int32_t *)nullptr, publish, t.comp);
     if (ev_front) { const hipError_t e = hipEventRecord(ev_front, s); if (e != hipSuccess) return e; }
     const int es = p.obs_f32 ? 4 : 1;
     const unsigned long long n_chunks = (unsigned long long)p.n * (FB / (16 / es));

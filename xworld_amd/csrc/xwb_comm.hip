@@ -113,6 +113,7 @@ struct xwb_comm {
         size_t bytes[2] = {0, 0};
         hipEvent_t done[2] = {nullptr, nullptr};
         bool busy[2] = {false, false};
+        bool queued[2] = {false, false};      // begun inside an open group: its done[k] is only recorded when that group ends
         int next = 0;
     };
     std::map<const xwb_sim *, Slabs> slabs;
@@ -395,8 +396,11 @@ int xwb_gather_grids_begin(xwb_sim *sim, xwb_comm *c, void *dst_dev, const int32
     const size_t envs = root ? total : (size_t)x.n;
     const size_t grid_bytes = (envs * cells * 2 + 15) & ~(size_t)15, need = grid_bytes + ((envs + 15) & ~(size_t)15);
     xwb_comm::Slabs &sl = c->slabs[sim];
-    const int k = sl.next;
-    sl.next ^= 1;
+    const int k = sl.next;                    // (committed below, once nothing can fail any more before the transfers are posted)
+    // a third begin for one batch inside ONE open group would pack into a slab whose transfer is still only queued -- its
+    // completion event is not recorded yet, so waiting for it would wait for nothing
+    if (sl.queued[k])
+        return fail(XWB_ERR_STATE, "more than two gathers of one batch inside one open group: close the group first");
     if (!sl.done[k]) HIP_TRY(hipEventCreateWithFlags(&sl.done[k], hipEventDisableTiming));
     if (sl.bytes[k] < need) {
         if (c->group_depth > 0 && sl.busy[k])
@@ -412,7 +416,10 @@ int xwb_gather_grids_begin(xwb_sim *sim, xwb_comm *c, void *dst_dev, const int32
     uint16_t *grids = static_cast<uint16_t *>(sl.slab[k]);
     uint8_t *flags = static_cast<uint8_t *>(sl.slab[k]) + grid_bytes;
     const size_t row0 = root ? first : 0;
+    // (a pack that is refused -- e.g. context > 1 with two draws since the last pack -- leaves the slab rotation as it was and
+    // posts nothing; the OTHER ranks cannot know: like any collective, a gather one rank drops out of has to be abandoned by all)
     if (x.n > 0 && (rc = xwb_xw_pack_grids(sim, grids + row0 * cells, flags + row0, x.st))) return rc;
+    sl.next = k ^ 1;
     HIP_TRY(hipEventRecord(c->ready, x.st));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ready, 0));
     if (root) {
@@ -438,9 +445,12 @@ int xwb_gather_grids_begin(xwb_sim *sim, xwb_comm *c, void *dst_dev, const int32
     }
     c->in_flight += 1;
     sl.busy[k] = true;
+    sl.queued[k] = c->group_depth > 0;
     hipEvent_t slab_done = sl.done[k];
     // behind the transfers: the root draws the whole batch from the gathered state; the slab is free again after that
     return after_transfers(c, [=]() -> int {
+        auto it = c->slabs.find(sim);
+        if (it != c->slabs.end()) it->second.queued[k] = false;
         if (root && total > 0) {
             const int rr = xwb_xw_render_grids(sim, grids, flags, (int32_t)total, dst_dev, c->stream);
             if (rr) return rr;
@@ -448,6 +458,21 @@ int xwb_gather_grids_begin(xwb_sim *sim, xwb_comm *c, void *dst_dev, const int32
         HIP_TRY(hipEventRecord(slab_done, c->stream));
         return XWB_OK;
     });
+}
+
+int xwb_comm_release_sim(xwb_comm *c, const xwb_sim *sim) {
+    if (!c || !sim) return fail(XWB_ERR_ARG, "NULL argument");
+    if (c->group_depth > 0) return fail(XWB_ERR_STATE, "xwb_comm_release_sim inside an open group: its transfers are not enqueued yet");
+    auto it = c->slabs.find(sim);
+    if (it == c->slabs.end()) return XWB_OK;
+    DeviceGuard g(c->device);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 2; ++k) {
+        if (it->second.done[k]) (void)hipEventDestroy(it->second.done[k]);
+        if (it->second.slab[k]) (void)hipFree(it->second.slab[k]);
+    }
+    c->slabs.erase(it);
+    return XWB_OK;
 }
 
 int xwb_gather_screens_end(xwb_comm *c, void *stream) {

@@ -293,6 +293,7 @@ struct XwParams {
     int wait_slot;               // the list render's wait: sync[wait_slot] >= wait_epoch (3: the reset kernel's epoch, 8: the regeneration's)
     uint32_t *minstd;            // nullable: XWB_RNG_MINSTD, one libstdc++ minstd_rand0 state per env: the teacher's task draw
     int dbg_ego_per, dbg_ego_pad, dbg_render_shape;   // xwb_config.debug_* (launch-shape A/B switches; 0 = defaults)
+    int dbg_ego_miss_blocks;     // XWB_DEBUG ego_miss_blocks=N: goal-cell workgroups of the whole-batch evaluation launch (0 = the default)
     int dbg_ego_fused;           // XWB_DEBUG ego_fused=N: bit 0 the fused span render (xw_ego_fused_kernel), bit 1 its evaluation stubbed
                                  // (lab: frames wrong next to goals), bits 4.. its launch shape
     int no_draw;                 // xwb_xw_set_draw(sim, 0): the renders keep their bookkeeping (epochs, installs, fresh / done flags) and store no pixels

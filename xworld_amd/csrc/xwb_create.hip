@@ -22,7 +22,7 @@ const char *const POISON_MSG = "a device-side queue hand-off was not released wi
 namespace {
 
 // XWB_DEBUG (include/xwb.h, xwb_config "Debug configuration"): parsed once per process, OR-ed into every batch created
-struct DebugEnv { int32_t flags = 0, ego_per = 0, ego_pad = 0, render_shape = 0, ego_fused = 0; };
+struct DebugEnv { int32_t flags = 0, ego_per = 0, ego_pad = 0, render_shape = 0, ego_fused = 0, ego_miss_blocks = 0; };
 const DebugEnv &debug_env() {
     static const DebugEnv d = [] {
         DebugEnv e;
@@ -42,6 +42,7 @@ const DebugEnv &debug_env() {
             else if (t.compare(0, 8, "ego_per=") == 0) e.ego_per = atoi(t.c_str() + 8);
             else if (t.compare(0, 8, "ego_pad=") == 0) e.ego_pad = atoi(t.c_str() + 8) + 1;
             else if (t.compare(0, 10, "ego_fused=") == 0) e.ego_fused = atoi(t.c_str() + 10);
+            else if (t.compare(0, 16, "ego_miss_blocks=") == 0) { const int v = atoi(t.c_str() + 16); e.ego_miss_blocks = v >= 4 && v <= 65536 ? (v & ~3) : 0; }
             else if (t == "render_shape=64x2") e.render_shape = 1;
             else if (t == "render_shape=256x2") e.render_shape = 2;
             else if (!t.empty()) fprintf(stderr, "libxwb: XWB_DEBUG: unknown entry '%s' ignored\n", t.c_str());
@@ -356,7 +357,7 @@ int xw_setup(xwb_sim *s) {
     p.channels = ch; p.n_icons = c.n_icons;
     p.obs_f32 = f32 ? 1 : 0;
     p.dbg_ego_per = c.debug_ego_per; p.dbg_ego_pad = c.debug_ego_pad; p.dbg_render_shape = c.debug_render_shape;
-    p.dbg_ego_fused = debug_env().ego_fused;
+    p.dbg_ego_fused = debug_env().ego_fused; p.dbg_ego_miss_blocks = debug_env().ego_miss_blocks;
     p.n_tasks = c.n_tasks;
     p.group2d = c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET;
     p.curriculum = curriculum ? c.curriculum : 0.0; p.cur_level = s->d_cur_level; p.cur_counter = s->d_cur_counter; p.cur_usage = s->d_cur_usage;

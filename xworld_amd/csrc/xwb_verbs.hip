@@ -69,8 +69,19 @@ bool epoch_probe(xwb_sim *s, hipStream_t st, int *reason) {
 // verdict for `st`; nothing changes when no candidate passes.
 bool side_beside(xwb_sim *s, hipStream_t st, int *reason) {
     if (epoch_probe(s, st, reason) || *reason != XWB_SYNC_REASON_PROBE_FAILED) return *reason == XWB_SYNC_REASON_PROBE_OK;
+    // the streams that passed earlier are probed again against each candidate -- but only those that are still alive: a caller
+    // may have destroyed one without xwb_queue_sync_forget.  hipStreamQuery validates the handle (hipSuccess / hipErrorNotReady
+    // for a live stream); anything else means "forget this stream", not "candidate rejected".
     std::vector<hipStream_t> keep;
-    for (auto &pr : s->probes) if (pr.ok && pr.st != st) keep.push_back(pr.st);
+    for (size_t i = 0; i < s->probes.size();) {
+        const hipStream_t q = s->probes[i].st;
+        if (q != st && q != nullptr) {
+            const hipError_t live = hipStreamQuery(q);
+            if (live != hipSuccess && live != hipErrorNotReady) { (void)hipGetLastError(); s->probes.erase(s->probes.begin() + (long)i); continue; }
+        }
+        if (s->probes[i].ok && q != st) keep.push_back(q);
+        ++i;
+    }
     hipStream_t original = s->side;
     std::vector<hipStream_t> rejected;                              // kept alive until the choice is made: the next one maps elsewhere
     bool found = false;
