@@ -145,7 +145,11 @@ typedef struct xwb_config {
      * XWorldNav* ones.  Run NON-exclusively -- Teacher::teach's else branch (teacher.cpp:221-225) --, every teach() runs
      * each group's stage in conf order, rewards add up, the last group's event ("" included) is what game_over() sees, and
      * only the first group's task sees the step's collision events (xworld_simulator.cpp:118-122) -- unless
-     * task_groups_exclusive is in force, see below. */
+     * task_groups_exclusive is in force, see below.
+     * LIMIT: at most TWO built groups per batch.  The reference's Teacher takes any number (teacher.cpp:110-163); none of
+     * its shipped confs lists more than two whose tasks exist in this snapshot (confs/walls.json: XWorldNav + the Rec / Lan
+     * groups this tier leaves out; confs/navigation2d.json: one).  A conf with a third built group is refused by the loader
+     * (assets.conf_groups), and xwb_xw_load_map_task replays a map for ONE group's task. */
     int32_t  n_tasks2;
     int32_t  tasks2[8];
     int32_t  task_schedule2;
@@ -304,8 +308,16 @@ int xwb_xw_grid_dev(xwb_sim *sim, uint16_t **ptr);      /* xworld: uint16[num_en
 int xwb_minstd_state_dev(xwb_sim *sim, uint32_t **ptr); /* XWB_RNG_MINSTD: uint32[num_envs] engine states (else NULL) */
 int xwb_done_count(xwb_sim *sim, void *stream, int32_t *n_done);   /* envs reset by the last reset_done (sync) */
 /* xworld, egocentric: which kernels draw the whole-batch frames: 1 = the span path (cells -> evaluated pixels -> gather,
- * kernels_xworld_ego.hip), 0 = one workgroup per env (geometries / palettes the span path cannot take, or not enough free
- * memory for its tables).  Both are bit-exact; callers that report kernel times need to know which ran. */
+ * kernels_xworld_ego.hip), 0 = one workgroup per env.  Both are bit-exact; callers that report kernel times need to know
+ * which ran.  The per-env kernel (XWB_PATH_EGO_PER_ENV) is what draws, and the only thing that can draw:
+ *   - visible_radius = 1 and visible_radius >= 9: the frame is not r x r equal squares of a multiple of four pixels
+ *     (r = 9: 81 x 81, r = 11: 77 x 77, r = 13: 78 x 78 -- rows are not whole dwords, frames not whole 16-byte chunks), or a
+ *     row / column whose taps straddle two view cells is not the first one of a square (xw_ego_tables decides, per geometry);
+ *   - palettes with more than 16 images that every env shares (blocks, agents, empty, black): the span path's table of
+ *     squares is keyed by three such classes and is capped at 128 MB;
+ *   - XWB_DEBUG_EGO_NO_SPAN / _NO_CACHE, or not enough free device memory for the span path's tables at xwb_create.
+ * It is an order of magnitude slower per frame (bench.py --workload xworld11_ego9 prints a line for it); the reference's
+ * own configurations (visible_radius 3, 5, 7 on 7x7 / 8x8 / 11x11 worlds) all take the span path. */
 int xwb_ego_render_path(xwb_sim *sim, int32_t *path);
 
 /* The whole batch's outputs copied into caller-owned memory, host or device (hipMemcpyDefault), ordered on `stream`;
