@@ -70,7 +70,9 @@ def test_debug_env_override_is_read_once_per_process():
 
 
 def test_streams_are_probed_only_on_request():
-    """No step verb synchronises the host: a stream nobody probed hands over through events; xwb_queue_sync_mode probes it."""
+    """No step verb of the C ABI synchronises the host: a stream nobody probed hands over through events; xwb_queue_sync_mode
+    probes it.  (BatchedSimulator makes that explicit call itself the first time it sees a stream handle -- ADVICE round 4,
+    tests below -- so this test drives the C ABI directly for the unprobed calls.)"""
     torch = _torch()
     from xworld_amd import lib
     from xworld_amd.batched import BatchedSimulator
@@ -79,8 +81,9 @@ def test_streams_are_probed_only_on_request():
     default_mode = sim.queue_sync_mode()                          # the default stream was probed by xwb_create
     assert default_mode[1] in ("probe_ok", "probe_failed", "tool", "env")
     mine = torch.cuda.Stream()
+    mh = C.c_void_p(mine.cuda_stream)
     for t in range(5):
-        sim.step(stream=mine); sim.reset_done(stream=mine)
+        lib.check(sim.L.xwb_step(sim.h, None, 1, mh)); lib.check(sim.L.xwb_reset_done(sim.h, mh))
         ref.step(); ref.reset_done()
     assert sim.step_path()["queue_sync"] == "events"              # never probed: events
     mode = sim.queue_sync_mode(mine)                              # the explicit probe
@@ -90,7 +93,7 @@ def test_streams_are_probed_only_on_request():
         ref.step(); ref.reset_done()
     assert sim.step_path()["queue_sync"] == mode[0]
     lib.check(sim.L.xwb_queue_sync_forget(sim.h, C.c_void_p(mine.cuda_stream)))
-    sim.step(stream=mine); ref.step()
+    lib.check(sim.L.xwb_step(sim.h, None, 1, mh)); ref.step()
     assert sim.step_path()["queue_sync"] == "events"              # forgotten: events again
     mine.synchronize()
     torch.cuda.synchronize()

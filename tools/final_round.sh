@@ -3,13 +3,13 @@
 # per-workload bench lines + kernel traces + HBM counters (tools/profile_round.sh), the soaks, the PCIe-inclusive rates, the
 # forced one-rank exchange and the leak check.  Usage: GIT_HEAD=$(git rev-parse --short HEAD) tools/final_round.sh <tag>
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 OUT=$PWD/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 HEAD=${GIT_HEAD:-unknown}
 { echo "== python -m pytest tests -q -m gpu at commit $HEAD, one MI355X =="; timeout 2400 python -m pytest tests -q -m gpu --slow --timeout 600 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path"; } > $OUT/gputest.txt
 tail -2 $OUT/gputest.txt
-GIT_HEAD=$HEAD bash tools/profile_round.sh $TAG xworld7 xworld7_f32 xworld8 xworld11 xworld7_ego3 xworld8_ego5 xworld7_ego7 simple_game simple_race > $OUT/profile_round.log 2>&1
+GIT_HEAD=$HEAD bash tools/profile_round.sh $TAG xworld7 xworld7_f32 xworld8 xworld11 xworld7_ego3 xworld8_ego5 xworld7_ego7 xworld11_ego9 simple_game simple_race > $OUT/profile_round.log 2>&1
 {
   echo "== soaks at commit $HEAD (tools/soak.py, tools/ego_soak.py, tools/soak_pregen.py, tools/pcie_rate.py; one MI355X) =="
   for a in "nav7 0 4096 2000" "nav7 3 4096 1500" "nav8_dim5 5 2048 1500" "walls7 0 4096 1500 2d" "nav8 0 4096 3000" "nav8 0 2048 6000 curriculum=0.1" \
