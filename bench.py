@@ -521,7 +521,15 @@ def main():
     from xworld_amd import sharding
     counts = [n_local] * world
     forced = world == 1 and args.force_exchange
-    results = sharding.ResultGather(counts, rank, dev, force_collective=forced) if (world > 1 or forced) else None
+    # --exchange lib: the library's own communicator carries the per-step results too, beside the step loop (no packet on the
+    # step's stream: xwb_gather_results_beside); the torch path stays the default
+    lib_comm_main = None
+    if (world > 1 or forced) and args.exchange == "lib" and args.backend == "nccl":
+        lib_comm_main = sharding.LibComm(rank, world, local_rank)
+    if lib_comm_main is not None:
+        results = sharding.LibResultGather(sim, lib_comm_main, counts, rank)
+    else:
+        results = sharding.ResultGather(counts, rank, dev, force_collective=forced) if (world > 1 or forced) else None
     with_screens = (world > 1 or forced) and not args.no_screens_gather
     screens = None                                   # ScreensGather while the screens regions run
 
@@ -722,8 +730,10 @@ def main():
                        "obs": list(sim.obs.shape[1:]), "seed": args.seed, "policy": "uniform random, drawn on device",
                        "loop": ("step_n(%d): %d steps per launch, auto-reset" % (fused, fused)) if fused > 1 else
                                ("step_autoreset" if args.autoreset else "step + reset_done"),
-                       "exchange": ("all_gather(reward,done) per step (%s), screens device-resident" %
-                                    ("the step's stream waits for it one step late" if args.results_wait else "released: no reader on the step's stream"))
+                       "exchange": ("all_gather(reward,done) per step (%s; %s), screens device-resident" %
+                                    ("the step's stream waits for it one step late" if args.results_wait else "released: no reader on the step's stream",
+                                     ("libxwb.so on its communicator's stream, ordered by the step's %s" % ("epoch" if results.by_epoch else "event"))
+                                     if lib_comm_main is not None else "torch.distributed"))
                                    if (world > 1 or forced) else "none",
                        "parallelism": "env-sharded x%d" % world},
             "regions": {"repetitions": R, "statistic": "median", "steps_per_region": args.steps,
@@ -809,7 +819,7 @@ def main():
     # (link-bound), and -- full observation, library exchange -- the cell codes with the root drawing every frame ----
     sg_line = None
     if with_screens:
-        lib_comm = sharding.LibComm(rank, world, local_rank) if args.exchange == "lib" else None
+        lib_comm = lib_comm_main if lib_comm_main is not None else (sharding.LibComm(rank, world, local_rank) if args.exchange == "lib" else None)
         grids_ok = is_xworld and not sim.cfg.visible_radius
         modes = [m for m in (("screens", "grids", "grids_nodraw") if args.gather == "both" else (args.gather,)) if m == "screens" or grids_ok]
         blocks = {}

@@ -507,6 +507,17 @@ int xwb_comm_group_end(xwb_comm *comm);
  * Empty shards (counts[i] == 0) are legal: they send nothing and still receive everybody's rows. */
 int xwb_gather_results(xwb_comm *comm, const float *packed_dev, float *all_dev, const int32_t *counts, const int32_t *peers,
                        int32_t n_shards, int32_t shard, void *stream);
+/* The same exchange BESIDE the step loop (round 5): the rows the LAST xwb_step / xwb_step_autoreset call of `sim` wrote into
+ * its results ring (xwb_bind_results / xwb_bind_results_ring: XWB_ERR_STATE without one, or before the first step) are
+ * gathered on the COMMUNICATOR's stream, ordered behind that call's step kernel.  When the call handed over through epochs
+ * (full-observation xworld batches on a probed stream: xwb_step_path) nothing at all is enqueued on `stream` -- a
+ * one-wavefront kernel on the communicator's stream waits for the step's epoch, *by_epoch (nullable) = 1 --; otherwise one
+ * event is recorded on `stream` (*by_epoch = 0).  A marker packet on the step's stream costs the loop ~6 us per step of idle
+ * GPU (profiles/r5: forced one-rank exchange).  The caller keeps all_dev and the ring's row untouched until the exchange is
+ * complete: xwb_comm_mark / xwb_comm_wait or xwb_gather_screens_end order a reader behind it; exchanges of one communicator
+ * run in issue order.  Not inside an open group. */
+int xwb_gather_results_beside(xwb_sim *sim, xwb_comm *comm, float *all_dev, const int32_t *counts, const int32_t *peers,
+                              int32_t n_shards, int32_t shard, void *stream, int32_t *by_epoch);
 /* The screens of every shard as ONE contiguous tensor on the root shard's GPU: dst_dev (root only; else NULL) =
  * [sum(counts)][bytes_per_env].  _begin orders the transfer behind the work already queued on `stream` (the step's render)
  * and issues it on the communicator's own stream -- the root posts one ncclRecv per remote shard into that shard's slice

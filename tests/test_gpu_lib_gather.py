@@ -124,3 +124,54 @@ def test_lib_screens_gather_class_world_of_one():
         assert torch.equal(out[:, 0], ref.reward)
     assert torch.equal(sg.drain(), ref.obs)
     sim.close(); ref.close(); comm.close()
+
+
+@pytest.mark.parametrize("game,opts,want_epoch", [("xworld", {"xwd_conf_path": os.path.join(ROOT, "xworld_amd", "confs", "navigation2d.json"),
+                                                              "task_mode": "lang_acquisition", "max_dim": 7, "color": True}, True),
+                                                  ("xworld", {"xwd_conf_path": os.path.join(ROOT, "xworld_amd", "confs", "navigation2d.json"),
+                                                              "task_mode": "lang_acquisition", "max_dim": 7, "visible_radius": 3}, False),
+                                                  ("simple_game", {"array_size": 16}, False)], ids=["xworld", "ego", "simple_game"])
+def test_results_gathered_beside_the_step_loop(game, opts, want_epoch):
+    """xwb_gather_results_beside (LibResultGather): the last step's rows of the results ring, all-gathered on the communicator's
+    stream behind that step's kernel -- by the step's epoch on a full-observation xworld batch (nothing enqueued on the caller's
+    stream), by an event otherwise -- equal the batch's own reward / codes every step, whether the caller waits (finish) or lets
+    the exchange go (release) and reads after a drain."""
+    torch = _torch()
+    from xworld_amd import sharding
+    from xworld_amd.batched import BatchedSimulator
+    n = 4096
+    sim = BatchedSimulator(game, opts, num_envs=n, seed=12, policy_seed=5)
+    comm = sharding.LibComm(0, 1, 0)
+    # before a ring is bound / before the first step: refused
+    rg = sharding.LibResultGather(sim, comm, [n], 0)
+    with pytest.raises(Exception, match="results ring"):
+        rg.start()
+    ring = torch.zeros((4, n, 2), dtype=torch.float32, device="cuda")
+    sim.bind_results_ring(ring)
+    rg = sharding.LibResultGather(sim, comm, [n], 0)
+    with pytest.raises(Exception, match="no step"):
+        rg.start()
+    mode = sim.queue_sync_mode()[0] if game == "xworld" else "events"
+    kept = []
+    for t in range(24):
+        sim.step()
+        rg.start()
+        if t % 3 == 0:
+            r, c = rg.finish(convert=False)
+            torch.cuda.synchronize()
+            assert torch.equal(r, sim.reward) and torch.equal(c, sim.game_over_codes.float()), t
+        else:
+            rg.release()
+            kept.append((t, rg.out[rg.slot ^ 1], sim.reward.clone(), sim.game_over_codes.float().clone()))
+        assert rg.by_epoch == (want_epoch and mode == "epochs"), (t, rg.by_epoch, mode)
+        sim.reset_done()
+        if len(kept) == 2:                                          # the two buffers alternate: read them before they come round
+            rg.drain()
+            torch.cuda.synchronize()
+            for (tt, out, rr, cc) in kept:
+                assert torch.equal(out[:, 0], rr) and torch.equal(out[:, 1], cc), tt
+            kept = []
+    rg.drain()
+    assert sim.check_errors() == 0
+    sim.close()
+    comm.close()

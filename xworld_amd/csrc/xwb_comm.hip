@@ -25,6 +25,8 @@
 #include <vector>
 
 extern "C" __attribute__((visibility("hidden"))) int xwb_internal_fail(int code, const char *msg);     // xwb_create.hip: sets xwb_last_error on this thread
+// xwb_verbs.hip: the last step's rows of the results ring, `beside` ordered behind that step's kernel (1: through its epoch, 0: an event)
+extern "C" __attribute__((visibility("hidden"))) int xwb_internal_last_results(xwb_sim *s, void *beside, void *step_stream, const float **rows, int32_t *n);
 
 namespace {
 
@@ -314,6 +316,23 @@ int xwb_gather_results(xwb_comm *c, const float *packed_dev, float *all_dev, con
     }
     RCCL_TRY(R->GroupEnd());
     return XWB_OK;
+}
+
+int xwb_gather_results_beside(xwb_sim *sim, xwb_comm *c, float *all_dev, const int32_t *counts, const int32_t *peers, int32_t n_shards,
+                              int32_t shard, void *stream, int32_t *by_epoch) {
+    int rc = check_layout(c, counts, peers, n_shards, shard);
+    if (rc) return rc;
+    if (!sim || !all_dev) return fail(XWB_ERR_ARG, "NULL argument");
+    if (c->group_depth > 0) return fail(XWB_ERR_STATE, "xwb_gather_results_beside inside an open group");
+    DeviceGuard g(c->device);
+    const float *rows = nullptr;
+    int32_t n = 0;
+    rc = xwb_internal_last_results(sim, c->stream, stream, &rows, &n);
+    if (rc < 0) return rc;
+    if (by_epoch) *by_epoch = rc;
+    if (n != counts[shard]) return fail(XWB_ERR_ARG, "counts[shard] is not this batch's num_envs");
+    c->in_flight += 1;
+    return xwb_gather_results(c, rows, all_dev, counts, peers, n_shards, shard, c->stream);
 }
 
 // what the two gathers of frames share: arguments, the hand-over from `stream` to the communicator's stream

@@ -662,6 +662,7 @@ int xwb_destroy(xwb_sim *s) {
     if (s->ev_reset) (void)hipEventDestroy(s->ev_reset);
     if (s->ev_term) (void)hipEventDestroy(s->ev_term);
     if (s->ev_cells) (void)hipEventDestroy(s->ev_cells);
+    if (s->ev_results) (void)hipEventDestroy(s->ev_results);
     for (KernelTimer *t : {&s->t_render, &s->t_step, &s->t_reset, &s->t_list})
         for (auto &ep : t->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     delete s;

@@ -87,6 +87,8 @@ struct xwb_sim {
     uint32_t *h_poison = nullptr;          // pinned host word: a watchdog expired (XwParams::poison_host points at it)
     bool poisoned = false;
     hipEvent_t ev_step = nullptr, ev_reset = nullptr, ev_term = nullptr, ev_cells = nullptr;
+    hipEvent_t ev_results = nullptr;       // xwb_gather_results_beside's hand-over when the last step did not run on epochs (made on first use)
+    bool results_by_epoch = false;         // the last step call published "step kernel complete" as an epoch in sync[1]
     bool span_epochs = false;              // ... and handed over through epochs (d_sync[5..7]) rather than those events
     bool span_step = false;                // the last step drew its frames on the egocentric span path (ev_cells / ev_step / ev_term are its)
     // common device buffers

@@ -462,6 +462,9 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
         }
     }
     s->span_step = !autoreset && xw_ego_span(s->xw);
+    // sync[1] = this call's epoch once its step kernel is complete: published by render_all's first thread on every full-observation
+    // path that hands over through epochs (the egocentric paths publish other slots, or record events)
+    s->results_by_epoch = s->cfg.game == XWB_XWORLD2D && s->step_epochs && !s->cfg.visible_radius;
     s->last_path = s->cfg.game != XWB_XWORLD2D ? XWB_PATH_NONE :
                    (s->cfg.visible_radius ? (xw_ego_span(s->xw) ? XWB_PATH_EGO_SPAN : XWB_PATH_EGO_PER_ENV) :
                     (autoreset && s->pregen ? XWB_PATH_PREGEN : (s->step_lazy ? XWB_PATH_LAZY : XWB_PATH_CLASSIC)));
@@ -698,6 +701,28 @@ int xwb_bind_results_ring(xwb_sim *s, float *packed_dev, int64_t slots) {
     s->packed_slots = slots;
     s->packed_pos = 0;
     return XWB_OK;
+}
+
+// xwb_comm.hip's way in (it only uses the public ABI otherwise): the rows the LAST step call wrote into the results ring, and
+// `beside` (the communicator's stream) ordered behind that call's step kernel -- through the step's epoch when it published one
+// (nothing is enqueued on the caller's stream then), else through one event recorded on `step_stream`.
+extern "C" __attribute__((visibility("hidden"))) int xwb_internal_last_results(xwb_sim *s, void *beside, void *step_stream, const float **rows, int32_t *n) {
+    if (!s || !rows || !n) return fail(XWB_ERR_ARG, "NULL argument");
+    XWB_ON_DEVICE(s);
+    XWB_LIVE(s);
+    if (!s->d_packed) return fail(XWB_ERR_STATE, "no results ring is bound (xwb_bind_results / xwb_bind_results_ring)");
+    if (s->packed_pos < 1) return fail(XWB_ERR_STATE, "no step has written the results ring yet");
+    *rows = reinterpret_cast<const float *>(s->d_packed + (size_t)((s->packed_pos - 1) % s->packed_slots) * (size_t)s->n);
+    *n = s->n;
+    hipStream_t bs = reinterpret_cast<hipStream_t>(beside);
+    if (s->results_by_epoch && s->d_sync) {
+        HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->d_sync + 4, s->xw.poison_host, bs));
+    } else {
+        if (!s->ev_results) HIP_TRY(hipEventCreateWithFlags(&s->ev_results, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(s->ev_results, as_stream(step_stream)));
+        HIP_TRY(hipStreamWaitEvent(bs, s->ev_results, 0));
+    }
+    return s->results_by_epoch && s->d_sync ? 1 : 0;            // (>= 0: fine; 1 = nothing was enqueued on the caller's stream)
 }
 
 int xwb_bind_obs(xwb_sim *s, void *obs_dev) {

@@ -151,6 +151,7 @@ _SIGS = [
     ("xwb_gather_screens_begin", C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, _vp]),
     ("xwb_gather_screens_end", C.c_int, [_vp, _vp]),
     ("xwb_comm_release_sim", C.c_int, [_vp, _vp]),
+    ("xwb_gather_results_beside", C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32, _vp, C.POINTER(C.c_int32)]),
     ("xwb_gather_grids_begin", C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, _vp]),
     ("xwb_comm_mark", C.c_int, [_vp, C.c_int32]),
     ("xwb_comm_wait", C.c_int, [_vp, C.c_int32, _vp]),

@@ -414,6 +414,66 @@ class LibComm:
             pass
 
 
+class LibResultGather:
+    """ResultGather through the library, BESIDE the step loop (xwb_gather_results_beside): the rows the last step call wrote into
+    the batch's results ring (BatchedSimulator.bind_results_ring) are all-gathered on the communicator's own stream, ordered
+    behind that step's kernel by the batch's epoch hand-over -- on a full-observation xworld batch nothing is enqueued on the
+    caller's stream at all (the torch path's collective records an event there every step: ~6 us of idle GPU per step).  Same
+    protocol as ResultGather: start() after the step call, then release() (nobody on this stream reads the result) or finish()
+    (orders the current stream behind the exchange, -> (reward, code) columns on every rank).  Two output buffers alternate;
+    marks 2 / 3 of the communicator are this object's (LibScreensGather uses 0 / 1).  Equal shards, one shard per rank."""
+
+    def __init__(self, sim, comm, counts, rank, stream=None):
+        import ctypes as C
+        from . import lib
+        self.C, self.lib, self.L = C, lib, comm.L
+        self.sim, self.comm, self.rank = sim, comm, rank
+        self.counts = list(counts)
+        self.c_counts = (C.c_int32 * len(counts))(*counts)
+        self.total = sum(counts)
+        dev = sim.obs.device
+        self.out = [torch.empty((self.total, 2), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.slot = 0
+        self.pending = None
+        self.stream = stream
+        self.by_epoch = None                                  # True once an exchange was ordered by the step's epoch
+
+    def _st(self):
+        s = self.stream if self.stream is not None else torch.cuda.current_stream()
+        return self.C.c_void_p(int(s.cuda_stream))
+
+    def start(self, packed=None):
+        if self.pending is not None:
+            raise RuntimeError("LibResultGather.start() called twice without finish() / release()")
+        k = self.slot
+        self.slot ^= 1
+        flag = self.C.c_int32()
+        self.lib.check(self.L.xwb_gather_results_beside(self.sim.h, self.comm.h, self.C.c_void_p(self.out[k].data_ptr()), self.c_counts, None,
+                                                        len(self.counts), self.rank, self._st(), self.C.byref(flag)))
+        self.lib.check(self.L.xwb_comm_mark(self.comm.h, 2 + k))
+        self.by_epoch = bool(flag.value)
+        self.pending = k
+
+    def release(self):
+        self.pending = None
+
+    def finish(self, convert=True):
+        if self.pending is None:
+            return None, None
+        k = self.pending
+        self.pending = None
+        self.lib.check(self.L.xwb_comm_wait(self.comm.h, 2 + k, self._st()))
+        out = self.out[k]
+        return out[:, 0], (out[:, 1].to(torch.uint8) if convert else out[:, 1])
+
+    def drain(self):
+        """Orders the current stream behind every exchange issued so far (before reading `out`, or tearing down)."""
+        self.pending = None
+        for k in (0, 1):
+            self.lib.check(self.L.xwb_comm_wait(self.comm.h, 2 + k, self._st()))
+        return None, None
+
+
 class LibScreensGather:
     """ScreensGather through the library (xwb_gather_screens_begin, or mode="grids": xwb_gather_grids_begin -- every shard
     ships its cell codes, 2 * max_dim^2 + 1 bytes per env, and the root draws all frames itself): same protocol (bind_next /
