@@ -348,7 +348,7 @@ def gather_regions(sim, mode, lib_comm, counts, rank, world, n_local, K, R, args
     return gather_block(sim, mode, lib_comm, g.depth, world, n_local, args.steps, regs), g
 
 
-def c5_block(args, world, rank, local_rank, dev, K):
+def c5_block(args, world, rank, local_rank, dev, K, lib_comm_main=None):
     """BASELINE.json config C5 -- XWorld2D 11x11, 32 768 envs per GPU (262 144 over 8), "sharded 8 x MI355X with RCCL gather
     of screens" -- as a sub-object of the N > 1 line: the same loop as the main measurement on the xworld11 workload, once
     with the screens left device-resident (value) and once with every shard's screens gathered into one tensor on rank 0
@@ -359,10 +359,11 @@ def c5_block(args, world, rank, local_rank, dev, K):
     n_local = args.envs_per_gpu or WORKLOADS["xworld11"][2]
     sim = make_sim("xworld11", n_local, local_rank, rank * n_local, args.seed)
     counts = [n_local] * world
-    results = sharding.ResultGather(counts, rank, dev)
     # (eight slots: with the exchanges released, a slot is rewritten eight steps after it was shipped)
     packed = torch.zeros((8, n_local, 2), dtype=torch.float32, device=dev)
     sim.bind_results_ring(packed)
+    # (the per-step results as in the main measurement: through the library's communicator when it is up)
+    results = sharding.LibResultGather(sim, lib_comm_main, counts, rank) if lib_comm_main is not None else sharding.ResultGather(counts, rank, dev)
     state = {"screens": None, "calls": 0}
 
     def one_step():
@@ -424,7 +425,8 @@ def c5_block(args, world, rank, local_rank, dev, K):
     first = "screens" if "screens" in gathers else "grids"
     out = {"workload": "xworld11", "config": "BASELINE C5: 11x11, 132x132x3 u8, %d envs per GPU, %d in all" % (n_local, n_local * world),
            "value": n_local * world * K / d_med, "unit": "env-steps/s", "ms_per_step": d_med / K * 1e3,
-           "exchange": "all_gather(reward,done) per step, screens device-resident", "regions": 3, "steps_per_region": K,
+           "exchange": "all_gather(reward,done) per step (%s), screens device-resident" % ("libxwb.so, beside the step loop" if lib_comm_main is not None else "torch.distributed"),
+           "regions": 3, "steps_per_region": K,
            "action_errors": errs, "screens_gather": gathers[first]}
     if first == "screens" and "grids" in gathers:
         out["screens_gather"] = dict(gathers["screens"], grids=gathers["grids"])
@@ -454,8 +456,11 @@ def main():
     ap.add_argument("--autoreset", action="store_true", help="use the fused step+reset+single-render call")
     ap.add_argument("--fused", type=int, default=1, help="simple games only: steps per launch (xwb_step_n); --steps must be "
                     "a multiple; every step still writes its reward / code / observation")
-    ap.add_argument("--exchange", default="torch", choices=["torch", "lib"], help="N > 1 screens gather: torch.distributed "
-                    "point-to-point (default) or libxwb.so's own RCCL calls (xwb_gather_screens_begin / _end; backend nccl only)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "torch", "lib"], help="N > 1: who issues the exchanges.  torch: "
+                    "torch.distributed for everything.  lib: libxwb.so's own RCCL calls for everything (results beside the step loop: "
+                    "xwb_gather_results_beside; screens: xwb_gather_screens_begin / grids; backend nccl only).  auto (default): the "
+                    "per-step results through the library when its communicator comes up on every rank within 90 s (else torch), the "
+                    "screens gathers through torch.distributed")
     ap.add_argument("--gather", default="both", choices=["screens", "grids", "grids_nodraw", "both"], help="N > 1, full observation: what crosses "
                     "the links per step -- every shard's pixels (screens), or its cell codes with the root drawing all frames "
                     "(grids: xwb_gather_grids_begin, needs --exchange lib), or one set of regions each (both; grids only with --exchange lib)")
@@ -523,9 +528,29 @@ def main():
     forced = world == 1 and args.force_exchange
     # --exchange lib: the library's own communicator carries the per-step results too, beside the step loop (no packet on the
     # step's stream: xwb_gather_results_beside); the torch path stays the default
-    lib_comm_main = None
-    if (world > 1 or forced) and args.exchange == "lib" and args.backend == "nccl":
-        lib_comm_main = sharding.LibComm(rank, world, local_rank)
+    lib_comm_main, lib_note = None, None
+    if (world > 1 or forced) and args.exchange in ("lib", "auto") and args.backend == "nccl":
+        # the library's communicator is made in a thread with a deadline: a second ncclCommInitRank that hangs on some box must
+        # cost the faster exchange, not the run; every rank then agrees (over the torch group, which is up) on what to use
+        import threading
+        box = {}
+
+        def make_comm():
+            try:
+                box["comm"] = sharding.LibComm(rank, world, local_rank)
+            except Exception as e:                       # noqa: BLE001
+                box["err"] = "%s: %s" % (type(e).__name__, e)
+        th = threading.Thread(target=make_comm, daemon=True)
+        th.start()
+        th.join(90.0)
+        ok = torch.tensor([1 if "comm" in box else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()):
+            lib_comm_main = box["comm"]
+        else:
+            lib_note = box.get("err", "timed out after 90 s" if th.is_alive() else "another rank failed")
+            if args.exchange == "lib":
+                raise RuntimeError("--exchange lib: the library's communicator did not come up: %s" % lib_note)
     if lib_comm_main is not None:
         results = sharding.LibResultGather(sim, lib_comm_main, counts, rank)
     else:
@@ -757,7 +782,9 @@ def main():
                          **traffic_info},
             "timed_with_events_ms_per_step": statistics.median(ev_regions) / args.steps * 1e3,
             "host_us_per_step": host_us_per_step,
-            "rccl": dict(sharding.backend_info(), **ranks_seen),
+            "rccl": dict(sharding.backend_info(), **ranks_seen,
+                         **({"results_exchange": "libxwb.so" if lib_comm_main is not None else "torch.distributed",
+                             "results_exchange_note": lib_note} if (world > 1 or forced) else {})),
         }
         return line
 
@@ -819,7 +846,7 @@ def main():
     # (link-bound), and -- full observation, library exchange -- the cell codes with the root drawing every frame ----
     sg_line = None
     if with_screens:
-        lib_comm = lib_comm_main if lib_comm_main is not None else (sharding.LibComm(rank, world, local_rank) if args.exchange == "lib" else None)
+        lib_comm = lib_comm_main if args.exchange == "lib" else None
         grids_ok = is_xworld and not sim.cfg.visible_radius
         modes = [m for m in (("screens", "grids", "grids_nodraw") if args.gather == "both" else (args.gather,)) if m == "screens" or grids_ok]
         blocks = {}
@@ -852,7 +879,7 @@ def main():
     if world > 1 and (args.c5 or world == 8) and args.workload != "xworld11":
         try:
             with phase("c5", 2 * PT if PT else None):
-                c5 = c5_block(args, world, rank, local_rank, dev, K)
+                c5 = c5_block(args, world, rank, local_rank, dev, K, lib_comm_main)
         except Exception as e:                           # the main line must not die with its second measurement
             c5 = {"error": "%s: %s" % (type(e).__name__, e)}
         if rank == 0:

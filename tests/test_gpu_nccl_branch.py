@@ -98,7 +98,7 @@ def test_device_tensor_exchanges_over_nccl_world_of_one():
     assert out.returncode == 0 and "NCCL_BRANCH_OK 25" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
 
 
-@pytest.mark.parametrize("exchange", ["torch", pytest.param("lib", marks=pytest.mark.slow)])
+@pytest.mark.parametrize("exchange", ["auto", pytest.param("torch", marks=pytest.mark.slow), pytest.param("lib", marks=pytest.mark.slow)])
 def test_bench_forced_exchange_reports_rccl(exchange):
     """torchrun --nproc-per-node 1 bench.py --gpus 1 --backend nccl --force-exchange: the line says which RCCL ran."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
@@ -112,6 +112,10 @@ def test_bench_forced_exchange_reports_rccl(exchange):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["rccl"]["backend"] == "nccl" and line["rccl"]["world_size"] == 1 and line["rccl"]["version"]
     assert "forced_exchange" in line and line["parity"]["mismatches"] == 0
+    # auto / lib: the per-step results run beside the step loop through the library's communicator, ordered by the step's epoch
+    want = "torch.distributed" if exchange == "torch" else "libxwb.so"
+    assert line["rccl"]["results_exchange"] == want, line["rccl"]
+    assert (want in line["config"]["exchange"]) and (exchange == "torch" or "epoch" in line["config"]["exchange"])
     sg = line["screens_gather"]
     assert sg["mode"] == "screens" and sg["value"] > 0 and "error" not in sg
     assert sg["grids"]["value"] > 0 and "error" not in sg["grids"], sg["grids"]
