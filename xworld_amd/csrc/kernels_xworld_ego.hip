@@ -584,19 +584,16 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
 // frame, four workgroups per CU: 14 us per frame and workgroup, 0.20 of the HBM roofline); split by what is parallel in:
 //   xw_ego_cells_kernel   lane per env: shadow rays and scan lines on bit masks -> cellinfo[env][view cell], and the list
 //                         of goal cells the cache does not hold yet
-//   xw_ego_eval_kernel    the pixels that have to be evaluated: four workgroups per listed goal cell (its U x U pixels ->
-//                         cache entry, valid bit), and, eight envs per workgroup, the border-line runs next to goal cells and
-//                         the pixels where border lines cross -> ego_border
+//   xw_ego_eval_kernel    the pixels that have to be evaluated: four workgroups per listed goal cell -- the U x U pixels of its
+//                         square and the border lines next to it that blend the goal's image -> cache entry (EgoEntry), valid
+//                         bit.  (Rounds 2-4 evaluated those lines and the crossing pixels of EVERY env on every step into a
+//                         per-env buffer: a second kind of workgroup whose chain of dependent reads made this kernel 42 us.)
 //   xw_ego_gather_kernel  one-shot workgroups over 16-byte chunk spans of the batch's frame bytes, cut by the global chunk
 //                         index exactly like the full-observation render (kernels_xworld.hip): U-byte runs gathered through
 //                         L2, assembled in LDS in output order, border-column bytes patched in, one non-temporal 16-byte
 //                         store per lane
 // The frames of the done list's envs (new episodes) take the same three stages over the list, on the reset's queue.
 
-// envs per workgroup of the border-line evaluation (8: 49 us for the evaluation kernel on the C4-sized batch -- four rounds
-// of workgroups that mostly wait for their staging loads; 32: one round).  r = 7: 16 -- 49 cells and up to 120 runs / crossings
-// per env make a 32-env workgroup a long serial one (0.3365 -> 0.308 ms per step; 8: 0.306; r = 3 / 5 lose with either)
-template <int R> struct EgoBorderGeom { static constexpr int EPW = R >= 7 ? 16 : 32; };
 // threads per workgroup of the gather kernels (A/B hook: -DEGO_BS=...).  Round 3: 256 threads x 4 chunks = 16 KB spans, four waves
 // per barrier: r = 3 colour 0.236 -> 0.228 ms per step, +2 .. 6 % on every geometry tried; 128 (round 2) and 512 lose
 #ifndef EGO_BS
@@ -768,32 +765,61 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
         if (active) info_e[f] = info | hd | lines;
     }
     __syncthreads();                                            // (a square's word needs its neighbours', other wavefronts' work)
-    // what the gather reads, per square: where its pixels come from (16-byte units: into ego_tab3, keyed by the classes of the
-    // cell, the one above and the one to the left -- the cell's own where the neighbour does not show in this square -- or, bit
-    // 23, into this env's part of the goal-cell cache), bit 24 / 25 its border row / column is evaluated for this env (a goal
-    // in or next to the cell), 26 a border row crosses a border column here, 27 finished by this step, 28-29 fresh[]
+    // What the gather reads, per square -- two words.
+    // .x: where its pixels come from (bits 0-22, 16-byte units: into ego_tab3, keyed by the classes of the cell, the one above
+    // and the one to the left -- the cell's own where the neighbour does not show in this square or is a goal -- or, bit 23,
+    // into this env's part of the goal-cell cache), bit 24 / 25 its border row / column blends a goal's image (the cell above /
+    // to the left shows a goal): the gather places that line itself, from the goal's cache entry; 26 a border row crosses a
+    // border column here; 27 finished by this step; 28-29 fresh[]; 30-31 flat.
+    // .y: what the gather places itself.  Bits 24 / 25 of .x: the cache entry (slot * r * r + view cell) * 4 + heading of the
+    // goal above (bits 0-11: its BELOW line) and of the goal to the left (bits 12-23: its RIGHT line); both lines were
+    // evaluated on the real view and hold the crossing pixel.  Bit 26 alone: the crossing pixel itself, B | G << 8 | R << 16
+    // from ego_xtab (four classes: the same in every env), or, bit 31, the entry of the goal above left (its DIAG pixel).
+    // A square that shows a goal carries no flags: its cache entry holds its border row, column and crossing as well.
+    // (Why a goal's lines can be cached: the entry is keyed by (goal slot, view cell, heading), which fixes the agent's cell --
+    // and with it the whole view, the map being constant over an episode but for the agent; whatever changes a map or a
+    // pose redraws the goal images, which clears the env's valid bits: warp_goals_body.)
     if (!active && valid) {
-        for (int f = kb; f < kb + Q && f < r * r; ++f) p.ego_cellsrc[(size_t)e * (r * r) + f] = 1u << 27;      // (skipped: finished by this step)
+        for (int f = kb; f < kb + Q && f < r * r; ++f) p.ego_cellsrc[(size_t)e * (r * r) + f] = make_uint2(1u << 27, 0u);      // (skipped: finished by this step)
     }
     if (active) {
         typedef EgoSq<r> Sq;
         const uint32_t nc = (uint32_t)p.ego_ncls, ch_n = (uint32_t)p.channels, entry16 = p.ego_cache_entry / 16;
-        uint32_t *src_e = p.ego_cellsrc + (size_t)e * (r * r);
+        uint2 *src_e = p.ego_cellsrc + (size_t)e * (r * r);
+        auto eidx = [&](uint32_t wg) { return ((wg & 0xfu) * (r * r) + ((wg >> 4) & 0x3fu)) * 4u + (uint32_t)dir; };
+        uint32_t sx[Q], sy[Q];
+        int xi[Q];                                              // index into ego_xtab of a square's crossing pixel, -1: none
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const int f = kb + j;
+            sx[j] = 0; sy[j] = 0; xi[j] = -1;
+            if (f >= r * r) break;
+            const uint32_t w = s_sq[lane][f], wa = f >= r ? s_sq[lane][f - r] : w, wl = f % r ? s_sq[lane][f - 1] : w;
+            const uint32_t wd = (f >= r && f % r) ? s_sq[lane][f - r - 1] : w;
+            const bool rowb = (w >> 29 & 1u) != 0, colb = (w >> 30 & 1u) != 0, goal = (w & 0x8000u) != 0;
+            const bool ga = !goal && rowb && (wa & 0x8000u), gl = !goal && colb && (wl & 0x8000u), cross = !goal && rowb && colb;
+            const uint32_t c = (w >> 16) & 0xffu, ca = rowb && !ga ? (wa >> 16) & 0xffu : c, cl = colb && !gl ? (wl >> 16) & 0xffu : c;
+            const uint32_t key = (((uint32_t)dir * nc + c) * nc + ca) * nc + cl;
+            const uint32_t off = goal ? eidx(w) * entry16 : key * ch_n * (Sq::PBP / 16) + f * (Sq::CBP / 16);
+            // bits 30-31: the table entry is one flat colour (1: 255, 2: 0) -- the gather reads the shared constant line instead
+            const uint32_t flat = goal ? 0u : (uint32_t)p.ego_flat[key * (r * r) + f];
+            sx[j] = off | (goal ? 1u << 23 : 0u) | (ga ? 1u << 24 : 0u) | (gl ? 1u << 25 : 0u) | (cross ? 1u << 26 : 0u) |
+                    (term ? 1u << 27 : 0u) | ((uint32_t)fresh & 3u) << 28 | flat << 30;
+            if (ga) sy[j] |= eidx(wa);
+            if (gl) sy[j] |= eidx(wl) << 12;
+            if (cross && !ga && !gl) {
+                if (wd & 0x8000u) sy[j] = 1u << 31 | eidx(wd);
+                else xi[j] = (int)((((key * nc) + ((wd >> 16) & 0xffu)) * (r * r)) + f);
+            }
+        }
+        uint32_t xv[Q];                                         // (every read in flight, no branch around them)
+#pragma unroll
+        for (int j = 0; j < Q; ++j) xv[j] = p.ego_xtab[xi[j] >= 0 ? xi[j] : 0];
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
             const int f = kb + j;
             if (f >= r * r) break;
-            const uint32_t w = s_sq[lane][f], wa = f >= r ? s_sq[lane][f - r] : w, wl = f % r ? s_sq[lane][f - 1] : w;
-            const bool rowb = (w >> 29 & 1u) != 0, colb = (w >> 30 & 1u) != 0, goal = (w & 0x8000u) != 0;
-            const bool row_dirty = rowb && ((wa | w) & 0x8000u), col_dirty = colb && ((wl | w) & 0x8000u);
-            const uint32_t c = (w >> 16) & 0xffu, ca = rowb && !row_dirty ? (wa >> 16) & 0xffu : c, cl = colb && !col_dirty ? (wl >> 16) & 0xffu : c;
-            const uint32_t key = (((uint32_t)dir * nc + c) * nc + ca) * nc + cl;
-            const uint32_t off = goal ? (((w & 0xfu) * (r * r) + ((w >> 4) & 0x3fu)) * 4 + dir) * entry16
-                                      : key * ch_n * (Sq::PBP / 16) + f * (Sq::CBP / 16);
-            // bits 30-31: the table entry is one flat colour (1: 255, 2: 0) -- the gather reads the shared constant line instead
-            const uint32_t flat = goal ? 0u : (uint32_t)p.ego_flat[key * (r * r) + f];
-            src_e[f] = off | (goal ? 1u << 23 : 0u) | (row_dirty ? 1u << 24 : 0u) | (col_dirty ? 1u << 25 : 0u) | (rowb && colb ? 1u << 26 : 0u) |
-                       (term ? 1u << 27 : 0u) | ((uint32_t)fresh & 3u) << 28 | flat << 30;
+            src_e[f] = make_uint2(sx[j], xi[j] >= 0 ? xv[j] : sy[j]);
         }
     }
     // the cache bits of this wavefront's goal cells, fetched together, then one list append for its whole lot (one atomic per view
@@ -843,28 +869,44 @@ __global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uin
     ego_cells_body<R, LIST, false>(p, map, skip_term, count_now, (int)blockIdx.x, smem4);
 }
 
-// (cache entries hold the whole square of the frame the cell occupies, in EgoSq's layout; its border row / column, if it has
-// one, is left as it is: the gather overwrites those bytes.  This is not the layout the kernel above keeps -- it leaves the
-// cache alone when the span path is on.)
+// A cache entry [env][goal slot][view cell][heading] on the span path (EgoEntry): everything of the frame that blends this goal's
+// image while it shows in that view cell --
+//   SQ     the square of the frame the cell occupies, in EgoSq's layout ([channel][U rows][UP bytes]), its border row, border
+//          column and crossing pixel included;
+//   BELOW  [channel][U] the first row of the square below, where that is a border row (it blends the goal with the cell below);
+//   RIGHT  [channel][U] the first column of the square to the right, where that is a border column;
+//   DIAG   [channel] the first pixel of the square below right, where a border row crosses a border column (four cells).
+// The lines are evaluated on the env's real view (ego_cellinfo, which the cells kernel queued before this one wrote): the entry's
+// key fixes the agent's cell and heading, so for the rest of the episode the same key means the same view (xw_ego_cells_kernel).
 template <int CH, int R>
-__device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t *atlas4, const EgoTap *tap_h1, const EgoTap *tap_v1,
-                                              const EgoTap *tap_h2, const EgoTap *tap_v2, const uint16_t *layout, const uint8_t *map,
+struct EgoEntry {
+    typedef EgoSq<R> Q;
+    static constexpr int BELOW = CH * Q::CBP, RIGHT = BELOW + CH * Q::U, DIAG = RIGHT + CH * Q::U, BYTES = (DIAG + 4 + 15) & ~15;
+};
+
+// The goal cells the cache does not hold yet (ego_miss): four workgroups per listed cell, one pixel per lane -- the square's
+// U * U pixels on the first lanes, the 2 U + 1 pixels of the BELOW / RIGHT / DIAG lines on the lanes behind them.
+template <int CH, int R>
+__device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t *atlas4, const uint16_t *layout, const uint8_t *map,
                                               int block, int nblocks, EgoTap (*s_row)[3], EgoTap (*s_col)[3]) {
-    constexpr int U = 84 / R, O = R * U, O4 = O;
+    constexpr int U = 84 / R, O = R * U, O4 = O, RR = R * R;
     constexpr int PARTS = 4, PP = (U * U + PARTS - 1) / PARTS;       // a goal cell is shared by four workgroups: <= one pixel per lane
-    static_assert(PP <= 256, "one pixel per lane");
-    // (s_row / s_col: the kernel's, shared with the other body)
-    // The count and (speculatively) the first item come in one round trip, the taps, the flag rows of all four headings and
-    // the view-cell -> square map in the next: per goal cell the chain is item -> pixel reads -> stores
-    __shared__ EgoCell s_cells[R * R];
+    constexpr int NX = 2 * U + 1, XP = (NX + PARTS - 1) / PARTS;     // ... and a share of the entry's lines
+    static_assert(PP + XP <= 256, "one pixel per lane");
+    typedef EgoEntry<CH, R> E;
+    // (s_row / s_col: the kernel's)
+    // The count and (speculatively) the first item come in one round trip, the flag rows of all four headings, the view-cell ->
+    // square maps and the class images in the next: per goal cell the chain is item -> its env's cell words -> pixel reads -> stores
+    __shared__ EgoCell s_cells[RR];
     __shared__ uint16_t s_flags[4][2][84];                 // [heading][row terms | column terms]
-    __shared__ uint8_t s_inv[4 * R * R];
+    __shared__ uint8_t s_inv[4 * RR], s_fwd[4 * RR];
+    __shared__ uint2 s_clsimg[4 * 16];
     const int tid = threadIdx.x, part = block % PARTS, first = block / PARTS;
-    const int cap = p.n * (p.num_goals < R * R ? p.num_goals : R * R);
+    const int cap = p.n * (p.num_goals < RR ? p.num_goals : RR);
     uint2 item = p.ego_miss[first < cap ? first : cap - 1];
     const int cnt = *p.ego_miss_count;
-    // (the tables are requested before the count is looked at: waiting for it first put one more round trip -- 4 of this
-    // body's 23 us -- in front of them; the workgroups that then leave have asked for a few hundred bytes for nothing)
+    // (the tables are requested before the count is looked at: waiting for it first put one more round trip in front of them;
+    // the workgroups that then leave have asked for a few hundred bytes for nothing)
     const int lw = ego_layout_words(O4, R);
     constexpr int NF = (4 * 2 * O + 255) / 256;
     uint16_t fl[NF];
@@ -873,35 +915,56 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
         const int i = tid + q * 256, d = i / (2 * O), rem = i - d * 2 * O;
         fl[q] = i < 4 * 2 * O ? layout[d * lw + (rem / O) * O4 + rem % O] : (uint16_t)0;
     }
-    const uint8_t inv = tid < 4 * R * R ? map[8 * R + 4 * R * R + tid] : (uint8_t)0;
+    const uint8_t inv = tid < 4 * RR ? map[8 * R + 4 * RR + tid] : (uint8_t)0, fwd = tid < 4 * RR ? map[tid] : (uint8_t)0;
+    const uint2 ci = p.ego_clsimg[tid < 4 * p.ego_ncls ? tid : 0];
+    // (speculatively, with the item: the cell words of its env)
+    uint32_t info = tid < RR ? p.ego_cellinfo[(size_t)(item.x < (uint32_t)p.n ? item.x : 0u) * RR + tid] : 0u;      // (a slot past the count holds anything)
     if (first >= cnt) return;                              // (most workgroups: the list is short)
 #pragma unroll
     for (int q = 0; q < NF; ++q) {
         const int i = tid + q * 256, d = i / (2 * O), rem = i - d * 2 * O;
         if (i < 4 * 2 * O) s_flags[d][rem / O][rem % O] = fl[q];
     }
-    if (tid < 4 * R * R) s_inv[tid] = inv;
+    if (tid < 4 * RR) { s_inv[tid] = inv; s_fwd[tid] = fwd; }
+    if (tid < 4 * 16) s_clsimg[tid] = ci;
     const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
     for (int it = first; it < cnt; it += nblocks / PARTS) {
-        if (it != first) item = p.ego_miss[it];
+        if (it != first) { item = p.ego_miss[it]; info = tid < RR ? p.ego_cellinfo[(size_t)item.x * RR + tid] : 0u; }
         const int e = (int)item.x, k = item.y & 0xff, slot = (item.y >> 8) & 0xff, dir = (item.y >> 16) & 3;
         __syncthreads();
-        // every tap that falls inside the view falls into cell k: the whole table shows the goal's image
-        if (tid < R * R) s_cells[tid] = EgoCell{p.goal_img + ((size_t)e * p.num_goals + slot) * 4096, -1, -1};
+        // the env's view: lane = square of the frame, stored under the view cell it shows
+        if (tid < RR) {
+            EgoCell c;
+            if (info & 0x8000u) c = EgoCell{p.goal_img + ((size_t)e * p.num_goals + (info & 0xfu)) * 4096, -1, -1};
+            else { const uint2 q = s_clsimg[dir * p.ego_ncls + (int)((info >> 16) & 0xffu)]; c = EgoCell{atlas4 + q.x, (int)q.y, -1}; }
+            s_cells[s_fwd[dir * RR + tid]] = c;
+        }
         __syncthreads();
-        const int f = s_inv[dir * (R * R) + k];                              // the square view cell k occupies
-        const int x0 = (f % R) * U, y0 = (f / R) * U;
+        const int f = s_inv[dir * RR + k];                                   // the square view cell k occupies
+        const int fx = f % R, fy = f / R, x0 = fx * U, y0 = fy * U;
         const uint16_t *rt = s_flags[dir][0], *ct = s_flags[dir][1];
         EgoCtx ctx{s_cells, white, black, R, 64 * R, dir};
-        const int entry = (slot * R * R + k) * 4 + dir;
-        uint8_t *dst = p.ego_cache + ((size_t)e * p.num_goals * (R * R * 4) + entry) * p.ego_cache_entry;
+        const int entry = (slot * RR + k) * 4 + dir;
+        uint8_t *dst = p.ego_cache + ((size_t)e * p.num_goals * (RR * 4) + entry) * p.ego_cache_entry;
         const int j = part * PP + tid;
         if (tid < PP && j < U * U) {
             const int py = j / U, px = j - py * U, ox = x0 + px, oy = y0 + py;
             const uint32_t fl = (uint32_t)rt[oy] | (uint32_t)ct[ox];
-            if (!(fl & EGO_BORDER)) {
-                if (fl & EGO_EDGE) ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, 0);
-                else ego_pixel<CH, -1, true>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, 0);
+            // (a pixel of the border row / column blends the neighbours; an edge pixel has taps outside the view; the rest lie in cell k)
+            if (fl & (EGO_BORDER | EGO_EDGE)) ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, 0);
+            else ego_pixel<CH, -1, true>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, k);
+        }
+        const int x = part * XP + tid - PP;
+        if (tid >= PP && tid < PP + XP && x < NX) {
+            const bool below = x < U, right = !below && x < 2 * U;
+            const int q = below ? x : x - U;
+            const int ox = below ? x0 + q : x0 + U, oy = below ? y0 + U : (right ? y0 + q : y0 + U);
+            const bool ok = below ? (fy + 1 < R && (rt[oy] & EGO_BORDER)) : (right ? (fx + 1 < R && (ct[ox] & EGO_BORDER))
+                                  : (fx + 1 < R && fy + 1 < R && (rt[oy] & EGO_BORDER) && (ct[ox] & EGO_BORDER)));
+            if (ok) {
+                if (below) ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst + E::BELOW, U, q, ox, oy, 0);
+                else if (right) ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst + E::RIGHT, U, q, ox, oy, 0);
+                else ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst + E::DIAG, 1, 0, ox, oy, 0);
             }
         }
         // (the bit is read by kernels launched after this one: all four parts are complete by then)
@@ -909,10 +972,21 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
     }
 }
 
-// ego_border[env][line][channel][O], line fy - 1 = the border row at frame row fy * U, line r - 1 + fx - 1 = the border column
-// at frame column fx * U (indexed by output row): the pixels of those lines that the square table (ego_tab3: the cell and its
-// neighbour show images every env shares) cannot hold -- a run of U pixels next to a goal cell, and the pixels where a
-// border row crosses a border column (four cells).  EPW envs per workgroup, lanes = consecutive pixels of a run.
+// The goal cells the cache lacks, four workgroups each.
+template <int CH, int R>
+__global__ __launch_bounds__(256) void xw_ego_eval_kernel(XwParams p, const uint32_t *atlas4, const uint16_t *layout, const uint8_t *map,
+                                                          int publish, const EgoTap *comp) {
+    // (this kernel running = the cells kernel queued before it is complete: xw_device.h, epochs instead of event packets)
+    if (publish && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 5, p.sig_epoch);
+    __shared__ EgoTap s_row[84][3], s_col[84][3];         // composed taps
+    {   // (the host composed them: xw_ego_tables -- requested here, in front of everything else the body waits for)
+        constexpr int O = R * (84 / R);
+        for (int i = threadIdx.x; i < 3 * O; i += 256) { (&s_row[0][0])[i] = comp[i]; (&s_col[0][0])[i] = comp[3 * O + i]; }
+    }
+    ego_miss_body<CH, R>(p, atlas4, layout, map, (int)blockIdx.x, (int)gridDim.x, s_row, s_col);
+}
+
+// ego_cell_of_info: what a cell word of xw_ego_cells_kernel's ego_cellinfo shows (the table kernels below)
 __device__ __forceinline__ EgoCell ego_cell_of_info(const XwParams &p, const uint32_t *atlas4, uint32_t info, int e, int dir) {
     const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
     EgoCell c{black, 0, -1};
@@ -923,100 +997,52 @@ __device__ __forceinline__ EgoCell ego_cell_of_info(const XwParams &p, const uin
     return c;
 }
 
-template <int CH, int R>
-__device__ __forceinline__ void ego_border_body(const XwParams &p, const uint32_t *atlas4, const EgoTap *tap_h1, const EgoTap *tap_v1,
-                                                const EgoTap *tap_h2, const EgoTap *tap_v2, const uint8_t *map, int skip_term, int block,
-                                                const int32_t *count_now, EgoTap (*s_row)[3], EgoTap (*s_col)[3]) {
-    constexpr int U = 84 / R, O = R * U, EPW = EgoBorderGeom<R>::EPW, NL = 2 * (R - 1);
-    constexpr int NSEG = R * (R - 1), NITEM = 2 * NSEG + (R - 1) * (R - 1);   // row runs, column runs, crossings
-    constexpr int RL = 4 * R * R, CL = RL + 4 * R;
-    // (s_row / s_col: the kernel's, shared with the other body)
-    __shared__ EgoCell s_cells[EPW][R * R];
-    __shared__ uint8_t s_goal[EPW][R * R];               // view cell shows a goal
-    __shared__ uint8_t s_map[4 * R * R + 8 * R], s_edir[EPW];
-    __shared__ uint16_t s_runs[EPW * 2 * NSEG], s_cross[EPW * (R - 1) * (R - 1)];
-    __shared__ int s_nrun, s_ncross;
-    __shared__ int s_eid[EPW];
-    const int tid = threadIdx.x, e_base = block * EPW, total = count_now ? *count_now : p.n;      // (a count: the done list's envs)
-    if (e_base >= total) return;
-    if (tid == 0) { s_nrun = 0; s_ncross = 0; }
-    for (int i = tid; i < 4 * R * R + 8 * R; i += 256) s_map[i] = map[i];
-    for (int i = tid; i < EPW * R * R; i += 256) {
-        const int le = i / (R * R), f = i - le * (R * R), ix = e_base + le < total ? e_base + le : total - 1;
-        const int e = count_now ? p.done_list[ix] : ix;
-        const uint32_t info = p.ego_cellinfo[(size_t)e * (R * R) + f];
-        const int dir = (int)(info >> 24) & 3, k = map[dir * (R * R) + f];
-        s_cells[le][k] = ego_cell_of_info(p, atlas4, info, e, dir);
-        s_goal[le][k] = (info & 0x8000u) ? 1 : 0;
-        if (f == 0) { s_edir[le] = (uint8_t)(e_base + le < total && !(skip_term && p.term_flag[e]) ? dir : 4); s_eid[le] = e; }   // 4: nothing to do
-    }
-    __syncthreads();
-    // which runs / crossings this workgroup has to evaluate
-    for (int i = tid; i < EPW * NITEM; i += 256) {
-        const int le = i / NITEM, it = i - le * NITEM, dir = s_edir[le];
-        bool need = false;
-        if (dir < 4) {
-            const uint8_t *cm = s_map + dir * (R * R);
-            if (it < NSEG) {                              // the run of border row fy over square column fx
-                const int fy = it / R + 1, fx = it % R;
-                need = s_map[RL + dir * R + fy] != 0xff && (s_goal[le][cm[(fy - 1) * R + fx]] | s_goal[le][cm[fy * R + fx]]);
-            } else if (it < 2 * NSEG) {                   // the run of border column fx over square row fy
-                const int q = it - NSEG, fx = q / R + 1, fy = q % R;
-                need = s_map[CL + dir * R + fx] != 0xff && (s_goal[le][cm[fy * R + fx - 1]] | s_goal[le][cm[fy * R + fx]]);
-            } else {
-                const int q = it - 2 * NSEG, fy = q / (R - 1) + 1, fx = q % (R - 1) + 1;
-                need = s_map[RL + dir * R + fy] != 0xff && s_map[CL + dir * R + fx] != 0xff;
-            }
-        }
-        // compacted: a run gets UP consecutive lanes, a crossing one (evaluating straight off the sparse item table kept one
-        // lane in a few busy and cost ~450 VALU instructions per pass: 1 235 per wave, the kernel was VALU-bound)
-        if (need) {
-            if (it < 2 * NSEG) s_runs[atomicAdd(&s_nrun, 1)] = (uint16_t)i;
-            else s_cross[atomicAdd(&s_ncross, 1)] = (uint16_t)i;
-        }
-    }
-    __syncthreads();
-    const int nrun = s_nrun, ncross = s_ncross;
-    if (nrun + ncross == 0) return;
-    const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
-    constexpr int UP = U <= 16 ? 16 : 32;                 // lanes per run
-    for (int i = tid; i < nrun * UP + ncross; i += 256) {
-        const bool is_run = i < nrun * UP;
-        const int gi = is_run ? s_runs[i / UP] : s_cross[i - nrun * UP], j = is_run ? i % UP : 0;
-        if (j >= U) continue;
-        const int le = gi / NITEM, it = gi - le * NITEM, dir = s_edir[le];
-        int ox, oy, line, o;
-        if (it < NSEG) {
-            const int fy = it / R + 1, fx = it % R;
-            ox = fx * U + j; oy = fy * U; line = fy - 1; o = ox;
-        } else if (it < 2 * NSEG) {
-            const int q = it - NSEG, fx = q / R + 1, fy = q % R;
-            ox = fx * U; oy = fy * U + j; line = R - 1 + fx - 1; o = oy;
-        } else {
-            const int q = it - 2 * NSEG, fy = q / (R - 1) + 1, fx = q % (R - 1) + 1;
-            ox = fx * U; oy = fy * U; line = R - 1 + fx - 1; o = oy;
-        }
-        EgoCtx ctx{s_cells[le], white, black, R, 64 * R, dir};
-        uint8_t *dst = p.ego_border + ((size_t)s_eid[le] * NL + line) * (CH * O);
-        ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst, O, o, ox, oy, 0);
-    }
+// ego_clsimg [heading][class]: the image a class shows under a heading, as (pixel offset in the atlas, index mask)
+__global__ __launch_bounds__(64) void xw_ego_build_clsimg_kernel(XwParams p, const uint32_t *atlas4, uint2 *out) {
+    const int nc = p.ego_ncls, tid = threadIdx.x;
+    if (tid >= 4 * nc) return;
+    const EgoCell c = ego_cell_of_info(p, atlas4, (uint32_t)p.ego_cls_icon[tid % nc] << 2, 0, tid / nc);
+    out[tid] = make_uint2((uint32_t)(c.img - atlas4), (uint32_t)c.mask);
 }
 
-// Both in one launch (they are independent, short and latency-bound: side by side they take the time of the longer one): the
-// first nb_border workgroups evaluate border lines, the rest listed goal cells.
+// ego_xtab [heading][c][a][l][d][square]: the pixel where the border row and the border column of a square cross -- it blends the
+// square's own cell (class c), the cell above (a), the one to the left (l) and the one above left (d), which no table of
+// squares keyed by three classes can hold.  One workgroup per (heading, c, a, l, d); a lane per crossing would need a cell table
+// of its own, so the crossings take turns (once per batch).
 template <int CH, int R>
-__global__ __launch_bounds__(256) void xw_ego_eval_kernel(XwParams p, const uint32_t *atlas4, const EgoTap *tap_h1, const EgoTap *tap_v1,
-                                                          const EgoTap *tap_h2, const EgoTap *tap_v2, const uint16_t *layout, const uint8_t *map,
-                                                          int skip_term, int nb_border, const int32_t *list_count, int publish, const EgoTap *comp) {
-    // (this kernel running = the cells kernel queued before it is complete: xw_device.h, epochs instead of event packets)
-    if (publish && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 5, p.sig_epoch);
-    __shared__ EgoTap s_row[84][3], s_col[84][3];         // composed taps: one copy for whichever body this workgroup runs
-    {   // (the host composed them: xw_ego_tables -- requested here, in front of everything else either body waits for)
-        constexpr int O = R * (84 / R);
-        for (int i = threadIdx.x; i < 3 * O; i += 256) { (&s_row[0][0])[i] = comp[i]; (&s_col[0][0])[i] = comp[3 * O + i]; }
+__global__ __launch_bounds__(64) void xw_ego_build_xtab_kernel(XwParams p, const uint32_t *atlas4, const EgoTap *comp, const uint16_t *layout,
+                                                               const uint8_t *map, uint32_t *xtab) {
+    constexpr int U = 84 / R, O = R * U, RR = R * R;
+    __shared__ EgoTap s_row[84][3], s_col[84][3];
+    __shared__ EgoCell s_cells[RR];
+    __shared__ uint8_t s_px[4];
+    const int tid = threadIdx.x, nc = p.ego_ncls;
+    int id = blockIdx.x;
+    const int d = id % nc; id /= nc;
+    const int l = id % nc; id /= nc;
+    const int a = id % nc; id /= nc;
+    const int c = id % nc, dir = id / nc;
+    for (int i = tid; i < 3 * O; i += 64) { (&s_row[0][0])[i] = comp[i]; (&s_col[0][0])[i] = comp[3 * O + i]; }
+    const uint16_t *L = layout + (size_t)dir * ego_layout_words(O, R), *rt = L, *ct = L + O;
+    const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
+    for (int sq = 0; sq < RR; ++sq) {
+        const int fy = sq / R, fx = sq % R;
+        uint32_t v = 0;
+        if (fy > 0 && fx > 0 && (rt[fy * U] & EGO_BORDER) && (ct[fx * U] & EGO_BORDER)) {       // (uniform)
+            __syncthreads();
+            if (tid < RR) {
+                const int gy = tid / R, gx = tid % R;
+                const int cls = (gy == fy - 1 && gx == fx) ? a : ((gy == fy && gx == fx - 1) ? l : ((gy == fy - 1 && gx == fx - 1) ? d : c));
+                s_cells[map[dir * RR + tid]] = ego_cell_of_info(p, atlas4, (uint32_t)p.ego_cls_icon[cls] << 2, 0, dir);
+            }
+            __syncthreads();
+            EgoCtx ctx{s_cells, white, black, R, 64 * R, dir};
+            if (tid == 0) ego_pixel<CH, -1, false>(ctx, s_row, s_col, s_px, 1, 0, fx * U, fy * U, 0);
+            __syncthreads();
+            v = CH == 3 ? (uint32_t)s_px[0] | (uint32_t)s_px[1] << 8 | (uint32_t)s_px[2] << 16 : (uint32_t)s_px[0];
+        }
+        if (tid == 0) xtab[(size_t)blockIdx.x * RR + sq] = v;
     }
-    if ((int)blockIdx.x < nb_border) ego_border_body<CH, R>(p, atlas4, tap_h1, tap_v1, tap_h2, tap_v2, map, skip_term, blockIdx.x, list_count, s_row, s_col);
-    else ego_miss_body<CH, R>(p, atlas4, tap_h1, tap_v1, tap_h2, tap_v2, layout, map, (int)blockIdx.x - nb_border, (int)gridDim.x - nb_border, s_row, s_col);
 }
 
 // ego_tab3: the squares of every constant-image neighbourhood.  Entry (heading, c, a, l, channel, square) = the pixels of that
@@ -1084,10 +1110,6 @@ struct EgoSpanGeom {
 // the cell (its lines are evaluated per env into ego_border) or where a border row crosses a border column (four cells)
 // does the unit's lane place a row or first dwords itself -- the pieces leave those dwords alone.
 // flag_all: the context flag of every env touched (list render), -1: the cell words say.
-// The span's LDS belongs to the kernel (EGO_GATHER_LDS declares it; the fused kernel lays it over its front's arrays).
-// FUSED (xw_ego_fused_kernel): the cell words and the evaluated border lines of the envs from e0 on are in LDS (csrc, lines_lds)
-// instead of ego_cellsrc / ego_border, and the barriers order LDS only -- the workgroup goes on to its next span with this one's
-// stores still on their way.
 struct EgoGatherLds { uint4 *out4; uint32_t *env; const uint8_t **usrc; int *uo; };
 #define EGO_GATHER_LDS(G, R_, name) \
     __shared__ uint4 name##_out4[(G::GB + G::SB + G::GB) / 16 + 17]; \
@@ -1095,14 +1117,8 @@ struct EgoGatherLds { uint4 *out4; uint32_t *env; const uint8_t **usrc; int *uo;
     __shared__ const uint8_t *name##_usrc[EgoUnitShfl<R_>::value ? 1 : G::NU]; \
     __shared__ int name##_uo[EgoUnitShfl<R_>::value ? 1 : G::NU]; \
     const EgoGatherLds name{name##_out4, name##_env, name##_usrc, name##_uo}
-__device__ __forceinline__ void ego_lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-template <int CH, int R, bool CTX1, int ES, int PER, bool FUSED = false>
-__device__ __forceinline__ void ego_gather_span(const XwParams &p, const EgoGatherLds &lds, unsigned e0, unsigned cr, int nc, int skip_term, int flag_all,
-                                                const uint32_t *csrc = nullptr, const uint8_t *lines_lds = nullptr) {
+template <int CH, int R, bool CTX1, int ES, int PER>
+__device__ __forceinline__ void ego_gather_span(const XwParams &p, const EgoGatherLds &lds, unsigned e0, unsigned cr, int nc, int skip_term, int flag_all) {
     typedef EgoSq<R> Q;
     constexpr int BS = EGO_BS, SPAN = BS * PER;
     constexpr int U = Q::U, UD = Q::UD, O = R * U, RR = R * R;
@@ -1120,7 +1136,7 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, const EgoGath
     static_assert(64 % PPU == 0 && BS % 64 == 0, "whole units per wavefront");
     constexpr int NE = SB / (int)FB + 2;                                    // envs a span can touch
     constexpr int cpf = (int)FB / BPC;
-    constexpr int NL = 2 * (R - 1);
+    typedef EgoEntry<CH, R> EN;
     static_assert(GB % 16 == 0 && U % 4 == 0, "aligned pieces");
     static_assert(4 * Q::UP <= 128, "a unit fits the constant line");
     static_assert(NE == EgoSpanGeom<CH, R, ES, PER>::SB / (int)EgoSpanGeom<CH, R, ES, PER>::FB + 2 && NU == EgoSpanGeom<CH, R, ES, PER>::NU, "EGO_GATHER_LDS sizes");
@@ -1133,9 +1149,10 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, const EgoGath
     const unsigned br = cr * BPC, be = br + (unsigned)nc * BPC;             // bytes, from the start of env e0's frame
     const int ne = (int)((be - 1) / FB) + 1;
     typedef const unsigned int __attribute__((address_space(1))) *g_u32;
+    typedef const unsigned char __attribute__((address_space(1))) *g_u8;
     typedef const u32x4 __attribute__((address_space(1))) *g_u32x4;
     const unsigned g0 = br / GB, g1 = (be + GB - 1) / GB;                   // row groups, counted from env e0's first
-    if (tid >= BS - ne) s_env[BS - 1 - tid] = FUSED ? csrc[(BS - 1 - tid) * RR] : p.ego_cellsrc[((size_t)e0 + (BS - 1 - tid)) * RR];
+    if (tid >= BS - ne) s_env[BS - 1 - tid] = p.ego_cellsrc[((size_t)e0 + (BS - 1 - tid)) * RR].x;
     const size_t env_cache = (size_t)p.num_goals * (RR * 4) * p.ego_cache_entry;
     int uo[ITU];                                                            // the unit's first dword in s_out | flags << 24, -1: none
     const uint8_t *usrc_r[ITU];
@@ -1157,40 +1174,34 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, const EgoGath
         usrc_r[iu] = p.ego_tab3;
         if (ut < NU && gq < g1) {
             const unsigned le = gq / GPF, gi = gq - le * GPF, ch = gi / GPP, oy0 = 4u * (gi - ch * GPP), fy = oy0 / (unsigned)U, py0 = oy0 - fy * U;
-            uint32_t w = FUSED ? csrc[le * RR + fy * R + fx] : p.ego_cellsrc[((size_t)e0 + le) * RR + fy * R + fx];
+            const uint2 ww = p.ego_cellsrc[((size_t)e0 + le) * RR + fy * R + fx];
+            uint32_t w = ww.x;
+            const uint32_t w2 = ww.y;
             if (skip_term && (w >> 27 & 1u)) w = 0;
             const bool cached = (w >> 23 & 1u) != 0;
             const uint32_t flat = w >> 30;
-            const uint8_t *base = cached ? p.ego_cache + ((size_t)e0 + le) * env_cache : p.ego_tab3;
+            const uint8_t *ecache = p.ego_cache + ((size_t)e0 + le) * env_cache;
+            const uint8_t *base = cached ? ecache : p.ego_tab3;
             const uint8_t *from = base + (size_t)(w & 0x7fffffu) * 16 + ch * (cached ? (unsigned)Q::CBP : (unsigned)Q::PBP) + py0 * Q::UP;
             // a flat square: every unit of it is the same 4 * UP bytes -- one line shared by the whole batch (L1-resident)
             const uint8_t *usrc = flat ? p.ego_constline + (flat - 1u) * 128u : from;
             usrc_r[iu] = usrc;
-            // what this lane places itself: bit 0 the first row (evaluated for this env), bit 1 the first dword of every row
-            // (an evaluated border column), bit 2 the first dword of the first row (the crossing)
+            // what this lane places itself: bit 0 the first row (it blends the goal above), bit 1 the first dword of every row
+            // (a border column that blends the goal to the left), bit 2 the first dword of the first row (the crossing)
             const bool f_row = (w >> 24 & 1u) && py0 == 0, f_col = (w >> 25 & 1u) != 0, f_x = (w >> 26 & 1u) && py0 == 0 && !f_col;
             uo[iu] = ((int)(GB + gq * GB - br) / 4 + (int)(fx * UD)) | (f_row ? 1 << 24 : 0) | (f_col ? 2 << 24 : 0) | (f_x ? 4 << 24 : 0);
-            // What this lane will place itself (rare: a goal in or next to the cell, a crossing) is fetched NOW, with the
-            // cell word just read: the round trip runs under the barrier and the pieces' own loads instead of after them
-            // (round 4: it was a dependent round trip at the end of nearly every workgroup, ~0.4 of its ~6 us)
+            // What this lane will place itself (rare: a goal next to the cell; one byte per crossing) is fetched NOW, with the
+            // cell words just read: the round trip runs under the barrier and the pieces' own loads instead of after them
+            // (round 4: it was a dependent round trip at the end of nearly every workgroup, ~0.4 of its ~6 us).  Round 5: the
+            // lines come from the goals' cache entries (EgoEntry) and the plain crossing pixel rides in the second cell word.
             if (f_row || f_col || f_x) {
                 const uint8_t *src = usrc;
-                if (FUSED) {
-                    const uint8_t *lines = lines_lds + (le * NL * CH + ch) * O;
-                    if (f_col || f_x) pcb[iu] = *reinterpret_cast<const uint32_t *>(lines + (R - 1 + fx - 1) * (CH * O) + oy0);
-                    if (f_row) {
-                        const uint8_t *row = lines + (fy - 1) * (CH * O) + fx * U;
+                if (f_col) pcb[iu] = *(g_u32)(ecache + (size_t)((w2 >> 12) & 0xfffu) * p.ego_cache_entry + EN::RIGHT + ch * U + py0);
+                else if (!f_row) pcb[iu] = (w2 >> 31) ? (uint32_t)*(g_u8)(ecache + (size_t)(w2 & 0xfffu) * p.ego_cache_entry + EN::DIAG + ch) : (w2 >> (8 * ch)) & 0xffu;
+                if (f_row) {
+                    const uint8_t *row = ecache + (size_t)(w2 & 0xfffu) * p.ego_cache_entry + EN::BELOW + ch * U;
 #pragma unroll
-                        for (int d = 0; d < UD; ++d) prow[iu][d] = *reinterpret_cast<const uint32_t *>(row + 4 * d);
-                    }
-                } else {
-                    const uint8_t *lines = p.ego_border + (((size_t)e0 + le) * NL * CH + ch) * O;
-                    if (f_col || f_x) pcb[iu] = *(g_u32)(lines + (size_t)(R - 1 + fx - 1) * (CH * O) + oy0);
-                    if (f_row) {
-                        const uint8_t *row = lines + (size_t)(fy - 1) * (CH * O) + fx * U;
-#pragma unroll
-                        for (int d = 0; d < UD; ++d) prow[iu][d] = *(g_u32)(row + 4 * d);
-                    }
+                    for (int d = 0; d < UD; ++d) prow[iu][d] = *(g_u32)(row + 4 * d);
                 }
                 if (f_col || f_x) {
 #pragma unroll
@@ -1200,7 +1211,7 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, const EgoGath
         }
         if (!SHFL && ut < NU) { s_uo[ut] = uo[iu]; s_usrc[ut] = usrc_r[iu]; }
     }
-    if (!SHFL) { if (FUSED) ego_lds_barrier(); else __syncthreads(); }
+    if (!SHFL) __syncthreads();
     // ---- one lane per 16-byte piece
     {
         u32x4 q[ITP];
@@ -1302,7 +1313,7 @@ __device__ __forceinline__ void ego_gather_span(const XwParams &p, const EgoGath
             }
         }
     }
-    if (FUSED) ego_lds_barrier(); else __syncthreads();
+    __syncthreads();
     uint4 *obs4 = reinterpret_cast<uint4 *>(p.obs);
     const float scale = (float)(1 / 255.0);
     bool any_skip = false;                                                  // (uniform: a scalar branch)
@@ -1379,328 +1390,6 @@ __global__ __launch_bounds__(EGO_BS) void xw_ego_gather_list_kernel(XwParams p, 
     if (blockIdx.x == 0 && threadIdx.x == 0) *p.ego_miss_count = 0;          // (the list this path's cells kernel filled is consumed)
 }
 
-#ifdef XWB_EGO_FUSED_LAB
-// ------------------------------------------------------------------------------------------------ fused span render ----
-// LAB BUILD ONLY (XWB_EXTRA_FLAGS=-DXWB_EGO_FUSED_LAB, tools/lab/ego_fused_ab.sh; selected with XWB_DEBUG=ego_fused=N).  Built,
-// frame-exact (tests/test_gpu_ego.py, test_gpu_doc_image.py green under it) and SLOWER than the three-kernel path -- measured
-// round 5, r = 3, C4-sized batch, same box: this kernel 426 us (evaluation stubbed: ~170 us) against cells 19 + eval 42 + gather
-// 126 us; profiles/NOTES.md "round 5: the fused egocentric render" says why.  Kept out of the product build.
-// Round 5: ONE kernel in which a workgroup owns E consecutive envs end to end -- cell table -> the
-// pixels that have to be evaluated (border runs next to goals, crossings: into LDS, never to HBM; goal cells the cache lacks:
-// into the cache) -> the gather of their frames, span after span, with the stores of a span on their way while the next one is
-// assembled (ego_lds_barrier: the barriers order LDS only).  The three-kernel form above runs its two front kernels -- chains of
-// dependent round trips over a few thousand wavefronts -- with HBM idle (~60 us of a 190 us render at r = 3); here the front of a
-// workgroup runs under the stores of the workgroups that started before it.
-// E = 8: 8 frames of 84 x 84 x {1, 3} bytes are a whole number of 128-byte lines, so every workgroup starts on a line (80 x 80
-// frames do for every E).
-struct EgoFusedFront {
-    EgoTap row[84][3], col[84][3];                 // composed taps (evaluation only)
-    uint4 gc[8];                                    // goal slot -> cell tables
-    int axy[8];
-    uint8_t dir[8], term[8], fresh[8], edir[8];
-    int nrun, ncross, nmiss, pad;
-};
-template <int R, int E>
-struct EgoFusedLds {
-    static constexpr int RR = R * R, NSEG = R * (R - 1);
-    // byte offsets into the workgroup's dynamic LDS of what follows the fixed part; cells = max_dim^2, ni = n_icons
-    static constexpr int CELLS = (int)((sizeof(EgoFusedFront) + 15) & ~15u);       // EgoCell[E][RR]
-    static constexpr int GCELLS = CELLS + E * RR * (int)sizeof(EgoCell);             // EgoCell[RR]: "every cell shows this goal's image"
-    static constexpr int SQ = GCELLS + RR * (int)sizeof(EgoCell);                    // uint32[E][RR]
-    static constexpr int MISS = SQ + E * RR * 4;                                      // uint32[E * RR]
-    static constexpr int RUNS = MISS + E * RR * 4;                                    // uint16[E * 2 * NSEG]
-    static constexpr int CROSS = RUNS + ((E * 2 * NSEG * 2 + 15) & ~15);              // uint16[E * (R - 1)^2]
-    static constexpr int GOAL = CROSS + ((E * (R - 1) * (R - 1) * 2 + 15) & ~15);     // uint8[E][RR]
-    static constexpr int MAP = GOAL + ((E * RR + 15) & ~15);                          // uint8[8 RR + 8 R]
-    static constexpr int CODE = MAP + ((8 * RR + 8 * R + 15) & ~15);                  // uint16[E][cells], then uint8 type[E][cells], itype[ni], cls[ni + 2]
-    __host__ __device__ static constexpr int type_off(int cells) { return CODE + ((E * cells * 2 + 15) & ~15); }
-    __host__ __device__ static constexpr int itype_off(int cells) { return type_off(cells) + ((E * cells + 15) & ~15); }
-    __host__ __device__ static constexpr int cls_off(int cells, int ni) { return itype_off(cells) + ((ni + 15) & ~15); }
-    __host__ __device__ static constexpr int front_bytes(int cells, int ni) { return cls_off(cells, ni) + ((ni + 2 + 15) & ~15); }
-};
-
-template <int CH, int R, bool CTX1, int ES, int PER, int E>
-__global__ __launch_bounds__(EGO_BS) void xw_ego_fused_kernel(XwParams p, const uint8_t *map, const EgoTap *comp, const uint16_t *layout,
-                                                              const uint32_t *atlas4, int skip_term, int publish_step, int publish_list, int no_eval) {
-    typedef EgoSpanGeom<CH, R, ES, PER> G;
-    typedef EgoSq<R> Sq;
-    typedef EgoFusedLds<R, E> L;
-    constexpr int BS = EGO_BS, RR = R * R, U = 84 / R, O = R * U, NL = 2 * (R - 1), TPE = BS / E;
-    constexpr int NSEG = R * (R - 1), NITEM = 2 * NSEG + (R - 1) * (R - 1);
-    constexpr int RL = 4 * RR, CL = RL + 4 * R, INV = CL + 4 * R;
-    static_assert(E <= 8 && BS % E == 0 && E * 16 <= BS, "lanes per env");
-    extern __shared__ uint4 smem4[];
-    __shared__ uint32_t s_src[E][RR];                        // the squares' source words (what ego_cellsrc holds on the three-kernel path)
-    __shared__ uint4 s_border4[(E * NL * CH * O + 15) / 16]; // the evaluated border lines of the workgroup's envs: [env][line][channel][O]
-    uint8_t *const s_border = reinterpret_cast<uint8_t *>(s_border4);
-    uint8_t *const sm = reinterpret_cast<uint8_t *>(smem4);
-    EgoFusedFront &F = *reinterpret_cast<EgoFusedFront *>(sm);
-    EgoCell (*s_cells)[RR] = reinterpret_cast<EgoCell (*)[RR]>(sm + L::CELLS);
-    EgoCell *s_gcells = reinterpret_cast<EgoCell *>(sm + L::GCELLS);
-    uint32_t (*s_sq)[RR] = reinterpret_cast<uint32_t (*)[RR]>(sm + L::SQ);
-    uint32_t *s_miss = reinterpret_cast<uint32_t *>(sm + L::MISS);
-    uint16_t *s_runs = reinterpret_cast<uint16_t *>(sm + L::RUNS), *s_cross = reinterpret_cast<uint16_t *>(sm + L::CROSS);
-    uint8_t (*s_goal)[RR] = reinterpret_cast<uint8_t (*)[RR]>(sm + L::GOAL);
-    uint8_t *s_map = sm + L::MAP;
-    const int tid = threadIdx.x, D = p.max_dim, cells = D * D, ni = p.n_icons;
-    uint16_t *s_code = reinterpret_cast<uint16_t *>(sm + L::CODE);
-    uint8_t *s_type = sm + L::type_off(cells), *s_itype = sm + L::itype_off(cells), *s_cls = sm + L::cls_off(cells, ni);
-    const int e_base = (int)blockIdx.x * E;
-    const int n_here = p.n - e_base < E ? p.n - e_base : E;
-    if (blockIdx.x == 0 && tid == 0) {
-        // this kernel running = everything queued before it is complete: the step kernel (xwb_step_autoreset), or the three short
-        // kernels that drew the step's terminal frames from the list (xwb_step: nothing reads the finished envs' grids, goal
-        // images or the list's buffers any more)
-        if (publish_step) xw_publish_epoch(p.sync + 1, p.sig_epoch);
-        if (publish_list) { xw_publish_epoch(p.sync + 5, p.sig_epoch); xw_publish_epoch(p.sync + 6, p.sig_epoch); xw_publish_epoch(p.sync + 7, p.sig_epoch); }
-    }
-    // ---- A. the cell table (ego_cells_body, for E envs): first round trip -- everything that depends on nothing
-    {
-        constexpr int NGI = (E * XW_MAX_DIM * XW_MAX_DIM + BS - 1) / BS;
-        uint16_t gv[NGI];
-        const uint16_t *g = p.grid + (size_t)e_base * cells;
-#pragma unroll
-        for (int q = 0; q < NGI; ++q) { const int i = q * BS + tid; gv[q] = i < n_here * cells ? g[i] : (uint16_t)0; }
-        int axy = 0, dir = 0, term = 0, fresh = 0;
-        uint4 gc = make_uint4(~0u, ~0u, ~0u, ~0u);
-        if (tid < n_here) {
-            const int e = e_base + tid;
-            axy = p.agent_xy[e]; dir = p.agent_dir[e] & 3; term = p.term_flag[e]; fresh = p.fresh[e];
-            gc = reinterpret_cast<const uint4 *>(p.goal_cells)[e];
-        }
-        const uint8_t it0 = tid < ni ? p.icon_type[tid] : (uint8_t)0, it1 = tid + BS < ni ? p.icon_type[tid + BS] : (uint8_t)0;
-        const uint8_t cl0 = tid < ni + 2 ? p.ego_cls[tid] : (uint8_t)0, cl1 = tid + BS < ni + 2 ? p.ego_cls[tid + BS] : (uint8_t)0;
-        const uint8_t mp0 = tid < 8 * RR + 8 * R ? map[tid] : (uint8_t)0, mp1 = tid + BS < 8 * RR + 8 * R ? map[tid + BS] : (uint8_t)0;
-        uint4 tp = make_uint4(0, 0, 0, 0);
-        constexpr int TAP4 = 3 * O / 2;                      // uint4 (two taps) per table
-        if (!no_eval && (tid & 127) < TAP4) tp = reinterpret_cast<const uint4 *>(comp)[(tid >> 7) * TAP4 + (tid & 127)];
-#pragma unroll
-        for (int q = 0; q < NGI; ++q) { const int i = q * BS + tid; if (i < n_here * cells) s_code[i] = gv[q] & CELL_ICON_MASK; }
-        if (tid < E) { F.axy[tid] = axy; F.dir[tid] = (uint8_t)dir; F.term[tid] = (uint8_t)term; F.fresh[tid] = (uint8_t)fresh; F.gc[tid] = gc; }
-        if (tid < ni) s_itype[tid] = it0;
-        if (tid + BS < ni) s_itype[tid + BS] = it1;
-        for (int i = tid + 2 * BS; i < ni; i += BS) s_itype[i] = p.icon_type[i];
-        if (tid < ni + 2) s_cls[tid] = cl0;
-        if (tid + BS < ni + 2) s_cls[tid + BS] = cl1;
-        for (int i = tid + 2 * BS; i < ni + 2; i += BS) s_cls[i] = p.ego_cls[i];
-        if (tid < 8 * RR + 8 * R) s_map[tid] = mp0;
-        if (tid + BS < 8 * RR + 8 * R) s_map[tid + BS] = mp1;
-        static_assert(8 * 49 + 8 * 7 <= 2 * BS, "the map in two reads per lane");
-        if (!no_eval && (tid & 127) < TAP4) reinterpret_cast<uint4 *>(tid < 128 ? &F.row[0][0] : &F.col[0][0])[tid & 127] = tp;
-        if (tid == 0) { F.nrun = 0; F.ncross = 0; F.nmiss = 0; }
-    }
-    ego_lds_barrier();
-    for (int i = tid; i < n_here * cells; i += BS) { const int code = s_code[i]; s_type[i] = code ? s_itype[code - 1] : (uint8_t)3; }
-    ego_lds_barrier();
-    // the goal slot of a cell rides in its type byte (bits 2-5)
-    if (tid < n_here * XW_MAX_GOALS) {
-        const int le = tid / XW_MAX_GOALS, slot = tid - le * XW_MAX_GOALS;
-        const int cell = reinterpret_cast<const uint8_t *>(&F.gc[le])[slot];
-        if (cell < cells) s_type[le * cells + cell] |= (uint8_t)(slot << 2);
-    }
-    ego_lds_barrier();
-    // the walk: TPE lanes per env, each with the env's shadow mask (computed redundantly: a short serial chain of LDS reads) and a
-    // share of its r * r view cells
-    const int le = tid / TPE, j0 = tid - le * TPE;
-    const bool valid = le < n_here;
-    const int lv = valid ? le : 0, e = e_base + lv;
-    const int axy = F.axy[lv], dir = F.dir[lv], term = F.term[lv], fresh = F.fresh[lv];
-    const bool active = valid && !(skip_term && term);
-    {
-        const int ax = axy & 0xffff, ay = axy >> 16;
-        const uint16_t *code_e = s_code + lv * cells;
-        const uint8_t *type_e = s_type + lv * cells;
-        auto is_block = [&](int x, int y) { return (unsigned)x < (unsigned)D && (unsigned)y < (unsigned)D && (type_e[y * D + x] & 3) == 1; };
-        // XMap::image_masking (xmap.cpp:273-362), as in ego_cells_body
-        constexpr int r = R;
-        int major_x = 0, major_y = 0, minor_x = 0, minor_y = 0, scan_x0 = 0, scan_y0 = 0, xa = ax + r, ya = ay + r;
-        if (dir == 0) { xa += r / 2; major_y = 1; minor_x = 1; }
-        else if (dir == 3) { ya -= r / 2; major_x = 1; minor_y = -1; scan_y0 = r - 1; }
-        else if (dir == 2) { xa -= r / 2; major_y = 1; minor_x = -1; scan_x0 = r - 1; }
-        else { ya += r / 2; major_x = 1; minor_y = 1; }
-        const int x_st = xa - r / 2, y_st = ya - r / 2;
-        uint32_t ray = (1u << r) - 1u;
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const int o = side ? 1 : -1;
-            bool block = false;
-            int rx = ax, ry = ay;
-#pragma unroll
-            for (int k = 1; k <= r / 2; ++k) {
-                rx += o * major_x; ry += o * major_y;
-                if (block) ray &= ~(1u << (r / 2 + o * k));
-                if (is_block(rx, ry)) block = true;
-            }
-        }
-        unsigned long long shadow = 0;
-#pragma unroll
-        for (int t = 0; t < r; ++t) {
-            bool block = !((ray >> t) & 1u);
-            int cx = scan_x0 + t * major_x, cy = scan_y0 + t * major_y;
-#pragma unroll
-            for (int j = 0; j < r; ++j) {
-                if (block) shadow |= 1ull << (cy * r + cx);
-                if (is_block(x_st - r + cx, y_st - r + cy)) block = true;
-                cx += minor_x; cx = cx < 0 ? cx + r : (cx >= r ? cx - r : cx);
-                cy += minor_y; cy = cy < 0 ? cy + r : (cy >= r ? cy - r : cy);
-            }
-        }
-        if (p.no_wall_shadow) shadow = 0;
-        const uint32_t cls_white = s_cls[ni], cls_black = s_cls[ni + 1];
-        const uint32_t hd = (uint32_t)dir << 24 | (term ? 1u << 26 : 0u) | ((uint32_t)fresh & 3u) << 27;
-        for (int k = j0; k < RR; k += TPE) {
-            const int gx = x_st - r + k % r, gy = y_st - r + k / r;
-            uint32_t info = (uint32_t)((ni + 1) * 4 + dir) | cls_black << 16;
-            if (active && (unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && !((shadow >> k) & 1ull)) {
-                const int code = code_e[gy * D + gx], ty = type_e[gy * D + gx];
-                if (code == 0) info = (uint32_t)(ni * 4 + dir) | cls_white << 16;
-                else if ((ty & 3) != 0) info = (uint32_t)((code - 1) * 4 + dir) | (uint32_t)s_cls[code - 1] << 16;
-                else info = 0x8000u | (uint32_t)(ty >> 2) | (uint32_t)k << 4 | 0xffu << 16;
-            }
-            const int f = s_map[INV + dir * RR + k];
-            const uint32_t lines = (s_map[RL + dir * r + f / r] != 0xff ? 1u << 29 : 0u) | (s_map[CL + dir * r + f % r] != 0xff ? 1u << 30 : 0u);
-            if (valid) s_sq[le][f] = info | hd | lines;
-        }
-    }
-    ego_lds_barrier();
-    // the squares' source words (second round trip: the flat-colour table, the cache bits of the goal cells in view)
-    if (valid) {
-        const uint32_t nc = (uint32_t)p.ego_ncls, ch_n = (uint32_t)p.channels, entry16 = p.ego_cache_entry / 16;
-        const uint32_t *valid_e = p.ego_cache_valid + (size_t)e * p.ego_cache_words;
-        for (int f = j0; f < RR; f += TPE) {
-            if (!active) { s_src[le][f] = 1u << 27; continue; }
-            const uint32_t w = s_sq[le][f], wa = f >= R ? s_sq[le][f - R] : w, wl = f % R ? s_sq[le][f - 1] : w;
-            const bool rowb = (w >> 29 & 1u) != 0, colb = (w >> 30 & 1u) != 0, goal = (w & 0x8000u) != 0;
-            const bool row_dirty = rowb && ((wa | w) & 0x8000u), col_dirty = colb && ((wl | w) & 0x8000u);
-            const uint32_t c = (w >> 16) & 0xffu, ca = rowb && !row_dirty ? (wa >> 16) & 0xffu : c, cl = colb && !col_dirty ? (wl >> 16) & 0xffu : c;
-            const uint32_t key = (((uint32_t)dir * nc + c) * nc + ca) * nc + cl;
-            const uint32_t slot = w & 0xfu, k = (w >> 4) & 0x3fu;
-            const uint32_t off = goal ? ((slot * RR + k) * 4 + dir) * entry16 : key * ch_n * (Sq::PBP / 16) + f * (Sq::CBP / 16);
-            const int bit = (int)((slot * RR + k) * 4 + dir);
-            const uint32_t flat = goal ? 0u : (uint32_t)p.ego_flat[key * RR + f];
-            const uint32_t vw = goal ? valid_e[bit >> 5] : ~0u;
-            if (goal && !((vw >> (bit & 31)) & 1u) && !no_eval) s_miss[atomicAdd(&F.nmiss, 1)] = (uint32_t)le | k << 8 | slot << 16 | (uint32_t)dir << 24;
-            s_src[le][f] = off | (goal ? 1u << 23 : 0u) | (row_dirty ? 1u << 24 : 0u) | (col_dirty ? 1u << 25 : 0u) | (rowb && colb ? 1u << 26 : 0u) |
-                           (term ? 1u << 27 : 0u) | ((uint32_t)fresh & 3u) << 28 | flat << 30;
-        }
-    }
-    // ---- B. the pixels that have to be evaluated
-    if (!no_eval) {
-        // the view-cell descriptors of the workgroup's envs (ego_border_body)
-        for (int i = tid; i < n_here * RR; i += BS) {
-            const int l2 = i / RR, f = i - l2 * RR;
-            const uint32_t info = s_sq[l2][f];
-            const int d2 = (int)(info >> 24) & 3, k = s_map[d2 * RR + f];
-            const uint32_t *white = atlas4 + (size_t)ni * 4096, *black = white + 1;
-            EgoCell c{black, 0, -1};
-            const int t = (int)((info & 0x7fffu) >> 2);
-            if (info & 0x8000u) c = EgoCell{p.goal_img + ((size_t)(e_base + l2) * p.num_goals + (info & 0xfu)) * 4096, -1, -1};
-            else if (t == ni) c.img = white;
-            else if (t < ni) {
-                c = EgoCell{atlas4 + (size_t)t * 4096, -1, t * 4 + d2};
-                if (s_itype[t] == 2 && d2 != 1) c.img = atlas4 + p.ego_agent_rot[t] + (size_t)(d2 == 0 ? 0 : (d2 == 2 ? 1 : 2)) * 4096;
-            }
-            s_cells[l2][k] = c;
-            s_goal[l2][k] = (info & 0x8000u) ? 1 : 0;
-        }
-        if (tid < E) F.edir[tid] = (uint8_t)(tid < n_here && !(skip_term && F.term[tid]) ? F.dir[tid] : 4);
-        ego_lds_barrier();
-        for (int i = tid; i < E * NITEM; i += BS) {
-            const int l2 = i / NITEM, it = i - l2 * NITEM, d2 = F.edir[l2];
-            bool need = false;
-            if (d2 < 4) {
-                const uint8_t *cm = s_map + d2 * RR;
-                if (it < NSEG) {
-                    const int fy = it / R + 1, fx = it % R;
-                    need = s_map[RL + d2 * R + fy] != 0xff && (s_goal[l2][cm[(fy - 1) * R + fx]] | s_goal[l2][cm[fy * R + fx]]);
-                } else if (it < 2 * NSEG) {
-                    const int q = it - NSEG, fx = q / R + 1, fy = q % R;
-                    need = s_map[CL + d2 * R + fx] != 0xff && (s_goal[l2][cm[fy * R + fx - 1]] | s_goal[l2][cm[fy * R + fx]]);
-                } else {
-                    const int q = it - 2 * NSEG, fy = q / (R - 1) + 1, fx = q % (R - 1) + 1;
-                    need = s_map[RL + d2 * R + fy] != 0xff && s_map[CL + d2 * R + fx] != 0xff;
-                }
-            }
-            if (need) {
-                if (it < 2 * NSEG) s_runs[atomicAdd(&F.nrun, 1)] = (uint16_t)i;
-                else s_cross[atomicAdd(&F.ncross, 1)] = (uint16_t)i;
-            }
-        }
-        ego_lds_barrier();
-        const uint32_t *white = atlas4 + (size_t)ni * 4096, *black = white + 1;
-        {
-            const int nrun = F.nrun, ncross = F.ncross;
-            constexpr int UPL = U <= 16 ? 16 : 32;                 // lanes per run
-            for (int i = tid; i < nrun * UPL + ncross; i += BS) {
-                const bool is_run = i < nrun * UPL;
-                const int gi = is_run ? s_runs[i / UPL] : s_cross[i - nrun * UPL], j = is_run ? i % UPL : 0;
-                if (j >= U) continue;
-                const int l2 = gi / NITEM, it = gi - l2 * NITEM, d2 = F.edir[l2];
-                int ox, oy, line, o;
-                if (it < NSEG) {
-                    const int fy = it / R + 1, fx = it % R;
-                    ox = fx * U + j; oy = fy * U; line = fy - 1; o = ox;
-                } else if (it < 2 * NSEG) {
-                    const int q = it - NSEG, fx = q / R + 1, fy = q % R;
-                    ox = fx * U; oy = fy * U + j; line = R - 1 + fx - 1; o = oy;
-                } else {
-                    const int q = it - 2 * NSEG, fy = q / (R - 1) + 1, fx = q % (R - 1) + 1;
-                    ox = fx * U; oy = fy * U; line = R - 1 + fx - 1; o = oy;
-                }
-                EgoCtx ctx{s_cells[l2], white, black, R, 64 * R, d2};
-                ego_pixel<CH, -1, false>(ctx, F.row, F.col, s_border + (l2 * NL + line) * (CH * O), O, o, ox, oy, 0);
-            }
-        }
-        // goal cells the cache does not hold (ego_miss_body): one at a time, all lanes on its U x U pixels
-        const int nmiss = F.nmiss;
-        const int lw = ego_layout_words(O, R);
-        for (int m = 0; m < nmiss; ++m) {
-            const uint32_t item = s_miss[m];
-            const int l2 = item & 0xff, k = (item >> 8) & 0xff, slot = (item >> 16) & 0xff, d2 = (item >> 24) & 3, e2 = e_base + l2;
-            ego_lds_barrier();
-            if (tid < RR) s_gcells[tid] = EgoCell{p.goal_img + ((size_t)e2 * p.num_goals + slot) * 4096, -1, -1};
-            ego_lds_barrier();
-            const int f = s_map[INV + d2 * RR + k];
-            const int x0 = (f % R) * U, y0 = (f / R) * U;
-            const uint16_t *rt = layout + (size_t)d2 * lw, *ct = rt + O;
-            EgoCtx ctx{s_gcells, white, black, R, 64 * R, d2};
-            const int entry = (slot * RR + k) * 4 + d2;
-            uint8_t *dst = p.ego_cache + ((size_t)e2 * p.num_goals * (RR * 4) + entry) * p.ego_cache_entry;
-            for (int j = tid; j < U * U; j += BS) {
-                const int py = j / U, px = j - py * U, ox = x0 + px, oy = y0 + py;
-                const uint32_t fl = (uint32_t)rt[oy] | (uint32_t)ct[ox];
-                if (!(fl & EGO_BORDER)) {
-                    if (fl & EGO_EDGE) ego_pixel<CH, -1, false>(ctx, F.row, F.col, dst, Sq::CBP, py * Sq::UP + px, ox, oy, 0);
-                    else ego_pixel<CH, -1, true>(ctx, F.row, F.col, dst, Sq::CBP, py * Sq::UP + px, ox, oy, 0);
-                }
-            }
-            if (tid == 0) atomicOr(p.ego_cache_valid + (size_t)e2 * p.ego_cache_words + (entry >> 5), 1u << (entry & 31));
-        }
-        if (nmiss) __threadfence();                          // the gather below reads those cache entries back through L2
-    }
-    ego_lds_barrier();                                       // (the front's arrays are dead: the gather's lie over them)
-    // ---- C. the frames, span after span
-    EgoGatherLds lds;
-    lds.out4 = smem4;
-    lds.env = reinterpret_cast<uint32_t *>(smem4 + ((G::GB + G::SB + G::GB) / 16 + 17));
-    lds.usrc = reinterpret_cast<const uint8_t **>(lds.env + ((G::SB / (int)G::FB + 2 + 3) & ~3));
-    lds.uo = reinterpret_cast<int *>(lds.usrc + (EgoUnitShfl<R>::value ? 2 : G::NU));
-    const unsigned total = (unsigned)n_here * G::cpf;
-    for (unsigned c = 0; c < total; c += G::SPAN) {
-        if (c) ego_lds_barrier();                            // (every lane has read the previous span out of LDS)
-        const unsigned q = c / G::cpf;
-        ego_gather_span<CH, R, CTX1, ES, PER, true>(p, lds, (unsigned)e_base + q, c - q * G::cpf, (int)(total - c < (unsigned)G::SPAN ? total - c : G::SPAN),
-                                                    skip_term, -1, &s_src[q][0], s_border + q * (NL * CH * O));
-    }
-}
-template <int CH, int R, int ES, int PER, int E>
-static size_t ego_fused_lds_bytes(int cells, int ni) {
-    typedef EgoSpanGeom<CH, R, ES, PER> G;
-    const size_t gather = ((G::GB + G::SB + G::GB) / 16 + 17) * 16 + ((G::SB / (int)G::FB + 2 + 3) & ~3) * 4 + (EgoUnitShfl<R>::value ? 2 : G::NU) * 12;
-    const size_t front = (size_t)EgoFusedLds<R, E>::front_bytes(cells, ni);
-    return (gather > front ? gather : front) + 16;
-}
-#endif  // XWB_EGO_FUSED_LAB
 
 // The warped 64x64 image of every goal of the listed envs (XItem::get_item_image, xitem.cpp:46-60): cv::warpAffine with
 // the goal's inverse matrix, INTER_LINEAR, BORDER_CONSTANT white.  A goal keeps its pose for the whole episode, so this
@@ -1999,35 +1688,11 @@ hipError_t ego_span_render(const XwParams &p, const EgoTables &t, int mode, hipS
     const int skip_front = mode == 2, skip_gather = mode != 0;
     // mode 4 without events: the hand-overs to the reset's queue are epochs, published by the kernel that FOLLOWS the producer
     const int publish = mode == 4 && !ev_front && p.sig_epoch != 0;
-#ifdef XWB_EGO_FUSED_LAB
-    if (p.dbg_ego_fused && !p.obs_f32) {
-        // the fused kernel (xw_ego_fused_kernel).  mode 4: the step's terminal frames first, through the list's three short
-        // kernels (p.list_flag = 1: the caller set it); once the fused kernel runs, nothing reads the finished envs' state,
-        // their goal images or the list's buffers any more -- every hand-over to the reset's queue is due at that point.
-        if (mode == 4) {
-            const hipError_t e = ego_span_render_list<CH, R>(p, t, s, 3);
-            if (e != hipSuccess) return e;
-            if (ev_cells) { const hipError_t e2 = hipEventRecord(ev_cells, s); if (e2 != hipSuccess) return e2; }
-            if (ev_front) { const hipError_t e2 = hipEventRecord(ev_front, s); if (e2 != hipSuccess) return e2; }
-            if (ev_list) { const hipError_t e2 = hipEventRecord(ev_list, s); if (e2 != hipSuccess) return e2; }
-        }
-        const int no_eval = (p.dbg_ego_fused >> 1) & 1, variant = p.dbg_ego_fused >> 4;
-        const int publish_step = mode == 2 && p.sig_epoch != 0;
-#define EGO_FUSED(CTXV, PERV, EV) hipLaunchKernelGGL((xw_ego_fused_kernel<CH, R, CTXV, 1, PERV, EV>), dim3((unsigned)((p.n + EV - 1) / EV)), dim3(EGO_BS), \
-            (ego_fused_lds_bytes<CH, R, 1, PERV, EV>((int)cells, p.n_icons)), s, p, t.map, t.comp, t.lut, a4, skip_gather, publish_step, publish, no_eval)
-#define EGO_FUSED_V(CTXV) do { if (variant == 1) EGO_FUSED(CTXV, 2, 8); else if (variant == 2) EGO_FUSED(CTXV, 4, 4); else EGO_FUSED(CTXV, 4, 8); } while (0)
-        if (p.context == 1) EGO_FUSED_V(true); else EGO_FUSED_V(false);
-#undef EGO_FUSED_V
-#undef EGO_FUSED
-        return hipGetLastError();
-    }
-#endif
     const size_t cells_lds = 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15);
     hipLaunchKernelGGL((xw_ego_cells_kernel<R, false>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, skip_front, nullptr, mode == 2 && p.sig_epoch != 0);
     if (ev_cells) { const hipError_t e = hipEventRecord(ev_cells, s); if (e != hipSuccess) return e; }
-    const int nb_border = (p.n + EgoBorderGeom<R>::EPW - 1) / EgoBorderGeom<R>::EPW;
     const int nb_miss = p.dbg_ego_miss_blocks ? p.dbg_ego_miss_blocks : 4096;    // (a multiple of 4: four workgroups per goal cell)
-    hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + nb_miss), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, skip_front, nb_border, (const int32_t *)nullptr, publish, t.comp);
+    hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_miss), dim3(256), 0, s, p, a4, t.lut, t.map, publish, t.comp);
     if (ev_front) { const hipError_t e = hipEventRecord(ev_front, s); if (e != hipSuccess) return e; }
     const int es = p.obs_f32 ? 4 : 1;
     const unsigned long long n_chunks = (unsigned long long)p.n * (FB / (16 / es));
@@ -2062,19 +1727,31 @@ size_t xw_ego_square_tab_bytes(const XwParams &p) {
     return (size_t)4 * p.ego_ncls * p.ego_ncls * p.ego_ncls * p.channels * r * r * U * UP;
 }
 
-// bytes of one cache entry on the span path: a square, all channels, in EgoSq's layout
+// bytes of one cache entry on the span path (EgoEntry): a square in EgoSq's layout, all channels, and the lines next to it
 size_t xw_ego_square_entry_bytes(const XwParams &p) {
     const int r = p.visible_radius, U = 84 / r, UP = 4 * ((U / 4 + 3) & ~3);
-    return (size_t)p.channels * U * UP;
+    return (size_t)((p.channels * U * UP + 2 * p.channels * U + 4 + 15) & ~15);
 }
 
+size_t xw_ego_xtab_bytes(const XwParams &p) {
+    const size_t nc = (size_t)p.ego_ncls;
+    return 4 * nc * nc * nc * nc * p.visible_radius * p.visible_radius * sizeof(uint32_t);
+}
+
+// the span path's tables: ego_tab3 (squares), ego_xtab (crossing pixels), ego_clsimg -- once per batch
 hipError_t launch_xw_ego_build_squares(const XwParams &p, hipStream_t s) {
     const EgoTables t = ego_tables_of(p);
-    const int r = p.visible_radius;
+    const int r = p.visible_radius, nc = p.ego_ncls;
     const uint32_t *a4 = reinterpret_cast<const uint32_t *>(p.atlas64);
-    const unsigned blocks = (unsigned)(4 * p.ego_ncls * p.ego_ncls * p.ego_ncls * r * r);
+    const unsigned blocks = (unsigned)(4 * nc * nc * nc * r * r), xblocks = (unsigned)(4 * nc * nc * nc * nc);
     uint8_t *tab3 = const_cast<uint8_t *>(p.ego_tab3);
-#define EGO_SQ(CHV, RV) hipLaunchKernelGGL((xw_ego_build_squares_kernel<CHV, RV>), dim3(blocks), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.map, tab3)
+    uint32_t *xtab = const_cast<uint32_t *>(p.ego_xtab);
+    hipLaunchKernelGGL(xw_ego_build_clsimg_kernel, dim3(1), dim3(64), 0, s, p, a4, const_cast<uint2 *>(p.ego_clsimg));
+#define EGO_SQ(CHV, RV) do { \
+        static_assert(EgoEntry<CHV, RV>::BYTES == ((CHV * (84 / RV) * EgoSq<RV>::UP + 2 * CHV * (84 / RV) + 4 + 15) & ~15), "xw_ego_square_entry_bytes"); \
+        hipLaunchKernelGGL((xw_ego_build_squares_kernel<CHV, RV>), dim3(blocks), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.map, tab3); \
+        hipLaunchKernelGGL((xw_ego_build_xtab_kernel<CHV, RV>), dim3(xblocks), dim3(64), 0, s, p, a4, t.comp, t.lut, t.map, xtab); \
+    } while (0)
     if (p.channels == 3) { if (r == 3) EGO_SQ(3, 3); else if (r == 5) EGO_SQ(3, 5); else EGO_SQ(3, 7); }
     else { if (r == 3) EGO_SQ(1, 3); else if (r == 5) EGO_SQ(1, 5); else EGO_SQ(1, 7); }
 #undef EGO_SQ
@@ -2107,8 +1784,7 @@ hipError_t ego_span_render_list(const XwParams &p0, const EgoTables &t, hipStrea
         const int nb_cells = (p.n + EPW - 1) / EPW;
         if (parts & 4) hipLaunchKernelGGL((xw_ego_list_front_kernel<R>), dim3(nb_cells + 4096), dim3(256), cells_lds, s, p, t.map, a4, cnt, nb_cells);
         else hipLaunchKernelGGL((xw_ego_cells_kernel<R, true>), dim3(nb_cells), dim3(256), cells_lds, s, p, t.map, 0, cnt, 0);
-        const int nb_border = (p.n + EgoBorderGeom<R>::EPW - 1) / EgoBorderGeom<R>::EPW;
-        hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_border + 1024), dim3(256), 0, s, p, a4, t.h1, t.v1, t.h2, t.v2, t.lut, t.map, 0, nb_border, cnt, 0, t.comp);
+        hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(1024), dim3(256), 0, s, p, a4, t.lut, t.map, 0, t.comp);
     }
     if (!(parts & 2)) return hipGetLastError();
     const int es = p.obs_f32 ? 4 : 1;

@@ -235,13 +235,16 @@ struct XwParams {
                                  //     128-byte line (ego_constline: 128 x 0xff, 128 x 0x00), which stays in every CU's L1 -- two thirds of a
                                  //     frame's squares, whose table lines otherwise each miss to L2 (the gather was bound by L1 miss handling)
     const uint8_t *ego_constline;
-    uint32_t *ego_cellsrc;       // [n][r * r] per square: where the gather finds its pixels (xw_ego_cells_kernel has the bit layout)
+    uint2 *ego_cellsrc;          // [n][r * r] per square: where the gather finds its pixels, and what it patches in from where
+                                 //     (xw_ego_cells_kernel has the bit layout of both words)
     uint2 *ego_miss;             // goal cells the cache does not hold yet: (env, view cell | slot << 8 | heading << 16)
     int32_t *ego_miss_count;
-    uint32_t *ego_cellsrc_list;  // the same three for the done-list render, which runs beside the whole-batch gather
+    uint2 *ego_cellsrc_list;     // the same three for the done-list render, which runs beside the whole-batch gather
     uint2 *ego_miss_list;
     int32_t *ego_miss_count_list;
-    uint8_t *ego_border;         // [n][2 (r - 1)][channels][out_dim] evaluated border rows, then border columns, of each frame
+    const uint32_t *ego_xtab;    // [heading][c][a][l][d][square]: the pixel where a border row crosses a border column (B | G << 8 | R << 16, or the
+                                 //     gray value), when the four cells around it show classes c (the square's own), a (above), l (left), d (above left)
+    const uint2 *ego_clsimg;     // [heading][class]: (pixel offset of the class's image in atlas64, index mask: -1 an image, 0 one constant pixel)
     uint32_t *cand2d;            // [n] goal slots the agent can reach, blocks as the only obstacles: bits 0..15
                                  //     any goal (XWorldNavTarget), bits 16..31 coloured goals (XWorldNavColorTarget)
     const uint8_t *icon_colored; // [n_icons] properties.txt colour != "na"
@@ -294,7 +297,6 @@ struct XwParams {
     uint32_t *minstd;            // nullable: XWB_RNG_MINSTD, one libstdc++ minstd_rand0 state per env: the teacher's task draw
     int dbg_ego_per, dbg_ego_pad, dbg_render_shape;   // xwb_config.debug_* (launch-shape A/B switches; 0 = defaults)
     int dbg_ego_miss_blocks;     // XWB_DEBUG ego_miss_blocks=N: goal-cell workgroups of the whole-batch evaluation launch (0 = the default)
-    int dbg_ego_fused;           // XWB_DEBUG ego_fused=N: bit 0 the fused span render (xw_ego_fused_kernel), bit 1 its evaluation stubbed
                                  // (lab: frames wrong next to goals), bits 4.. its launch shape
     int no_draw;                 // xwb_xw_set_draw(sim, 0): the renders keep their bookkeeping (epochs, installs, fresh / done flags) and store no pixels
 };
@@ -334,6 +336,7 @@ size_t xw_ego_tab_bytes(const XwParams &p);
 hipError_t launch_xw_ego_build_tab(const XwParams &p, hipStream_t s);
 size_t xw_ego_square_tab_bytes(const XwParams &p);
 size_t xw_ego_square_entry_bytes(const XwParams &p);
+size_t xw_ego_xtab_bytes(const XwParams &p);
 hipError_t launch_xw_ego_build_squares(const XwParams &p, hipStream_t s);
 
 // host: builds the 12x12 tile table (OpenCV 3.2 fixed-point bilinear + BGR2GRAY) from 64x64 icons

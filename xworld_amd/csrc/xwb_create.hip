@@ -22,7 +22,7 @@ const char *const POISON_MSG = "a device-side queue hand-off was not released wi
 namespace {
 
 // XWB_DEBUG (include/xwb.h, xwb_config "Debug configuration"): parsed once per process, OR-ed into every batch created
-struct DebugEnv { int32_t flags = 0, ego_per = 0, ego_pad = 0, render_shape = 0, ego_fused = 0, ego_miss_blocks = 0; };
+struct DebugEnv { int32_t flags = 0, ego_per = 0, ego_pad = 0, render_shape = 0, ego_miss_blocks = 0; };
 const DebugEnv &debug_env() {
     static const DebugEnv d = [] {
         DebugEnv e;
@@ -41,7 +41,7 @@ const DebugEnv &debug_env() {
             else if (t == "ego_no_flat") e.flags |= XWB_DEBUG_EGO_NO_FLAT;
             else if (t.compare(0, 8, "ego_per=") == 0) e.ego_per = atoi(t.c_str() + 8);
             else if (t.compare(0, 8, "ego_pad=") == 0) e.ego_pad = atoi(t.c_str() + 8) + 1;
-            else if (t.compare(0, 10, "ego_fused=") == 0) e.ego_fused = atoi(t.c_str() + 10);
+            else if (t.compare(0, 10, "ego_fused=") == 0) { fprintf(stderr, "xwb: XWB_DEBUG ego_fused: the fused lab kernel was removed (see profiles/NOTES.md)\n"); }
             else if (t.compare(0, 16, "ego_miss_blocks=") == 0) { const int v = atoi(t.c_str() + 16); e.ego_miss_blocks = v >= 4 && v <= 65536 ? (v & ~3) : 0; }
             else if (t == "render_shape=64x2") e.render_shape = 1;
             else if (t == "render_shape=256x2") e.render_shape = 2;
@@ -357,7 +357,7 @@ int xw_setup(xwb_sim *s) {
     p.channels = ch; p.n_icons = c.n_icons;
     p.obs_f32 = f32 ? 1 : 0;
     p.dbg_ego_per = c.debug_ego_per; p.dbg_ego_pad = c.debug_ego_pad; p.dbg_render_shape = c.debug_render_shape;
-    p.dbg_ego_fused = debug_env().ego_fused; p.dbg_ego_miss_blocks = debug_env().ego_miss_blocks;
+    p.dbg_ego_miss_blocks = debug_env().ego_miss_blocks;
     p.n_tasks = c.n_tasks;
     p.group2d = c.n_tasks > 0 && c.tasks[0] >= XWB_TASK2D_TARGET;
     p.curriculum = curriculum ? c.curriculum : 0.0; p.cur_level = s->d_cur_level; p.cur_counter = s->d_cur_counter; p.cur_usage = s->d_cur_usage;
@@ -408,7 +408,7 @@ int xw_setup(xwb_sim *s) {
         if ((rc = dev_alloc(s, &s->d_ego_tab, xw_ego_tab_bytes(p)))) return rc;
         p.ego_tab = s->d_ego_tab;
         p.ego_cache = nullptr; p.ego_cache_valid = nullptr; p.ego_cache_entry = 0; p.ego_cache_words = 0;
-        p.ego_cellinfo = nullptr; p.ego_miss = nullptr; p.ego_miss_count = nullptr; p.ego_border = nullptr; p.ego_tab3 = nullptr; p.ego_cellsrc = nullptr;
+        p.ego_cellinfo = nullptr; p.ego_miss = nullptr; p.ego_miss_count = nullptr; p.ego_xtab = nullptr; p.ego_clsimg = nullptr; p.ego_tab3 = nullptr; p.ego_cellsrc = nullptr;
         p.ego_cellsrc_list = nullptr; p.ego_miss_list = nullptr; p.ego_miss_count_list = nullptr;
         if (p.ego_fast && !(c.debug_flags & XWB_DEBUG_EGO_NO_CACHE)) {
             // rendered goal cells, [env][goal slot][view cell][heading]: ~340 KB per env at r = 3 (11 GB for a C4-sized batch;
@@ -444,7 +444,6 @@ int xw_setup(xwb_sim *s) {
                         p.ego_cellsrc_list = s->d_ego_cellsrc_list; p.ego_miss_list = s->d_ego_miss_list; p.ego_miss_count_list = s->d_ego_miss_count_list;
                         if ((rc = dev_alloc(s, &s->d_ego_miss, (size_t)n * (p.num_goals < rr ? p.num_goals : rr)))) return rc;
                         if ((rc = dev_alloc(s, &s->d_ego_miss_count, 4))) return rc;
-                        if ((rc = dev_alloc(s, &s->d_ego_border, (size_t)n * 2 * (c.visible_radius - 1) * p.channels * p.out_dim + 16))) return rc;
                         if ((rc = dev_alloc(s, &s->d_ego_cls, cls.size()))) return rc;
                         if ((rc = dev_alloc(s, &s->d_ego_cls_icon, cls_icon.size()))) return rc;
                         HIP_TRY(hipMemcpy(s->d_ego_cls, cls.data(), cls.size(), hipMemcpyHostToDevice));
@@ -452,7 +451,9 @@ int xw_setup(xwb_sim *s) {
                         p.ego_cls = s->d_ego_cls; p.ego_cls_icon = s->d_ego_cls_icon; p.ego_ncls = (int)cls_icon.size();
                         if ((rc = dev_alloc(s, &s->d_ego_tab3, xw_ego_square_tab_bytes(p) + 16))) return rc;
                         p.ego_tab3 = s->d_ego_tab3;
-                        p.ego_border = s->d_ego_border;
+                        if ((rc = dev_alloc(s, &s->d_ego_xtab, xw_ego_xtab_bytes(p) / sizeof(uint32_t)))) return rc;
+                        if ((rc = dev_alloc(s, &s->d_ego_clsimg, (size_t)4 * 16))) return rc;
+                        p.ego_xtab = s->d_ego_xtab; p.ego_clsimg = s->d_ego_clsimg;
                         p.ego_cellinfo = s->d_ego_cellinfo; p.ego_miss = s->d_ego_miss; p.ego_miss_count = s->d_ego_miss_count;
                     }
                 } else {

@@ -138,13 +138,15 @@ struct xwb_sim {
     int ego_cell_edge = 1;
     uint8_t *d_ego_cache = nullptr;        // lazily filled cache of rendered goal cells (XwParams::ego_cache)
     uint32_t *d_ego_cache_valid = nullptr;
-    uint32_t *d_ego_cellsrc = nullptr, *d_ego_cellsrc_list = nullptr;
+    uint2 *d_ego_cellsrc = nullptr, *d_ego_cellsrc_list = nullptr;
     uint2 *d_ego_miss_list = nullptr;
     int32_t *d_ego_miss_count_list = nullptr;
     uint32_t *d_ego_cellinfo = nullptr;    // span path of the egocentric render (XwParams::ego_span)
     uint2 *d_ego_miss = nullptr;
     int32_t *d_ego_miss_count = nullptr;
-    uint8_t *d_ego_border = nullptr, *d_ego_cls = nullptr, *d_ego_tab3 = nullptr, *d_ego_flat = nullptr, *d_ego_constline = nullptr;
+    uint32_t *d_ego_xtab = nullptr;
+    uint2 *d_ego_clsimg = nullptr;
+    uint8_t *d_ego_cls = nullptr, *d_ego_tab3 = nullptr, *d_ego_flat = nullptr, *d_ego_constline = nullptr;
     uint16_t *d_ego_cls_icon = nullptr;
     double *d_goal_warp = nullptr;
     int16_t *d_icon_name = nullptr, *d_name_first = nullptr, *d_name_variants = nullptr;
