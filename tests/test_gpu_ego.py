@@ -298,6 +298,31 @@ def test_ego_span_path_equals_per_env_path(oracle, key, r, opts):
     b.close()
 
 
+@pytest.mark.parametrize("key,r,steps", [("nav8_dim5", 3, 160), ("nav7", 5, 120)])
+def test_ego_goal_lines_cached_across_revisits(oracle, key, r, steps):
+    """Round 5: a goal's cache entry also holds the border lines that blend its image (its own first row / column, the first row
+    of the square below, the first column of the square to the right, the crossing pixel below right), evaluated ONCE per (goal slot,
+    view cell, heading) on the view of that moment and reused whenever the key comes back.  On a small map the agent keeps coming
+    back to the same cells with goals next to each other, next to blocks and next to the map's edge: long episodes of the span path
+    against the one-workgroup-per-env kernel, which evaluates every such pixel on every frame."""
+    torch = _torch()
+    n = 520
+    a, _, _ = _make(oracle, key, n, r, seed=29, policy_seed=31, color=True, max_steps=400)
+    b, _, _ = _make(oracle, key, n, r, seed=29, policy_seed=31, color=True, max_steps=400, debug=["ego_no_span"])
+    assert a.ego_render_path == "span" and b.ego_render_path == "per_env"
+    for sim in (a, b):
+        sim.reset()
+    for t in range(steps):
+        for sim in (a, b):
+            sim.step()
+        assert torch.equal(a.obs, b.obs), ("stepped frames", t)
+        for sim in (a, b):
+            sim.reset_done()
+        assert torch.equal(a.obs, b.obs), ("first frames", t)
+    a.close()
+    b.close()
+
+
 def test_ego_render_path_by_geometry(oracle):
     """r = 3, 5, 7: the frame is r x r equal squares -> span path; r = 1 and r >= 9 (81, 77 pixel edges): one workgroup per env."""
     _torch()

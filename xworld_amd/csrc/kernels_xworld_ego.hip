@@ -35,11 +35,16 @@ namespace xwb {
 
 #ifdef XWB_EGO_PROF
 __device__ unsigned long long g_ego_prof[12];
+__device__ unsigned long long g_ego_prof2[12];     // stage stamps of the whole-batch cells kernel
+#define EGO_C(i) do { if (!LIST && tid == 0) { const unsigned long long now = wall_clock64(); atomicAdd(&g_ego_prof2[i], now - t_c); t_c = now; } } while (0)
+#define EGO_C0() unsigned long long t_c = wall_clock64()
 #define EGO_T0() unsigned long long t_last = wall_clock64()
 #define EGO_T(i) do { if (tid == 0) { const unsigned long long now = wall_clock64(); atomicAdd(&g_ego_prof[i], now - t_last); t_last = now; } } while (0)
 #else
 #define EGO_T0()
 #define EGO_T(i)
+#define EGO_C0()
+#define EGO_C(i)
 #endif
 
 struct EgoTap { int16_t s0, s1, w0, w1; };        // cv::resize: source indices and 11-bit weights of one output index
@@ -60,6 +65,7 @@ struct EgoCtx {
     const uint32_t *white, *black;
     int r, S;
     int dir;                     // the heading, where it is not a template argument (ego_pixel<.., -1, ..>)
+    const uint32_t *lds_img;     // ego_pixel<.., 2>: cell `one`'s 64 x 64 image, staged in LDS by the caller
 };
 
 // cv::resize INTER_LINEAR on 8-bit data, one output value: HResizeLinear (11-bit) then VResizeLinear<uchar>
@@ -72,8 +78,9 @@ __device__ __forceinline__ int vresize(int b0, int h0, int b1, int h1) {
 // row / column -- quarter turns are exact integer maps, separable in x and y; the source index S falls outside and
 // leaves one black row / column (borderValue 0).
 // (DIR = -1: the heading is c.dir, a run-time value -- the same arithmetic with selects, for lanes of mixed headings)
-// ONE: all sixteen view pixels lie in the view cell `one` (an interior pixel of that cell, whose image is indexed: a goal)
-template <int CH, int DIR, bool ONE>
+// ONE: all sixteen view pixels lie in the view cell `one` (an interior pixel of that cell, whose image is indexed: a goal);
+// 2: ... and the caller holds that image in LDS (c.lds_img): sixteen LDS reads instead of sixteen scattered loads
+template <int CH, int DIR, int ONE>
 __device__ __forceinline__ void ego_pixel(const EgoCtx &c, const EgoTap (*s_row)[3], const EgoTap (*s_col)[3],
                                           uint8_t *s_frame, int plane, int o, int ox, int oy, int one) {
     const int S = c.S;
@@ -94,13 +101,15 @@ __device__ __forceinline__ void ego_pixel(const EgoCtx &c, const EgoTap (*s_row)
         // fr is sy for headings up / down and sx for right / left (and fc the other one)
         const bool ROW_IS_Y = dir == 3 || dir == 1;
         const uint32_t *src[16];
+        int off[16];
         if (ONE) {
             const uint32_t *img = c.cells[one].img;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int i = k >> 2, j = k & 3;
                 const int px = (ROW_IS_Y ? fc[j] : fr[i]) & 63, py = (ROW_IS_Y ? fr[i] : fc[j]) & 63;
-                src[k] = img + (py * 64 + px);
+                off[k] = py * 64 + px;
+                src[k] = img + off[k];
             }
         } else {
             int cr[4], cc[4], pr[4], pc[4];
@@ -127,7 +136,7 @@ __device__ __forceinline__ void ego_pixel(const EgoCtx &c, const EgoTap (*s_row)
         typedef const uint32_t __attribute__((address_space(1))) *global_u32;
         uint32_t v[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = *(global_u32)src[k];
+        for (int k = 0; k < 16; ++k) v[k] = ONE == 2 ? c.lds_img[off[k]] : *(global_u32)src[k];
         int out[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
@@ -642,6 +651,7 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
     __shared__ uint32_t s_sq[EPW][R * R];                                   // the cell words, frame order
     const int e_base = bid * EPW, total = LIST ? *count_now : p.n;
     if (e_base >= total) return;
+    EGO_C0();
     const int n_here = total - e_base < EPW ? total - e_base : EPW;
     uint8_t *s_itype = s_type + EPW * cells;                                // [n_icons]
     uint8_t *s_cls = s_itype + ((p.n_icons + 15) & ~15);                   // [n_icons + 2]
@@ -675,6 +685,7 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
     static_assert(XW_MAX_GOALS == 16, "one uint4 per env");
     if (tid >= 64 && tid < 64 + n_here) s_gc[tid - 64] = reinterpret_cast<const uint4 *>(p.goal_cells)[LIST ? p.done_list[e_base + tid - 64] : e_base + tid - 64];
     __syncthreads();
+    EGO_C(0);
     for (int i = tid; i < n_here * cells; i += 256) { const int code = s_code[i]; s_type[i] = code ? s_itype[code - 1] : (uint8_t)3; }
     __syncthreads();
     // the goal slot of a cell rides in its type byte (bits 2-5): one LDS read in the walk below instead of a search through the
@@ -685,6 +696,7 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
         if (cell < cells) s_type[le * cells + cell] |= (uint8_t)(slot << 2);
     }
     __syncthreads();
+    EGO_C(1);
     // The walk: lane = env, and every wavefront of the workgroup takes a share of the r * r view cells of the same envs (one
     // wavefront walking them all was 3.4 / 6.8 / 12.6 thousand instructions at r = 3 / 5 / 7 -- issue-bound with the other
     // three gone, and at r = 7 more code than the instruction cache holds)
@@ -764,7 +776,9 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
         if (valid) s_sq[lane][f] = info | hd | lines;          // (LIST: lanes past EPW have no row)
         if (active) info_e[f] = info | hd | lines;
     }
-    __syncthreads();                                            // (a square's word needs its neighbours', other wavefronts' work)
+    EGO_C(2);
+    __syncthreads();
+    EGO_C(3);                                            // (a square's word needs its neighbours', other wavefronts' work)
     // What the gather reads, per square -- two words.
     // .x: where its pixels come from (bits 0-22, 16-byte units: into ego_tab3, keyed by the classes of the cell, the one above
     // and the one to the left -- the cell's own where the neighbour does not show in this square or is a goal -- or, bit 23,
@@ -822,6 +836,7 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
             src_e[f] = make_uint2(sx[j], xi[j] >= 0 ? xv[j] : sy[j]);
         }
     }
+    EGO_C(4);
     // the cache bits of this wavefront's goal cells, fetched together, then one list append for its whole lot (one atomic per view
     // cell was up to r * r dependent round trips)
     unsigned long long miss = 0;                                // bit k: view cell k shows a goal whose square is not cached
@@ -844,6 +859,7 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
             if (goal && !((vw[j] >> (bit & 31)) & 1u)) miss |= 1ull << k;
         }
     }
+    EGO_C(5);
     int total_miss = 0;
 #pragma unroll
     for (int j = 0; j < Q; ++j) total_miss += __popcll(__ballot((miss >> (kb + j)) & 1ull));
@@ -859,6 +875,7 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
         if (m) p.ego_miss[base + __popcll(mk & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)e, (uint32_t)(k | gslot[j] << 8 | dir << 16));
         base += __popcll(mk);
     }
+    EGO_C(6);
 }
 
 template <int R, bool LIST>
@@ -901,6 +918,9 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
     __shared__ uint16_t s_flags[4][2][84];                 // [heading][row terms | column terms]
     __shared__ uint8_t s_inv[4 * RR], s_fwd[4 * RR];
     __shared__ uint2 s_clsimg[4 * 16];
+    // the goal's 64 x 64 image: nearly every pixel of the entry reads sixteen of its pixels and nothing else -- fetched once, in 16-byte
+    // pieces (the scattered 4-byte reads kept the texture addresser busy for a third of this kernel's time)
+    __shared__ uint4 s_img4[1024];
     const int tid = threadIdx.x, part = block % PARTS, first = block / PARTS;
     const int cap = p.n * (p.num_goals < RR ? p.num_goals : RR);
     uint2 item = p.ego_miss[first < cap ? first : cap - 1];
@@ -918,7 +938,13 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
     const uint8_t inv = tid < 4 * RR ? map[8 * R + 4 * RR + tid] : (uint8_t)0, fwd = tid < 4 * RR ? map[tid] : (uint8_t)0;
     const uint2 ci = p.ego_clsimg[tid < 4 * p.ego_ncls ? tid : 0];
     // (speculatively, with the item: the cell words of its env)
-    uint32_t info = tid < RR ? p.ego_cellinfo[(size_t)(item.x < (uint32_t)p.n ? item.x : 0u) * RR + tid] : 0u;      // (a slot past the count holds anything)
+    const bool sane = item.x < (uint32_t)p.n && ((item.y >> 8) & 0xffu) < (uint32_t)p.num_goals;       // (a slot past the count holds anything)
+    uint32_t info = tid < RR ? p.ego_cellinfo[(size_t)(sane ? item.x : 0u) * RR + tid] : 0u;
+    uint4 im0, im1, im2, im3;
+    {
+        const uint4 *g4 = reinterpret_cast<const uint4 *>(p.goal_img + ((size_t)(sane ? item.x : 0u) * p.num_goals + (sane ? (item.y >> 8) & 0xffu : 0u)) * 4096) + tid;
+        im0 = g4[0]; im1 = g4[256]; im2 = g4[512]; im3 = g4[768];
+    }
     if (first >= cnt) return;                              // (most workgroups: the list is short)
 #pragma unroll
     for (int q = 0; q < NF; ++q) {
@@ -929,9 +955,14 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
     if (tid < 4 * 16) s_clsimg[tid] = ci;
     const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
     for (int it = first; it < cnt; it += nblocks / PARTS) {
-        if (it != first) { item = p.ego_miss[it]; info = tid < RR ? p.ego_cellinfo[(size_t)item.x * RR + tid] : 0u; }
+        if (it != first) {
+            item = p.ego_miss[it]; info = tid < RR ? p.ego_cellinfo[(size_t)item.x * RR + tid] : 0u;
+            const uint4 *g4 = reinterpret_cast<const uint4 *>(p.goal_img + ((size_t)item.x * p.num_goals + ((item.y >> 8) & 0xffu)) * 4096) + tid;
+            im0 = g4[0]; im1 = g4[256]; im2 = g4[512]; im3 = g4[768];
+        }
         const int e = (int)item.x, k = item.y & 0xff, slot = (item.y >> 8) & 0xff, dir = (item.y >> 16) & 3;
         __syncthreads();
+        s_img4[tid] = im0; s_img4[tid + 256] = im1; s_img4[tid + 512] = im2; s_img4[tid + 768] = im3;
         // the env's view: lane = square of the frame, stored under the view cell it shows
         if (tid < RR) {
             EgoCell c;
@@ -943,7 +974,7 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
         const int f = s_inv[dir * RR + k];                                   // the square view cell k occupies
         const int fx = f % R, fy = f / R, x0 = fx * U, y0 = fy * U;
         const uint16_t *rt = s_flags[dir][0], *ct = s_flags[dir][1];
-        EgoCtx ctx{s_cells, white, black, R, 64 * R, dir};
+        EgoCtx ctx{s_cells, white, black, R, 64 * R, dir, reinterpret_cast<const uint32_t *>(s_img4)};
         const int entry = (slot * RR + k) * 4 + dir;
         uint8_t *dst = p.ego_cache + ((size_t)e * p.num_goals * (RR * 4) + entry) * p.ego_cache_entry;
         const int j = part * PP + tid;
@@ -952,7 +983,11 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
             const uint32_t fl = (uint32_t)rt[oy] | (uint32_t)ct[ox];
             // (a pixel of the border row / column blends the neighbours; an edge pixel has taps outside the view; the rest lie in cell k)
             if (fl & (EGO_BORDER | EGO_EDGE)) ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, 0);
-            else ego_pixel<CH, -1, true>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, k);
+#ifdef EGO_EVAL_GLOBAL_TAPS                                 // (A/B hook: the sixteen pixels straight from memory, as before round 5)
+            else ego_pixel<CH, -1, 1>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, k);
+#else
+            else ego_pixel<CH, -1, 2>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, k);
+#endif
         }
         const int x = part * XP + tid - PP;
         if (tid >= PP && tid < PP + XP && x < NX) {
@@ -973,8 +1008,13 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
 }
 
 // The goal cells the cache lacks, four workgroups each.
+#ifdef EGO_EVAL_WAVES
+#define EGO_EVAL_ATTR __attribute__((amdgpu_waves_per_eu(EGO_EVAL_WAVES)))
+#else
+#define EGO_EVAL_ATTR
+#endif
 template <int CH, int R>
-__global__ __launch_bounds__(256) void xw_ego_eval_kernel(XwParams p, const uint32_t *atlas4, const uint16_t *layout, const uint8_t *map,
+__global__ __launch_bounds__(256) EGO_EVAL_ATTR void xw_ego_eval_kernel(XwParams p, const uint32_t *atlas4, const uint16_t *layout, const uint8_t *map,
                                                           int publish, const EgoTap *comp) {
     // (this kernel running = the cells kernel queued before it is complete: xw_device.h, epochs instead of event packets)
     if (publish && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 5, p.sig_epoch);
@@ -1367,7 +1407,12 @@ __global__ __launch_bounds__(EGO_BS) void xw_ego_gather_kernel(XwParams p, int s
     // (chunk indices fit 32 bits: the launcher checks)
     const unsigned n_chunks = (unsigned)p.n * G::cpf, c_lo = blockIdx.x * G::SPAN;
     const unsigned e0 = c_lo / G::cpf;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *p.ego_miss_count = 0;         // the kernels before this one consumed the list
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+#ifdef XWB_EGO_PROF
+        atomicAdd(&g_ego_prof[9], (unsigned long long)*p.ego_miss_count); atomicAdd(&g_ego_prof[10], 1ull);     // (tools/lab/ego_stats.py)
+#endif
+        *p.ego_miss_count = 0;                                               // the kernels before this one consumed the list
+    }
     EGO_GATHER_LDS(G, R, lds);
     ego_gather_span<CH, R, CTX1, ES, PER>(p, lds, e0, c_lo - e0 * G::cpf, (int)(n_chunks - c_lo < (unsigned)G::SPAN ? n_chunks - c_lo : G::SPAN), skip_term, -1);
 }
@@ -1837,9 +1882,14 @@ hipError_t launch_xw_render_ego(const XwParams &p, int indexed, hipStream_t s, h
 }  // namespace xwb
 
 #ifdef XWB_EGO_PROF
-extern "C" int xwb_debug_ego_prof(unsigned long long *out) {
+extern "C" __attribute__((visibility("default"))) int xwb_debug_ego_prof(unsigned long long *out) {
     unsigned long long z[12] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(xwb::g_ego_prof), sizeof(z)) != hipSuccess) return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(xwb::g_ego_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+extern "C" __attribute__((visibility("default"))) int xwb_debug_ego_prof2(unsigned long long *out) {
+    unsigned long long z[12] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(xwb::g_ego_prof2), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(xwb::g_ego_prof2), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif
