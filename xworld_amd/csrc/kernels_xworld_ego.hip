@@ -65,7 +65,6 @@ struct EgoCtx {
     const uint32_t *white, *black;
     int r, S;
     int dir;                     // the heading, where it is not a template argument (ego_pixel<.., -1, ..>)
-    const uint32_t *lds_img;     // ego_pixel<.., 2>: cell `one`'s 64 x 64 image, staged in LDS by the caller
 };
 
 // cv::resize INTER_LINEAR on 8-bit data, one output value: HResizeLinear (11-bit) then VResizeLinear<uchar>
@@ -78,9 +77,8 @@ __device__ __forceinline__ int vresize(int b0, int h0, int b1, int h1) {
 // row / column -- quarter turns are exact integer maps, separable in x and y; the source index S falls outside and
 // leaves one black row / column (borderValue 0).
 // (DIR = -1: the heading is c.dir, a run-time value -- the same arithmetic with selects, for lanes of mixed headings)
-// ONE: all sixteen view pixels lie in the view cell `one` (an interior pixel of that cell, whose image is indexed: a goal);
-// 2: ... and the caller holds that image in LDS (c.lds_img): sixteen LDS reads instead of sixteen scattered loads
-template <int CH, int DIR, int ONE>
+// ONE: all sixteen view pixels lie in the view cell `one` (an interior pixel of that cell, whose image is indexed: a goal)
+template <int CH, int DIR, bool ONE>
 __device__ __forceinline__ void ego_pixel(const EgoCtx &c, const EgoTap (*s_row)[3], const EgoTap (*s_col)[3],
                                           uint8_t *s_frame, int plane, int o, int ox, int oy, int one) {
     const int S = c.S;
@@ -101,15 +99,13 @@ __device__ __forceinline__ void ego_pixel(const EgoCtx &c, const EgoTap (*s_row)
         // fr is sy for headings up / down and sx for right / left (and fc the other one)
         const bool ROW_IS_Y = dir == 3 || dir == 1;
         const uint32_t *src[16];
-        int off[16];
         if (ONE) {
             const uint32_t *img = c.cells[one].img;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int i = k >> 2, j = k & 3;
                 const int px = (ROW_IS_Y ? fc[j] : fr[i]) & 63, py = (ROW_IS_Y ? fr[i] : fc[j]) & 63;
-                off[k] = py * 64 + px;
-                src[k] = img + off[k];
+                src[k] = img + (py * 64 + px);
             }
         } else {
             int cr[4], cc[4], pr[4], pc[4];
@@ -136,7 +132,7 @@ __device__ __forceinline__ void ego_pixel(const EgoCtx &c, const EgoTap (*s_row)
         typedef const uint32_t __attribute__((address_space(1))) *global_u32;
         uint32_t v[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = ONE == 2 ? c.lds_img[off[k]] : *(global_u32)src[k];
+        for (int k = 0; k < 16; ++k) v[k] = *(global_u32)src[k];
         int out[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
@@ -918,9 +914,6 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
     __shared__ uint16_t s_flags[4][2][84];                 // [heading][row terms | column terms]
     __shared__ uint8_t s_inv[4 * RR], s_fwd[4 * RR];
     __shared__ uint2 s_clsimg[4 * 16];
-    // the goal's 64 x 64 image: nearly every pixel of the entry reads sixteen of its pixels and nothing else -- fetched once, in 16-byte
-    // pieces (the scattered 4-byte reads kept the texture addresser busy for a third of this kernel's time)
-    __shared__ uint4 s_img4[1024];
     const int tid = threadIdx.x, part = block % PARTS, first = block / PARTS;
     const int cap = p.n * (p.num_goals < RR ? p.num_goals : RR);
     uint2 item = p.ego_miss[first < cap ? first : cap - 1];
@@ -938,13 +931,7 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
     const uint8_t inv = tid < 4 * RR ? map[8 * R + 4 * RR + tid] : (uint8_t)0, fwd = tid < 4 * RR ? map[tid] : (uint8_t)0;
     const uint2 ci = p.ego_clsimg[tid < 4 * p.ego_ncls ? tid : 0];
     // (speculatively, with the item: the cell words of its env)
-    const bool sane = item.x < (uint32_t)p.n && ((item.y >> 8) & 0xffu) < (uint32_t)p.num_goals;       // (a slot past the count holds anything)
-    uint32_t info = tid < RR ? p.ego_cellinfo[(size_t)(sane ? item.x : 0u) * RR + tid] : 0u;
-    uint4 im0, im1, im2, im3;
-    {
-        const uint4 *g4 = reinterpret_cast<const uint4 *>(p.goal_img + ((size_t)(sane ? item.x : 0u) * p.num_goals + (sane ? (item.y >> 8) & 0xffu : 0u)) * 4096) + tid;
-        im0 = g4[0]; im1 = g4[256]; im2 = g4[512]; im3 = g4[768];
-    }
+    uint32_t info = tid < RR ? p.ego_cellinfo[(size_t)(item.x < (uint32_t)p.n ? item.x : 0u) * RR + tid] : 0u;      // (a slot past the count holds anything)
     if (first >= cnt) return;                              // (most workgroups: the list is short)
 #pragma unroll
     for (int q = 0; q < NF; ++q) {
@@ -955,14 +942,9 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
     if (tid < 4 * 16) s_clsimg[tid] = ci;
     const uint32_t *white = atlas4 + (size_t)p.n_icons * 4096, *black = white + 1;
     for (int it = first; it < cnt; it += nblocks / PARTS) {
-        if (it != first) {
-            item = p.ego_miss[it]; info = tid < RR ? p.ego_cellinfo[(size_t)item.x * RR + tid] : 0u;
-            const uint4 *g4 = reinterpret_cast<const uint4 *>(p.goal_img + ((size_t)item.x * p.num_goals + ((item.y >> 8) & 0xffu)) * 4096) + tid;
-            im0 = g4[0]; im1 = g4[256]; im2 = g4[512]; im3 = g4[768];
-        }
+        if (it != first) { item = p.ego_miss[it]; info = tid < RR ? p.ego_cellinfo[(size_t)item.x * RR + tid] : 0u; }
         const int e = (int)item.x, k = item.y & 0xff, slot = (item.y >> 8) & 0xff, dir = (item.y >> 16) & 3;
         __syncthreads();
-        s_img4[tid] = im0; s_img4[tid + 256] = im1; s_img4[tid + 512] = im2; s_img4[tid + 768] = im3;
         // the env's view: lane = square of the frame, stored under the view cell it shows
         if (tid < RR) {
             EgoCell c;
@@ -974,7 +956,7 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
         const int f = s_inv[dir * RR + k];                                   // the square view cell k occupies
         const int fx = f % R, fy = f / R, x0 = fx * U, y0 = fy * U;
         const uint16_t *rt = s_flags[dir][0], *ct = s_flags[dir][1];
-        EgoCtx ctx{s_cells, white, black, R, 64 * R, dir, reinterpret_cast<const uint32_t *>(s_img4)};
+        EgoCtx ctx{s_cells, white, black, R, 64 * R, dir};
         const int entry = (slot * RR + k) * 4 + dir;
         uint8_t *dst = p.ego_cache + ((size_t)e * p.num_goals * (RR * 4) + entry) * p.ego_cache_entry;
         const int j = part * PP + tid;
@@ -983,11 +965,7 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
             const uint32_t fl = (uint32_t)rt[oy] | (uint32_t)ct[ox];
             // (a pixel of the border row / column blends the neighbours; an edge pixel has taps outside the view; the rest lie in cell k)
             if (fl & (EGO_BORDER | EGO_EDGE)) ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, 0);
-#ifdef EGO_EVAL_GLOBAL_TAPS                                 // (A/B hook: the sixteen pixels straight from memory, as before round 5)
-            else ego_pixel<CH, -1, 1>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, k);
-#else
-            else ego_pixel<CH, -1, 2>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, k);
-#endif
+            else ego_pixel<CH, -1, true>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, k);
         }
         const int x = part * XP + tid - PP;
         if (tid >= PP && tid < PP + XP && x < NX) {
@@ -1008,13 +986,8 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
 }
 
 // The goal cells the cache lacks, four workgroups each.
-#ifdef EGO_EVAL_WAVES
-#define EGO_EVAL_ATTR __attribute__((amdgpu_waves_per_eu(EGO_EVAL_WAVES)))
-#else
-#define EGO_EVAL_ATTR
-#endif
 template <int CH, int R>
-__global__ __launch_bounds__(256) EGO_EVAL_ATTR void xw_ego_eval_kernel(XwParams p, const uint32_t *atlas4, const uint16_t *layout, const uint8_t *map,
+__global__ __launch_bounds__(256) void xw_ego_eval_kernel(XwParams p, const uint32_t *atlas4, const uint16_t *layout, const uint8_t *map,
                                                           int publish, const EgoTap *comp) {
     // (this kernel running = the cells kernel queued before it is complete: xw_device.h, epochs instead of event packets)
     if (publish && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 5, p.sig_epoch);
