@@ -897,15 +897,21 @@ struct EgoEntry {
     static constexpr int BELOW = CH * Q::CBP, RIGHT = BELOW + CH * Q::U, DIAG = RIGHT + CH * Q::U, BYTES = (DIAG + 4 + 15) & ~15;
 };
 
-// The goal cells the cache does not hold yet (ego_miss): four workgroups per listed cell, one pixel per lane -- the square's
-// U * U pixels on the first lanes, the 2 U + 1 pixels of the BELOW / RIGHT / DIAG lines on the lanes behind them.
+// The goal cells the cache does not hold yet (ego_miss): PARTS workgroups per listed cell; a workgroup takes a contiguous share of
+// the entry's pixels -- the square's U * U, then the 2 U + 1 of the BELOW / RIGHT / DIAG lines -- 256 at a time.
 template <int CH, int R>
 __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t *atlas4, const uint16_t *layout, const uint8_t *map,
                                               int block, int nblocks, EgoTap (*s_row)[3], EgoTap (*s_col)[3]) {
     constexpr int U = 84 / R, O = R * U, O4 = O, RR = R * R;
-    constexpr int PARTS = 4, PP = (U * U + PARTS - 1) / PARTS;       // a goal cell is shared by four workgroups: <= one pixel per lane
-    constexpr int NX = 2 * U + 1, XP = (NX + PARTS - 1) / PARTS;     // ... and a share of the entry's lines
-    static_assert(PP + XP <= 256, "one pixel per lane");
+    // Workgroups per goal cell: as few as give every lane one pixel -- r = 7: the entry's 169 pixels are ONE workgroup's single pass,
+    // r = 5: 289 pixels in two workgroups, r = 3: 841 pixels in four.  (Round 5, same box, render's four launches: four workgroups
+    // per cell at every radius 208.4 / 228.8 us at r = 5 / 7, this 201.5 / 215.8; r = 3 with 4 / 2 / 1 workgroups of 1 / 2 / 4 passes:
+    // 184.8 / 185.5 / 188.1 us -- profiles/r5/ego_concurrent_eval_experiments.txt.)
+#ifndef EGO_EVAL_PARTS3
+#define EGO_EVAL_PARTS3 4
+#endif
+    constexpr int PARTS = R >= 7 ? 1 : (R >= 5 ? 2 : EGO_EVAL_PARTS3);
+    constexpr int NX = 2 * U + 1, NP = U * U + NX, PPT = (NP + PARTS - 1) / PARTS;      // the square's pixels, then its lines
     typedef EgoEntry<CH, R> E;
     // (s_row / s_col: the kernel's)
     // The count and (speculatively) the first item come in one round trip, the flag rows of all four headings, the view-cell ->
@@ -959,28 +965,27 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
         EgoCtx ctx{s_cells, white, black, R, 64 * R, dir};
         const int entry = (slot * RR + k) * 4 + dir;
         uint8_t *dst = p.ego_cache + ((size_t)e * p.num_goals * (RR * 4) + entry) * p.ego_cache_entry;
-        const int j = part * PP + tid;
-        if (tid < PP && j < U * U) {
-            const int py = j / U, px = j - py * U, ox = x0 + px, oy = y0 + py;
-            const uint32_t fl = (uint32_t)rt[oy] | (uint32_t)ct[ox];
-            // (a pixel of the border row / column blends the neighbours; an edge pixel has taps outside the view; the rest lie in cell k)
-            if (fl & (EGO_BORDER | EGO_EDGE)) ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, 0);
-            else ego_pixel<CH, -1, true>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, k);
-        }
-        const int x = part * XP + tid - PP;
-        if (tid >= PP && tid < PP + XP && x < NX) {
-            const bool below = x < U, right = !below && x < 2 * U;
-            const int q = below ? x : x - U;
-            const int ox = below ? x0 + q : x0 + U, oy = below ? y0 + U : (right ? y0 + q : y0 + U);
-            const bool ok = below ? (fy + 1 < R && (rt[oy] & EGO_BORDER)) : (right ? (fx + 1 < R && (ct[ox] & EGO_BORDER))
-                                  : (fx + 1 < R && fy + 1 < R && (rt[oy] & EGO_BORDER) && (ct[ox] & EGO_BORDER)));
-            if (ok) {
-                if (below) ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst + E::BELOW, U, q, ox, oy, 0);
-                else if (right) ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst + E::RIGHT, U, q, ox, oy, 0);
-                else ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst + E::DIAG, 1, 0, ox, oy, 0);
+        for (int qq = tid; qq < PPT; qq += 256) {
+            const int q = part * PPT + qq;
+            if (q >= NP) break;
+            if (q < U * U) {
+                const int py = q / U, px = q - py * U, ox = x0 + px, oy = y0 + py;
+                const uint32_t fl = (uint32_t)rt[oy] | (uint32_t)ct[ox];
+                // (a pixel of the border row / column blends the neighbours; an edge pixel has taps outside the view; the rest lie in cell k)
+                if (fl & (EGO_BORDER | EGO_EDGE)) ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, 0);
+                else ego_pixel<CH, -1, true>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, k);
+            } else {
+                const int x = q - U * U;
+                const bool below = x < U, right = !below && x < 2 * U;
+                const int t = below ? x : x - U;
+                const int ox = below ? x0 + t : x0 + U, oy = below ? y0 + U : (right ? y0 + t : y0 + U);
+                const bool ok = below ? (fy + 1 < R && (rt[oy] & EGO_BORDER)) : (right ? (fx + 1 < R && (ct[ox] & EGO_BORDER))
+                                      : (fx + 1 < R && fy + 1 < R && (rt[oy] & EGO_BORDER) && (ct[ox] & EGO_BORDER)));
+                // (one call for the three lines: a wavefront that holds several kinds runs the ~400 instructions once)
+                if (ok) ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst + (below ? E::BELOW : (right ? E::RIGHT : E::DIAG)), below || right ? U : 1, below || right ? t : 0, ox, oy, 0);
             }
         }
-        // (the bit is read by kernels launched after this one: all four parts are complete by then)
+        // (the bit is read by kernels launched after this one: all parts are complete by then)
         if (tid == 0 && part == 0) atomicOr(p.ego_cache_valid + (size_t)e * p.ego_cache_words + (entry >> 5), 1u << (entry & 31));
     }
 }
@@ -1709,7 +1714,7 @@ hipError_t ego_span_render(const XwParams &p, const EgoTables &t, int mode, hipS
     const size_t cells_lds = 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15);
     hipLaunchKernelGGL((xw_ego_cells_kernel<R, false>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, skip_front, nullptr, mode == 2 && p.sig_epoch != 0);
     if (ev_cells) { const hipError_t e = hipEventRecord(ev_cells, s); if (e != hipSuccess) return e; }
-    const int nb_miss = p.dbg_ego_miss_blocks ? p.dbg_ego_miss_blocks : 4096;    // (a multiple of 4: four workgroups per goal cell)
+    const int nb_miss = p.dbg_ego_miss_blocks ? p.dbg_ego_miss_blocks : 4096;    // (a multiple of 4: up to four workgroups per goal cell)
     hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_miss), dim3(256), 0, s, p, a4, t.lut, t.map, publish, t.comp);
     if (ev_front) { const hipError_t e = hipEventRecord(ev_front, s); if (e != hipSuccess) return e; }
     const int es = p.obs_f32 ? 4 : 1;
