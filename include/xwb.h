@@ -304,7 +304,9 @@ int xwb_actions_dev(xwb_sim *sim, int32_t **ptr);       /* int32[num_envs]: acti
 int xwb_num_steps_dev(xwb_sim *sim, int32_t **ptr);     /* int32[num_envs]: get_num_steps() */
 int xwb_success_dev(xwb_sim *sim, uint8_t **ptr);       /* uint8[num_envs]: last_action_success() */
 int xwb_episode_dev(xwb_sim *sim, uint32_t **ptr);      /* uint32[num_envs]: resets so far (RNG episode index) */
-int xwb_xw_grid_dev(xwb_sim *sim, uint16_t **ptr);      /* xworld: uint16[num_envs][max_dim*max_dim] cell codes */
+int xwb_xw_grid_dev(xwb_sim *sim, uint16_t **ptr);      /* xworld: uint16[num_envs][max_dim*max_dim] cell codes -- for reading: the egocentric
+                                                         * render caches pixels that depend on the cells around a goal for the length of an
+                                                         * episode; a map is changed through xwb_xw_load_map_task / xwb_xw_refresh_obs */
 int xwb_minstd_state_dev(xwb_sim *sim, uint32_t **ptr); /* XWB_RNG_MINSTD: uint32[num_envs] engine states (else NULL) */
 int xwb_done_count(xwb_sim *sim, void *stream, int32_t *n_done);   /* envs reset by the last reset_done (sync) */
 /* xworld, egocentric: which kernels draw the whole-batch frames: 1 = the span path (cells -> evaluated pixels -> gather,
