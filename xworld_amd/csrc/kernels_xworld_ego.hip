@@ -845,7 +845,7 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
             const int k = kb + j;
             const bool goal = (goal_mask >> k) & 1ull;
             const int bit = (gslot[j] * r * r + k) * 4 + dir;
-            vw[j] = valid_e[goal ? bit >> 5 : 0];               // (no branch around the read)
+            vw[j] = *(goal ? valid_e + (bit >> 5) : p.ego_cache_valid);       // (no branch around the read; the lanes without a goal share one line)
         }
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
@@ -965,25 +965,60 @@ __device__ __forceinline__ void ego_miss_body(const XwParams &p, const uint32_t 
         EgoCtx ctx{s_cells, white, black, R, 64 * R, dir};
         const int entry = (slot * RR + k) * 4 + dir;
         uint8_t *dst = p.ego_cache + ((size_t)e * p.num_goals * (RR * 4) + entry) * p.ego_cache_entry;
+        // The entry's pixels in an order that keeps the two code paths of ego_pixel (~400 VALU instructions each) in different
+        // wavefronts: first the pixels whose sixteen taps all lie in the goal's image (rows [r0, r1) x columns [c0, c1) of the square),
+        // then the rest -- the square's border row / column and, at the frame's edges, its edge rows / columns, then the three lines.
+        // In the natural order every wavefront holds a border-column pixel (one every U lanes) and runs BOTH paths.  The rows / columns
+        // that take the general path are a prefix and a suffix of the square; if they ever were not, everything takes the general
+        // path, which is right for every pixel.
+        // (r = 3 only -- same box, render's four launches: 180.0 against 183.1 us there, 198.9 / 214.9 against 197.7 / 212.7 at r = 5 / 7)
+        constexpr bool ORDERED = R == 3;
+        int r0 = 0, r1 = 0, c0 = 0, c1 = 0;
+        if (ORDERED) {
+            const int ln = tid & 63;
+            const unsigned long long all = (1ull << U) - 1ull;
+            const unsigned long long rm = __ballot(ln < U && (rt[y0 + (ln < U ? ln : 0)] & (EGO_BORDER | EGO_EDGE))) & all;
+            const unsigned long long cm = __ballot(ln < U && (ct[x0 + (ln < U ? ln : 0)] & (EGO_BORDER | EGO_EDGE))) & all;
+            auto range = [&](unsigned long long m, int &lo, int &hi) {
+                lo = m == all ? U : __ffsll((long long)(~m & all)) - 1;                            // leading rows of the general path
+                int t = 0;
+                while (t < U - lo && ((m >> (U - 1 - t)) & 1ull)) ++t;                              // trailing ones (uniform: a scalar loop)
+                hi = U - t;
+                const unsigned long long want = ((1ull << lo) - 1ull) | (all & ~((1ull << hi) - 1ull));
+                if (m != want) { lo = 0; hi = 0; }                                                  // not a prefix and a suffix: no fast pixels
+            };
+            range(rm, r0, r1); range(cm, c0, c1);
+            if (r1 <= r0 || c1 <= c0) { r0 = r1 = 0; c0 = c1 = 0; }
+        }
+        const int h1 = r1 - r0, w1 = c1 - c0, n_one = h1 * w1, n_a = (U - h1) * U, gw = U - w1, n_b = h1 * gw;
         for (int qq = tid; qq < PPT; qq += 256) {
             const int q = part * PPT + qq;
             if (q >= NP) break;
-            if (q < U * U) {
-                const int py = q / U, px = q - py * U, ox = x0 + px, oy = y0 + py;
-                const uint32_t fl = (uint32_t)rt[oy] | (uint32_t)ct[ox];
-                // (a pixel of the border row / column blends the neighbours; an edge pixel has taps outside the view; the rest lie in cell k)
-                if (fl & (EGO_BORDER | EGO_EDGE)) ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, 0);
-                else ego_pixel<CH, -1, true>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, py * EgoSq<R>::UP + px, ox, oy, k);
-            } else {
-                const int x = q - U * U;
+            int px = 0, py = 0, x = -1;
+            bool one = false;
+            if (!ORDERED) {
+                if (q < U * U) { py = q / U; px = q - py * U; one = !(((uint32_t)rt[y0 + py] | (uint32_t)ct[x0 + px]) & (EGO_BORDER | EGO_EDGE)); }
+                else x = q - U * U;
+            }
+            else if (q < n_one) { const int i = q / w1; py = r0 + i; px = c0 + (q - i * w1); one = true; }
+            else if (q < n_one + n_a) { const int g = q - n_one, a = g / U; px = g - a * U; py = a < r0 ? a : r1 + (a - r0); }
+            else if (q < n_one + n_a + n_b) { const int g = q - n_one - n_a, i = g / gw, b = g - i * gw; py = r0 + i; px = b < c0 ? b : c1 + (b - c0); }
+            else x = q - n_one - n_a - n_b;
+            // (a pixel of the border row / column blends the neighbours; an edge pixel has taps outside the view; the rest lie in cell k.
+            // ONE call of the general path for the square's pixels and the three lines: a wavefront that holds several kinds runs it once)
+            uint8_t *d = dst;
+            int plane = EgoSq<R>::CBP, o = py * EgoSq<R>::UP + px, ox = x0 + px, oy = y0 + py;
+            bool ok = true;
+            if (x >= 0) {
                 const bool below = x < U, right = !below && x < 2 * U;
                 const int t = below ? x : x - U;
-                const int ox = below ? x0 + t : x0 + U, oy = below ? y0 + U : (right ? y0 + t : y0 + U);
-                const bool ok = below ? (fy + 1 < R && (rt[oy] & EGO_BORDER)) : (right ? (fx + 1 < R && (ct[ox] & EGO_BORDER))
-                                      : (fx + 1 < R && fy + 1 < R && (rt[oy] & EGO_BORDER) && (ct[ox] & EGO_BORDER)));
-                // (one call for the three lines: a wavefront that holds several kinds runs the ~400 instructions once)
-                if (ok) ego_pixel<CH, -1, false>(ctx, s_row, s_col, dst + (below ? E::BELOW : (right ? E::RIGHT : E::DIAG)), below || right ? U : 1, below || right ? t : 0, ox, oy, 0);
+                ox = below ? x0 + t : x0 + U; oy = below ? y0 + U : (right ? y0 + t : y0 + U);
+                ok = below ? (fy + 1 < R && (rt[oy] & EGO_BORDER)) : (right ? (fx + 1 < R && (ct[ox] & EGO_BORDER))
+                           : (fx + 1 < R && fy + 1 < R && (rt[oy] & EGO_BORDER) && (ct[ox] & EGO_BORDER)));
+                d = dst + (below ? E::BELOW : (right ? E::RIGHT : E::DIAG)); plane = below || right ? U : 1; o = below || right ? t : 0;
             }
+            if (one) ego_pixel<CH, -1, true>(ctx, s_row, s_col, dst, EgoSq<R>::CBP, o, ox, oy, k);
+            else if (ok) ego_pixel<CH, -1, false>(ctx, s_row, s_col, d, plane, o, ox, oy, 0);
         }
         // (the bit is read by kernels launched after this one: all parts are complete by then)
         if (tid == 0 && part == 0) atomicOr(p.ego_cache_valid + (size_t)e * p.ego_cache_words + (entry >> 5), 1u << (entry & 31));
