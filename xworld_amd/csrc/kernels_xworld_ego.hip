@@ -652,6 +652,8 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
     uint8_t *s_itype = s_type + EPW * cells;                                // [n_icons]
     uint8_t *s_cls = s_itype + ((p.n_icons + 15) & ~15);                   // [n_icons + 2]
     __shared__ uint8_t s_map[8 * R * R + 8 * R];
+    __shared__ unsigned long long s_shadow[64];                            // per env: the shadow mask, a quarter from each wavefront
+    if (tid < 64) s_shadow[tid] = 0;
     const bool valid = lane < EPW && e_base + lane < total;
     const int li = valid ? e_base + lane : total - 1;
     const int e = LIST ? p.done_list[li] : li, ec = e;
@@ -724,18 +726,29 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
             if (is_block(rx, ry)) block = true;
         }
     }
-    unsigned long long shadow = 0;                              // bit k: view cell k lies behind a wall
+    // bit k: view cell k lies behind a wall.  The r scan lines are independent: each of the workgroup's four wavefronts (they walk
+    // different cells of the SAME envs) takes every fourth line and the masks meet in LDS -- repeated by all four, the scan was a
+    // third of a wavefront's instructions at r = 7 (round 5: cells kernel 42 -> 39 us there, 156 -> 87 VGPRs)
+    unsigned long long shadow = 0;
+    {
+        unsigned long long part = 0;
+        const int wv = tid >> 6;
 #pragma unroll
-    for (int t = 0; t < r; ++t) {
-        bool block = !((ray >> t) & 1u);
-        int cx = scan_x0 + t * major_x, cy = scan_y0 + t * major_y;
+        for (int t = 0; t < r; ++t) {
+            if ((t & 3) != wv) continue;                        // (uniform per wavefront)
+            bool block = !((ray >> t) & 1u);
+            int cx = scan_x0 + t * major_x, cy = scan_y0 + t * major_y;
 #pragma unroll
-        for (int j = 0; j < r; ++j) {
-            if (block) shadow |= 1ull << (cy * r + cx);
-            if (is_block(x_st - r + cx, y_st - r + cy)) block = true;
-            cx += minor_x; cx = cx < 0 ? cx + r : (cx >= r ? cx - r : cx);
-            cy += minor_y; cy = cy < 0 ? cy + r : (cy >= r ? cy - r : cy);
+            for (int j = 0; j < r; ++j) {
+                if (block) part |= 1ull << (cy * r + cx);
+                if (is_block(x_st - r + cx, y_st - r + cy)) block = true;
+                cx += minor_x; cx = cx < 0 ? cx + r : (cx >= r ? cx - r : cx);
+                cy += minor_y; cy = cy < 0 ? cy + r : (cy >= r ? cy - r : cy);
+            }
         }
+        if (part != 0) atomicOr(&s_shadow[lane], part);
+        __syncthreads();
+        shadow = s_shadow[lane];
     }
     if (p.no_wall_shadow) shadow = 0;
     uint32_t *info_e = p.ego_cellinfo + (size_t)ec * (r * r);
