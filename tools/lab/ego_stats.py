@@ -26,5 +26,5 @@ for _ in range(50):
 torch.cuda.synchronize()
 sim.L.xwb_debug_ego_prof2(buf2)
 wg = 50 * ((32768 + 63) // 64)
-names = ["state + grids -> LDS", "types, goal slots", "walk", "barrier", "words + table reads + stores", "valid bits", "miss list"]
+names = ["state + grids -> LDS", "types, goal slots", "walk (cells)", "barrier", "words: table reads + stores", "valid bits", "miss list", "rays + own scan lines", "shadow barrier", "words: keys + flat reads"]
 print("cells kernel, us per workgroup: " + ", ".join("%s %.2f" % (n, buf2[i] / 100.0 / wg) for i, n in enumerate(names)))

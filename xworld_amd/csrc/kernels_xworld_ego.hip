@@ -637,7 +637,8 @@ __device__ __forceinline__ void ego_wave_append(bool flag, uint32_t a, uint32_t 
 template <bool LIST> struct EgoCellsGeom { static constexpr int EPW = LIST ? 16 : 64; };
 // ALL_MISS (list of freshly reset envs whose goal images are being redrawn beside this: xw_ego_list_front_kernel): every goal
 // cell in view goes on the miss list, the cache bits are not looked at
-template <int R, bool LIST, bool ALL_MISS>
+// NW: wavefronts per workgroup (they share the walk over the view cells of the same envs)
+template <int R, bool LIST, bool ALL_MISS, int NW = 4>
 __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t *map, int skip_term, const int32_t *count_now, int bid, uint4 *smem4) {
     constexpr int EPW = EgoCellsGeom<LIST>::EPW;
     const int D = p.max_dim, cells = D * D, tid = threadIdx.x, lane = tid & 63;
@@ -660,12 +661,12 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
     int axy = 0, dir = 0, term = 0;
     int fresh = 0;
     { axy = p.agent_xy[ec]; dir = p.agent_dir[ec] & 3; term = p.term_flag[ec]; fresh = p.fresh[ec]; }
-    for (int i = tid; i < p.n_icons; i += 256) s_itype[i] = p.icon_type[i];
-    for (int i = tid; i < p.n_icons + 2; i += 256) s_cls[i] = p.ego_cls[i];
-    for (int i = tid; i < 8 * R * R + 8 * R; i += 256) s_map[i] = map[i];
+    for (int i = tid; i < p.n_icons; i += 64 * NW) s_itype[i] = p.icon_type[i];
+    for (int i = tid; i < p.n_icons + 2; i += 64 * NW) s_cls[i] = p.ego_cls[i];
+    for (int i = tid; i < 8 * R * R + 8 * R; i += 64 * NW) s_map[i] = map[i];
     if (LIST) {
 #pragma unroll 4
-        for (int i = tid; i < n_here * cells; i += 256) {
+        for (int i = tid; i < n_here * cells; i += 64 * NW) {
             const int le = i / cells;
             s_code[i] = (uint16_t)(p.grid[(size_t)p.done_list[e_base + le] * cells + (i - le * cells)] & CELL_ICON_MASK);
         }
@@ -676,19 +677,19 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
         uint4 *s4 = reinterpret_cast<uint4 *>(s_code);
         const uint32_t m2 = CELL_ICON_MASK | CELL_ICON_MASK << 16;
 #pragma unroll 4
-        for (int i = tid; i < 8 * cells; i += 256) { uint4 v = g4[i]; v.x &= m2; v.y &= m2; v.z &= m2; v.w &= m2; s4[i] = v; }
+        for (int i = tid; i < 8 * cells; i += 64 * NW) { uint4 v = g4[i]; v.x &= m2; v.y &= m2; v.z &= m2; v.w &= m2; s4[i] = v; }
     } else {
-        for (int i = tid; i < n_here * cells; i += 256) s_code[i] = (uint16_t)(p.grid[(size_t)e_base * cells + i] & CELL_ICON_MASK);
+        for (int i = tid; i < n_here * cells; i += 64 * NW) s_code[i] = (uint16_t)(p.grid[(size_t)e_base * cells + i] & CELL_ICON_MASK);
     }
     static_assert(XW_MAX_GOALS == 16, "one uint4 per env");
     if (tid >= 64 && tid < 64 + n_here) s_gc[tid - 64] = reinterpret_cast<const uint4 *>(p.goal_cells)[LIST ? p.done_list[e_base + tid - 64] : e_base + tid - 64];
     __syncthreads();
     EGO_C(0);
-    for (int i = tid; i < n_here * cells; i += 256) { const int code = s_code[i]; s_type[i] = code ? s_itype[code - 1] : (uint8_t)3; }
+    for (int i = tid; i < n_here * cells; i += 64 * NW) { const int code = s_code[i]; s_type[i] = code ? s_itype[code - 1] : (uint8_t)3; }
     __syncthreads();
     // the goal slot of a cell rides in its type byte (bits 2-5): one LDS read in the walk below instead of a search through the
     // env's sixteen slots per visible goal (that search was a third of the kernel's instructions)
-    for (int i = tid; i < n_here * XW_MAX_GOALS; i += 256) {
+    for (int i = tid; i < n_here * XW_MAX_GOALS; i += 64 * NW) {
         const int le = i / XW_MAX_GOALS, slot = i - le * XW_MAX_GOALS;
         const int cell = reinterpret_cast<const uint8_t *>(&s_gc[le])[slot];
         if (cell < cells) s_type[le * cells + cell] |= (uint8_t)(slot << 2);
@@ -698,7 +699,7 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
     // The walk: lane = env, and every wavefront of the workgroup takes a share of the r * r view cells of the same envs (one
     // wavefront walking them all was 3.4 / 6.8 / 12.6 thousand instructions at r = 3 / 5 / 7 -- issue-bound with the other
     // three gone, and at r = 7 more code than the instruction cache holds)
-    constexpr int Q = (R * R + 3) / 4;
+    constexpr int Q = (R * R + NW - 1) / NW;
     const int kb = (tid >> 6) * Q;
     const bool active = valid && !(skip_term && term);
     const int ax = axy & 0xffff, ay = axy >> 16;
@@ -735,7 +736,7 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
         const int wv = tid >> 6;
 #pragma unroll
         for (int t = 0; t < r; ++t) {
-            if ((t & 3) != wv) continue;                        // (uniform per wavefront)
+            if (t % NW != wv) continue;                         // (uniform per wavefront)
             bool block = !((ray >> t) & 1u);
             int cx = scan_x0 + t * major_x, cy = scan_y0 + t * major_y;
 #pragma unroll
@@ -746,9 +747,11 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
                 cy += minor_y; cy = cy < 0 ? cy + r : (cy >= r ? cy - r : cy);
             }
         }
+        EGO_C(7);
         if (part != 0) atomicOr(&s_shadow[lane], part);
         __syncthreads();
         shadow = s_shadow[lane];
+        EGO_C(8);
     }
     if (p.no_wall_shadow) shadow = 0;
     uint32_t *info_e = p.ego_cellinfo + (size_t)ec * (r * r);
@@ -811,11 +814,12 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
         uint2 *src_e = p.ego_cellsrc + (size_t)e * (r * r);
         auto eidx = [&](uint32_t wg) { return ((wg & 0xfu) * (r * r) + ((wg >> 4) & 0x3fu)) * 4u + (uint32_t)dir; };
         uint32_t sx[Q], sy[Q];
+        int fi[Q];                                              // index into ego_flat of a square's table entry, -1: a goal's square
         int xi[Q];                                              // index into ego_xtab of a square's crossing pixel, -1: none
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
             const int f = kb + j;
-            sx[j] = 0; sy[j] = 0; xi[j] = -1;
+            sx[j] = 0; sy[j] = 0; xi[j] = -1; fi[j] = -1;
             if (f >= r * r) break;
             const uint32_t w = s_sq[lane][f], wa = f >= r ? s_sq[lane][f - r] : w, wl = f % r ? s_sq[lane][f - 1] : w;
             const uint32_t wd = (f >= r && f % r) ? s_sq[lane][f - r - 1] : w;
@@ -824,10 +828,10 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
             const uint32_t c = (w >> 16) & 0xffu, ca = rowb && !ga ? (wa >> 16) & 0xffu : c, cl = colb && !gl ? (wl >> 16) & 0xffu : c;
             const uint32_t key = (((uint32_t)dir * nc + c) * nc + ca) * nc + cl;
             const uint32_t off = goal ? eidx(w) * entry16 : key * ch_n * (Sq::PBP / 16) + f * (Sq::CBP / 16);
-            // bits 30-31: the table entry is one flat colour (1: 255, 2: 0) -- the gather reads the shared constant line instead
-            const uint32_t flat = goal ? 0u : (uint32_t)p.ego_flat[key * (r * r) + f];
+            // bits 30-31 (added below): the table entry is one flat colour (1: 255, 2: 0) -- the gather reads the shared constant line instead
+            if (!goal) fi[j] = (int)(key * (r * r) + f);
             sx[j] = off | (goal ? 1u << 23 : 0u) | (ga ? 1u << 24 : 0u) | (gl ? 1u << 25 : 0u) | (cross ? 1u << 26 : 0u) |
-                    (term ? 1u << 27 : 0u) | ((uint32_t)fresh & 3u) << 28 | flat << 30;
+                    (term ? 1u << 27 : 0u) | ((uint32_t)fresh & 3u) << 28;
             if (ga) sy[j] |= eidx(wa);
             if (gl) sy[j] |= eidx(wl) << 12;
             if (cross && !ga && !gl) {
@@ -835,14 +839,18 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
                 else xi[j] = (int)((((key * nc) + ((wd >> 16) & 0xffu)) * (r * r)) + f);
             }
         }
-        uint32_t xv[Q];                                         // (every read in flight, no branch around them)
+        EGO_C(9);
+        // (every table read of this wavefront's squares in flight together, no branch around any: read one by one inside the loop
+        // above -- a branch and a wait per square -- the flat bytes were up to Q dependent round trips, 8 us of this kernel at r = 7)
+        uint32_t xv[Q];
+        uint8_t fv[Q];
 #pragma unroll
-        for (int j = 0; j < Q; ++j) xv[j] = p.ego_xtab[xi[j] >= 0 ? xi[j] : 0];
+        for (int j = 0; j < Q; ++j) { xv[j] = p.ego_xtab[xi[j] >= 0 ? xi[j] : 0]; fv[j] = p.ego_flat[fi[j] >= 0 ? fi[j] : 0]; }
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
             const int f = kb + j;
             if (f >= r * r) break;
-            src_e[f] = make_uint2(sx[j], xi[j] >= 0 ? xv[j] : sy[j]);
+            src_e[f] = make_uint2(sx[j] | (fi[j] >= 0 ? (uint32_t)fv[j] << 30 : 0u), xi[j] >= 0 ? xv[j] : sy[j]);
         }
     }
     EGO_C(4);
@@ -887,12 +895,17 @@ __device__ __forceinline__ void ego_cells_body(const XwParams &p, const uint8_t 
     EGO_C(6);
 }
 
+// (A/B hook -DEGO_CELLS_NW=8 | 16: the whole batch's workgroups with more wavefronts per 64 envs -- measured, no gain: profiles/r5)
+#ifndef EGO_CELLS_NW
+#define EGO_CELLS_NW 4
+#endif
+template <bool LIST> struct EgoCellsWaves { static constexpr int NW = LIST ? 4 : EGO_CELLS_NW; };
 template <int R, bool LIST>
-__global__ __launch_bounds__(256) void xw_ego_cells_kernel(XwParams p, const uint8_t *map, int skip_term, const int32_t *count_now, int publish_step) {
+__global__ __launch_bounds__(64 * EgoCellsWaves<LIST>::NW) void xw_ego_cells_kernel(XwParams p, const uint8_t *map, int skip_term, const int32_t *count_now, int publish_step) {
     extern __shared__ uint4 smem4[];
     // (xwb_step_autoreset: this kernel running = the step kernel before it is complete; the reset's queue waits for that)
     if (publish_step && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 1, p.sig_epoch);
-    ego_cells_body<R, LIST, false>(p, map, skip_term, count_now, (int)blockIdx.x, smem4);
+    ego_cells_body<R, LIST, false, EgoCellsWaves<LIST>::NW>(p, map, skip_term, count_now, (int)blockIdx.x, smem4);
 }
 
 // A cache entry [env][goal slot][view cell][heading] on the span path (EgoEntry): everything of the frame that blends this goal's
@@ -1760,7 +1773,7 @@ hipError_t ego_span_render(const XwParams &p, const EgoTables &t, int mode, hipS
     // mode 4 without events: the hand-overs to the reset's queue are epochs, published by the kernel that FOLLOWS the producer
     const int publish = mode == 4 && !ev_front && p.sig_epoch != 0;
     const size_t cells_lds = 64 * cells * 3 + ((p.n_icons + 15) & ~15) + ((p.n_icons + 2 + 15) & ~15);
-    hipLaunchKernelGGL((xw_ego_cells_kernel<R, false>), dim3((p.n + 63) / 64), dim3(256), cells_lds, s, p, t.map, skip_front, nullptr, mode == 2 && p.sig_epoch != 0);
+    hipLaunchKernelGGL((xw_ego_cells_kernel<R, false>), dim3((p.n + 63) / 64), dim3(64 * EgoCellsWaves<false>::NW), cells_lds, s, p, t.map, skip_front, nullptr, mode == 2 && p.sig_epoch != 0);
     if (ev_cells) { const hipError_t e = hipEventRecord(ev_cells, s); if (e != hipSuccess) return e; }
     const int nb_miss = p.dbg_ego_miss_blocks ? p.dbg_ego_miss_blocks : 4096;    // (a multiple of 4: up to four workgroups per goal cell)
     hipLaunchKernelGGL((xw_ego_eval_kernel<CH, R>), dim3(nb_miss), dim3(256), 0, s, p, a4, t.lut, t.map, publish, t.comp);
