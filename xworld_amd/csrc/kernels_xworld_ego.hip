@@ -44,7 +44,11 @@ __device__ unsigned long long g_ego_prof2[12];     // stage stamps of the whole-
 #define EGO_T0()
 #define EGO_T(i)
 #define EGO_C0()
+#ifdef EGO_CELLS_STOP                                    // lab: the whole-batch cells kernel ends at stage i (wrong frames; for a kernel trace:
+#define EGO_C(i) do { if (!LIST && (i) == EGO_CELLS_STOP) return; } while (0)      // tools/lab/ego_cells_ablate.sh)
+#else
 #define EGO_C(i)
+#endif
 #endif
 
 struct EgoTap { int16_t s0, s1, w0, w1; };        // cv::resize: source indices and 11-bit weights of one output index
