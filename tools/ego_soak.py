@@ -17,15 +17,18 @@ cases = [
   dict(xwd_conf_path=CONF+'navigation2d.json', task_mode='lang_acquisition', max_dim=7, dim=7, visible_radius=3, color=True, obs_format='float32', context=2),
   dict(xwd_conf_path=CONF+'navigation2d.json', task_mode='lang_acquisition', max_dim=7, dim=7, visible_radius=3, color=True, wall_shadow=False),
 ]
+# python tools/ego_soak.py [steps [seed ...]]  (default 200 steps, seeds 3 and 17)
+STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+SEEDS = tuple(int(a) for a in sys.argv[2:]) or (3, 17)
 bad = 0
 for ci, opts in enumerate(cases):
-    for seed in (3, 17):
+    for seed in SEEDS:
         n = 8192
         a = make(opts, n, seed, False); b = make(opts, n, seed, True)
         assert a.ego_render_path == 'span' and b.ego_render_path == 'per_env'
         for s in (a, b): s.reset()
         ok = torch.equal(a.obs, b.obs)
-        for t in range(200):
+        for t in range(STEPS):
             auto = (t % 5 == 4)
             for s in (a, b):
                 if auto: s.step_autoreset()
