@@ -588,9 +588,11 @@ __global__ __launch_bounds__(BS, 4) void xw_render_ego_kernel(XwParams p, const 
 // The whole-batch render when the frame is a grid of r x r equal squares, one per view cell (U = O / r pixels), and the only
 // rows / columns whose taps straddle two cells are first rows / columns of a square (xw_ego_tables checks; true of r = 3,
 // 5, 7 on every map size tried): then a frame is U-byte runs, each copied from the table frame of what its view cell
-// shows or from the env's rendered goal cell, plus at most r - 1 border rows and r - 1 border columns per frame, which are
-// evaluated pixel by pixel into a small per-env buffer first.  The one-workgroup-per-env kernel above spends its time waiting (three barriers and a serial set-up per
-// frame, four workgroups per CU: 14 us per frame and workgroup, 0.20 of the HBM roofline); split by what is parallel in:
+// shows or from the env's rendered goal cell; the first row / column of a square that blends a goal's image comes from that
+// goal's cache entry, the pixel where a border row crosses a border column from a table of four classes (round 5; rounds 2-4
+// evaluated those lines for every env on every step).  The one-workgroup-per-env kernel above spends its time waiting (three
+// barriers and a serial set-up per frame, four workgroups per CU: 14 us per frame and workgroup, 0.20 of the HBM roofline);
+// split by what is parallel in:
 //   xw_ego_cells_kernel   lane per env: shadow rays and scan lines on bit masks -> cellinfo[env][view cell], and the list
 //                         of goal cells the cache does not hold yet
 //   xw_ego_eval_kernel    the pixels that have to be evaluated: four workgroups per listed goal cell -- the U x U pixels of its
@@ -1188,10 +1190,11 @@ struct EgoSpanGeom {
 // Hence this shape: the sources hold whole squares with their border row and column already in them (ego_tab3 is keyed by
 // the classes of the cell, the one above and the one to the left), rows padded to whole 16-byte pieces; a UNIT is four
 // consecutive frame rows of one square column (U is a multiple of four: one square, one plane, one env), 4 UP contiguous
-// source bytes.  One lane per unit reads three cell words and posts one address; one lane per piece loads 16 bytes and
-// drops its dwords into output order in LDS; one barrier; 16-byte non-temporal stores.  Only where a goal is in or next to
-// the cell (its lines are evaluated per env into ego_border) or where a border row crosses a border column (four cells)
-// does the unit's lane place a row or first dwords itself -- the pieces leave those dwords alone.
+// source bytes.  One lane per unit reads the square's two words and posts one address; one lane per piece loads 16 bytes and
+// drops its dwords into output order in LDS; one barrier; 16-byte non-temporal stores.  Only where a goal is next to the
+// cell (the line that blends its image lies in the goal's cache entry: EgoEntry) or where a border row crosses a border column
+// (four cells: the pixel rides in the square's second word) does the unit's lane place a row or first dwords itself -- the
+// pieces leave those dwords alone.
 // flag_all: the context flag of every env touched (list render), -1: the cell words say.
 struct EgoGatherLds { uint4 *out4; uint32_t *env; const uint8_t **usrc; int *uo; };
 #define EGO_GATHER_LDS(G, R_, name) \
