@@ -180,7 +180,8 @@ enum { XWB_DEBUG_NO_PREGEN = 1,      /* no pre-generated episodes: every verb on
        XWB_DEBUG_NO_LAZY = 2,        /* xwb_step + xwb_reset_done on the classic path (xwb_step_autoreset keeps its pre-generation) */
        XWB_DEBUG_EGO_NO_CACHE = 4,   /* egocentric: no cache of rendered goal cells (and hence no span path) */
        XWB_DEBUG_EGO_NO_SPAN = 8,    /* egocentric: one workgroup per env instead of the span path */
-       XWB_DEBUG_EGO_NO_FLAT = 16 }; /* egocentric span path: no shared constant line for one-colour squares */
+       XWB_DEBUG_EGO_NO_FLAT = 16,   /* egocentric span path: no shared constant line for one-colour squares */
+       XWB_DEBUG_NO_FUSED = 32 };    /* xwb_step of the default loop as two launches (step, render) instead of one */
 
 /* xwb_config.queue_sync.  AUTO: device-side epochs (no event / barrier packets: 12 us per step on the C4 loop) on every caller
  * stream that passed a one-time concurrency probe against the batch's internal stream -- the default stream is probed by
@@ -275,7 +276,9 @@ enum { XWB_PATH_NONE = 0,        /* SimpleGame / SimpleRace (one kernel), or no 
        XWB_PATH_CLASSIC = 1,     /* step -> render(all; finished envs from terminal snapshots); reset on the internal queue */
        XWB_PATH_LAZY = 2,        /* pre-generated episodes installed by xwb_reset_done's list render (the default loop) */
        XWB_PATH_PREGEN = 3,      /* xwb_step_autoreset: the step kernel itself starts the pre-generated episode */
-       XWB_PATH_EGO_SPAN = 4, XWB_PATH_EGO_PER_ENV = 5 /* egocentric renders, see xwb_ego_render_path */ };
+       XWB_PATH_EGO_SPAN = 4, XWB_PATH_EGO_PER_ENV = 5, /* egocentric renders, see xwb_ego_render_path */
+       XWB_PATH_LAZY_FUSED = 6 };/* XWB_PATH_LAZY with the step kernel's work inside the render's launch: the render blocks draw from a
+                                  * snapshot of the state before the step plus the call's actions (context 1; from the second step on) */
 int xwb_step_path(xwb_sim *sim, int32_t *path, int32_t *sync_mode, int32_t *shadow_breaks);
 /* drops what the batch remembers about `stream` (call before destroying a probed stream: a later stream may reuse the handle) */
 int xwb_queue_sync_forget(xwb_sim *sim, void *stream);

@@ -28,6 +28,8 @@ def test_step_path_reports_the_kernel_sequence():
     assert sim.step_path()["path"] == "none"                       # no step yet
     sim.step(); sim.reset_done()
     assert sim.step_path() == {"path": "lazy", "queue_sync": sim.queue_sync_mode()[0], "shadow_breaks": 0}
+    sim.step(); sim.reset_done()                                   # the second step finds a snapshot: one launch
+    assert sim.step_path() == {"path": "lazy_fused", "queue_sync": sim.queue_sync_mode()[0], "shadow_breaks": 0}
     sim.step_autoreset()
     assert sim.step_path()["path"] == "pregen"
     mask = torch.zeros(512, dtype=torch.uint8, device="cuda")
@@ -38,6 +40,11 @@ def test_step_path_reports_the_kernel_sequence():
     p = sim.step_path()
     assert p["path"] == "classic" and p["shadow_breaks"] >= 3
     sim.close()
+    for opts in (dict(OPTS, debug=["no_fused"]), dict(OPTS, context=2)):      # no fused launch: switched off, or a context ring
+        s = BatchedSimulator("xworld", opts, num_envs=256)
+        s.step(); s.reset_done(); s.step()
+        assert s.step_path()["path"] == "lazy", (opts, s.step_path())
+        s.close()
     for opts, want in ((dict(OPTS, debug=["no_pregen"]), "classic"), (dict(OPTS, debug=["no_lazy"]), "classic"),
                        (dict(OPTS, obs_format="float32"), "classic"), (dict(OPTS, visible_radius=3), "ego_span"),
                        (dict(OPTS, visible_radius=3, debug=["ego_no_span"]), "ego_per_env")):
@@ -135,8 +142,8 @@ def test_checkpoint_blob_of_another_version_is_named():
     sim = BatchedSimulator("simple_game", {"array_size": 16}, num_envs=64)
     sim.step()
     blob = bytearray(sim.save_state())
-    assert blob[:8] == b"XWBSTATE" and int(np.frombuffer(bytes(blob[8:12]), np.uint32)[0]) == 3
-    blob[8:12] = np.uint32(2).tobytes()                            # what round 3 wrote
+    assert blob[:8] == b"XWBSTATE" and int(np.frombuffer(bytes(blob[8:12]), np.uint32)[0]) == 4
+    blob[8:12] = np.uint32(2).tobytes()                            # what round 3 wrote (rounds 4-5: 3)
     with pytest.raises(Exception, match="version 2"):
         sim.load_state(np.frombuffer(bytes(blob), np.uint8))
     blob[:8] = b"NOTSTATE"

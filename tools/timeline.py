@@ -6,7 +6,7 @@ import sys
 
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-steps = [i for i, r in enumerate(rows) if "xw_step_kernel" in r["Kernel_Name"]]
+steps = [i for i, r in enumerate(rows) if "xw_step_kernel" in r["Kernel_Name"] or "xw_step_render_kernel" in r["Kernel_Name"]]
 k = steps[len(steps) // 2]
 t0 = int(rows[k]["Start_Timestamp"])
 for r in rows[k:steps[len(steps) // 2 + 2]]:

@@ -182,13 +182,6 @@ struct Move {
     bool success;
 };
 
-// The common configuration -- full observation, ONE XWorld3DNav* task group, no curriculum, no minstd engines, no exclusive
-// scheduling (what pre-generated episodes need as well).  (A kernel specialised on it by overwriting those fields of its
-// by-value XwParams was tried: the struct then lives in scratch memory -- 1 KB per lane -- and the kernel takes twice as long.)
-inline bool xw_fast_config(const XwParams &p) {
-    return !p.visible_radius && p.n_tasks2 == 0 && !p.group2d && p.curriculum == 0.0 && !p.minstd && !p.exclusive && !p.idle_list;
-}
-
 __device__ __forceinline__ void xw_load_step_in(const XwParams &p, int e, StepIn &in) {
     in.axy = p.agent_xy[e]; in.steps = p.num_steps[e]; in.ts = p.task_state[e]; in.tsteps = p.task_steps[e];
     in.ts2 = 0; in.tsteps2 = 0; in.dir = 1; in.level = 0; in.action = 0; in.ep = 0;
@@ -336,7 +329,10 @@ __device__ __forceinline__ void xw_teach_store(const XwParams &p, int e, const S
     is_done = code != ALIVE;
 }
 
-__global__ __launch_bounds__(64) void xw_step_kernel(XwParams p) {
+// The step of `epb` consecutive envs by ONE wavefront (lane = env): the body of xw_step_kernel (epb = 64, one wavefront per
+// workgroup) and of the step blocks of xw_step_render_kernel (the first wavefront of a 128-thread block; epb = as many grids
+// as that kernel's LDS holds).
+__device__ __forceinline__ void xw_step_body(const XwParams &p, const int blk, const int epb, uint4 *s_dyn) {
     // The kernel is a chain of dependent memory round trips for a few hundred wavefronts (it moves ~4 MB): everything that
     // does not depend on a previous load is fetched in the FIRST round trip -- the env's scalars, its goal-slot table (which
     // answers "is the thing I bumped into a goal" without a look-up at the end of the chain) and the GRIDS of the wavefront's
@@ -344,10 +340,9 @@ __global__ __launch_bounds__(64) void xw_step_kernel(XwParams p) {
     // instead of paying a second round trip that depends on the agent's position.  One wavefront per workgroup: 512 workgroups
     // at C4, so every CU has one or two (256-thread groups left half the chip idle).
     SP_T(0, 0);
-    extern __shared__ uint4 s_dyn[];                       // [64][max_dim^2] cell codes of this wavefront's envs
-    uint16_t *s_grid = reinterpret_cast<uint16_t *>(s_dyn);
+    uint16_t *s_grid = reinterpret_cast<uint16_t *>(s_dyn);   // [epb][max_dim^2] cell codes of this wavefront's envs
     const int lane = threadIdx.x;
-    const int e0 = blockIdx.x * 64, e = e0 + lane;
+    const int e0 = blk * epb, e = lane < epb ? e0 + lane : p.n;   // (a lane without an env: e = n)
     const int cells_all = p.max_dim * p.max_dim;
     int32_t *count_now = p.done_count;
     if (e == 0) {
@@ -362,8 +357,9 @@ __global__ __launch_bounds__(64) void xw_step_kernel(XwParams p) {
     in.dir = 1;
     in.gc = make_uint4(~0u, ~0u, ~0u, ~0u);
     if (e < p.n) xw_load_step_in(p, e, in);
+    int axy_new = in.axy;                                  // (an env that sits this call out keeps its cell)
     {
-        const int n_here = p.n - e0 < 64 ? p.n - e0 : 64;
+        const int n_here = p.n - e0 < epb ? p.n - e0 : epb;
         const int total = n_here * cells_all;              // u16 elements of this block; the block starts 16-byte aligned
         const uint16_t *src = p.grid + (size_t)e0 * cells_all;
         const int full = total / 8;
@@ -386,9 +382,28 @@ __global__ __launch_bounds__(64) void xw_step_kernel(XwParams p) {
             // the live grid gets the move's two cells; they are read from (and kept current in) the wavefront's LDS copy
             const Move m = xw_move(p, e, a, in.axy, in.dir, s_grid + lane * cells_all, p.grid + (size_t)e * cells_all);
             xw_teach_store(p, e, in, m, is_done, idle3d);
+            axy_new = m.ax | (m.ay << 16);
         }
     }
     SP_T(0, 2);
+    if (p.snap_grid_out) {
+        // Look-ahead (XwParams::snap_grid_out): the built-in policy's NEXT action is known now, so the wavefront's LDS copy of the
+        // grids -- this step's moves applied -- gets the next step's move as well and goes to the snapshot that step's render
+        // blocks draw from while its own step blocks rewrite the live state beside them (xw_step_render_kernel).
+        if (e < p.n) {
+            uint16_t *lg = s_grid + lane * cells_all;
+            int from;
+            const int to = xw_predict_move(lg, p.max_dim, axy_new, policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step + 1u, 4),
+                                           p.act_rep, &from);
+            if (to != from) { lg[to] = lg[from]; lg[from] = 0; }
+        }
+        __syncthreads();                                   // (one wavefront: the lanes' moves are in the LDS copy)
+        const int n_here = p.n - e0 < epb ? p.n - e0 : epb;
+        const int total = n_here * cells_all, full = total / 8;
+        uint16_t *dst = p.snap_grid_out + (size_t)e0 * cells_all;
+        for (int c = lane; c < full; c += 64) reinterpret_cast<uint4 *>(dst)[c] = s_dyn[c];
+        for (int k = full * 8 + lane; k < total; k += 64) dst[k] = s_grid[k];
+    }
     if (p.swap_shadow == 2) {
         // a plain step whose reset_done will install pre-generated episodes (list_swap): nothing to install here, but the list
         // appended below may still be read by the previous step's regeneration
@@ -459,6 +474,11 @@ __global__ __launch_bounds__(64) void xw_step_kernel(XwParams p) {
             for (int c = lane; c < cells_all; c += 64) t[c] = s_grid[j * cells_all + c];
         }
     }
+}
+
+__global__ __launch_bounds__(64) void xw_step_kernel(XwParams p) {
+    extern __shared__ uint4 s_dyn[];                       // [64][max_dim^2] cell codes of this wavefront's envs
+    xw_step_body(p, (int)blockIdx.x, 64, s_dyn);
 }
 
 hipError_t launch_xw_step(const XwParams &p, hipStream_t s) {
@@ -537,17 +557,24 @@ __device__ __forceinline__ uint4 xw_expand_chunk(const uint32_t *atlas, const ui
 // the side stream, so that render runs beside this kernel instead of after it.
 // ES = bytes per pixel: 1 = uint8 frames; 4 = float32 frames (pixel * 1/255, py_simulator.cpp:262-272) expanded from
 // a float copy of the tile table (628 KB, still L2-resident): the same kernel with 48-byte tile rows.
-template <int DIM_T, int CH, bool CTX1, int BS, int PER, int RMODE, int ES>
-__global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
+// LDS of one span: s_out4 [SPAN + PAD / 4 + TD / 4 + 1] uint4, s_code [SPAN * 16 / (144 * CH * ES) + 2 * XW_MAX_DIM^2] u16, s_done [NE]
+template <int CH, int BS, int PER, int ES>
+struct RenderLds {
+    static constexpr int SPAN = BS * PER, TD = 3 * ES, PAD = (TD + 3) / 4 * 4;
+    static constexpr int OUT4 = SPAN + PAD / 4 + TD / 4 + 1;
+    static constexpr int CODES = SPAN * 16 / (144 * CH * ES) + 2 * XW_MAX_DIM * XW_MAX_DIM;
+    static constexpr int NE = SPAN * 16 / (144 * CH * ES) + 2;               // envs a span can touch
+};
+
+// One span (workgroup `blk`) of the whole-batch render.  SNAP (xw_step_render_kernel): the cell codes come from the look-ahead
+// snapshot the previous step left (p.snap_grid_in: the grids with THIS step's moves already applied).
+template <int DIM_T, int CH, bool CTX1, int BS, int PER, int RMODE, int ES, bool SNAP>
+__device__ __forceinline__ void xw_render_span(const XwParams &p, const unsigned blk, uint4 *s_out4, uint16_t *s_code, uint8_t *s_done) {
     constexpr bool SKIP_DONE = RMODE == 2, TERM = RMODE == 3;
     constexpr int SPAN = BS * PER;
     constexpr int TB = 12 * ES, TD = 3 * ES;                               // bytes / dwords per tile row
     constexpr int PAD = (TD + 3) / 4 * 4;                                   // dword index of the span's first chunk
     constexpr int IT = ((SPAN * 16 + TB - 1) / TB + 1 + BS - 1) / BS;       // tile rows per lane
-    constexpr int NE = SPAN * 16 / (144 * CH * ES) + 2;                     // envs a span can touch
-    __shared__ uint4 s_out4[SPAN + PAD / 4 + TD / 4 + 1];
-    __shared__ uint16_t s_code[SPAN * 16 / (144 * CH * ES) + 2 * XW_MAX_DIM * XW_MAX_DIM];
-    __shared__ uint8_t s_done[NE];
     uint32_t *s_out = reinterpret_cast<uint32_t *>(s_out4);
     const int D = DIM_T ? DIM_T : p.max_dim;
     const int cells = D * D;
@@ -555,16 +582,14 @@ __global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
     const int cpf = (int)(FB / 16);
     const int tid = threadIdx.x;
     const unsigned long long n_chunks = (unsigned long long)p.n * cpf;
-    const unsigned long long c_lo = (unsigned long long)blockIdx.x * SPAN;
+    const unsigned long long c_lo = (unsigned long long)blk * SPAN;
     const unsigned long long c_hi = c_lo + SPAN < n_chunks ? c_lo + SPAN : n_chunks;
     const unsigned long long b_lo = c_lo * 16, b_hi = c_hi * 16;
     const int e0 = (int)(b_lo / FB), e1 = (int)((b_hi - 1) / FB);
     const int ncode = (e1 - e0 + 1) * cells;
-    // this kernel running = the step kernel queued before it is complete: tell the reset kernel's queue (xw_device.h)
-    if (p.sig_epoch && blockIdx.x == 0 && tid == 0) xw_publish_epoch(p.sync + 1, p.sig_epoch);
-    if (p.no_draw) return;                                 // (xwb_xw_set_draw(sim, 0): launched with one workgroup, for the epoch)
     for (int i = tid; i < ncode; i += BS) {
         const size_t gi = (size_t)e0 * cells + i;
+        if (SNAP) { s_code[i] = p.snap_grid_in[gi] & CELL_ICON_MASK; continue; }
         // (TERM: the flag, the live cell and the snapshot's cell are fetched together and selected -- flag-then-cell was two
         // dependent round trips at the head of every workgroup; worth ~1 us of the 101 on C4)
         // (uint8 frames; float32 frames -- four times the bytes per workgroup -- measured better with the dependent form)
@@ -637,6 +662,44 @@ __global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
     }
 }
 
+template <int DIM_T, int CH, bool CTX1, int BS, int PER, int RMODE, int ES>
+__global__ __launch_bounds__(BS) void xw_render_all_kernel(XwParams p) {
+    typedef RenderLds<CH, BS, PER, ES> L;
+    __shared__ uint4 s_out4[L::OUT4];
+    __shared__ uint16_t s_code[L::CODES];
+    __shared__ uint8_t s_done[L::NE];
+    // this kernel running = the step kernel queued before it is complete: tell the reset kernel's queue (xw_device.h)
+    if (p.sig_epoch && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 1, p.sig_epoch);
+    if (p.no_draw) return;                                 // (xwb_xw_set_draw(sim, 0): launched with one workgroup, for the epoch)
+    xw_render_span<DIM_T, CH, CTX1, BS, PER, RMODE, ES, false>(p, blockIdx.x, s_out4, s_code, s_done);
+}
+
+// xwb_step of the default loop in ONE launch (XWB_PATH_LAZY_FUSED): blocks [0, step_blocks) step `epb` envs each (first
+// wavefront; xw_step_body), every other block draws one span of the batch's frames from the look-ahead snapshot the previous
+// step left (xw_render_span<SNAP>).  Nothing a render block reads is written by a step block of the same launch: the step
+// blocks write the live state and the OTHER snapshot set.  The step's dependent round trips (8 us as a launch
+// of its own, in front of a render that is bound by the chip's write stream) run beside the render's first workgroups.
+constexpr int XW_FUSED_LDS = 8192;                         // bytes: a step block's grids (epb x cells x 2) or a span's staging
+__host__ __device__ inline int xw_fused_epb(int max_dim) {
+    const int per = max_dim * max_dim * 2;
+    return XW_FUSED_LDS / per >= 64 ? 64 : (XW_FUSED_LDS / per >= 32 ? 32 : 16);
+}
+
+template <int DIM_T, int CH>
+__global__ __launch_bounds__(128, 8) void xw_step_render_kernel(XwParams p, int step_blocks) {
+    typedef RenderLds<CH, 128, 2, 1> L;
+    static_assert((L::OUT4 * 16 + L::CODES * 2 + L::NE + 15) / 16 * 16 <= XW_FUSED_LDS, "a span's staging must fit");
+    __shared__ uint4 s_mem[XW_FUSED_LDS / 16];
+    if ((int)blockIdx.x < step_blocks) {
+        if (threadIdx.x >= 64) return;
+        xw_step_body(p, (int)blockIdx.x, xw_fused_epb(DIM_T ? DIM_T : p.max_dim), s_mem);
+        return;
+    }
+    uint16_t *s_code = reinterpret_cast<uint16_t *>(s_mem + L::OUT4);
+    xw_render_span<DIM_T, CH, true, 128, 2, 0, 1, true>(p, blockIdx.x - (unsigned)step_blocks, s_mem, s_code,
+                                                          reinterpret_cast<uint8_t *>(s_code + L::CODES));
+}
+
 // the compacted list of freshly reset envs, tile table through L1/L2.  A frame is cut into `parts` pieces of at most 512
 // chunks, one workgroup pass each: a lane owns at most two chunks and has the eight gathers of both in flight before its first
 // store (one env per workgroup looped five times over load -> store: 10.8 us for the ~115 envs a C4 step finishes).  The chain
@@ -652,6 +715,9 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
     // first round trip: the count, this workgroup's first list entry (the list is the step kernel's, complete long ago) and
     // the epoch, together
     SP_T(1, 0);
+    // (after a fused step + render launch this kernel is the first one behind the step in the caller's queue: it tells the
+    // internal queue, whose regeneration pass reads the done list, that the step is complete)
+    if (p.sig_epoch && blockIdx.x == 0 && threadIdx.x == 0) xw_publish_epoch(p.sync + 1, p.sig_epoch);
     const int cnt = *count_now;
     const int i_first = (int)blockIdx.x / parts;
     const int e_first = p.done_list[i_first < p.n ? i_first : 0];
@@ -678,7 +744,10 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
             const size_t es = (size_t)((ep_old + 1u) & 1u) * (size_t)p.n + (size_t)e;
             for (int k = threadIdx.x; k < cells; k += 256) {
                 const uint16_t code = p.sh_grid[es * cells + k];
-                if (part == 0) p.grid[(size_t)e * cells + k] = code;
+                if (part == 0) {
+                    p.grid[(size_t)e * cells + k] = code;
+                    if (p.snap_grid_out) p.snap_grid_out[(size_t)e * cells + k] = code;   // (the snapshot the next fused step draws from)
+                }
                 s_grid[k] = code & CELL_ICON_MASK;
             }
             if (part == 0 && threadIdx.x == 64) {         // (a lane of the second wavefront: beside the first one's gathers)
@@ -697,6 +766,15 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
             for (int k = threadIdx.x; k < cells; k += 256) s_grid[k] = p.grid[(size_t)e * cells + k] & CELL_ICON_MASK;
         }
         __syncthreads();
+        if (p.list_swap && p.snap_grid_out && part == 0 && threadIdx.x == 64) {
+            // look-ahead: the snapshot row written above gets the next step's move of the new episode (the built-in policy's
+            // action of step p.policy_step, the step the caller runs next), beside the gathers
+            const size_t es = (size_t)(((first ? ep_first : p.done_ep[i]) + 1u) & 1u) * (size_t)p.n + (size_t)e;
+            int from;
+            const int to = xw_predict_move(s_grid, D, p.sh_agent_xy[es], policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step, 4),
+                                           p.snap_act_rep, &from);
+            if (to != from) { p.snap_grid_out[(size_t)e * cells + to] = s_grid[from]; p.snap_grid_out[(size_t)e * cells + from] = 0; }
+        }
         uint4 *frame0 = reinterpret_cast<uint4 *>(p.obs) + (size_t)e * ctx * cpf;
         SP_T(1, 2);
         const int lo = part * per, hi = p.no_draw ? 0 : (lo + per < cpf ? lo + per : cpf);   // (drawing off: the install and the flags only)
@@ -731,6 +809,26 @@ static hipError_t render_all(const XwParams &p, hipStream_t s) {
         case 2: return render_all_shape<DIM_T, CH, 256, 2, SKIP, ES>(p, s);
         default: return render_all_shape<DIM_T, CH, 128, 2, SKIP, ES>(p, s);
     }
+}
+
+template <int DIM_T, int CH>
+static hipError_t step_render(const XwParams &p, hipStream_t s) {
+    const unsigned long long n_chunks = (unsigned long long)p.n * (CH * 9 * p.max_dim * p.max_dim);
+    const int epb = xw_fused_epb(p.max_dim);
+    const int step_blocks = (p.n + epb - 1) / epb;
+    const unsigned blocks = (unsigned)step_blocks + (unsigned)((n_chunks + 255) / 256);
+    hipLaunchKernelGGL((xw_step_render_kernel<DIM_T, CH>), dim3(blocks), dim3(128), 0, s, p, step_blocks);
+    return hipGetLastError();
+}
+
+hipError_t launch_xw_step_render(const XwParams &p, hipStream_t s) {
+    if (p.visible_radius || p.obs_f32 || p.context != 1 || p.no_draw || p.actions || !p.snap_grid_in || !p.snap_grid_out) return hipErrorInvalidValue;
+#define XW_CASE(DIMV) case DIMV: return p.channels == 3 ? step_render<DIMV, 3>(p, s) : step_render<DIMV, 1>(p, s);
+    switch (p.max_dim) {
+        XW_CASE(7) XW_CASE(8) XW_CASE(11)
+        default: return p.channels == 3 ? step_render<0, 3>(p, s) : step_render<0, 1>(p, s);
+    }
+#undef XW_CASE
 }
 
 template <int DIM_T, int CH, int ES>

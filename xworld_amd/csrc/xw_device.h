@@ -215,6 +215,21 @@ __device__ inline int curriculum_configure(const XwParams &p, int e) {
     return level;
 }
 
+// The move XAgent::act x act_rep (xitem.cpp:89-101) + XMap::move_item (xmap.cpp:76-101) makes on the cell codes `lg` of one env
+// under full observation: the agent's code goes up to act_rep cells along action a (MOVE_UP, MOVE_DOWN, MOVE_LEFT, MOVE_RIGHT)
+// while the next cell is inside the map and empty.  Returns the agent's new cell; *from = its old one (equal: no move).
+__device__ __forceinline__ int xw_predict_move(const uint16_t *lg, int D, int axy, int a, int act_rep, int *from) {
+    int ax = axy & 0xffff, ay = axy >> 16;
+    *from = ay * D + ax;
+    const int ddx = a == 2 ? -1 : (a == 3 ? 1 : 0), ddy = a == 0 ? -1 : (a == 1 ? 1 : 0);
+    for (int i = 0; i < act_rep; ++i) {
+        const int tx = ax + ddx, ty = ay + ddy;
+        if (tx < 0 || ty < 0 || tx >= D || ty >= D || lg[ty * D + tx] != 0) break;      // (blocked once = blocked for good)
+        ax = tx; ay = ty;
+    }
+    return ay * D + ax;
+}
+
 // ---- shared by the render kernels ----
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 

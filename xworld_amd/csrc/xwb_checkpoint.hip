@@ -24,7 +24,8 @@ std::vector<StateArray> state_arrays(xwb_sim *s, bool include_obs) {
         const size_t cells = (size_t)s->cfg.max_dim * s->cfg.max_dim;
         add(s->d_grid, n * cells * 2); add(s->d_agent, n * 4); add(s->d_task_steps, n * 4); add(s->d_task_state, n * 4);
         add(s->d_task_steps2, n * 4); add(s->d_task_state2, n * 4); add(s->d_grp_order, n);
-        add(s->d_done_list, n * 4); add(s->d_done_count, 8); add(s->d_fresh, n); add(s->d_perf, 40 * 8);
+        // (the done list and its counter rotate through two / three buffers: the current ones are saved, a load rewinds the rotation)
+        add(s->d_done_list + (size_t)s->list_sel * n, n * 4); add(s->d_done_count + s->count_sel, 4); add(s->d_fresh, n); add(s->d_perf, 40 * 8);
         add(s->d_goal_cells, n * XW_MAX_GOALS); add(s->d_cand2d, n * 4); add(s->d_agent_dir, n); add(s->d_sent_names, n * 4);
         add(s->d_goal_warp, n * XW_MAX_GOALS * 6 * sizeof(double));     // goal images are re-warped from these on load
         add(s->d_cur_level, n); add(s->d_cur_counter, n * 4); add(s->d_cur_usage, n * 9 * XW_USAGE_BYTES);
@@ -35,7 +36,8 @@ std::vector<StateArray> state_arrays(xwb_sim *s, bool include_obs) {
 
 // version 3 (round 4): per-workgroup reset counts (d_reset_partial, sized by num_envs) replaced the single counter, the
 // exclusive schedule's group order and the task performance counters joined, count_sel lost its rc_sel bit
-constexpr uint32_t XWB_STATE_VERSION = 3;
+// version 4 (round 6): ONE done counter (the current one of the rotation) instead of the pair
+constexpr uint32_t XWB_STATE_VERSION = 4;
 struct StateHeader {
     char magic[8];
     uint32_t version, game, num_envs, include_obs, n_arrays, policy_step, count_sel, list_valid;
@@ -79,7 +81,7 @@ int xwb_save_state(xwb_sim *s, int32_t include_obs, uint8_t *out_host, size_t ca
     StateHeader h{};
     memcpy(h.magic, "XWBSTATE", 8);
     h.version = XWB_STATE_VERSION; h.game = (uint32_t)s->cfg.game; h.num_envs = (uint32_t)s->n; h.include_obs = include_obs ? 1u : 0u;
-    h.n_arrays = (uint32_t)arrays.size(); h.policy_step = s->policy_step; h.count_sel = (uint32_t)s->count_sel;
+    h.n_arrays = (uint32_t)arrays.size(); h.policy_step = s->policy_step; h.count_sel = 0;
     h.list_valid = (s->list_valid ? 1u : 0u) | (s->autoreset_done ? 2u : 0u); h.obs_bytes_per_env = s->obs_bytes_per_env; h.cfg_hash = config_hash(s->cfg);
     uint8_t *w = out_host;
     memcpy(w, &h, sizeof h); w += sizeof h;
@@ -106,9 +108,11 @@ int xwb_load_state(xwb_sim *s, const uint8_t *in_host, size_t bytes) {
     if (h.game != (uint32_t)s->cfg.game || h.num_envs != (uint32_t)s->n || h.obs_bytes_per_env != s->obs_bytes_per_env ||
         h.cfg_hash != config_hash(s->cfg))
         return fail(XWB_ERR_ARG, "state blob was saved from a batch with another configuration");
+    HIP_TRY(hipDeviceSynchronize());
+    s->count_sel = 0; s->list_sel = 0;                  // the saved list and counter become the rotation's current ones
     const auto arrays = state_arrays(s, h.include_obs != 0);
     if (arrays.size() != h.n_arrays) return fail(XWB_ERR_ARG, "state blob layout mismatch");
-    HIP_TRY(hipDeviceSynchronize());
+    if (s->d_done_count) HIP_TRY(hipMemset(s->d_done_count, 0, 3 * sizeof(int32_t)));
     const uint8_t *r = in_host + sizeof h, *end = in_host + bytes;
     for (auto &a : arrays) {
         uint64_t b;
@@ -118,9 +122,9 @@ int xwb_load_state(xwb_sim *s, const uint8_t *in_host, size_t bytes) {
         HIP_TRY(hipMemcpy(a.ptr, r, a.bytes, hipMemcpyHostToDevice));
         r += b;
     }
-    s->shadow_ok = false; s->regen_pending = false; s->step_lazy = false;
+    s->shadow_ok = false; s->regen_pending = false; s->step_lazy = false; s->snap_ok = false; s->step_fused = false;
     s->frame_src = 0; s->draws_since_pack = 0;
-    s->policy_step = h.policy_step; s->count_sel = (int)(h.count_sel & 1u); s->list_valid = (h.list_valid & 1u) != 0; s->autoreset_done = (h.list_valid & 2u) != 0;
+    s->policy_step = h.policy_step; s->list_valid = (h.list_valid & 1u) != 0; s->autoreset_done = (h.list_valid & 2u) != 0;
     if (s->cfg.game == XWB_XWORLD2D) {
         XwParams p = xw_params(s);
         if (p.visible_radius) HIP_TRY(launch_xw_warp_goals(p, false, nullptr));

@@ -285,6 +285,18 @@ struct XwParams {
     int32_t *sh_agent_xy, *sh_task_state, *sh_task_state2;
     uint32_t *sh_sent_names, *sh_cand2d;
     uint8_t *sh_goal_cells;
+    // Look-ahead snapshots for the fused step + render launch (xw_step_render_kernel, the default loop's xwb_step under the built-in
+    // policy): a step changes at most two cells of an env's grid (XMap::move_item, xmap.cpp:76-101), whether it does is a function
+    // of (grid, agent cell, action) alone, and the built-in policy's action of step t + 1 is a function of (seed, env, t + 1).  A
+    // lazy step t therefore also writes, into one of two snapshot sets (snap_grid_out), every env's grid AS STEP t + 1 WILL LEAVE
+    // IT; the installing list render does the same for the episodes it starts.  xwb_step t + 1 is then ONE launch: its render
+    // blocks draw from that snapshot (snap_grid_in) -- the plain whole-batch render, reading another array -- while its step
+    // blocks update the live state and fill the other set beside them.  Null on every other path.  (Deriving the moved cells
+    // inside the render blocks from a descriptor + the call's actions was built first: every extra load, vector or scalar, at the
+    // head of the 85 000 workgroups cost more than the step kernel it saved -- profiles/NOTES.md round 6.)
+    const uint16_t *snap_grid_in;
+    uint16_t *snap_grid_out;
+    int snap_act_rep;            // act_rep of the predicted move (the list render's; the step kernel predicts with its own)
     // device-side hand-off between the two queues of the step loop, instead of event / barrier packets (each costs the
     // loop ~3-6 us of idle GPU): sync[1] = epoch of the last completed step kernel, sync[3] = of the last completed reset
     // kernel, sync[4] != 0: a wait gave up (xw_device.h: xw_publish_epoch / xw_wait_epoch).  render_all with sig_epoch != 0 publishes it to sync[1] when it
@@ -301,6 +313,9 @@ struct XwParams {
     int no_draw;                 // xwb_xw_set_draw(sim, 0): the renders keep their bookkeeping (epochs, installs, fresh / done flags) and store no pixels
 };
 hipError_t launch_xw_step(const XwParams &p, hipStream_t s);
+// step + render(all) in ONE launch: the render blocks draw from the snapshot p.snap_*_in + this call's actions (uint8 frames,
+// context 1, full observation); hipErrorInvalidValue when the configuration has no such kernel
+hipError_t launch_xw_step_render(const XwParams &p, hipStream_t s);
 // exclusive scheduling of two groups: the idle stages of the XWorld3DNav* group that the step kernel deferred (idle_list)
 hipError_t launch_xw_idle3d(const XwParams &p, hipStream_t s);
 // one wavefront that ends once *epoch_slot has reached `want`: orders the work queued behind it after the publisher

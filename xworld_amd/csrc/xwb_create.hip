@@ -39,6 +39,7 @@ const DebugEnv &debug_env() {
             else if (t == "ego_no_cache") e.flags |= XWB_DEBUG_EGO_NO_CACHE;
             else if (t == "ego_no_span") e.flags |= XWB_DEBUG_EGO_NO_SPAN;
             else if (t == "ego_no_flat") e.flags |= XWB_DEBUG_EGO_NO_FLAT;
+            else if (t == "no_fused") e.flags |= XWB_DEBUG_NO_FUSED;
             else if (t.compare(0, 8, "ego_per=") == 0) e.ego_per = atoi(t.c_str() + 8);
             else if (t.compare(0, 8, "ego_pad=") == 0) e.ego_pad = atoi(t.c_str() + 8) + 1;
             else if (t.compare(0, 10, "ego_fused=") == 0) { fprintf(stderr, "xwb: XWB_DEBUG ego_fused: the fused lab kernel was removed (see profiles/NOTES.md)\n"); }
@@ -248,7 +249,7 @@ int xw_setup(xwb_sim *s) {
     if (exclusive && c.n_tasks2 > 0) {
         if ((rc = dev_alloc(s, &s->d_grp_order, n))) return rc;
         if ((rc = dev_alloc(s, &s->d_idle_list, n))) return rc;
-        if ((rc = dev_alloc(s, &s->d_idle_count, 2))) return rc;
+        if ((rc = dev_alloc(s, &s->d_idle_count, 3))) return rc;
     }
     if ((rc = dev_alloc(s, &s->d_perf, 40))) return rc;
     // Pre-generated next episodes: possible where an env's next episode is a pure function of (seed, global id, episode + 1)
@@ -267,10 +268,15 @@ int xw_setup(xwb_sim *s) {
         if ((rc = dev_alloc(s, &s->d_sh_sent_names, (size_t)2 * n))) return rc;
         if ((rc = dev_alloc(s, &s->d_sh_cand2d, (size_t)2 * n))) return rc;
         if ((rc = dev_alloc(s, &s->d_sh_goal_cells, (size_t)2 * n * XW_MAX_GOALS))) return rc;
+        // the default loop's xwb_step as ONE launch (XwParams::snap_*): frames without a context ring only
+        if (c.context == 1 && !(c.debug_flags & XWB_DEBUG_NO_FUSED))
+            for (int k = 0; k < 2; ++k) {
+                if ((rc = dev_alloc(s, &s->d_snap_grid[k], (size_t)n * cells))) return rc;
+            }
     }
-    if ((rc = dev_alloc(s, &s->d_done_list, n))) return rc;
-    if ((rc = dev_alloc(s, &s->d_done_ep, n))) return rc;
-    if ((rc = dev_alloc(s, &s->d_done_count, 2))) return rc;
+    if ((rc = dev_alloc(s, &s->d_done_list, (size_t)2 * n))) return rc;       // two lists, three counters: xwb_sim.h count_sel
+    if ((rc = dev_alloc(s, &s->d_done_ep, (size_t)2 * n))) return rc;
+    if ((rc = dev_alloc(s, &s->d_done_count, 3))) return rc;
     if ((rc = dev_alloc(s, &s->d_fresh, n))) return rc;
     if ((rc = dev_alloc(s, &s->d_icon_type, ((size_t)c.n_icons + 3) & ~(size_t)3))) return rc;   // the step kernel stages it dword-wise
     if ((rc = dev_alloc(s, &s->d_icon_colored, c.n_icons))) return rc;
@@ -535,7 +541,7 @@ int xwb_create(const xwb_config *cfg, xwb_sim **out) {
         return fail(XWB_ERR_HIP, "no HIP device: libxwb.so has no CPU path");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(XWB_ERR_ARG, "bad device ordinal");
     DeviceGuard _device_guard(cfg->device);           // the caller's current device is restored on return
-    if (cfg->debug_flags & ~31) return fail(XWB_ERR_ARG, "unknown debug_flags bit");
+    if (cfg->debug_flags & ~63) return fail(XWB_ERR_ARG, "unknown debug_flags bit");
     if ((cfg->debug_ego_per != 0 && cfg->debug_ego_per != 2 && cfg->debug_ego_per != 4 && cfg->debug_ego_per != 8) || cfg->debug_ego_pad < 0 ||
         cfg->debug_ego_pad > 65536 || cfg->debug_render_shape < 0 || cfg->debug_render_shape > 2)
         return fail(XWB_ERR_ARG, "debug_ego_per must be 0 | 2 | 4 | 8, debug_ego_pad 0 .. 65536, debug_render_shape 0 .. 2");

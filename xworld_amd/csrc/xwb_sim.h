@@ -69,7 +69,11 @@ struct xwb_sim {
     int frame_src = 0, draws_since_pack = 0;
     bool draw_off = false;                 // xwb_xw_set_draw(sim, 0): frames are not drawn (their consumer draws them from xwb_xw_pack_grids)
     bool autoreset_done = false;           // the last step call already reset the envs whose codes are still set
-    int count_sel = 0;
+    // the done list lives in two buffers and its counter in three, rotated by every xworld step call (list_sel, count_sel): step k
+    // appends to list k & 1 / counter k % 3 and zeroes counter (k + 1) % 3, so the regeneration pass of step k - 1, which reads that
+    // step's list and counter on the internal queue, is never in the way -- only the one of step k - 2 has to be through
+    int count_sel = 0, list_sel = 0;
+    uint64_t step_seq = 0;                 // xworld step calls so far
     bool profiling = false;
     xwb::host::KernelTimer t_render, t_step, t_reset, t_list;   // t_list: the list render (first frames of the envs a reset started)
     int last_path = XWB_PATH_NONE;           // xwb_step_path: which kernel sequence the last step call ran
@@ -117,7 +121,15 @@ struct xwb_sim {
     bool pregen = false, shadow_ok = false, regen_pending = false, regen_by_epoch = false;
     bool step_lazy = false;                // the last plain step kept no terminal snapshot: its reset_done installs shadows
     int shadow_breaks = 0;                 // times another verb made the shadows stale (the lazy default path gives up after a few)
-    uint32_t epoch_regen = 0;
+    uint32_t epoch_regen = 0, epoch_regen_prev = 0;   // epochs of the last two regeneration passes handed over by epoch ...
+    uint64_t regen_seq = 0, regen_seq_prev = 0;       // ... and the step calls (step_seq) whose lists they read
+    // look-ahead snapshots (XwParams::snap_grid_*): while snap_ok, set snap_sel holds the grids as the built-in policy's step
+    // number snap_step with act_rep = snap_act_rep WILL leave them; every verb that writes the live state without patching the
+    // snapshot clears snap_ok, and the next xwb_step then runs step -> render as two launches again
+    uint16_t *d_snap_grid[2] = {nullptr, nullptr};
+    int snap_sel = 0, snap_act_rep = 1;
+    bool snap_ok = false, step_fused = false;
+    uint32_t snap_step = 0;
     uint32_t *d_sh_ep = nullptr, *d_done_ep = nullptr;
     uint8_t *d_sh_goal_cells = nullptr;
     uint16_t *d_sh_grid = nullptr;

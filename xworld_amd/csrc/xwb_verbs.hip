@@ -210,9 +210,11 @@ XwParams xw_params(xwb_sim *s) {
     p.policy_step = s->policy_step;
     p.no_draw = s->draw_off ? 1 : 0;
     p.list_flag = 2;
+    p.done_list = s->d_done_list + (size_t)s->list_sel * (size_t)s->n;
+    p.done_ep = s->d_done_ep + (size_t)s->list_sel * (size_t)s->n;
     p.done_count = s->d_done_count + s->count_sel;
-    p.done_count_next = s->d_done_count + (1 - s->count_sel);
-    if (s->d_idle_count) { p.idle_count = s->d_idle_count + s->count_sel; p.idle_count_next = s->d_idle_count + (1 - s->count_sel); }
+    p.done_count_next = s->d_done_count + (s->count_sel + 1) % 3;
+    if (s->d_idle_count) { p.idle_count = s->d_idle_count + s->count_sel; p.idle_count_next = s->d_idle_count + (s->count_sel + 1) % 3; }
     return p;
 }
 
@@ -245,6 +247,7 @@ int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t
     if (render) { s->frame_src = mode == MODE_RESET_ALL ? 0 : 2; s->draws_since_pack += 1; }
     if (s->shadow_ok) s->shadow_breaks += 1;
     s->shadow_ok = false;                  // the episodes these envs start now are the ones their shadows held
+    s->snap_ok = false;                    // ... and the live grids are rewritten without the snapshot
     XwParams p = xw_params(s);
     // 0: the reset kernel clears the done codes; 1: they are kept (step_autoreset); 2: the reset runs on the side stream
     // beside work already queued on `st` that may still read this step's codes -> the list render, which is ordered
@@ -362,17 +365,40 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
             if (rcj) return rcj;
         }
         s->step_lazy = lazy;
-        s->count_sel ^= 1;                     // this step appends to the counter the previous one zeroed
+        s->count_sel = (s->count_sel + 1) % 3; // this step appends to the counter the previous one zeroed ...
+        s->list_sel ^= 1;                      // ... and to the list the one before it filled
+        s->step_seq += 1;
         XwParams p = xw_params(s);
         p.actions = actions_dev; p.act_rep = act_rep;
-        if (pregen || lazy) { p.swap_shadow = pregen ? 1 : 2; p.regen_wait = s->regen_pending ? s->epoch_regen : 0; }
+        if (pregen) { p.swap_shadow = 1; p.regen_wait = s->regen_pending ? s->epoch_regen : 0; }   // (it rewrites shadows: the newest pass)
+        if (lazy) {
+            // the buffers this step writes were last read by the regeneration pass of the step call two back (xwb_sim.h count_sel)
+            p.swap_shadow = 2;
+            p.regen_wait = !s->regen_pending || !s->regen_by_epoch ? 0u : (s->regen_seq + 2 <= s->step_seq ? s->epoch_regen : s->epoch_regen_prev);
+        }
+        // A lazy step under the built-in policy also writes the grids as the NEXT step will leave them (XwParams::snap_grid_out);
+        // when the previous verbs kept such a snapshot current for exactly this step, this call is ONE launch: render blocks that
+        // draw from it, step blocks beside them (XWB_PATH_LAZY_FUSED).
+        const bool snaps = lazy && s->d_snap_grid[0] != nullptr && actions_dev == nullptr;
+        const bool fused = snaps && s->snap_ok && s->snap_step == s->policy_step && s->snap_act_rep == act_rep && !s->draw_off;
+        if (snaps) {
+            p.snap_grid_out = s->d_snap_grid[s->snap_sel ^ 1];
+            if (fused) p.snap_grid_in = s->d_snap_grid[s->snap_sel];
+        }
         if (++s->epoch_step == 0) s->epoch_step = 1;
         p.sig_epoch = epochs ? s->epoch_step : 0;   // published by the render kernel queued behind the step kernel
-        timer_begin(s, s->t_step, st);
-        HIP_TRY(launch_xw_step(p, st));
-        // exclusive scheduling of two groups: idle XWorld3DNav* groups the step picked run their idle stage now
-        if (p.idle_list) HIP_TRY(launch_xw_idle3d(p, st));
-        timer_end(s, s->t_step, st);
+        if (!fused) {
+            timer_begin(s, s->t_step, st);
+            HIP_TRY(launch_xw_step(p, st));
+            // exclusive scheduling of two groups: idle XWorld3DNav* groups the step picked run their idle stage now
+            if (p.idle_list) HIP_TRY(launch_xw_idle3d(p, st));
+            timer_end(s, s->t_step, st);
+        }
+        if (snaps) s->snap_sel ^= 1;
+        s->snap_ok = snaps;
+        s->snap_step = s->policy_step + 1u;
+        s->snap_act_rep = act_rep;
+        s->step_fused = fused;
         s->list_valid = true;
         XwParams pr = xw_params(s);
         pr.sig_epoch = 0;
@@ -389,6 +415,7 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
             HIP_TRY(launch_xw_reset(q, MODE_RESET_DONE, s->side));
             timer_end(s, s->t_reset, s->side);
             if (epochs) {
+                s->epoch_regen_prev = s->epoch_regen; s->regen_seq_prev = s->regen_seq; s->regen_seq = s->step_seq;
                 if (++s->epoch_regen == 0) s->epoch_regen = 1;
                 HIP_TRY(launch_xw_signal(s->d_sync + 8, s->epoch_regen, s->side));
             } else {
@@ -431,6 +458,13 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
                 HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
             }
             s->list_valid = false;
+        } else if (fused) {
+            // the step is complete when this kernel is: nothing publishes its epoch here -- xwb_reset_done's list render does
+            p.sig_epoch = 0;
+            timer_begin(s, s->t_render, st);
+            HIP_TRY(launch_xw_step_render(p, st));
+            timer_end(s, s->t_render, st);
+            if (!epochs) HIP_TRY(hipEventRecord(s->ev_step, st));
         } else {
             if (!p.visible_radius && !epochs) HIP_TRY(hipEventRecord(s->ev_step, st));
             // Finished envs keep a terminal snapshot of their grid (step kernel) from which the big render draws their
@@ -464,10 +498,10 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
     s->span_step = !autoreset && xw_ego_span(s->xw);
     // sync[1] = this call's epoch once its step kernel is complete: published by render_all's first thread on every full-observation
     // path that hands over through epochs (the egocentric paths publish other slots, or record events)
-    s->results_by_epoch = s->cfg.game == XWB_XWORLD2D && s->step_epochs && !s->cfg.visible_radius;
+    s->results_by_epoch = s->cfg.game == XWB_XWORLD2D && s->step_epochs && !s->cfg.visible_radius && !s->step_fused;
     s->last_path = s->cfg.game != XWB_XWORLD2D ? XWB_PATH_NONE :
                    (s->cfg.visible_radius ? (xw_ego_span(s->xw) ? XWB_PATH_EGO_SPAN : XWB_PATH_EGO_PER_ENV) :
-                    (autoreset && s->pregen ? XWB_PATH_PREGEN : (s->step_lazy ? XWB_PATH_LAZY : XWB_PATH_CLASSIC)));
+                    (autoreset && s->pregen ? XWB_PATH_PREGEN : (s->step_lazy ? (s->step_fused ? XWB_PATH_LAZY_FUSED : XWB_PATH_LAZY) : XWB_PATH_CLASSIC)));
     if (s->cfg.game == XWB_XWORLD2D) {     // a plain step on the classic path drew the finished envs from their terminal snapshots
         s->frame_src = (!autoreset && !s->step_lazy && !s->cfg.visible_radius) ? 1 : 0;
         s->draws_since_pack += 1;
@@ -522,6 +556,10 @@ int xwb_reset_done(xwb_sim *s, void *stream) {
         XwParams p = xw_params(s);
         p.auto_reset = 2; p.list_swap = 1;
         const bool by_epoch = s->step_epochs;
+        // (the installs go to the live state AND to the snapshot of it that the next fused step draws from; after a fused step
+        // this render is the first kernel behind the step in the caller's queue: it publishes that step's epoch)
+        if (s->snap_ok) { p.snap_grid_out = s->d_snap_grid[s->snap_sel]; p.snap_act_rep = s->snap_act_rep; }
+        p.sig_epoch = s->step_fused && by_epoch ? s->epoch_step : 0;
         if (s->regen_pending && !s->regen_by_epoch) { HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0)); s->regen_pending = false; }
         p.wait_slot = 8;
         p.wait_epoch = s->regen_pending ? s->epoch_regen : 0;
@@ -535,6 +573,7 @@ int xwb_reset_done(xwb_sim *s, void *stream) {
         HIP_TRY(launch_xw_reset(q, MODE_RESET_DONE, s->side));
         timer_end(s, s->t_reset, s->side);
         if (by_epoch) {
+            s->epoch_regen_prev = s->epoch_regen; s->regen_seq_prev = s->regen_seq; s->regen_seq = s->step_seq;
             if (++s->epoch_regen == 0) s->epoch_regen = 1;
             HIP_TRY(launch_xw_signal(s->d_sync + 8, s->epoch_regen, s->side));
         } else {

@@ -16,8 +16,8 @@ XWB_MAP_NAV, XWB_MAP_WALLS = 0, 1
 XWB_TASKMODE_LANG_ACQ, XWB_TASKMODE_ONE_CHANNEL = 0, 1
 ALIVE, MAX_STEP, DEAD, SUCCESS, LOST_LIFE = 0, 1, 2, 4, 8
 XWB_QUEUE_SYNC_AUTO, XWB_QUEUE_SYNC_EVENTS, XWB_QUEUE_SYNC_EPOCHS = 0, 1, 2
-DEBUG_FLAGS = {"no_pregen": 1, "no_lazy": 2, "ego_no_cache": 4, "ego_no_span": 8, "ego_no_flat": 16}
-STEP_PATHS = ["none", "classic", "lazy", "pregen", "ego_span", "ego_per_env"]
+DEBUG_FLAGS = {"no_pregen": 1, "no_lazy": 2, "ego_no_cache": 4, "ego_no_span": 8, "ego_no_flat": 16, "no_fused": 32}
+STEP_PATHS = ["none", "classic", "lazy", "pregen", "ego_span", "ego_per_env", "lazy_fused"]
 SYNC_REASONS = ["probe_ok", "config", "env", "tool", "probe_failed", "probe_error", "not_used", "not_probed"]
 
 
