@@ -371,9 +371,9 @@ def c5_block(args, world, rank, local_rank, dev, K, lib_comm_main=None):
             state["screens"].bind_next()
         state["calls"] += 1
         sim.step()
+        sim.reset_done()
         (results.finish(convert=False) if args.results_wait else results.release())
         results.start(packed=packed[(state["calls"] - 1) % 8])
-        sim.reset_done()
         if state["screens"] is not None:
             state["screens"].start()
 
@@ -582,8 +582,11 @@ def main():
             exchange_results()
         else:
             sim.step()
-            exchange_results()                           # this step's results, before reset_done clears the codes
             sim.reset_done()
+            # this step's results: the (reward, code) rows the step wrote into the record, which reset_done leaves alone.  Behind
+            # reset_done, whose list render publishes the epoch of a fused step + render launch: the exchange waits for that
+            # epoch on its own stream instead of an event recorded on this one
+            exchange_results()
         if screens is not None:
             screens.start()                              # the frames the next policy step would see
 

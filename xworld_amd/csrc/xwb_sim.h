@@ -129,6 +129,8 @@ struct xwb_sim {
     uint16_t *d_snap_grid[2] = {nullptr, nullptr};
     int snap_sel = 0, snap_act_rep = 1;
     bool snap_ok = false, step_fused = false;
+    bool step_pub_queued = false;          // a kernel that publishes the last step call's epoch is in the caller's queue (after a fused
+                                           // launch that is xwb_reset_done's list render: until then, results are handed over by an event)
     uint32_t snap_step = 0;
     uint32_t *d_sh_ep = nullptr, *d_done_ep = nullptr;
     uint8_t *d_sh_goal_cells = nullptr;

@@ -498,7 +498,8 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
     s->span_step = !autoreset && xw_ego_span(s->xw);
     // sync[1] = this call's epoch once its step kernel is complete: published by render_all's first thread on every full-observation
     // path that hands over through epochs (the egocentric paths publish other slots, or record events)
-    s->results_by_epoch = s->cfg.game == XWB_XWORLD2D && s->step_epochs && !s->cfg.visible_radius && !s->step_fused;
+    s->results_by_epoch = s->cfg.game == XWB_XWORLD2D && s->step_epochs && !s->cfg.visible_radius;
+    s->step_pub_queued = !s->step_fused;
     s->last_path = s->cfg.game != XWB_XWORLD2D ? XWB_PATH_NONE :
                    (s->cfg.visible_radius ? (xw_ego_span(s->xw) ? XWB_PATH_EGO_SPAN : XWB_PATH_EGO_PER_ENV) :
                     (autoreset && s->pregen ? XWB_PATH_PREGEN : (s->step_lazy ? (s->step_fused ? XWB_PATH_LAZY_FUSED : XWB_PATH_LAZY) : XWB_PATH_CLASSIC)));
@@ -560,6 +561,7 @@ int xwb_reset_done(xwb_sim *s, void *stream) {
         // this render is the first kernel behind the step in the caller's queue: it publishes that step's epoch)
         if (s->snap_ok) { p.snap_grid_out = s->d_snap_grid[s->snap_sel]; p.snap_act_rep = s->snap_act_rep; }
         p.sig_epoch = s->step_fused && by_epoch ? s->epoch_step : 0;
+        if (p.sig_epoch) s->step_pub_queued = true;
         if (s->regen_pending && !s->regen_by_epoch) { HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0)); s->regen_pending = false; }
         p.wait_slot = 8;
         p.wait_epoch = s->regen_pending ? s->epoch_regen : 0;
@@ -754,14 +756,15 @@ extern "C" __attribute__((visibility("hidden"))) int xwb_internal_last_results(x
     *rows = reinterpret_cast<const float *>(s->d_packed + (size_t)((s->packed_pos - 1) % s->packed_slots) * (size_t)s->n);
     *n = s->n;
     hipStream_t bs = reinterpret_cast<hipStream_t>(beside);
-    if (s->results_by_epoch && s->d_sync) {
+    const bool by_epoch = s->results_by_epoch && s->d_sync && s->step_pub_queued;   // (publisher first, waiter second: xw_device.h)
+    if (by_epoch) {
         HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->d_sync + 4, s->xw.poison_host, bs));
     } else {
         if (!s->ev_results) HIP_TRY(hipEventCreateWithFlags(&s->ev_results, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(s->ev_results, as_stream(step_stream)));
         HIP_TRY(hipStreamWaitEvent(bs, s->ev_results, 0));
     }
-    return s->results_by_epoch && s->d_sync ? 1 : 0;            // (>= 0: fine; 1 = nothing was enqueued on the caller's stream)
+    return by_epoch ? 1 : 0;                                    // (>= 0: fine; 1 = nothing was enqueued on the caller's stream)
 }
 
 int xwb_bind_obs(xwb_sim *s, void *obs_dev) {
