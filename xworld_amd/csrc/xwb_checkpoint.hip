@@ -122,7 +122,7 @@ int xwb_load_state(xwb_sim *s, const uint8_t *in_host, size_t bytes) {
         HIP_TRY(hipMemcpy(a.ptr, r, a.bytes, hipMemcpyHostToDevice));
         r += b;
     }
-    s->shadow_ok = false; s->regen_pending = false; s->step_lazy = false; s->snap_ok = false; s->step_fused = false;
+    s->shadow_ok = false; s->regen_pending = false; s->step_lazy = false; s->regen_deferred = false; s->snap_ok = false; s->step_fused = false;
     s->frame_src = 0; s->draws_since_pack = 0;
     s->policy_step = h.policy_step; s->list_valid = (h.list_valid & 1u) != 0; s->autoreset_done = (h.list_valid & 2u) != 0;
     if (s->cfg.game == XWB_XWORLD2D) {

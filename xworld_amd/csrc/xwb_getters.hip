@@ -262,7 +262,7 @@ int xwb_xw_load_map_task(xwb_sim *s, int32_t env, const uint16_t *grid_host, int
         if (goals > XW_MAX_GOALS) return fail(XWB_ERR_ARG, "a map holds at most 16 goals");
     }
     HIP_TRY(hipDeviceSynchronize());
-    s->shadow_ok = false; s->regen_pending = false; s->snap_ok = false;
+    s->shadow_ok = false; s->regen_pending = false; s->regen_deferred = false; s->snap_ok = false;
     const size_t cells = (size_t)D * D;
     int32_t axy = agent_x | (agent_y << 16);
     const bool is2d = task >= XWB_TASK2D_TARGET;

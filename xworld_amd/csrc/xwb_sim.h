@@ -119,6 +119,7 @@ struct xwb_sim {
     unsigned long long *d_perf = nullptr;  // XwParams::perf
     // pre-generated next episodes (XwParams::shadow / swap_shadow): xwb_step_autoreset's fast path
     bool pregen = false, shadow_ok = false, regen_pending = false, regen_by_epoch = false;
+    bool regen_deferred = false, regen_deferred_by_epoch = false;   // xwb_reset_done after a fused step: the pass is queued by the next verb
     bool step_lazy = false;                // the last plain step kept no terminal snapshot: its reset_done installs shadows
     int shadow_breaks = 0;                 // times another verb made the shadows stale (the lazy default path gives up after a few)
     uint32_t epoch_regen = 0, epoch_regen_prev = 0;   // epochs of the last two regeneration passes handed over by epoch ...
@@ -213,6 +214,8 @@ SgParams sg_params(xwb_sim *s);
 RaceParams race_params(xwb_sim *s);
 XwParams xw_params(xwb_sim *s);
 int join_regen(xwb_sim *s, hipStream_t st);
+int launch_regen(xwb_sim *s, bool by_epoch);
+int flush_regen(xwb_sim *s);
 int xw_reset_list(xwb_sim *s, int mode, bool keep_done, bool render, hipStream_t st, bool beside_render = false);
 
 }  // namespace host

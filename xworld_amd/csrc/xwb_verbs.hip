@@ -230,11 +230,40 @@ XwParams shadow_params(xwb_sim *s) {
 // A regeneration pass of xwb_step_autoreset may still be reading the done list and the episode counters on the side queue:
 // every other verb that touches them orders `st` behind it first (the next xwb_step_autoreset waits inside its step kernel).
 int join_regen(xwb_sim *s, hipStream_t st) {
+    { const int rcf = flush_regen(s); if (rcf) return rcf; }
     if (!s->regen_pending) return XWB_OK;
     if (s->regen_by_epoch) HIP_TRY(launch_xw_wait(s->d_sync + 8, s->epoch_regen, s->d_sync + 4, s->xw.poison_host, st));
     else HIP_TRY(hipStreamWaitEvent(st, s->ev_reset, 0));
     s->regen_pending = false;
     return XWB_OK;
+}
+
+// The regeneration pass of the lazy loop: the episodes after the ones the last step's finished envs are about to start (or have
+// just started), into the free shadow slots, on the internal queue behind that step's kernel.
+int launch_regen(xwb_sim *s, bool by_epoch) {
+    XwParams q = shadow_params(s);
+    if (by_epoch) HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->d_sync + 4, s->xw.poison_host, s->side));
+    else HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
+    timer_begin(s, s->t_reset, s->side);
+    HIP_TRY(launch_xw_reset(q, MODE_RESET_DONE, s->side));
+    timer_end(s, s->t_reset, s->side);
+    if (by_epoch) {
+        s->epoch_regen_prev = s->epoch_regen; s->regen_seq_prev = s->regen_seq; s->regen_seq = s->step_seq;
+        if (++s->epoch_regen == 0) s->epoch_regen = 1;
+        HIP_TRY(launch_xw_signal(s->d_sync + 8, s->epoch_regen, s->side));
+    } else {
+        HIP_TRY(hipEventRecord(s->ev_reset, s->side));
+    }
+    s->regen_pending = true; s->regen_by_epoch = by_epoch;
+    return XWB_OK;
+}
+
+// ... which xwb_reset_done leaves to the next verb after a fused step (see there): every verb that steps, or that touches what
+// the pass reads or writes (join_regen), queues it first -- with the list and counter of the step it belongs to still current
+int flush_regen(xwb_sim *s) {
+    if (!s->regen_deferred) return XWB_OK;
+    s->regen_deferred = false;
+    return launch_regen(s, s->regen_deferred_by_epoch);
 }
 
 // xworld: reset the compacted list (or all), then re-render those envs.
@@ -342,6 +371,7 @@ int do_step(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, bool autore
     } else {
         // hand-over mode of this call: what xwb_create / xwb_queue_sync_mode found out about `st`; events for a stream
         // nobody probed (no verb synchronises the host by itself)
+        { const int rcf = flush_regen(s); if (rcf) return rcf; }
         const bool epochs = use_epochs(s, st, false);
         s->step_epochs = epochs;
         // xwb_step_autoreset with pre-generated episodes (XwParams::swap_shadow): the step kernel starts the next episode of
@@ -568,21 +598,12 @@ int xwb_reset_done(xwb_sim *s, void *stream) {
         timer_begin(s, s->t_list, st);
         HIP_TRY(launch_xw_render(p, 1, st));
         timer_end(s, s->t_list, st);
-        XwParams q = shadow_params(s);
-        if (by_epoch) HIP_TRY(launch_xw_wait(s->d_sync + 1, s->epoch_step, s->d_sync + 4, p.poison_host, s->side));
-        else HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
-        timer_begin(s, s->t_reset, s->side);
-        HIP_TRY(launch_xw_reset(q, MODE_RESET_DONE, s->side));
-        timer_end(s, s->t_reset, s->side);
-        if (by_epoch) {
-            s->epoch_regen_prev = s->epoch_regen; s->regen_seq_prev = s->regen_seq; s->regen_seq = s->step_seq;
-            if (++s->epoch_regen == 0) s->epoch_regen = 1;
-            HIP_TRY(launch_xw_signal(s->d_sync + 8, s->epoch_regen, s->side));
-        } else {
-            HIP_TRY(hipEventRecord(s->ev_reset, s->side));
-        }
-        s->regen_pending = true; s->regen_by_epoch = by_epoch;
-        return XWB_OK;
+        // Behind a fused step + render launch the regeneration cannot start before this list render does (it publishes the step's
+        // epoch), and nothing needs it before the next step call: it is queued at the top of that call (flush_regen), where it
+        // runs beside the render exactly as it would from here -- but a caller that synchronises the device after this verb
+        // does not wait 70 us for pre-generated episodes nobody has asked for yet.
+        if (s->step_fused) { s->regen_deferred = true; s->regen_deferred_by_epoch = by_epoch; return XWB_OK; }
+        return launch_regen(s, by_epoch);
     }
     // (a lazy step's render reads the live grid: the classic reset may not rewrite it beside that render)
     const bool beside = s->list_valid && !s->step_lazy;
