@@ -106,6 +106,18 @@ def secondary_block(workload, local_rank, seed, K, steps, spin_seconds=0.15, par
                         "kernel_launches": kern_n, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "step_loop_frac": n * per_step * steps / med / 1e9 / HBM_PEAK_GBS}}
     if game != "xworld":
+        # the same two launches per step issued from C (xwb_run: no per-call binding cost), and one launch per step
+        def run_region():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sim.run(K)
+            host_run = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, host_run
+        rr = [run_region() for _ in range(4)][1:]
+        rmed = statistics.median([r[0] for r in rr])
+        out["xwb_run"] = {"loop": "xwb_run(K): K x (step; reset_done) issued from C", "value": n * steps / rmed, "ms_per_step": rmed / steps * 1e3,
+                          "host_us_per_step": statistics.median([r[1] for r in rr]) / steps * 1e6}
         ar = statistics.median([region(sim.step_autoreset) for _ in range(4)][1:])
         out["one_launch"] = {"loop": "step_autoreset (one launch per step)", "value": n * steps / ar, "ms_per_step": ar / steps * 1e3}
     assert sim.check_errors() == 0

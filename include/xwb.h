@@ -253,6 +253,14 @@ int xwb_step_autoreset(xwb_sim *sim, const int32_t *actions_dev, int32_t act_rep
  * step's reward, code and observation written exactly as separate launches would; XWorld2D loops on the host. */
 int xwb_step_n(xwb_sim *sim, int32_t n_steps, int32_t act_rep, void *stream);
 
+/* The reference example loop's body -- `if (game_over) reset_game(); take_actions(random action)`, examples/test_simple_race.cpp:26-53,
+ * python/examples/test_simple_game.py:15-30 -- `iterations` times over under the built-in policy, issued from C: flags 0 =
+ * xwb_step(NULL, act_rep) then xwb_reset_done per iteration (terminal frames, then first frames: both calls' effects, in order),
+ * XWB_RUN_AUTORESET = xwb_step_autoreset per iteration.  Exactly the launches of that many separate calls, one foreign-function
+ * call: a binding's per-call cost (ctypes: ~1.5 us) leaves the loop, which matters where a step is launch-bound (the simple games). */
+enum { XWB_RUN_AUTORESET = 1 };
+int xwb_run(xwb_sim *sim, int32_t iterations, int32_t act_rep, int32_t flags, void *stream);
+
 /* returns the number of envs that flagged an out-of-range action since the last call (synchronises stream).
  * Fails with XWB_ERR_STATE when the batch is poisoned (see xwb_queue_sync_mode). */
 int xwb_check_errors(xwb_sim *sim, void *stream, int32_t *n_bad);
@@ -282,9 +290,6 @@ enum { XWB_PATH_NONE = 0,        /* SimpleGame / SimpleRace (one kernel), or no 
 int xwb_step_path(xwb_sim *sim, int32_t *path, int32_t *sync_mode, int32_t *shadow_breaks);
 /* drops what the batch remembers about `stream` (call before destroying a probed stream: a later stream may reuse the handle) */
 int xwb_queue_sync_forget(xwb_sim *sim, void *stream);
-/* test hook: enqueue on `stream` a wait for an epoch nobody publishes, with a watchdog of budget_us microseconds -- the
- * batch is poisoned once it expires (tests/test_gpu_queue_sync.py) */
-int xwb_debug_stall_handoff(xwb_sim *sim, void *stream, int64_t budget_us);
 
 /* ---- observation / result buffers (device pointers, valid until xwb_destroy) ---- */
 /* "screen" of get_state(): [num_envs][context][c][h][w]; uint8 for simple_game / xworld (planar B,G,R),
@@ -474,12 +479,8 @@ int xwb_xw_set_draw(xwb_sim *sim, int32_t on);
 int xwb_xw_render_grids(xwb_sim *sim, const uint16_t *grids_dev, const uint8_t *flags_dev, int32_t n_envs, void *obs_dev,
                         void *stream);
 
-/* timing hook: average duration in microseconds of the named kernel ("step", "render" = the whole-batch render, "reset" = the
- * map generator, "list" = the render of the envs a reset started) over the launches recorded since xwb_profile_begin
- * (hipEvents on the stream each launch runs on). */
-int xwb_profile_begin(xwb_sim *sim);
-int xwb_profile_end(xwb_sim *sim, void *stream, const char *kernel, double *avg_us, int64_t *launches);
-int xwb_profile_stop(xwb_sim *sim);
+/* (test and measurement hooks -- xwb_debug_stall_handoff, xwb_profile_begin / _end / _stop -- are not part of this boundary:
+ * include/xwb_testing.h, version node XWB_TESTING of csrc/libxwb.map) */
 
 /* ---- multi-GPU: one xwb_sim per GPU holds a shard of the batch (contiguous global env ids, xwb_config.env_gid0); the per-step
  * exchange is RCCL over xGMI, issued by the library itself so that C / C++ holders of a xwb_sim shard like the Python layer

@@ -32,9 +32,18 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (xwb_[a-z0-9_]+)", out))
     assert declared <= exported
+    # ... the test / measurement hooks of include/xwb_testing.h under their own version node, outside the boundary ...
+    hooks = set(re.findall(r"\b(xwb_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "xwb_testing.h")).read()))
+    assert hooks == set(lib.TESTING_SYMBOLS) and not (hooks & declared)
+    versions = subprocess.check_output(["objdump", "-T", lib.LIB_PATH]).decode()
+    for ln in versions.splitlines():
+        m = re.search(r"\b(XWB_1|XWB_TESTING)\s+(xwb_[a-z0-9_]+)$", ln.strip())
+        if m:
+            assert (m.group(1) == "XWB_TESTING") == (m.group(2) in hooks), ln
+    assert "XWB_TESTING" in versions and "XWB_1" in versions
     # ... and nothing else: no kernel handles, launch helpers or other internals (-fvisibility=hidden + csrc/libxwb.map)
-    everything = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
-    assert everything == declared, sorted(everything ^ declared)
+    everything = {ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.strip()} - {"XWB_1", "XWB_TESTING"}
+    assert everything == declared | hooks, sorted(everything ^ (declared | hooks))
 
 
 def test_ctypes_struct_matches_header_layout():

@@ -71,3 +71,38 @@ def test_reset_verbs_agree(mode):
     assert int(done_list.episode.max()) >= 2
     for s in sims:
         s.close()
+
+
+@pytest.mark.parametrize("game,opts,n", [("simple_game", {"array_size": 16}, 3000), ("simple_race", {"track_width": 20.0, "track_length": 100.0, "track_radius": 30.0}, 3000),
+                                         ("xworld", MODES["gray"], 1024), ("xworld", MODES["ego"], 512)])
+@pytest.mark.parametrize("autoreset", [False, True])
+def test_run_equals_the_separate_calls(game, opts, n, autoreset):
+    """xwb_run(k) = k x (xwb_step; xwb_reset_done) -- or k x xwb_step_autoreset -- issued from C (the reference example loop,
+    examples/test_simple_race.cpp:26-53): same state, frames, results ring and policy draws as the separate calls."""
+    import torch
+    assert torch.cuda.is_available()
+    from xworld_amd.batched import BatchedSimulator
+    a = BatchedSimulator(game, opts, num_envs=n, seed=5, policy_seed=6)
+    b = BatchedSimulator(game, opts, num_envs=n, seed=5, policy_seed=6)
+    ra = torch.zeros((64, n, 2), dtype=torch.float32, device="cuda")
+    rb = torch.zeros_like(ra)
+    a.bind_results_ring(ra); b.bind_results_ring(rb)
+    done = 0
+    for k in (1, 7, 20, 3, 33):
+        a.run(k, autoreset=autoreset)
+        for _ in range(k):
+            if autoreset:
+                b.step_autoreset()
+            else:
+                b.step()
+                done += int((b.game_over_codes != 0).sum())
+                b.reset_done()
+        torch.cuda.synchronize()
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward) and torch.equal(a.game_over_codes, b.game_over_codes), k
+        assert torch.equal(a.num_steps, b.num_steps) and torch.equal(a.episode, b.episode) and torch.equal(a.actions, b.actions), k
+        assert torch.equal(ra, rb), k
+    assert autoreset or done > 0
+    with pytest.raises(Exception, match="iterations"):
+        a.run(0)
+    assert a.check_errors() == 0
+    a.close(); b.close()

@@ -262,6 +262,10 @@ class BatchedSimulator:
         """n_steps x step_autoreset under the built-in random policy; one launch for the simple games."""
         lib.check(self.L.xwb_step_n(self.h, int(n_steps), int(act_rep), self._stream(stream)))
 
+    def run(self, iterations, act_rep=1, autoreset=False, stream=None):
+        """xwb_run: `iterations` x (step; reset_done) -- or x step_autoreset -- under the built-in policy, one call into the library"""
+        lib.check(self.L.xwb_run(self.h, int(iterations), int(act_rep), 1 if autoreset else 0, self._stream(stream)))
+
     def step_autoreset(self, actions=None, act_rep=1, stream=None):
         ptr = None if actions is None else C.c_void_p(actions.data_ptr())
         lib.check(self.L.xwb_step_autoreset(self.h, ptr, int(act_rep), self._stream(stream)))

@@ -7,6 +7,7 @@
 // No CPU fallback exists: without a usable gfx950 device xwb_create fails.
 #pragma once
 #include "../../include/xwb.h"
+#include "../../include/xwb_testing.h"
 #include "xwb_common.h"
 
 #include <cmath>

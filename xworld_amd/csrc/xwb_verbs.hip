@@ -696,6 +696,18 @@ int xwb_step_n(xwb_sim *s, int32_t n_steps, int32_t act_rep, void *stream) {
     return XWB_OK;
 }
 
+int xwb_run(xwb_sim *s, int32_t iterations, int32_t act_rep, int32_t flags, void *stream) {
+    if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
+    if (iterations < 1 || act_rep < 1) return fail(XWB_ERR_ARG, "iterations and act_rep must be >= 1");
+    if (flags & ~XWB_RUN_AUTORESET) return fail(XWB_ERR_ARG, "unknown flag");
+    for (int32_t i = 0; i < iterations; ++i) {
+        int rc = (flags & XWB_RUN_AUTORESET) ? xwb_step_autoreset(s, nullptr, act_rep, stream) : xwb_step(s, nullptr, act_rep, stream);
+        if (rc == XWB_OK && !(flags & XWB_RUN_AUTORESET)) rc = xwb_reset_done(s, stream);
+        if (rc) return rc;
+    }
+    return XWB_OK;
+}
+
 int xwb_step_autoreset(xwb_sim *s, const int32_t *actions_dev, int32_t act_rep, void *stream) {
     if (!s) return fail(XWB_ERR_ARG, "sim is NULL");
     XWB_ON_DEVICE(s);

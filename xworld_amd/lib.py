@@ -87,7 +87,6 @@ _SIGS = [
     ("xwb_queue_sync_mode", C.c_int, [_vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("xwb_queue_sync_forget", C.c_int, [_vp, _vp]),
     ("xwb_step_path", C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    ("xwb_debug_stall_handoff", C.c_int, [_vp, _vp, C.c_int64]),
     ("xwb_obs_dev", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     ("xwb_bind_results", C.c_int, [_vp, _vp]),
     ("xwb_bind_results_ring", C.c_int, [_vp, _vp, C.c_int64]),
@@ -136,9 +135,6 @@ _SIGS = [
     ("xwb_task_performance_report", C.c_int, [_vp, _vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("xwb_decode_game_over_code", C.c_int, [C.c_int32, C.c_char_p, C.c_size_t]),
     ("xwb_xw_get_tile_table", C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
-    ("xwb_profile_begin", C.c_int, [_vp]),
-    ("xwb_profile_end", C.c_int, [_vp, _vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
-    ("xwb_profile_stop", C.c_int, [_vp]),
     ("xwb_comm_version", C.c_int, [C.POINTER(C.c_int32)]),
     ("xwb_comm_unique_id", C.c_int, [_vp]),
     ("xwb_comm_init_rank", C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
@@ -158,10 +154,19 @@ _SIGS = [
     ("xwb_xw_pack_grids", C.c_int, [_vp, _vp, _vp, _vp]),
     ("xwb_xw_set_draw", C.c_int, [_vp, C.c_int32]),
     ("xwb_xw_render_grids", C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, _vp]),
+    ("xwb_run", C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     ("xwb_last_error", C.c_char_p, []),
     ("xwb_version", C.c_char_p, []),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGS]
+# include/xwb_testing.h: test and measurement hooks, outside the drop-in boundary (version node XWB_TESTING)
+_TESTING_SIGS = [
+    ("xwb_debug_stall_handoff", C.c_int, [_vp, _vp, C.c_int64]),
+    ("xwb_profile_begin", C.c_int, [_vp]),
+    ("xwb_profile_end", C.c_int, [_vp, _vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    ("xwb_profile_stop", C.c_int, [_vp]),
+]
+TESTING_SYMBOLS = [s[0] for s in _TESTING_SIGS]
 
 _lib = None
 
@@ -187,7 +192,7 @@ def load(build_if_missing=True):
         from . import build as _build
         _build.build()
     L = C.CDLL(LIB_PATH)
-    for name, res, args in _SIGS:
+    for name, res, args in _SIGS + _TESTING_SIGS:
         f = getattr(L, name)          # AttributeError if the library lacks a declared symbol
         f.restype = res
         f.argtypes = args
