@@ -31,7 +31,7 @@ def c5_block(args, world, rank, local_rank, dev, K, lib_comm_main=None):
         sim.step()
         sim.reset_done()
         (results.finish(convert=False) if args.results_wait else results.release())
-        results.start(packed=packed[(state["calls"] - 1) % 8])
+        results.start() if lib_comm_main is not None else results.start(packed=packed[(state["calls"] - 1) % 8])
         if state["screens"] is not None:
             state["screens"].start()
 

@@ -17,7 +17,10 @@ class Loop:
         if self.results is None:
             return
         (self.results.finish(convert=False) if self.args.results_wait else self.results.release())
-        self.results.start(packed=self.rec[(self.calls - 1) % self.rec.shape[0]])
+        if hasattr(self.results, "ring_slots"):            # LibResultGather: the library knows which row of the ring the step wrote
+            self.results.start()
+        else:
+            self.results.start(packed=self.rec[(self.calls - 1) % self.rec.shape[0]])
 
     def one_step(self):
         if self.screens is not None:

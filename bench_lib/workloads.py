@@ -14,10 +14,8 @@ WORKLOADS = {
     "xworld7_ego3": ("xworld", {"max_dim": 7, "num_blocks": 16, "color": True, "visible_radius": 3}, 32768),
     "xworld8_ego5": ("xworld", {"color": True, "visible_radius": 5}, 32768),                       # 80x80x3 frames
     "xworld7_ego7": ("xworld", {"max_dim": 7, "num_blocks": 16, "color": True, "visible_radius": 7}, 32768),
-    # geometries whose frame squares are not a multiple of four pixels wide (include/xwb.h xwb_ego_render_path)
+    # a geometry the span path cannot take (81 x 81 frames: include/xwb.h xwb_ego_render_path): the one-workgroup-per-env kernel
     "xworld11_ego9": ("xworld", {"max_dim": 11, "num_blocks": 30, "color": True, "visible_radius": 9}, 32768),
-    "xworld7_ego2": ("xworld", {"max_dim": 7, "num_blocks": 16, "color": True, "visible_radius": 2}, 32768),
-    "xworld8_ego4": ("xworld", {"color": True, "visible_radius": 4}, 32768),
     "xworld8": ("xworld", {"color": True}, 32768),
     "xworld11": ("xworld", {"max_dim": 11, "num_blocks": 30, "color": True}, 32768),
     "simple_game": ("simple_game", {"array_size": 64}, 65536),

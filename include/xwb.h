@@ -312,22 +312,30 @@ int xwb_actions_dev(xwb_sim *sim, int32_t **ptr);       /* int32[num_envs]: acti
 int xwb_num_steps_dev(xwb_sim *sim, int32_t **ptr);     /* int32[num_envs]: get_num_steps() */
 int xwb_success_dev(xwb_sim *sim, uint8_t **ptr);       /* uint8[num_envs]: last_action_success() */
 int xwb_episode_dev(xwb_sim *sim, uint32_t **ptr);      /* uint32[num_envs]: resets so far (RNG episode index) */
-int xwb_xw_grid_dev(xwb_sim *sim, uint16_t **ptr);      /* xworld: uint16[num_envs][max_dim*max_dim] cell codes -- for reading: the egocentric
-                                                         * render caches pixels that depend on the cells around a goal for the length of an
-                                                         * episode; a map is changed through xwb_xw_load_map_task / xwb_xw_refresh_obs */
+int xwb_xw_grid_dev(xwb_sim *sim, uint16_t **ptr);      /* xworld: uint16[num_envs][max_dim*max_dim] cell codes -- READ-ONLY (since round 5): the
+                                                         * step kernel finds goals through a per-env goal-slot table, the default loop draws from
+                                                         * look-ahead snapshots of the grids, the egocentric render caches pixels that depend on
+                                                         * the cells around a goal for the length of an episode -- all of which a write through
+                                                         * this pointer would leave stale; a map is changed through xwb_xw_load_map_task */
 int xwb_minstd_state_dev(xwb_sim *sim, uint32_t **ptr); /* XWB_RNG_MINSTD: uint32[num_envs] engine states (else NULL) */
 int xwb_done_count(xwb_sim *sim, void *stream, int32_t *n_done);   /* envs reset by the last reset_done (sync) */
 /* xworld, egocentric: which kernels draw the whole-batch frames: 1 = the span path (cells -> evaluated pixels -> gather,
  * kernels_xworld_ego.hip), 0 = one workgroup per env.  Both are bit-exact; callers that report kernel times need to know
- * which ran.  The per-env kernel (XWB_PATH_EGO_PER_ENV) is what draws, and the only thing that can draw:
- *   - visible_radius = 1 and visible_radius >= 9: the frame is not r x r equal squares of a multiple of four pixels
- *     (r = 9: 81 x 81, r = 11: 77 x 77, r = 13: 78 x 78 -- rows are not whole dwords, frames not whole 16-byte chunks), or a
- *     row / column whose taps straddle two view cells is not the first one of a square (xw_ego_tables decides, per geometry);
+ * which ran.  Radii: XMap::image_masking admits ODD radii only (CHECK, xmap.cpp:277; xwb_create refuses even ones with the same
+ * words) and XWorldSimulator::init clips the radius to the map's edge (xworld_simulator.cpp:62-68), so r is one of 1, 3, ..., 15.
+ * The span path draws r = 3, 5, 7 -- squares of 28, 16 and 12 pixels -- on every map size.  The per-env kernel
+ * (XWB_PATH_EGO_PER_ENV) is what draws, and the only thing that can draw:
+ *   - visible_radius = 1, 9, 11, 13, 15: r = 1 is one 84-pixel square (the agent's own cell: nothing to tile); from r = 9 on the
+ *     square's edge is not a multiple of four pixels (r = 9: 9 px, 81 x 81 frames; 11: 7 px, 77 x 77; 13 and 15: 6 and 5 px) --
+ *     frame rows are not whole dwords, frames not whole 16-byte chunks -- and the view has more than 64 cells, which the
+ *     cells kernel's shadow masks (one 64-bit word per env) do not hold.  Not generalised: DESIGN.md section 9 has the
+ *     measurement (0.035 of the roofline at r = 9) and what the generalisation needs;
  *   - palettes with more than 16 images that every env shares (blocks, agents, empty, black): the span path's table of
  *     squares is keyed by three such classes and is capped at 128 MB;
  *   - XWB_DEBUG_EGO_NO_SPAN / _NO_CACHE, or not enough free device memory for the span path's tables at xwb_create.
- * It is an order of magnitude slower per frame (bench.py --workload xworld11_ego9 prints a line for it); the reference's
- * own configurations (visible_radius 3, 5, 7 on 7x7 / 8x8 / 11x11 worlds) all take the span path. */
+ * It is an order of magnitude slower per frame (bench.py --workload xworld11_ego9 prints a line for it).  (No conf of the
+ * reference sets visible_radius at all -- python/examples/test_xworld.py:39 passes 0 --; 3, 5 and 7 are the radii with whole
+ * squares that fit the 7x7 / 8x8 / 11x11 maps of its confs.) */
 int xwb_ego_render_path(xwb_sim *sim, int32_t *path);
 
 /* The whole batch's outputs copied into caller-owned memory, host or device (hipMemcpyDefault), ordered on `stream`;

@@ -114,7 +114,7 @@ def test_sharded_equals_unsharded(world, total, game, steps):
 
 
 @pytest.mark.parametrize("workload,extra", [("xworld7", []), pytest.param("simple_game", [], marks=pytest.mark.slow),
-                                            pytest.param("xworld7", ["--autoreset"], marks=pytest.mark.slow), ("xworld7", ["--c5"])])
+                                            ("xworld7", ["--autoreset"]), ("xworld7", ["--c5"])])
 def test_bench_two_ranks_on_one_gpu(workload, extra):
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run), on one GPU over gloo: the line carries the
     device-resident value, the screens-gather figures, what the exchange ran on, and a clean parity gate."""

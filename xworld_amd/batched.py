@@ -163,7 +163,6 @@ class BatchedSimulator:
             cfg.icon_name = self.palette.icon_name.ctypes.data
             cfg.icon_colored = self.palette.icon_colored.ctypes.data
         self.cfg = cfg
-        self._streams_seen = set()                           # stream handles whose hand-over mode was probed (see _stream)
         self._host_actions = None
         self.obs_is_float = name == "simple_race" or (name == "xworld" and cfg.obs_format == 1)
         h = C.c_void_p()
@@ -202,24 +201,18 @@ class BatchedSimulator:
             pass
 
     def _stream(self, stream):
-        """The stream handle for the C ABI.  A stream this batch has not seen is probed ONCE (xwb_queue_sync_mode: may the two
-        queues hand over through epochs on it?) -- the step verbs never probe by themselves, so a PyTorch user on a non-default
-        stream would otherwise run the event hand-over (the slower path, ~12 us per xworld step) without being told.  The
-        probe synchronises the stream, so it is skipped while the stream is being captured into a graph (xwb.h)."""
+        """The stream handle for the C ABI.  The step verbs never probe a stream by themselves (a stream nobody probed hands over
+        through events: the slower path, ~12 us per xworld step, without being told), so every call on an explicit stream asks
+        xwb_queue_sync_mode first: the library probes a handle it has not seen ONCE (that synchronises the stream), answers from
+        its table afterwards (a handful of compares), skips the probe while THIS stream -- the handle passed, not torch's current
+        one -- is being captured into a graph, and forgets handles whose streams died, so a new stream that reuses a handle is
+        probed again.  (No cache on this side: the library's table is the only one that knows all of that.)"""
         if stream is None:
             return None
         h = int(getattr(stream, "cuda_stream", stream))
-        if h and h not in self._streams_seen and self.cfg.game == lib.XWB_XWORLD2D:
-            capturing = False
-            try:
-                import torch
-                capturing = bool(torch.cuda.is_current_stream_capturing())
-            except Exception:                                # pragma: no cover
-                capturing = False
-            if not capturing:
-                self._streams_seen.add(h)
-                m, r = C.c_int32(), C.c_int32()
-                lib.check(self.L.xwb_queue_sync_mode(self.h, C.c_void_p(h), C.byref(m), C.byref(r)))
+        if h and self.cfg.game == lib.XWB_XWORLD2D:
+            m, r = C.c_int32(), C.c_int32()
+            lib.check(self.L.xwb_queue_sync_mode(self.h, C.c_void_p(h), C.byref(m), C.byref(r)))
         return C.c_void_p(h)
 
     # ------------------------------------------------------------------ batched verbs

@@ -327,12 +327,15 @@ int xwb_gather_results_beside(xwb_sim *sim, xwb_comm *c, float *all_dev, const i
     DeviceGuard g(c->device);
     const float *rows = nullptr;
     int32_t n = 0;
+    // validate before anything is enqueued: a refused call must leave no wait kernel / event behind on either stream
+    if ((rc = xwb_num_envs(sim, &n))) return rc;
+    if (n != counts[shard]) return fail(XWB_ERR_ARG, "counts[shard] is not this batch's num_envs");
     rc = xwb_internal_last_results(sim, c->stream, stream, &rows, &n);
     if (rc < 0) return rc;
     if (by_epoch) *by_epoch = rc;
-    if (n != counts[shard]) return fail(XWB_ERR_ARG, "counts[shard] is not this batch's num_envs");
-    c->in_flight += 1;
-    return xwb_gather_results(c, rows, all_dev, counts, peers, n_shards, shard, c->stream);
+    rc = xwb_gather_results(c, rows, all_dev, counts, peers, n_shards, shard, c->stream);
+    if (rc == XWB_OK) c->in_flight += 1;                     // (an exchange that was refused is not one xwb_gather_screens_end may wait for)
+    return rc;
 }
 
 // what the two gathers of frames share: arguments, the hand-over from `stream` to the communicator's stream

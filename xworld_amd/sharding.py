@@ -421,7 +421,11 @@ class LibResultGather:
     caller's stream at all (the torch path's collective records an event there every step: ~6 us of idle GPU per step).  Same
     protocol as ResultGather: start() after the step call, then release() (nobody on this stream reads the result) or finish()
     (orders the current stream behind the exchange, -> (reward, code) columns on every rank).  Two output buffers alternate;
-    marks 2 / 3 of the communicator are this object's (LibScreensGather uses 0 / 1).  Equal shards, one shard per rank."""
+    marks 2 / 3 of the communicator are this object's (LibScreensGather uses 0 / 1).  Equal shards, one shard per rank.
+    The results ring needs at least two slots (a one-slot ring's row is rewritten by the very next step while the exchange may
+    still read it): with `slots` of them the row exchange i reads is rewritten by step i + slots, and released exchanges are
+    never waited for, so every (slots - 2)-th start() orders the caller's stream behind the PREVIOUS exchange -- long complete
+    in a healthy run, and the guarantee that no step overwrites a row an exchange still reads, however far the host runs ahead."""
 
     def __init__(self, sim, comm, counts, rank, stream=None):
         import ctypes as C
@@ -437,15 +441,26 @@ class LibResultGather:
         self.pending = None
         self.stream = stream
         self.by_epoch = None                                  # True once an exchange was ordered by the step's epoch
+        ring = getattr(sim, "_results", None)
+        self.ring_slots = int(ring.shape[0]) if ring is not None and ring.dim() == 3 else (1 if ring is not None else 0)
+        self.started = 0
 
     def _st(self):
         s = self.stream if self.stream is not None else torch.cuda.current_stream()
         return self.C.c_void_p(int(s.cuda_stream))
 
-    def start(self, packed=None):
+    def start(self):
         if self.pending is not None:
             raise RuntimeError("LibResultGather.start() called twice without finish() / release()")
+        ring = getattr(self.sim, "_results", None)
+        slots = int(ring.shape[0]) if ring is not None and ring.dim() == 3 else (1 if ring is not None else 0)
+        if slots == 1:
+            raise RuntimeError("LibResultGather needs a results ring of at least two slots (bind_results_ring): the next step rewrites a "
+                               "one-slot ring's row while the exchange may still read it")
         k = self.slot
+        if slots >= 2 and self.started and self.started % max(1, slots - 2) == 0:
+            self.lib.check(self.L.xwb_comm_wait(self.comm.h, 2 + (k ^ 1), self._st()))    # (see the class comment)
+        self.started += 1
         self.slot ^= 1
         flag = self.C.c_int32()
         self.lib.check(self.L.xwb_gather_results_beside(self.sim.h, self.comm.h, self.C.c_void_p(self.out[k].data_ptr()), self.c_counts, None,
