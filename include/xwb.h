@@ -37,7 +37,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define XWB_ABI_VERSION 4
+#define XWB_ABI_VERSION 5
 
 enum {
     XWB_OK = 0,
@@ -275,7 +275,7 @@ int xwb_check_errors(xwb_sim *sim, void *stream, int32_t *n_bad);
  * xwb_check_errors) fails with XWB_ERR_STATE; results since the last successful xwb_check_errors are void and the batch can
  * only be destroyed.  Returns XWB_ERR_STATE itself when the batch is poisoned. */
 int xwb_queue_sync_mode(xwb_sim *sim, void *stream, int32_t *mode, int32_t *reason);
-/* Which kernel sequence the LAST step call (xwb_step / xwb_step_autoreset / xwb_step_n) ran -- the verbs choose it from the
+/* Which kernel sequence the LAST step call (xwb_step / xwb_step_autoreset / xwb_step_n / xwb_run) ran -- the verbs choose it from the
  * configuration and from what the caller did before, and a number measured on one path says nothing
  * about another: *path = XWB_PATH_*; *sync_mode (nullable) = XWB_QUEUE_SYNC_EVENTS | _EPOCHS of that call (AUTO: the game has
  * no internal queue); *shadow_breaks (nullable) = how often another verb made the pre-generated episodes stale (after three
@@ -285,8 +285,11 @@ enum { XWB_PATH_NONE = 0,        /* SimpleGame / SimpleRace (one kernel), or no 
        XWB_PATH_LAZY = 2,        /* pre-generated episodes installed by xwb_reset_done's list render (the default loop) */
        XWB_PATH_PREGEN = 3,      /* xwb_step_autoreset: the step kernel itself starts the pre-generated episode */
        XWB_PATH_EGO_SPAN = 4, XWB_PATH_EGO_PER_ENV = 5, /* egocentric renders, see xwb_ego_render_path */
-       XWB_PATH_LAZY_FUSED = 6 };/* XWB_PATH_LAZY with the step kernel's work inside the render's launch: the render blocks draw from a
-                                  * snapshot of the state before the step plus the call's actions (context 1; from the second step on) */
+       XWB_PATH_LAZY_FUSED = 6 };/* XWB_PATH_LAZY as ONE launch: under the built-in policy (actions_dev == NULL) the previous lazy step also
+                                  * left the grids as THIS step will leave them (the policy's next action is a function of seed, env and
+                                  * step number; a step moves at most two cells), so the render's workgroups draw from that look-ahead
+                                  * snapshot while the step's workgroups run beside them in the same kernel.  Context 1, same act_rep as
+                                  * the previous call, no verb in between that rewrote the maps; anything else: XWB_PATH_LAZY */
 int xwb_step_path(xwb_sim *sim, int32_t *path, int32_t *sync_mode, int32_t *shadow_breaks);
 /* drops what the batch remembers about `stream` (call before destroying a probed stream: a later stream may reuse the handle) */
 int xwb_queue_sync_forget(xwb_sim *sim, void *stream);

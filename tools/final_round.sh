@@ -3,7 +3,7 @@
 # per-workload bench lines + kernel traces + HBM counters (tools/profile_round.sh), the soaks, the PCIe-inclusive rates, the
 # forced one-rank exchange and the leak check.  Usage: GIT_HEAD=$(git rev-parse --short HEAD) tools/final_round.sh <tag>
 set -u
-TAG=${1:-r5}
+TAG=${1:-r6}
 OUT=$PWD/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 HEAD=${GIT_HEAD:-unknown}
@@ -22,6 +22,13 @@ GIT_HEAD=$HEAD bash tools/profile_round.sh $TAG xworld7 xworld7_f32 xworld8 xwor
   timeout 600 python tools/leak_check.py 2>&1 | grep "^no leak"
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 } > $OUT/soak.txt
+# >= 3 seeds per headline number
+for SEED in 1 2 3; do
+  timeout 600 python bench.py --seed $SEED --no-cpu-baseline --no-secondary 2>/dev/null | grep '^{"metric"' | tail -1 > $OUT/bench_xworld7_seed$SEED.json
+done
+# the default loop as two launches per step (the step kernel in front of the render: rounds 1-5), same box, same run
+XWB_DEBUG=no_fused timeout 600 python bench.py --no-cpu-baseline --no-secondary 2>/dev/null | grep '^{"metric"' | tail -1 > $OUT/bench_xworld7_no_fused.json
+timeout 60 python bench.py --gpus 8 --dry-run > $OUT/bench_dry_run_n8.json 2>/dev/null
 for X in torch lib; do
   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 2993$([ $X = lib ] && echo 2 || echo 1) \
     bench.py --gpus 1 --backend nccl --force-exchange --exchange $X --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | tail -1 > $OUT/bench_xworld7_forced_exchange_$X.json

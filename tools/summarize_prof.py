@@ -58,7 +58,8 @@ def main(out, bench_args):
             b = v / n * 1024.0
             print("%-70s dispatches %5d  %.0f B per dispatch = %.3f x buffer" % (k[:70], n, b, b / FILL_BYTES))
             cal.setdefault(counter, {})[k[:60]] = b / FILL_BYTES
-    dom = [k for k in per_kernel if "render_all" in k or "sg_kernel" in k or "race_kernel" in k or "render_ego" in k]
+    # (xw_step_render_kernel: the whole-batch render with the step's blocks in the same launch, the default loop since round 6)
+    dom = [k for k in per_kernel if "render_all" in k or "step_render" in k or "sg_kernel" in k or "race_kernel" in k or "render_ego" in k]
     span = [k for k in per_kernel if "xw_ego_gather_kernel" in k]
     if dom or span:
         # write side: the fill kernels of the calibration report ~1.0 x -> WRITE_SIZE taken at face value;

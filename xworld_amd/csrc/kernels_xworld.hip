@@ -735,6 +735,7 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
         const int i = (int)(b / parts), part = (int)(b - (long long)i * parts);
         const bool first = b == (long long)blockIdx.x;
         const int e = first ? e_first : p.done_list[i];
+        int la_axy = 0, la_act = 0;
         __syncthreads();
         if (p.list_swap) {
             // xwb_reset_done with pre-generated episodes: install the env's next episode (what the reset kernel made for it
@@ -751,7 +752,11 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
                 s_grid[k] = code & CELL_ICON_MASK;
             }
             if (part == 0 && threadIdx.x == 64) {         // (a lane of the second wavefront: beside the first one's gathers)
-                p.agent_xy[e] = p.sh_agent_xy[es];
+                la_axy = p.sh_agent_xy[es];
+                // (look-ahead, below: the built-in policy's action of step p.policy_step, the step the caller runs next -- drawn
+                // here, while the staging loads are in flight)
+                if (p.snap_grid_out) la_act = policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step, 4);
+                p.agent_xy[e] = la_axy;
                 p.task_state[e] = p.sh_task_state[es];
                 p.task_steps[e] = 0;
                 if (p.n_tasks2 > 0) { p.task_state2[e] = p.sh_task_state2[es]; p.task_steps2[e] = 0; }
@@ -767,12 +772,9 @@ __global__ __launch_bounds__(256) void xw_render_list_kernel(XwParams p, const i
         }
         __syncthreads();
         if (p.list_swap && p.snap_grid_out && part == 0 && threadIdx.x == 64) {
-            // look-ahead: the snapshot row written above gets the next step's move of the new episode (the built-in policy's
-            // action of step p.policy_step, the step the caller runs next), beside the gathers
-            const size_t es = (size_t)(((first ? ep_first : p.done_ep[i]) + 1u) & 1u) * (size_t)p.n + (size_t)e;
+            // look-ahead: the snapshot row written above gets the next step's move of the new episode, beside the gathers
             int from;
-            const int to = xw_predict_move(s_grid, D, p.sh_agent_xy[es], policy_action(p.policy_seed, p.env_gid0 + (uint32_t)e, p.policy_step, 4),
-                                           p.snap_act_rep, &from);
+            const int to = xw_predict_move(s_grid, D, la_axy, la_act, p.snap_act_rep, &from);
             if (to != from) { p.snap_grid_out[(size_t)e * cells + to] = s_grid[from]; p.snap_grid_out[(size_t)e * cells + from] = 0; }
         }
         uint4 *frame0 = reinterpret_cast<uint4 *>(p.obs) + (size_t)e * ctx * cpf;

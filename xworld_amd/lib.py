@@ -9,8 +9,10 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libxwb.so")
+if os.environ.get("XWB_LIB_AB"):                 # lab: another build of the same ABI, for A/B runs on ONE box (box-to-box spread is larger than most effects)
+    LIB_PATH = os.path.abspath(os.environ["XWB_LIB_AB"])
 
-XWB_ABI_VERSION = 4
+XWB_ABI_VERSION = 5
 XWB_SIMPLE_GAME, XWB_SIMPLE_RACE, XWB_XWORLD2D = 0, 1, 2
 XWB_MAP_NAV, XWB_MAP_WALLS = 0, 1
 XWB_TASKMODE_LANG_ACQ, XWB_TASKMODE_ONE_CHANNEL = 0, 1
