@@ -12,6 +12,7 @@ for W in "$@"; do
   cp gpurun_out/prof_$W/summary.txt $OUT/${W}_rocprof_summary.txt 2>/dev/null
   cp gpurun_out/prof_$W/traffic.json $OUT/traffic_$W.json 2>/dev/null
   mkdir -p profiles/$TAG && cp gpurun_out/prof_$W/traffic.json profiles/$TAG/traffic_$W.json 2>/dev/null
+  rm -rf gpurun_out/prof_$W                                # (raw traces: ~25 MB per workload; gpurun brings back at most 64 MiB)
   python bench.py --workload $W > $OUT/bench_$W.json 2> $OUT/bench_$W.err || true
   tail -c 300 $OUT/bench_$W.json | head -c 300; echo
 done
