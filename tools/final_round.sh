@@ -18,6 +18,7 @@ GIT_HEAD=$HEAD bash tools/profile_round.sh $TAG xworld7 xworld7_f32 xworld8 xwor
   done
   timeout 900 python tools/ego_soak.py 2>&1 | tail -14
   timeout 900 python tools/soak_pregen.py 2>&1 | tail -3
+  for a in "6000 40 7" "3000 40 11" "3000 40 8"; do timeout 600 python tools/soak_fused.py $a 2>&1 | grep "^soak_fused"; done
   timeout 600 python tools/pcie_rate.py 2>&1 | tail -3
   timeout 600 python tools/leak_check.py 2>&1 | grep "^no leak"
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
