@@ -89,7 +89,8 @@ def parse_args():
 
 def main():
     args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # (a dry run without a launcher plans for --gpus ranks; a real run is as wide as its launcher made it)
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus) if args.dry_run else "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.dry_run:
